@@ -1,0 +1,159 @@
+"""Pins the CPU oracle (oracle/) to vectors produced by the REAL reference (tests/golden, made by
+oracle/make_golden.py) -- CPU only, no GPU, no reference tree needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postproc_oracle as P
+from oracle import univtg_oracle as O
+
+CASES = ["tiny_eval_ragged", "tiny_eval_full", "tiny_train_droppath", "config1_real_feats"]
+
+
+def load_case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = O.make_cfg(**meta["cfg"])
+    grab = lambda pre: {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+    params, inputs, tg, out, grads = grab("param/"), grab("in/"), grab("tg/"), grab("out/"), grab("grad/")
+    losses = {k[5:]: float(z[k]) for k in z.files if k.startswith("loss/")}
+    rng = {"dp_scale": torch.from_numpy(z["rng/dp_scale"])} if "rng/dp_scale" in z.files else None
+    return meta, cfg, params, inputs, tg, out, grads, losses, rng
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_losses_grads_match_reference(golden_dir, name):
+    meta, cfg, params, inputs, tg, out_ref, grads_ref, losses_ref, rng = load_case(golden_dir, name)
+    params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = O.forward(params, cfg, rng=rng, **inputs)
+    for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj", "saliency_scores"):
+        torch.testing.assert_close(out[k], out_ref[k], rtol=2e-5, atol=2e-6, msg=lambda m: f"{k}: {m}")
+    losses = O.criterion(out, tg, cfg)
+    for k, v in losses.items():
+        assert abs(float(v.detach() if torch.is_tensor(v) else v) - losses_ref[k]) <= 2e-5 * max(1.0, abs(losses_ref[k])), (k, float(v), losses_ref[k])
+    total = O.total_loss(losses, cfg)
+    assert abs(float(total) - losses_ref["total"]) <= 2e-5 * abs(losses_ref["total"])
+    total.backward()
+    assert set(meta["no_grad_params"]) == {k for k, p in params.items() if p.grad is None}
+    for k, g in grads_ref.items():
+        scale = float(g.abs().max()) + 1e-12
+        err = float((params[k].grad - g).abs().max())
+        assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
+
+
+def test_checkpoint_layout_matches_reference(golden_dir):
+    """param_shapes == the reference's state_dict (names, shapes, order); the fixture weights went
+    through load_state_dict(strict=True) when it was made."""
+    z = np.load(os.path.join(golden_dir, "tiny_eval_full.npz"))
+    meta = json.loads(str(z["meta"]))
+    shapes = O.param_shapes(O.make_cfg(**meta["cfg"]))
+    stored = {k[6:]: tuple(z[k].shape) for k in z.files if k.startswith("param/")}
+    assert stored == {k: tuple(v) for k, v in shapes.items()}
+
+
+def test_log_mask_denormal():
+    v = O.log_mask(torch.tensor([0.0, 1.0]), torch.float32)
+    assert abs(float(v[0]) + 103.2789) < 1e-3 and float(v[1]) == 0.0
+
+
+def test_span_utils_known_answers(golden_dir):
+    z = np.load(os.path.join(golden_dir, "span_utils.npz"))
+    a, b = torch.from_numpy(z["a"]), torch.from_numpy(z["b"])
+    np.testing.assert_allclose(O.giou_matrix(a, b).numpy(), z["giou"], rtol=1e-6, atol=1e-7)
+    d1 = torch.tensor([[0, 0.2], [0.5, 1.0]])
+    d2 = torch.tensor([[0, 0.3], [0.0, 1.0]])
+    np.testing.assert_allclose(O.giou_matrix(d1, d2).numpy(), z["doc_giou"], rtol=1e-6)
+    # doctest values printed in utils/span_utils.py:106-110
+    np.testing.assert_allclose(z["doc_giou"], [[0.6667, 0.2], [-0.2, 0.5]], atol=1e-4)
+    np.testing.assert_allclose(np.diag(O.giou_matrix(a[:5], b).numpy()), O.paired_giou(a[:5], b).numpy(), rtol=1e-6)
+
+
+def test_postprocessing_matches_reference(golden_dir):
+    for name in CASES:
+        meta, cfg, params, inputs, tg, _, *_ = load_case(golden_dir, name)
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        out_ref = {k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("evalout/")}
+        durations = [float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(inputs["src_vid"].shape[0])]
+        pre = P.decode_windows(out_ref["pred_logits"].numpy(), out_ref["pred_spans"].numpy(),
+                               tg["timestamp"].numpy(), tg["timestamp_mask"].numpy(), durations)
+        assert pre == meta["post/raw"]["pre"]
+        nms = [P.temporal_nms(p[:1000], 0.7, 10) for p in pre]
+        assert nms == meta["post/raw"]["nms"]
+        rounded = [P.round_multiple(p, 2.0) for p in pre]
+        assert rounded == meta["post/rounded"]["pre"]
+        sal = P.saliency_for_eval(out_ref["saliency_scores"].numpy(), out_ref["pred_logits"].numpy(),
+                                  inputs["src_vid_mask"].numpy())
+        for a, b in zip(sal, meta["post/raw"]["sal"]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=0)
+
+
+def test_temporal_nms_known_answers(golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "nms.json")))
+    for c in d["cases"]:
+        assert P.temporal_nms([list(r) for r in c["inp"]], c["thd"], c["max_after"]) == c["out"]
+    for rin, rout in zip(d["round_in"], d["round_out"]):
+        assert P.round_multiple(rin, 2.0) == rout
+    assert P.temporal_nms([[0.0, 1.0, 0.5]], 0.7) == [[0.0, 1.0, 0.5]]
+
+
+def test_matcher_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "matcher.npz"))
+    sizes = z["sizes"].tolist()
+    tg, off = [], 0
+    for n in sizes:
+        tg.append(z["tgt"][off:off + n])
+        off += n
+    got = P.hungarian_match(z["logits"], z["spans"], tg)
+    for b, (i, j) in enumerate(got):
+        assert i.tolist() == z[f"i{b}"].tolist() and j.tolist() == z[f"j{b}"].tolist()
+    got = P.hungarian_match(z["logits1"], z["spans"], tg)
+    for b, (i, j) in enumerate(got):
+        assert i.tolist() == z[f"u_i{b}"].tolist() and j.tolist() == z[f"u_j{b}"].tolist()
+
+
+def test_lsap_against_scipy_random():
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n, m = rng.integers(1, 12), rng.integers(1, 12)
+        c = rng.standard_normal((n, m))
+        i, j = P.lsap(c)
+        ri, rj = linear_sum_assignment(c)
+        assert i.tolist() == ri.tolist() and j.tolist() == rj.tolist()
+
+
+def test_dense_targets_match_dataset(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "dense_targets.json")))
+    for c in cases:
+        g = torch.Generator().manual_seed(0)
+        lv = c["lv"]
+        t = O.dense_targets(lv, lv, torch.tensor(c["wins"]), 2, g)
+        np.testing.assert_allclose(t["timestamp"].numpy(), np.array(c["timestamp"], np.float32), rtol=1e-6)
+        np.testing.assert_allclose(t["span_labels_nn"].numpy(), np.array(c["span_labels_nn"], np.float32), rtol=1e-6, atol=1e-7)
+        assert t["timestamp_window"].int().tolist() == [int(x) for x in c["timestamp_window"]]
+        assert t["saliency_scores"].tolist() == [float(x) for x in c["saliency_scores"]]
+        np.testing.assert_allclose(t["span_labels"].numpy(), np.array(c["span_labels"], np.float32), rtol=1e-6)
+        assert c["timestamp_window"][c["pos"][0]] == 1 and t["timestamp_window"][t["saliency_pos_labels"]] == 1
+
+
+@pytest.mark.reference
+def test_oracle_vs_live_reference_full_width():
+    """Build container only: d=1024 production width, live reference vs oracle (no fixture)."""
+    from oracle.make_golden import build_reference, import_reference
+    ref = import_reference()
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0, enc_layers=2)
+    params = O.init_params(cfg, seed=5)
+    model, crit = build_reference(ref, cfg, params)
+    model.eval()
+    inputs, tg = O.make_batch(cfg, 3, 20, 9, seed=6, ragged=True)
+    with torch.no_grad():
+        a = model(**inputs)
+        b = O.forward(params, cfg, **inputs)
+    for k in ("pred_logits", "pred_spans", "saliency_scores", "vid_mem_proj", "txt_mem_proj"):
+        torch.testing.assert_close(b[k], a[k], rtol=1e-4, atol=1e-5)
+    la, lb = crit(a, tg), O.criterion(b, tg, cfg)
+    for k in la:
+        assert abs(float(la[k]) - float(lb[k])) < 1e-4 * max(1, abs(float(la[k])))
