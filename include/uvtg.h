@@ -1,0 +1,167 @@
+/*
+ * uvtg.h -- C ABI of libuvtg.so: the MI355X (gfx950) implementation of the UniVTG hot path.
+ *
+ * The reference (showlab/UniVTG) has no native code and no FFI: its hot path is PyTorch ATen calls
+ * issued from model/univtg.py.  This header is the boundary a reference maintainer binds instead
+ * (ctypes stub in INTEGRATION.md).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; plain pointers + sizes, no torch types
+ *   - the library never allocates or frees device memory: callers (PyTorch) own params, activations,
+ *     workspaces and outputs; required sizes come from the *_bytes() / *_floats() queries
+ *   - all work is enqueued on `stream` (a hipStream_t) and returns immediately
+ *   - return value: 0 = ok, >0 = hipError_t, <0 = invalid argument (see uvtg_strerror)
+ *   - threading: one caller thread per process/GPU (the reference runs one process per GPU,
+ *     scripts/pretrain.sh:98); re-entrant across processes
+ *   - fp32 tensors must be 16-byte aligned, row-major, innermost dimension contiguous
+ */
+#ifndef UVTG_H
+#define UVTG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* uvtg_stream_t;   /* hipStream_t */
+
+/* Geometry + mode of one forward/backward call.  Mirrors the fields build_model() reads from `args`
+ * (model/univtg.py:409-450) plus the batch shape. */
+typedef struct uvtg_dims {
+  int B, Lv, Lt;             /* batch, padded #clips, padded #text tokens (S = Lv + Lt)            */
+  int d, H, F, E;            /* hidden_dim, nheads, dim_feedforward, enc_layers                    */
+  int Dv, Dt;                /* v_feat_dim (incl. TEF), t_feat_dim                                 */
+  int n_proj;                /* n_input_proj; only 2 (the value every reference script uses)       */
+  int precise;               /* 0: bf16 MFMA encoder/heads; 1: split-bf16 (fp32-class), forward only */
+  int training;              /* 1: keep activations for backward, apply dropout / DropPath         */
+  int proj_precise;          /* 1: input projections in split-bf16 even when precise==0 (keeps the
+                                saliency logits within 1e-4 of the fp32 reference)                 */
+  float p_in, p_attn, p_path;/* input_dropout, dropout (attention), droppath                       */
+  unsigned long long seed;   /* Philox seed of this step (stochastic ops are counter-based)        */
+} uvtg_dims;
+
+/* ---- parameter table -------------------------------------------------------------------------
+ * Parameters are passed as an array of fp32 device pointers in the reference's state_dict order
+ * (model/univtg.py:76-103):
+ *   for l in 0..E-1 (base 12*l): in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
+ *       linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias,
+ *       norm2.weight, norm2.bias
+ *   then (base 12*E): token_type_embeddings.weight,
+ *       span_embed.layers.{0,1,2}.{weight,bias}, class_embed.layers.{0,1,2}.{weight,bias},
+ *       input_txt_proj.{0,1}.{LayerNorm.weight, LayerNorm.bias, net.1.weight, net.1.bias},
+ *       input_vid_proj.{0,1}.{...}, weightedpool.weight
+ *   (txt_position_embed.* is NOT in the table: it is unused unless --use_txt_pos, which no reference
+ *    script sets, and it receives no gradient in the reference either -- model/univtg.py:123.)
+ * uvtg_param_count() = 12*E + 30.  Gradients come back in ONE flat fp32 buffer; parameter i starts
+ * at element offsets[i] (uvtg_param_offsets; each start is a multiple of 4 elements). */
+int uvtg_param_count(const uvtg_dims* dm);
+int uvtg_param_numel(const uvtg_dims* dm, int index, long long* numel);
+int uvtg_param_offsets(const uvtg_dims* dm, long long* offsets /* host, [count + 1] */);
+
+/* ---- sizes -------------------------------------------------------------------------------- */
+size_t uvtg_workspace_bytes(const uvtg_dims* dm);   /* activations + scratch for forward(+backward) */
+size_t uvtg_wcache_bytes(const uvtg_dims* dm);      /* prepared GEMM operands (bf16 copies, transposes) */
+long long uvtg_loss_ws_floats(int B, int Lv);
+
+/* Re-layout / down-cast the weights into the MFMA operand cache.  Call after every parameter update
+ * (replaces nothing in the reference: ATen reads the fp32 weights directly). */
+int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* params, void* wcache, uvtg_stream_t stream);
+
+/* ---- model forward: replaces Model.forward (model/univtg.py:105-155) --------------------------
+ * inputs : src_txt [B,Lt,Dt], src_txt_mask [B,Lt], src_vid [B,Lv,Dv], src_vid_mask [B,Lv]  (fp32, 0/1 masks)
+ *          dim_t [d]: the sine-embedding denominators 10000^(2*(i/2)/d) (model/position_encoding.py:75-78)
+ * outputs: x0 [B,S,d]   projected tokens (vid rows then txt rows); vid_mem_proj = x0[:, :Lv]
+ *          pred_logits [B,Lv,1], pred_spans [B,Lv,2], txt_mem_proj [B,1,d], saliency [B,Lv]
+ *          memory [B,S,d] encoder output (optional, may be NULL) */
+int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wcache,
+                 const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
+                 const float* dim_t,
+                 float* x0, float* pred_logits, float* pred_spans, float* txt_mem_proj, float* saliency,
+                 float* memory, void* workspace, uvtg_stream_t stream);
+
+/* ---- model backward: replaces autograd through Model.forward ------------------------------------
+ * Needs the workspace, inputs and outputs (x0, pred_*, txt_mem_proj) of the matching
+ * uvtg_forward(training=1) call.  Upstream gradients (any may be
+ * NULL = zero): g_logits [B,Lv,1], g_spans [B,Lv,2], g_saliency [B,Lv], g_txt_mem [B,1,d],
+ * g_vid_mem addressed as g_vid_mem[b*g_vid_sb + t*g_vid_st + c] (so the gradient of the whole x0
+ * buffer, strides S*d and d, can be passed as is).  grads: flat fp32 buffer (uvtg_param_offsets), overwritten. */
+int uvtg_backward(const uvtg_dims* dm, const float* const* params, const void* wcache,
+                  const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
+                  const float* x0, const float* pred_logits, const float* pred_spans, const float* txt_mem_proj,
+                  const float* g_logits, const float* g_spans, const float* g_saliency,
+                  const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
+                  float* grads, void* workspace, uvtg_stream_t stream);
+
+/* ---- criterion: replaces SetCriterion.forward + its autograd (model/univtg.py:195-282,338-351) ---
+ * vid_mem_proj is addressed as vid[b*vid_sb + t*vid_st + c] so that the strided view of x0 works.
+ * losses_out [8] (device): loss_b, loss_g, loss_f, loss_s_inter, loss_s_intra, saliency_active, Nwin, Nvalid.
+ * which: bit0 spans, bit1 labels, bit2 saliency (the `losses` list of build_model). */
+int uvtg_criterion_fwd(int B, int Lv, int d, int which, float eos_coef,
+                       const float* pred_logits, const float* pred_spans,
+                       const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,
+                       const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
+                       const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
+                       float* loss_ws, float* losses_out, uvtg_stream_t stream);
+/* go [5] (device): upstream gradient of each of the five losses.  Outputs: g_logits [B,Lv],
+ * g_spans [B,Lv,2], g_vid [B,Lv,d] (dense), g_txt [B,d].  Must follow the matching _fwd call. */
+int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coef,
+                       const float* pred_logits, const float* pred_spans,
+                       const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,
+                       const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
+                       const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
+                       float* loss_ws, const float* losses_out, const float* go,
+                       float* g_logits, float* g_spans, float* g_vid, float* g_txt, uvtg_stream_t stream);
+
+/* ---- kernel-level entry points (used by the parity tests; same kernels the engine launches) ----- */
+/* C[M,N] = A[M,K] * W[N,K]^T + bias (nn.Linear).  bf16: A,W bf16, C fp32.  f32x3: A,W fp32. act: 0/1 relu/2 gelu */
+int uvtg_linear_bf16(const void* A, const void* W, const float* bias, float* C, int M, int N, int K, int act,
+                     uvtg_stream_t stream);
+int uvtg_linear_f32x3(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act,
+                      uvtg_stream_t stream);
+/* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 operands, fp32 atomic accumulate), dbias[N] += colsum(dY) (may be NULL) */
+int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits,
+                    uvtg_stream_t stream);
+int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t stream);
+/* LayerNorm rows (eps 1e-5): y fp32, optional mean/rstd */
+int uvtg_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int rows, int D, uvtg_stream_t stream);
+int uvtg_layernorm_bwd(const float* g, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, float* dgamma, float* dbeta, int rows, int D, uvtg_stream_t stream);
+/* masked MHA core on packed qkv [B*S, 3d] (q pre-scaled). bf16: qkv/o bf16; precise: fp32 */
+int uvtg_attention_fwd(const void* qkv, const unsigned char* kvalid, void* o, float* lse,
+                       int B, int S, int H, int hd, int precise, uvtg_stream_t stream);
+int uvtg_attention_bwd(const void* qkv, const unsigned char* kvalid, const void* o, const float* lse,
+                       const void* dO, float* delta_scratch, void* dqkv, float qscale,
+                       int B, int S, int H, int hd, uvtg_stream_t stream);
+int uvtg_sine_position(const float* vid_mask, const float* txt_mask, const float* dim_t, float* pos,
+                       unsigned char* kvalid, int B, int Lv, int Lt, int d, uvtg_stream_t stream);
+
+/* ---- Hungarian matcher: replaces HungarianMatcher.forward (model/matcher.py:36-100) ------------
+ * cost[b*Q + q, j] = w_span*L1(cxw) + w_giou*(-gIoU(xx)) + w_class*(-softmax(logits)[.,0]) for the targets
+ * of sample b (tgt_off[b] .. tgt_off[b+1]); then a per-sample rectangular LSAP on device.
+ * out_pred / out_tgt [B, max_t] int64 index pairs sorted by prediction index (-1 padded); n_match [B]. */
+int uvtg_hungarian(const float* pred_logits, int n_cls, const float* pred_spans_cxw, int B, int Q,
+                   const float* tgt_cxw, const int* tgt_off, int max_t,
+                   float w_class, float w_span, float w_giou,
+                   float* cost_out /* [B, Q, max_t] */, long long* out_pred, long long* out_tgt,
+                   int* n_match, uvtg_stream_t stream);
+
+/* ---- inference glue: replaces main/inference_mr.py:109-160 + utils/temporal_nms.py -----------
+ * windows[b,t] = clamp((timestamp + pred_spans) * duration[b], 0, duration[b]); scores masked to 0
+ * on padded clips; rank by score (stable, descending); greedy hull-IoU NMS.
+ * order [B,Lv] int32 = clip indices ranked; keep [B, max_after] int32 = ranked positions kept (-1 padded);
+ * windows_out [B,Lv,3] fp64 rows (st, ed, score) in ranked order, each rounded to 4 decimals exactly like
+ * float(f"{x:.4f}") (main/inference_mr.py:159), so they compare equal to the reference's Python floats. */
+int uvtg_decode_rank_nms(const float* pred_logits, const float* pred_spans, const float* timestamp,
+                         const float* timestamp_mask, const float* durations, int B, int Lv,
+                         float nms_thd, int max_before, int max_after,
+                         double* windows_out, int* order, int* keep, int* n_keep, uvtg_stream_t stream);
+
+const char* uvtg_strerror(int code);
+int uvtg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVTG_H */

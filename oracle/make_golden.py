@@ -321,13 +321,13 @@ def run_dense_targets(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
-    tiny = dict(hidden_dim=64, nheads=4, dim_feedforward=96, enc_layers=2, v_feat_dim=34, t_feat_dim=24,
+    tiny = dict(hidden_dim=64, nheads=2, dim_feedforward=96, enc_layers=2, v_feat_dim=34, t_feat_dim=24,
                 max_q_l=16, input_dropout=0.0, dropout=0.0, droppath=0.0)
     run_case(ref, "tiny_eval_ragged", O.make_cfg(**tiny), B=5, L_v=13, L_t=7, seed=11, ragged=True)
     run_case(ref, "tiny_eval_full", O.make_cfg(**tiny), B=4, L_v=12, L_t=8, seed=12, ragged=False, curve=True)
     run_case(ref, "tiny_train_droppath", O.make_cfg(**{**tiny, "droppath": 0.4}), B=6, L_v=10, L_t=6,
              seed=13, ragged=True, train_droppath=True)
-    mid = dict(hidden_dim=128, nheads=8, dim_feedforward=128, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+    mid = dict(hidden_dim=128, nheads=4, dim_feedforward=128, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
                max_q_l=32, input_dropout=0.0, dropout=0.0, droppath=0.0)
     run_case(ref, "config1_real_feats", O.make_cfg(**mid), B=1, L_v=15, L_t=12, seed=2018, ragged=False,
              real_feats=True)

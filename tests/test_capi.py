@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/uvtg.h
+declares (no compute calls without a GPU), size queries behave, and the Python mirror keeps the reference's
+checkpoint layout."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from univtg_amd.build import build
+    build(verbose=False)
+    from univtg_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from univtg_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "uvtg.h")).read()
+    declared = set(re.findall(r"\b(uvtg_[a-z0-9_]+)\s*\(", hdr)) - {"uvtg_stream_t"}
+    assert declared, "no prototypes found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/uvtg.h but not exported by libuvtg.so"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.uvtg_version() >= 100
+
+
+def test_size_queries_and_param_table(lib):
+    from univtg_amd import _lib
+    from oracle import univtg_oracle as O
+    d = _lib.Dims(B=256, Lv=75, Lt=32, d=1024, H=8, F=1024, E=4, Dv=2818, Dt=512, n_proj=2, precise=0, training=1,
+                  proj_precise=1, p_in=0.5, p_attn=0.0, p_path=0.1, seed=1)
+    n = lib.uvtg_param_count(C.byref(d))
+    assert n == 12 * 4 + 30
+    offs = (C.c_longlong * (n + 1))()
+    assert lib.uvtg_param_offsets(C.byref(d), offs) == 0
+    shapes = O.param_shapes(O.make_cfg())
+    total = sum(int(np.prod(s)) for k, s in shapes.items() if not k.startswith("txt_position_embed"))
+    assert total <= offs[n] <= total + 4 * n
+    ws, wc = lib.uvtg_workspace_bytes(C.byref(d)), lib.uvtg_wcache_bytes(C.byref(d))
+    assert 1 << 30 < ws < 40 << 30 and 50 << 20 < wc < 2 << 30
+    bad = _lib.Dims(B=1, Lv=4, Lt=4, d=100, H=3, F=64, E=2, Dv=10, Dt=10, n_proj=2)
+    assert lib.uvtg_workspace_bytes(C.byref(bad)) == 0
+    assert lib.uvtg_param_offsets(C.byref(bad), offs) != 0
+    assert b"hidden_dim" in lib.uvtg_strerror(-13)
+
+
+def test_model_keeps_reference_checkpoint_layout(golden_dir):
+    from univtg_amd.model import Model
+    z = np.load(os.path.join(golden_dir, "tiny_eval_full.npz"))
+    cfg = json.loads(str(z["meta"]))["cfg"]
+    m = Model(cfg["hidden_dim"], cfg["nheads"], cfg["dim_feedforward"], cfg["enc_layers"], cfg["t_feat_dim"], cfg["v_feat_dim"],
+              cfg["input_dropout"], cfg["dropout"], cfg["droppath"], max_q_l=cfg["max_q_l"])
+    sd = m.state_dict()
+    ref = {k[6:]: tuple(z[k].shape) for k in z.files if k.startswith("param/")}     # went through the reference's load_state_dict
+    assert list(sd.keys()) == list(ref.keys())
+    assert {k: tuple(v.shape) for k, v in sd.items()} == ref
+    m.load_state_dict({k: torch.from_numpy(z["param/" + k]) for k in ref}, strict=True)
+    ordered = m._ordered_params()
+    assert len(ordered) == 12 * cfg["enc_layers"] + 30
+
+
+def test_no_cpu_fallback(golden_dir):
+    """The product refuses CPU tensors instead of silently computing elsewhere."""
+    from univtg_amd.model import Model
+    m = Model(64, 2, 96, 2, 24, 34, 0.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 24), torch.ones(1, 4), torch.zeros(1, 5, 34), torch.ones(1, 5))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "univtg_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"

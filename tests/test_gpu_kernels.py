@@ -1,0 +1,166 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel family against a plain torch fp32/fp64 statement
+of the same op on the same seeded inputs (called through the C ABI via univtg_amd.ops)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(256, 256, 256, 0), (300, 200, 136, 1), (1024, 1024, 1024, 2), (77, 64, 96, 0),
+                                       (27392, 1024, 1024, 0)])
+def test_linear_bf16(dev, M, N, K, act):
+    from univtg_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)     # asymmetric operands (transpose-detecting)
+    b = torch.randn(N, generator=g).to(dev)
+    ab, wb = bf(a), bf(w)
+    got = ops.linear_bf16(ab, wb, b, act)
+    ref = ab.double() @ wb.double().t() + b.double()
+    ref = torch.relu(ref) if act == 1 else (torch.nn.functional.gelu(ref) if act == 2 else ref)
+    assert relerr(got, ref) < 2e-5, relerr(got, ref)               # fp32 accumulation of exact bf16 products
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (130, 96, 2880), (515, 1024, 1024)])
+def test_linear_f32x3(dev, M, N, K):
+    from univtg_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + K)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    got = ops.linear_f32x3(a, w, b, 0)
+    ref = a.double() @ w.double().t() + b.double()
+    fp32 = a @ w.t() + b
+    e3, e32 = relerr(got, ref), relerr(fp32, ref)
+    assert e3 < 2e-5, (e3, e32)                                     # split-bf16: ~2^-16 relative, fp32 class
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(256, 128, 128, 1), (1000, 136, 200, 3), (4096, 256, 2824, 4)])
+def test_wgrad_tn(dev, M, N, K, splits):
+    from univtg_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N)
+    dy = bf(torch.randn(M, N, generator=g)).to(dev)
+    x = bf(torch.randn(M, K, generator=g)).to(dev)
+    dw, db = ops.wgrad_bf16(dy, x, splits)
+    ref = dy.double().t() @ x.double()
+    assert relerr(dw, ref) < 3e-5, relerr(dw, ref)
+    assert relerr(db, dy.double().sum(0)) < 3e-5
+
+
+@pytest.mark.parametrize("rows,D", [(64, 1024), (37, 2818), (50, 512), (9, 514), (33, 64), (5, 2817)])
+def test_layernorm(dev, rows, D):
+    from univtg_amd import ops
+    g = torch.Generator().manual_seed(rows * D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(dev)
+    gam = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    bet = (0.1 * torch.randn(D, generator=g)).to(dev)
+    y, mean, rstd = ops.layernorm_fwd(x, gam, bet)
+    xr = x.double().requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    assert float((y - ref).abs().max()) < 2e-5
+    go = torch.randn(rows, D, generator=g).to(dev)
+    ref.backward(go.double())
+    dx, dg, db = ops.layernorm_bwd(go, x, mean, rstd, gam)
+    assert relerr(dx, xr.grad) < 1e-4
+    assert relerr(dg, gr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
+
+
+def _attn_ref(qkv, kvalid, B, S, H, hd):
+    d = H * hd
+    q, k, v = [t.view(B, S, H, hd).transpose(1, 2) for t in qkv.double().view(B, S, 3 * d).split(d, dim=-1)]
+    sc = q @ k.transpose(-1, -2)
+    sc = sc.masked_fill(~kvalid.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(sc, -1)
+    return (p @ v).transpose(1, 2).reshape(B * S, d), torch.logsumexp(sc, -1)
+
+
+def _kvalid(B, S, g, dev):
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    kv = (torch.arange(S)[None, :] < lens[:, None])
+    kv[:, S - 3:] = True                                           # text-like tail of valid keys after the padded gap
+    return kv.to(torch.uint8).to(dev)
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(3, 27, 2, 32), (2, 107, 4, 64), (2, 107, 8, 128), (1, 300, 2, 128)])
+@pytest.mark.parametrize("precise", [False, True])
+def test_attention_fwd(dev, B, S, H, hd, precise):
+    from univtg_amd import ops
+    g = torch.Generator().manual_seed(S + hd)
+    qkv = torch.randn(B * S, 3 * H * hd, generator=g)
+    qkv[:, : H * hd] *= hd ** -0.5
+    kv = _kvalid(B, S, g, dev)
+    x = qkv.to(dev) if precise else bf(qkv).to(dev)
+    o, lse = ops.attention_fwd(x, kv, B, S, H, hd, precise)
+    ref_o, ref_l = _attn_ref(x.float().cpu(), kv.cpu(), B, S, H, hd)
+    tol = 3e-5 if precise else 1.5e-2                              # bf16 P and O rounding in the fast path
+    assert float((o.float().cpu() - ref_o).abs().max()) < tol
+    assert float((lse.cpu() - ref_l).abs().max()) < (1e-4 if precise else 2e-3)
+
+
+def test_attention_softmax_rescale_branch(dev):
+    """One key spikes far above the rest in the SECOND key tile: forces the online-softmax rescale."""
+    from univtg_amd import ops
+    B, S, H, hd = 1, 150, 1, 64
+    g = torch.Generator().manual_seed(1)
+    qkv = 0.1 * torch.randn(B * S, 3 * H * hd, generator=g)
+    qkv[5, :hd] = 3.0
+    qkv[100, hd:2 * hd] = 3.0                                       # q5 . k100 = 576
+    kv = torch.ones(B, S, dtype=torch.uint8, device=dev)
+    o, _ = ops.attention_fwd(qkv.to(dev), kv, B, S, H, hd, True)
+    ref_o, _ = _attn_ref(qkv, kv.cpu(), B, S, H, hd)
+    assert float((o.cpu() - ref_o).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(2, 27, 2, 32), (2, 107, 2, 64), (2, 107, 4, 128), (1, 200, 2, 128)])
+def test_attention_bwd(dev, B, S, H, hd):
+    from univtg_amd import ops
+    g = torch.Generator().manual_seed(S * hd)
+    d = H * hd
+    qkv = torch.randn(B * S, 3 * d, generator=g)
+    qkv[:, :d] *= hd ** -0.5
+    kv = _kvalid(B, S, g, dev)
+    xb = bf(qkv).to(dev)
+    o, lse = ops.attention_fwd(xb, kv, B, S, H, hd, False)
+    do = bf(torch.randn(B * S, d, generator=g)).to(dev)
+    dqkv = ops.attention_bwd(xb, kv, o, lse, do, 1.0, B, S, H, hd)
+    xr = xb.double().cpu().requires_grad_(True)
+    ref_o, _ = _attn_ref(xr, kv.cpu(), B, S, H, hd)
+    ref_o.backward(do.double().cpu())
+    ref = xr.grad
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        e = relerr(dqkv[:, sl].float().cpu(), ref[:, sl])
+        assert e < 2.5e-2, (name, e)
+
+
+def test_sine_position(dev):
+    from oracle import univtg_oracle as O
+    from univtg_amd import ops
+    B, Lv, Lt, d = 4, 75, 9, 1024
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(5, Lv + 1, (B,), generator=g)
+    vm = (torch.arange(Lv)[None] < lens[:, None]).float()
+    tm = torch.ones(B, Lt)
+    tm[0, 5:] = 0
+    i = torch.arange(d, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(i, 2).int() / d)
+    pos, kvalid = ops.sine_position(vm.to(dev), tm.to(dev), dim_t.to(dev))
+    ref = O.sine_position(vm, d)
+    assert float((pos.cpu() - ref).abs().max()) < 5e-6
+    assert torch.equal(kvalid.cpu().bool(), torch.cat([vm, tm], 1).bool())

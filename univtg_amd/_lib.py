@@ -1,0 +1,76 @@
+"""ctypes binding of libuvtg.so (include/uvtg.h).  There is no fallback: if the library is missing the
+import of any compute entry point fails loudly with the build instruction."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuvtg.so")
+
+
+class Dims(C.Structure):
+    """struct uvtg_dims (include/uvtg.h)."""
+    _fields_ = [("B", C.c_int), ("Lv", C.c_int), ("Lt", C.c_int),
+                ("d", C.c_int), ("H", C.c_int), ("F", C.c_int), ("E", C.c_int),
+                ("Dv", C.c_int), ("Dt", C.c_int), ("n_proj", C.c_int),
+                ("precise", C.c_int), ("training", C.c_int), ("proj_precise", C.c_int),
+                ("p_in", C.c_float), ("p_attn", C.c_float), ("p_path", C.c_float),
+                ("seed", C.c_ulonglong)]
+
+
+_P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+_DP = C.POINTER(Dims)
+# name -> (restype, argtypes); the authoritative prototypes are in include/uvtg.h
+SIGNATURES = {
+    "uvtg_version": (_I, []),
+    "uvtg_strerror": (C.c_char_p, [_I]),
+    "uvtg_param_count": (_I, [_DP]),
+    "uvtg_param_numel": (_I, [_DP, _I, C.POINTER(_LL)]),
+    "uvtg_param_offsets": (_I, [_DP, C.POINTER(_LL)]),
+    "uvtg_workspace_bytes": (C.c_size_t, [_DP]),
+    "uvtg_wcache_bytes": (C.c_size_t, [_DP]),
+    "uvtg_loss_ws_floats": (_LL, [_I, _I]),
+    "uvtg_prepare_weights": (_I, [_DP, _P, _P, _P]),
+    "uvtg_forward": (_I, [_DP, _P, _P] + [_P] * 5 + [_P] * 6 + [_P, _P]),
+    "uvtg_backward": (_I, [_DP, _P, _P] + [_P] * 4 + [_P] * 4 + [_P] * 5 + [_LL, _LL] + [_P, _P, _P]),
+    "uvtg_criterion_fwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P]),
+    "uvtg_criterion_bwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P] + [_P] * 4 + [_P]),
+    "uvtg_linear_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "uvtg_linear_f32x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "uvtg_wgrad_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "uvtg_cast_bf16": (_I, [_P, _P, _LL, _P]),
+    "uvtg_layernorm_fwd": (_I, [_P] * 6 + [_I, _I, _P]),
+    "uvtg_layernorm_bwd": (_I, [_P] * 8 + [_I, _I, _P]),
+    "uvtg_attention_fwd": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "uvtg_attention_bwd": (_I, [_P] * 7 + [_F] + [_I] * 4 + [_P]),
+    "uvtg_sine_position": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "uvtg_hungarian": (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "uvtg_decode_rank_nms": (_I, [_P] * 5 + [_I, _I, _F, _I, _I] + [_P] * 4 + [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libuvtg.so once; raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the UniVTG MI355X kernels are not built. Run `python -m univtg_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "uvtg"):
+    if code != 0:
+        msg = load().uvtg_strerror(code)
+        raise RuntimeError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,498 @@
+// Masked multi-head self-attention for the UniVTG encoder (model/transformer_encoder_droppath.py:117-118
+// -> torch F.multi_head_attention_forward): softmax(q k^T + key_padding(-inf)) v per (sample, head),
+// S = L_v + L_t tokens, flash-style (no S x S matrix in HBM), on v_mfma_f32_32x32x16_bf16.
+//
+// Layout trick used throughout: every score tile is computed TRANSPOSED (keys along MFMA rows, queries
+// along lanes, or vice versa) so that the softmax statistics are lane-local and the probability tile
+// can be fed back to the next MFMA straight from registers; the operand that has to be transposed is
+// fetched with ds_read_b64_tr_b16.
+//   fwd : S^T = K Q^T (K: LDS b128, Q: registers)      O^T += V^T P^T (V^T: LDS tr-read, P^T: registers)
+//   dKdV: S   = Q K^T, dP = dO V^T                      dV^T += dO^T P, dK^T += Q^T dS
+//   dQ  : S^T = K Q^T, dP^T = V dO^T                    dQ^T += K^T dS^T
+#include "uvtg_kernels.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1e30f;
+
+template <int HD> struct KSwz {      // swizzle for [rows][HD] bf16 tiles read with ds_read_b128
+  static constexpr int CPR = HD / 8;
+  static constexpr int RPB = (128 / HD) > 0 ? (128 / HD) : 1;
+  __device__ static __forceinline__ int off(int r, int chunk) { return r * HD + ((chunk ^ ((r / RPB) % CPR)) * 8); }
+};
+
+__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned stream, int bh, int q, int k, int S, float p) {
+  unsigned r[4];
+  philox4(seed, ((unsigned long long)bh * S + q) * (unsigned long long)S + k, stream, r);
+  return (u01(r[0]) >= p) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+__device__ __forceinline__ s16x8 pack8(const float* v) {
+  s16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = (short)f2bf(v[e]);
+  return o;
+}
+__device__ __forceinline__ s16x8 pack8_lo(const float* v) {   // residual after bf16 rounding
+  s16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = (short)f2bf(v[e] - bf2f(f2bf(v[e])));
+  return o;
+}
+__device__ __forceinline__ s16x8 cat4(s16x4 a, s16x4 b) { return (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int HD, bool PRECISE>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int VSTR = HD + (HD >= 64 ? 32 : 0);
+  constexpr int NP = PRECISE ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[NP][64 * HD];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[NP][64 * VSTR];
+  __shared__ unsigned char sValid[64];
+  using KS = KSwz<HD>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.S;
+  const int q_raw = blockIdx.x * 128 + wave * 32 + l31;
+  const int qrow = min(q_raw, S - 1);
+  const size_t rowbase = (size_t)b * S;
+
+  // Q fragments (B operand of S^T = K Q^T): lane (query, g) holds q[16ks + 8g .. +7]
+  s16x8 qh[HD / 16], ql[PRECISE ? HD / 16 : 1];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ks++) {
+    const size_t off = (rowbase + qrow) * a.ldqkv + h * HD + 16 * ks + 8 * g;
+    if constexpr (!PRECISE) qh[ks] = *(const s16x8*)((const bf16_t*)a.qkv + off);
+    else {
+      float v[8];
+      const float* p = (const float*)a.qkv + off;
+      *(f32x4*)v = *(const f32x4*)p; *(f32x4*)(v + 4) = *(const f32x4*)(p + 4);
+      qh[ks] = pack8(v); ql[ks] = pack8_lo(v);
+    }
+  }
+  f32x16 oacc[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[i][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
+
+  const int ntiles = (S + 63) / 64;
+  for (int kt = 0; kt < ntiles; kt++) {
+    __syncthreads();
+    // ---- stage K / V tile (keys kt*64 .. +63), zero-filled beyond S ----
+    if constexpr (!PRECISE) {
+      constexpr int CH = HD / 8;                       // 16-byte chunks per row
+#pragma unroll
+      for (int i = 0; i < (64 * CH) / 256; i++) {
+        const int q = tid + 256 * i, r = q / CH, c = q % CH;
+        const int key = kt * 64 + r;
+        u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+        if (key < S) {
+          const bf16_t* base = (const bf16_t*)a.qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
+          kv = *(const u32x4*)(base + a.H * HD);
+          vv = *(const u32x4*)(base + 2 * a.H * HD);
+        }
+        *(u32x4*)(&sK[0][KS::off(r, c)]) = kv;
+        *(u32x4*)(&sV[0][r * VSTR + c * 8]) = vv;
+      }
+    } else {
+      constexpr int PC = HD / 4;                       // float4 pieces per row
+#pragma unroll
+      for (int i = 0; i < (64 * PC) / 256; i++) {
+        const int q = tid + 256 * i, r = q / PC, c = q % PC;
+        const int key = kt * 64 + r;
+        float kf[4] = {0, 0, 0, 0}, vf[4] = {0, 0, 0, 0};
+        if (key < S) {
+          const float* base = (const float*)a.qkv + (rowbase + key) * a.ldqkv + h * HD + c * 4;
+          *(f32x4*)kf = *(const f32x4*)(base + a.H * HD);
+          *(f32x4*)vf = *(const f32x4*)(base + 2 * a.H * HD);
+        }
+        const int ko = KS::off(r, c >> 1) + (c & 1) * 4, vo = r * VSTR + c * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bf16_t kh_ = f2bf(kf[e]), vh_ = f2bf(vf[e]);
+          sK[0][ko + e] = kh_; sK[NP - 1][ko + e] = f2bf(kf[e] - bf2f(kh_));
+          sV[0][vo + e] = vh_; sV[NP - 1][vo + e] = f2bf(vf[e] - bf2f(vh_));
+        }
+      }
+    }
+    if (tid < 64) { const int key = kt * 64 + tid; sValid[tid] = (key < S) ? a.kvalid[rowbase + key] : 0; }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : sc[kb][r] <-> key kb*32 + (r&3)+8(r>>2)+4g, query l31 ----
+    f32x16 sc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) sc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++) {
+        const int o = KS::off(kb * 32 + l31, 2 * ks + g);
+        const s16x8 kf = *(const s16x8*)(&sK[0][o]);
+        if constexpr (PRECISE) {
+          const s16x8 kl = *(const s16x8*)(&sK[NP - 1][o]);
+          sc[kb] = mfma32(kl, qh[ks], sc[kb]);
+          sc[kb] = mfma32(kf, ql[ks], sc[kb]);
+        }
+        sc[kb] = mfma32(kf, qh[ks], sc[kb]);
+      }
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        sc[kb][r] = sValid[kl] ? sc[kb][r] : NEG_BIG;
+        mx = fmaxf(mx, sc[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float rs = 0.f;
+    float pv[2][16];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float p = sValid[kl] ? __expf(sc[kb][r] - m_new) : 0.f;
+        rs += p;
+        pv[kb][r] = p;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    if (a.p_drop > 0.f) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          pv[kb][r] *= keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, key, S, a.p_drop);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[i][r] *= alpha;
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const s16x8 pb = pack8(&pv[kb][8 * hf]);
+        s16x8 pl;
+        if constexpr (PRECISE) pl = pack8_lo(&pv[kb][8 * hf]);
+        const int kr = kb * 32 + 16 * hf + 4 * g + (i16 >> 2);
+#pragma unroll
+        for (int dvb = 0; dvb < HD / 32; dvb++) {
+          const int col = dvb * 32 + 16 * qd + 4 * (i16 & 3);
+          const s16x8 vf = cat4(lds_tr16(&sV[0][kr * VSTR + col]), lds_tr16(&sV[0][(kr + 8) * VSTR + col]));
+          if constexpr (PRECISE) {
+            const s16x8 vl = cat4(lds_tr16(&sV[NP - 1][kr * VSTR + col]), lds_tr16(&sV[NP - 1][(kr + 8) * VSTR + col]));
+            oacc[dvb] = mfma32(vl, pb, oacc[dvb]);
+            oacc[dvb] = mfma32(vf, pl, oacc[dvb]);
+          }
+          oacc[dvb] = mfma32(vf, pb, oacc[dvb]);
+        }
+      }
+  }
+  if (q_raw < S) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int dvb = 0; dvb < HD / 32; dvb++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const int dv = dvb * 32 + 8 * rq + 4 * g;
+        const size_t off = (rowbase + q_raw) * a.ldo + h * HD + dv;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = oacc[dvb][4 * rq + e] * inv;
+        if constexpr (!PRECISE) {
+          u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
+          *(u32x2*)((bf16_t*)a.o + off) = t;
+        } else {
+          f32x4 t = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)a.o + off) = t;
+        }
+      }
+    if (a.lse && g == 0) a.lse[((size_t)b * a.H + h) * S + q_raw] = m_run + __logf(l_run);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: delta = rowsum(dO * O)
+// ------------------------------------------------------------------------------------------------
+__global__ void attn_delta_kernel(const AttnArgs a) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)a.B * a.S * a.H;
+  if (idx >= total) return;
+  const int h = (int)(idx % a.H);
+  const long long row = idx / a.H;
+  const int b = (int)(row / a.S), s = (int)(row % a.S);
+  const bf16_t* o = (const bf16_t*)a.o + row * a.ldo + h * a.hd;
+  const bf16_t* d = a.dO + row * a.lddo + h * a.hd;
+  float acc = 0.f;
+  for (int c = 0; c < a.hd; c += 8) {
+    const s16x8 ov = *(const s16x8*)(o + c), dv = *(const s16x8*)(d + c);
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc += bf2f((bf16_t)ov[e]) * bf2f((bf16_t)dv[e]);
+  }
+  a.delta[((size_t)b * a.H + h) * a.S + s] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dK, dV   (one wave = 32 keys, loops over 32-query blocks)
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+  constexpr int QSTR = HD + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[128 * HD];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[128 * HD];
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * QSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[32 * QSTR];
+  __shared__ float sL[32], sD[32];
+  using KS = KSwz<HD>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.S, d = a.H * HD;
+  const size_t rowbase = (size_t)b * S;
+  const int key0 = blockIdx.x * 128;
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  constexpr int CH = HD / 8;
+  // stage this block's 128 keys of K and V
+#pragma unroll
+  for (int i = 0; i < (128 * CH) / 256; i++) {
+    const int q = tid + 256 * i, r = q / CH, c = q % CH;
+    const int key = key0 + r;
+    u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+    if (key < S) {
+      const bf16_t* base = qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
+      kv = *(const u32x4*)(base + d);
+      vv = *(const u32x4*)(base + 2 * d);
+    }
+    *(u32x4*)(&sK[KS::off(r, c)]) = kv;
+    *(u32x4*)(&sV[KS::off(r, c)]) = vv;
+  }
+  const int key = key0 + wave * 32 + l31;            // this lane's key (lane <-> key in S, dP tiles)
+  const bool kok = key < S && a.kvalid[rowbase + min(key, S - 1)];
+  f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+  const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
+
+  const int nqb = (S + 31) / 32;
+  for (int qb = 0; qb < nqb; qb++) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (32 * CH + 255) / 256; i++) {
+      const int q = tid + 256 * i;
+      if (q < 32 * CH) {
+        const int r = q / CH, c = q % CH;
+        const int qi = qb * 32 + r;
+        u32x4 qv = {0, 0, 0, 0}, ov = {0, 0, 0, 0};
+        if (qi < S) {
+          qv = *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8);
+          ov = *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8);
+        }
+        *(u32x4*)(&sQ[r * QSTR + c * 8]) = qv;
+        *(u32x4*)(&sO[r * QSTR + c * 8]) = ov;
+      }
+    }
+    if (tid < 32) {
+      const int qi = qb * 32 + tid;
+      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * S + qi] : 0.f;
+      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * S + qi] : 0.f;
+    }
+    __syncthreads();
+    // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ks++) {
+      const s16x8 qf = *(const s16x8*)(&sQ[l31 * QSTR + 16 * ks + 8 * g]);
+      const s16x8 of = *(const s16x8*)(&sO[l31 * QSTR + 16 * ks + 8 * g]);
+      const int ko = KS::off(wave * 32 + l31, 2 * ks + g);
+      const s16x8 kf = *(const s16x8*)(&sK[ko]);
+      const s16x8 vf = *(const s16x8*)(&sV[ko]);
+      sc = mfma32(qf, kf, sc);
+      dp = mfma32(of, vf, dp);
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int ql = (r & 3) + 8 * (r >> 2) + 4 * g, qi = qb * 32 + ql;
+      float p = (kok && qi < S) ? __expf(sc[r] - sL[ql]) : 0.f;
+      float ksc = 1.f;
+      if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, S, a.p_drop);
+      pd[r] = p * ksc;
+      ds[r] = p * (dp[r] * ksc - sD[ql]);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      const s16x8 pb = pack8(&pd[8 * hf]);
+      const s16x8 db = pack8(&ds[8 * hf]);
+      const int qr = 16 * hf + 4 * g + (i16 >> 2);
+#pragma unroll
+      for (int blk = 0; blk < HD / 32; blk++) {
+        const int col = blk * 32 + 16 * qd + 4 * (i16 & 3);
+        const s16x8 ot = cat4(lds_tr16(&sO[qr * QSTR + col]), lds_tr16(&sO[(qr + 8) * QSTR + col]));
+        const s16x8 qt = cat4(lds_tr16(&sQ[qr * QSTR + col]), lds_tr16(&sQ[(qr + 8) * QSTR + col]));
+        dv[blk] = mfma32(ot, pb, dv[blk]);
+        dk[blk] = mfma32(qt, db, dk[blk]);
+      }
+    }
+  }
+  if (key < S) {
+#pragma unroll
+    for (int blk = 0; blk < HD / 32; blk++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const int c = blk * 32 + 8 * rq + 4 * g;
+        bf16_t* base = a.dqkv + (rowbase + key) * a.lddqkv + h * HD + c;
+        u32x2 t;
+        t[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); t[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]);
+        *(u32x2*)(base + d) = t;
+        t[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); t[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]);
+        *(u32x2*)(base + 2 * d) = t;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dQ   (one wave = 32 queries, loops over 64-key tiles)
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+  constexpr int KSTR = HD + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * KSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * KSTR];
+  __shared__ unsigned char sValid[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.S, d = a.H * HD;
+  const size_t rowbase = (size_t)b * S;
+  const int q_raw = blockIdx.x * 128 + wave * 32 + l31;
+  const int qrow = min(q_raw, S - 1);
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  s16x8 qf[HD / 16], of[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ks++) {
+    qf[ks] = *(const s16x8*)(qkv + (rowbase + qrow) * a.ldqkv + h * HD + 16 * ks + 8 * g);
+    of[ks] = *(const s16x8*)(a.dO + (rowbase + qrow) * a.lddo + h * HD + 16 * ks + 8 * g);
+  }
+  const float lse = a.lse[((size_t)b * a.H + h) * S + qrow];
+  const float dl = a.delta[((size_t)b * a.H + h) * S + qrow];
+  f32x16 dq[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
+  const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
+  constexpr int CH = HD / 8;
+  const int ntiles = (S + 63) / 64;
+  for (int kt = 0; kt < ntiles; kt++) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (64 * CH) / 256; i++) {
+      const int q = tid + 256 * i, r = q / CH, c = q % CH;
+      const int key = kt * 64 + r;
+      u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+      if (key < S) {
+        const bf16_t* base = qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
+        kv = *(const u32x4*)(base + d);
+        vv = *(const u32x4*)(base + 2 * d);
+      }
+      *(u32x4*)(&sK[r * KSTR + c * 8]) = kv;
+      *(u32x4*)(&sV[r * KSTR + c * 8]) = vv;
+    }
+    if (tid < 64) { const int key = kt * 64 + tid; sValid[tid] = (key < S) ? a.kvalid[rowbase + key] : 0; }
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++) {
+        const int o = (kb * 32 + l31) * KSTR + 16 * ks + 8 * g;
+        sc = mfma32(*(const s16x8*)(&sK[o]), qf[ks], sc);
+        dp = mfma32(*(const s16x8*)(&sV[o]), of[ks], dp);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float p = sValid[kl] ? __expf(sc[r] - lse) : 0.f;
+        float ksc = 1.f;
+        if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, kt * 64 + kl, S, a.p_drop);
+        ds[r] = p * (dp[r] * ksc - dl);
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const s16x8 db = pack8(&ds[8 * hf]);
+        const int kr = kb * 32 + 16 * hf + 4 * g + (i16 >> 2);
+#pragma unroll
+        for (int blk = 0; blk < HD / 32; blk++) {
+          const int col = blk * 32 + 16 * qd + 4 * (i16 & 3);
+          const s16x8 kt_ = cat4(lds_tr16(&sK[kr * KSTR + col]), lds_tr16(&sK[(kr + 8) * KSTR + col]));
+          dq[blk] = mfma32(kt_, db, dq[blk]);
+        }
+      }
+    }
+  }
+  if (q_raw < S) {
+#pragma unroll
+    for (int blk = 0; blk < HD / 32; blk++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const int c = blk * 32 + 8 * rq + 4 * g;
+        u32x2 t;
+        t[0] = pack_bf2(dq[blk][4 * rq] * a.qscale, dq[blk][4 * rq + 1] * a.qscale);
+        t[1] = pack_bf2(dq[blk][4 * rq + 2] * a.qscale, dq[blk][4 * rq + 3] * a.qscale);
+        *(u32x2*)(a.dqkv + (rowbase + q_raw) * a.lddqkv + h * HD + c) = t;
+      }
+  }
+}
+
+}  // namespace
+
+int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
+  if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
+  dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
+#define FWD(HD_)                                                                                  \
+  if (a.hd == HD_) {                                                                              \
+    if (a.precise) hipLaunchKernelGGL((attn_fwd_kernel<HD_, true>), grid, blk, 0, s, a);          \
+    else hipLaunchKernelGGL((attn_fwd_kernel<HD_, false>), grid, blk, 0, s, a);                   \
+  }
+  FWD(32) FWD(64) FWD(128)
+#undef FWD
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
+  if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
+  if (a.precise) return -6;
+  const long long total = (long long)a.B * a.S * a.H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
+#define BWD(HD_)                                                                                  \
+  if (a.hd == HD_) {                                                                              \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_>), grid, blk, 0, s, a);                          \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_>), grid, blk, 0, s, a);                            \
+  }
+  BWD(32) BWD(64) BWD(128)
+#undef BWD
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}

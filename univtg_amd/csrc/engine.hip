@@ -1,0 +1,798 @@
+// Host-side orchestration of the UniVTG hot path on one MI355X: the whole Model.forward
+// (model/univtg.py:105-155) and its backward as ONE C call each, enqueuing ~60 / ~110 kernels on the
+// caller's HIP stream (graph-capturable: no allocation, no host sync, all state in caller-owned buffers).
+// Token-major layout: row (b*S + s) of every [M, *] activation, s < Lv video clips then Lt text tokens.
+#include "uvtg_kernels.h"
+#include "../../include/uvtg.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+// ---- parameter table -------------------------------------------------------------------------
+enum { IPW = 0, IPB, OPW, OPB, L1W, L1B, L2W, L2B, N1W, N1B, N2W, N2B, PER_LAYER };
+enum { TOK = 0, SP0W, SP0B, SP1W, SP1B, SP2W, SP2B, CL0W, CL0B, CL1W, CL1B, CL2W, CL2B,
+       TP0G, TP0BE, TP0W, TP0B, TP1G, TP1BE, TP1W, TP1B,
+       VP0G, VP0BE, VP0W, VP0B, VP1G, VP1BE, VP1W, VP1B, POOL, N_TAIL };
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Dm {
+  uvtg_dims c;
+  int S, M, Mv, Mt, Rp, hd, Kpv, Kpt, np;
+  explicit Dm(const uvtg_dims& d) : c(d) {
+    S = d.Lv + d.Lt; M = d.B * S; Mv = d.B * d.Lv; Mt = d.B * d.Lt; Rp = d.B * (d.Lv + 2);
+    hd = d.H > 0 ? d.d / d.H : 0; Kpv = rup(d.Dv, 64); Kpt = rup(d.Dt, 64); np = PER_LAYER * d.E + N_TAIL;
+  }
+  int tail(int k) const { return PER_LAYER * c.E + k; }
+  int lay(int l, int k) const { return PER_LAYER * l + k; }
+};
+
+int check_dims(const uvtg_dims* d) {
+  if (!d) return -10;
+  if (d->B <= 0 || d->Lv <= 0 || d->Lt <= 0 || d->E <= 0 || d->H <= 0) return -11;
+  if (d->n_proj != 2) return -12;
+  if (d->d % 32 || d->F % 8) return -13;
+  const int hd = d->d / d->H;
+  if (hd * d->H != d->d || (hd != 32 && hd != 64 && hd != 128)) return -14;
+  if (d->precise && d->training) return -15;
+  if (d->Dv <= 0 || d->Dt <= 0) return -16;
+  return 0;
+}
+
+long long pnumel(const Dm& m, int i) {
+  const long long d = m.c.d, F = m.c.F;
+  if (i < PER_LAYER * m.c.E) {
+    switch (i % PER_LAYER) {
+      case IPW: return 3 * d * d; case IPB: return 3 * d; case OPW: return d * d; case OPB: return d;
+      case L1W: return F * d; case L1B: return F; case L2W: return d * F; case L2B: return d;
+      default: return d;
+    }
+  }
+  switch (i - PER_LAYER * m.c.E) {
+    case TOK: return 2 * d;
+    case SP0W: case SP1W: case CL0W: case CL1W: return d * d * 3;
+    case SP0B: case SP1B: case CL0B: case CL1B: return d;
+    case SP2W: return 2 * d * 3; case SP2B: return 2; case CL2W: return d * 3; case CL2B: return 1;
+    case TP0G: case TP0BE: return m.c.Dt; case TP0W: return d * m.c.Dt;
+    case VP0G: case VP0BE: return m.c.Dv; case VP0W: return d * m.c.Dv;
+    case TP1W: case VP1W: return d * d;
+    case POOL: return d;
+    default: return d;   // TP0B, TP1G, TP1BE, TP1B, VP0B, VP1G, VP1BE, VP1B
+  }
+}
+
+struct Arena {
+  char* base; size_t off;
+  explicit Arena(void* b) : base((char*)b), off(0) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+// ---- prepared-operand cache ------------------------------------------------------------------
+constexpr int MAXE = 16;
+struct WCache {
+  bf16_t *wqkv[MAXE], *wo[MAXE], *w1[MAXE], *w2[MAXE], *wqkvT[MAXE], *woT[MAXE], *w1T[MAXE], *w2T[MAXE];
+  bf16_t *wc0, *wc1, *wc0T, *wc1T;      // conv operands (fast)
+  float *wc0F, *wc1F;                   // conv operands (precise)
+  float *bc0, *bc1;                     // merged conv biases [2d]
+  float *vp0F, *tp0F;                   // fp32 zero-padded first projection weights [d, Kp]
+  bf16_t *vp0B, *tp0B, *vp1B, *tp1B;    // bf16 projection weights (proj_precise == 0)
+  bf16_t *vp1T, *tp1T, *vp0T, *tp0T;    // dgrad operands
+  size_t bytes;
+  WCache(const Dm& m, void* base) {
+    Arena a(base);
+    const size_t d = m.c.d, F = m.c.F;
+    const bool fast = !m.c.precise;
+    for (int l = 0; l < m.c.E; l++) {
+      wqkv[l] = fast ? a.take<bf16_t>(3 * d * d) : nullptr; wo[l] = fast ? a.take<bf16_t>(d * d) : nullptr;
+      w1[l] = fast ? a.take<bf16_t>(F * d) : nullptr; w2[l] = fast ? a.take<bf16_t>(d * F) : nullptr;
+      const bool tr = fast && m.c.training;
+      wqkvT[l] = tr ? a.take<bf16_t>(3 * d * d) : nullptr; woT[l] = tr ? a.take<bf16_t>(d * d) : nullptr;
+      w1T[l] = tr ? a.take<bf16_t>(F * d) : nullptr; w2T[l] = tr ? a.take<bf16_t>(d * F) : nullptr;
+    }
+    wc0 = fast ? a.take<bf16_t>(2 * d * 3 * d) : nullptr; wc1 = fast ? a.take<bf16_t>(2 * d * 3 * d) : nullptr;
+    wc0T = (fast && m.c.training) ? a.take<bf16_t>(d * 6 * d) : nullptr;
+    wc1T = (fast && m.c.training) ? a.take<bf16_t>(2 * d * 3 * d) : nullptr;
+    wc0F = !fast ? a.take<float>(2 * d * 3 * d) : nullptr; wc1F = !fast ? a.take<float>(2 * d * 3 * d) : nullptr;
+    bc0 = a.take<float>(2 * d); bc1 = a.take<float>(2 * d);
+    const bool pp = m.c.precise || m.c.proj_precise;
+    vp0F = pp ? a.take<float>(d * m.Kpv) : nullptr; tp0F = pp ? a.take<float>(d * m.Kpt) : nullptr;
+    vp0B = !pp ? a.take<bf16_t>(d * m.Kpv) : nullptr; tp0B = !pp ? a.take<bf16_t>(d * m.Kpt) : nullptr;
+    vp1B = !pp ? a.take<bf16_t>(d * d) : nullptr; tp1B = !pp ? a.take<bf16_t>(d * d) : nullptr;
+    const bool tr = fast && m.c.training;
+    vp1T = tr ? a.take<bf16_t>(d * d) : nullptr; tp1T = tr ? a.take<bf16_t>(d * d) : nullptr;
+    vp0T = tr ? a.take<bf16_t>((size_t)m.Kpv * d) : nullptr; tp0T = tr ? a.take<bf16_t>((size_t)m.Kpt * d) : nullptr;
+    bytes = a.off + 256;
+  }
+};
+
+// ---- workspace -------------------------------------------------------------------------------
+struct WSpace {
+  float* pos; unsigned char* kvalid; float* dps;
+  // projections (index 0 = video, 1 = text)
+  void* a1[2]; bf16_t* a1B[2]; float *m0[2], *r0[2], *h1[2]; void* a2[2]; bf16_t* a2B[2]; float *m1[2], *r1[2];
+  // encoder
+  float* xin[MAXE + 1]; void *xb[MAXE + 1], *ub[MAXE + 1];
+  void *qkv[MAXE], *o[MAXE], *x1b[MAXE], *h[MAXE]; bf16_t* apre[MAXE];
+  float *lse[MAXE], *y1[MAXE], *mean1[MAXE], *rstd1[MAXE], *y2[MAXE], *mean2[MAXE], *rstd2[MAXE], *x1;
+  // heads
+  void *vm_pad, *h1_pad, *h2_pad;
+  // saliency
+  float *alpha, *cosv, *vnorm, *qnorm;
+  // backward scratch
+  float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2];
+  bf16_t *dh2_pad, *dh1_pad, *dyB, *da, *dOb, *dqkv, *dyP[2], *dh1b[2];
+  size_t bytes;
+  WSpace(const Dm& m, void* base, float* x0) {
+    Arena a(base);
+    const size_t d = m.c.d, F = m.c.F, M = m.M, B = m.c.B, E = m.c.E;
+    const bool tr = m.c.training, fast = !m.c.precise;
+    const size_t es = fast ? 2 : 4;                       // compute-dtype element size
+    const bool pp = m.c.precise || m.c.proj_precise;
+    pos = a.take<float>((size_t)m.Mv * d); kvalid = a.take<unsigned char>(M); dps = a.take<float>(2 * E * B);
+    for (int i = 0; i < 2; i++) {
+      const size_t R = i == 0 ? m.Mv : m.Mt, Kp = i == 0 ? m.Kpv : m.Kpt;
+      a1[i] = a.take<char>(R * Kp * (pp ? 4 : 2));
+      a1B[i] = (tr && pp) ? a.take<bf16_t>(R * Kp) : nullptr;
+      m0[i] = a.take<float>(R); r0[i] = a.take<float>(R);
+      h1[i] = a.take<float>(R * d);
+      a2[i] = a.take<char>(R * d * (pp ? 4 : 2));
+      a2B[i] = (tr && pp) ? a.take<bf16_t>(R * d) : nullptr;
+      m1[i] = a.take<float>(R); r1[i] = a.take<float>(R);
+    }
+    x1 = a.take<float>(M * d);
+    float* xpp[2] = {nullptr, nullptr}; void* xbpp[2] = {nullptr, nullptr}; void* ubpp[2] = {nullptr, nullptr};
+    for (size_t l = 0; l <= E; l++) {       // layer l reads slot l, writes slot l + 1
+      if (tr) {
+        xin[l] = l == 0 ? x0 : a.take<float>(M * d);
+        xb[l] = fast ? (void*)a.take<char>(M * d * es) : (void*)xin[l];
+        ub[l] = a.take<char>(M * d * es);
+      } else {                              // eval: ping-pong
+        if (l == 0) xin[0] = x0;
+        else { if (l <= 2) xpp[l - 1] = a.take<float>(M * d); xin[l] = xpp[(l - 1) % 2]; }
+        if (fast) { if (l <= 1) xbpp[l] = a.take<char>(M * d * es); xb[l] = xbpp[l % 2]; }
+        else xb[l] = xin[l];
+        if (l <= 1) ubpp[l] = a.take<char>(M * d * es);
+        ub[l] = ubpp[l % 2];
+      }
+    }
+    for (size_t l = 0; l < E; l++) {
+      const bool own = tr || l == 0;
+      qkv[l] = own ? (void*)a.take<char>(M * 3 * d * es) : qkv[0];
+      o[l] = own ? (void*)a.take<char>(M * d * es) : o[0];
+      lse[l] = own ? a.take<float>(B * m.c.H * m.S) : lse[0];
+      y1[l] = own ? a.take<float>(M * d) : y1[0];
+      mean1[l] = own ? a.take<float>(M) : mean1[0]; rstd1[l] = own ? a.take<float>(M) : rstd1[0];
+      x1b[l] = fast ? (own ? (void*)a.take<char>(M * d * es) : x1b[0]) : (void*)x1;
+      apre[l] = tr ? a.take<bf16_t>(M * F) : nullptr;
+      h[l] = own ? (void*)a.take<char>(M * F * es) : h[0];
+      y2[l] = own ? a.take<float>(M * d) : y2[0];
+      mean2[l] = own ? a.take<float>(M) : mean2[0]; rstd2[l] = own ? a.take<float>(M) : rstd2[0];
+    }
+    vm_pad = a.take<char>((size_t)(m.Rp + 1) * d * es);
+    h1_pad = a.take<char>((size_t)(m.Rp + 1) * 2 * d * es);
+    h2_pad = a.take<char>((size_t)(m.Rp + 1) * 2 * d * es);
+    alpha = a.take<float>((size_t)B * m.c.Lt); cosv = a.take<float>(m.Mv); vnorm = a.take<float>(m.Mv); qnorm = a.take<float>(B);
+    if (tr) {
+      dvm = a.take<float>((size_t)m.Mv * d); gx[0] = a.take<float>(M * d); gx[1] = a.take<float>(M * d);
+      dyF = a.take<float>(M * d); delta = a.take<float>(B * m.c.H * m.S);
+      dh2_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d); dh1_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d);
+      dyB = a.take<bf16_t>(M * d); da = a.take<bf16_t>(M * F); dOb = a.take<bf16_t>(M * d); dqkv = a.take<bf16_t>(M * 3 * d);
+      for (int i = 0; i < 2; i++) {
+        const size_t R = i == 0 ? m.Mv : m.Mt, Kp = i == 0 ? m.Kpv : m.Kpt;
+        dyP[i] = a.take<bf16_t>(R * d); dh1b[i] = a.take<bf16_t>(R * d);
+        dA2[i] = a.take<float>(R * d); dA1[i] = a.take<float>(R * Kp);
+      }
+    } else {
+      dvm = gx[0] = gx[1] = dyF = delta = nullptr; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
+      for (int i = 0; i < 2; i++) { dyP[i] = dh1b[i] = nullptr; dA2[i] = dA1[i] = nullptr; }
+    }
+    bytes = a.off + 256;
+  }
+};
+
+// ---- tiny helper kernels ----------------------------------------------------------------------
+__global__ void zero_frame_rows_kernel(char* p, int B, int Lv, int row_bytes) {
+  // rows b*(Lv+2) and b*(Lv+2)+Lv+1 of a zero-framed [B*(Lv+2), *] buffer
+  const int which = blockIdx.x;                    // 2*B rows
+  const int b = which >> 1, r = b * (Lv + 2) + ((which & 1) ? Lv + 1 : 0);
+  u32x4* row = (u32x4*)(p + (size_t)r * row_bytes);
+  const u32x4 z = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) row[i] = z;
+}
+int zero_frame(void* p, int B, int Lv, int row_bytes, hipStream_t s) {
+  hipLaunchKernelGGL(zero_frame_rows_kernel, dim3(2 * B), dim3(256), 0, s, (char*)p, B, Lv, row_bytes);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void concat2_kernel(const float* a, const float* b, float* dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { dst[i] = a[i]; dst[n + i] = b[i]; }
+}
+// gather token rows (b*S + off + t) of a fp32 [B*S, d] tensor into a compact bf16 [B*L, d] one
+__global__ void gather_rows_bf16_kernel(const float* src, int S, int off, int L, int d, bf16_t* dst, long long n4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int dq = d / 4;
+  const long long row = i / dq; const int c = (int)(i % dq) * 4;
+  const int b = (int)(row / L), t = (int)(row % L);
+  const f32x4 v = *(const f32x4*)(src + ((size_t)b * S + off + t) * d + c);
+  u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]);
+  *(u32x2*)(dst + (size_t)row * d + c) = o;
+}
+__global__ void add_vec_kernel(float* dst, const float* src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+#define TRY(x) do { int e__ = (x); if (e__) return e__; } while (0)
+
+GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N, int K) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ktap = K; g.groups = 1; g.rs_seg = 1;
+  return g;
+}
+
+}  // namespace
+
+// =================================================================================================
+// public: sizes / tables
+// =================================================================================================
+extern "C" int uvtg_version(void) { return 100; }
+
+extern "C" const char* uvtg_strerror(int code) {
+  if (code == 0) return "ok";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  switch (code) {
+    case -1: return "gemm: non-positive dimension";
+    case -2: return "gemm: leading dimension / tap width not a multiple of the vector width";
+    case -3: return "gemm: operand pointer not 16-byte aligned";
+    case -4: return "layernorm: unsupported row width";
+    case -5: return "attention: head_dim must be 32, 64 or 128";
+    case -6: return "backward is only available in bf16 mode (precise == 0)";
+    case -10: return "null dims";
+    case -11: return "dims: non-positive size";
+    case -12: return "dims: n_proj must be 2";
+    case -13: return "dims: hidden_dim must be a multiple of 32 and dim_feedforward of 8";
+    case -14: return "dims: hidden_dim / nheads must be 32, 64 or 128";
+    case -15: return "dims: precise mode is forward-only (training must be 0)";
+    case -16: return "dims: feature dims must be positive";
+    case -17: return "dims: too many encoder layers";
+    case -20: return "null pointer argument";
+    default: return "invalid argument";
+  }
+}
+
+extern "C" int uvtg_param_count(const uvtg_dims* dm) { return dm ? PER_LAYER * dm->E + N_TAIL : -10; }
+extern "C" int uvtg_param_numel(const uvtg_dims* dm, int i, long long* numel) {
+  if (int e = check_dims(dm)) return e;
+  Dm m(*dm);
+  if (i < 0 || i >= m.np || !numel) return -20;
+  *numel = pnumel(m, i);
+  return 0;
+}
+extern "C" int uvtg_param_offsets(const uvtg_dims* dm, long long* off) {
+  if (int e = check_dims(dm)) return e;
+  if (!off) return -20;
+  Dm m(*dm);
+  long long o = 0;
+  for (int i = 0; i < m.np; i++) { off[i] = o; o += (pnumel(m, i) + 3) / 4 * 4; }
+  off[m.np] = o;
+  return 0;
+}
+extern "C" size_t uvtg_workspace_bytes(const uvtg_dims* dm) {
+  if (check_dims(dm) || dm->E > MAXE) return 0;
+  Dm m(*dm);
+  return WSpace(m, nullptr, nullptr).bytes;
+}
+extern "C" size_t uvtg_wcache_bytes(const uvtg_dims* dm) {
+  if (check_dims(dm) || dm->E > MAXE) return 0;
+  Dm m(*dm);
+  return WCache(m, nullptr).bytes;
+}
+extern "C" long long uvtg_loss_ws_floats(int B, int Lv) { return loss_ws_floats(B, Lv); }
+
+// =================================================================================================
+// weight preparation
+// =================================================================================================
+extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, void* wcache, uvtg_stream_t stream) {
+  if (int e = check_dims(dm)) return e;
+  if (dm->E > MAXE) return -17;
+  if (!P || !wcache) return -20;
+  hipStream_t s = (hipStream_t)stream;
+  Dm m(*dm);
+  WCache w(m, wcache);
+  const int d = m.c.d, F = m.c.F;
+  const bool fast = !m.c.precise, tr = fast && m.c.training;
+  for (int l = 0; l < m.c.E && fast; l++) {
+    TRY(launch_cast_bf16(P[m.lay(l, IPW)], w.wqkv[l], 3LL * d * d, s));
+    TRY(launch_cast_bf16(P[m.lay(l, OPW)], w.wo[l], (long long)d * d, s));
+    TRY(launch_cast_bf16(P[m.lay(l, L1W)], w.w1[l], (long long)F * d, s));
+    TRY(launch_cast_bf16(P[m.lay(l, L2W)], w.w2[l], (long long)d * F, s));
+    if (tr) {
+      TRY(launch_transpose_bf16(P[m.lay(l, IPW)], 3 * d, d, w.wqkvT[l], 3 * d, s));
+      TRY(launch_transpose_bf16(P[m.lay(l, OPW)], d, d, w.woT[l], d, s));
+      TRY(launch_transpose_bf16(P[m.lay(l, L1W)], F, d, w.w1T[l], F, s));
+      TRY(launch_transpose_bf16(P[m.lay(l, L2W)], d, F, w.w2T[l], d, s));
+    }
+  }
+  // conv heads: layer 0 of both heads merged along N (span rows then class rows), layer 1 grouped
+  const size_t cw = (size_t)d * 3 * d;
+  TRY(launch_conv_w_fwd(P[m.tail(SP0W)], d, d, fast ? w.wc0 : nullptr, fast ? nullptr : w.wc0F, 3 * d, s));
+  TRY(launch_conv_w_fwd(P[m.tail(CL0W)], d, d, fast ? w.wc0 + cw : nullptr, fast ? nullptr : w.wc0F + cw, 3 * d, s));
+  TRY(launch_conv_w_fwd(P[m.tail(SP1W)], d, d, fast ? w.wc1 : nullptr, fast ? nullptr : w.wc1F, 3 * d, s));
+  TRY(launch_conv_w_fwd(P[m.tail(CL1W)], d, d, fast ? w.wc1 + cw : nullptr, fast ? nullptr : w.wc1F + cw, 3 * d, s));
+  hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP0B)], P[m.tail(CL0B)], w.bc0, d);
+  hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP1B)], P[m.tail(CL1B)], w.bc1, d);
+  UVTG_CHECK_LAUNCH();
+  if (tr) {
+    // dgrad operands: conv0 merged [d, 3 * 2d] (taps flipped), conv1 per head [d, 3d]
+    TRY(launch_conv_w_bwd(P[m.tail(SP0W)], d, d, w.wc0T, 6 * d, 2 * d, 0, s));
+    TRY(launch_conv_w_bwd(P[m.tail(CL0W)], d, d, w.wc0T, 6 * d, 2 * d, d, s));
+    TRY(launch_conv_w_bwd(P[m.tail(SP1W)], d, d, w.wc1T, 3 * d, d, 0, s));
+    TRY(launch_conv_w_bwd(P[m.tail(CL1W)], d, d, w.wc1T + cw, 3 * d, d, 0, s));
+  }
+  // input projections
+  if (w.vp0F) {
+    TRY(launch_cast_pad_f32(P[m.tail(VP0W)], d, m.c.Dv, w.vp0F, m.Kpv, s));
+    TRY(launch_cast_pad_f32(P[m.tail(TP0W)], d, m.c.Dt, w.tp0F, m.Kpt, s));
+  } else {
+    TRY(launch_cast_pad_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0B, m.Kpv, s));
+    TRY(launch_cast_pad_bf16(P[m.tail(TP0W)], d, m.c.Dt, w.tp0B, m.Kpt, s));
+    TRY(launch_cast_bf16(P[m.tail(VP1W)], w.vp1B, (long long)d * d, s));
+    TRY(launch_cast_bf16(P[m.tail(TP1W)], w.tp1B, (long long)d * d, s));
+  }
+  if (tr) {
+    TRY(launch_transpose_bf16(P[m.tail(VP1W)], d, d, w.vp1T, d, s));
+    TRY(launch_transpose_bf16(P[m.tail(TP1W)], d, d, w.tp1T, d, s));
+    hipMemsetAsync(w.vp0T, 0, (size_t)m.Kpv * d * 2, s);
+    hipMemsetAsync(w.tp0T, 0, (size_t)m.Kpt * d * 2, s);
+    TRY(launch_transpose_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0T, d, s));
+    TRY(launch_transpose_bf16(P[m.tail(TP0W)], d, m.c.Dt, w.tp0T, d, s));
+  }
+  return 0;
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+namespace {
+
+struct Fwd {
+  const Dm& m; const float* const* P; WCache& w; WSpace& ws; hipStream_t s;
+  bool fast, tr, pp;
+  int run_gemm(GemmArgs& g, bool x3) { return x3 ? launch_gemm_nt_f32x3(g, s) : launch_gemm_nt_bf16(g, s); }
+  void set_out(GemmArgs& g, void* p, int ld) { if (fast) { g.outB = (bf16_t*)p; g.ldoB = ld; } else { g.outF = (float*)p; g.ldoF = ld; } }
+
+  // one modality of the input projection (model/univtg.py:91-100,399-406) -> rows of x0 / xb[0] / ub[0]
+  int project(int which, const float* src, float* x0) {
+    const int R = which == 0 ? m.Mv : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
+    const int L = which == 0 ? m.c.Lv : m.c.Lt, d = m.c.d;
+    const int t0 = which == 0 ? VP0G : TP0G, t1 = which == 0 ? VP1G : TP1G;
+    const unsigned rs = which == 0 ? UVTG_RNG_IN_VID : UVTG_RNG_IN_TXT;
+    const float p_in = tr ? m.c.p_in : 0.f;
+    LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
+    ln.x = src; ln.ldx = Din; ln.rows = R; ln.D = Din; ln.gamma = P[m.tail(t0)]; ln.beta = P[m.tail(t0 + 1)]; ln.eps = 1e-5f;
+    ln.mean = ws.m0[which]; ln.rstd = ws.r0[which]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs; ln.Dpad = Kp;
+    if (pp) { ln.yF2 = (float*)ws.a1[which]; ln.ldyF2 = Kp; ln.yB = ws.a1B[which]; ln.ldyB = Kp; }
+    else { ln.yB = (bf16_t*)ws.a1[which]; ln.ldyB = Kp; }
+    TRY(launch_ln_fwd(ln, s));
+    GemmArgs g = gemm_base(ws.a1[which], Kp, pp ? (const void*)(which == 0 ? w.vp0F : w.tp0F) : (const void*)(which == 0 ? w.vp0B : w.tp0B),
+                           Kp, R, d, Kp);
+    g.bias = P[m.tail(t0 + 3)]; g.act = 1; g.outF = ws.h1[which]; g.ldoF = d;
+    TRY(run_gemm(g, pp));
+    memset(&ln, 0, sizeof(ln));
+    ln.x = ws.h1[which]; ln.ldx = d; ln.rows = R; ln.D = d; ln.gamma = P[m.tail(t1)]; ln.beta = P[m.tail(t1 + 1)]; ln.eps = 1e-5f;
+    ln.mean = ws.m1[which]; ln.rstd = ws.r1[which]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs + 1; ln.Dpad = d;
+    if (pp) { ln.yF2 = (float*)ws.a2[which]; ln.ldyF2 = d; ln.yB = ws.a2B[which]; ln.ldyB = d; }
+    else { ln.yB = (bf16_t*)ws.a2[which]; ln.ldyB = d; }
+    TRY(launch_ln_fwd(ln, s));
+    GemmArgs g2 = gemm_base(ws.a2[which], d, pp ? (const void*)P[m.tail(t1 + 2)] : (const void*)(which == 0 ? w.vp1B : w.tp1B), d, R, d, d);
+    g2.bias = P[m.tail(t1 + 3)];
+    g2.bias2 = P[m.tail(TOK)] + (which == 0 ? d : 0);          // token-type row 1 = video, 0 = text (univtg.py:114-115)
+    g2.o_seg = L; g2.o_seg_stride = m.S; g2.o_off = which == 0 ? 0 : m.c.Lv;
+    g2.outF = x0; g2.ldoF = d;
+    if (fast) { g2.outB = (bf16_t*)ws.xb[0]; g2.ldoB = d; g2.outU = (bf16_t*)ws.ub[0]; }
+    else g2.outUF = (float*)ws.ub[0];
+    g2.ldoU = d;
+    if (which == 0) { g2.pos = ws.pos; g2.ldpos = d; g2.pos_rows = R; }
+    TRY(run_gemm(g2, pp));
+    return 0;
+  }
+
+  int layer(int l, float* memory_out) {
+    const int d = m.c.d, F = m.c.F, M = m.M, S = m.S;
+    const bool last = l == m.c.E - 1;
+    const void* Wqkv = fast ? (const void*)w.wqkv[l] : (const void*)P[m.lay(l, IPW)];
+    const size_t es = fast ? 2 : 4;
+    // q,k from (x + pos); v from x  (transformer_encoder_droppath.py:116-117)
+    GemmArgs g = gemm_base(ws.ub[l], d, Wqkv, d, M, 2 * d, d);
+    g.bias = P[m.lay(l, IPB)]; g.colscale = 1.0f / sqrtf((float)m.hd); g.colscale_n = d;
+    set_out(g, ws.qkv[l], 3 * d);
+    TRY(run_gemm(g, !fast));
+    g = gemm_base(ws.xb[l], d, (const char*)Wqkv + (size_t)2 * d * d * es, d, M, d, d);
+    g.bias = P[m.lay(l, IPB)] + 2 * d;
+    set_out(g, (char*)ws.qkv[l] + (size_t)2 * d * es, 3 * d);
+    TRY(run_gemm(g, !fast));
+    AttnArgs at; memset(&at, 0, sizeof(at));
+    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = ws.kvalid;
+    at.B = m.c.B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = tr ? m.c.p_attn : 0.f; at.seed = m.c.seed; at.layer = l;
+    at.precise = !fast;
+    TRY(launch_attn_fwd(at, s));
+    // out-proj + DropPath + residual -> y1 ; LN1
+    g = gemm_base(ws.o[l], d, fast ? (const void*)w.wo[l] : (const void*)P[m.lay(l, OPW)], d, M, d, d);
+    g.bias = P[m.lay(l, OPB)]; g.resid = ws.xin[l]; g.ldr = d; g.outF = ws.y1[l]; g.ldoF = d;
+    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l) * m.c.B; g.rs_seg = S; }
+    TRY(run_gemm(g, !fast));
+    LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
+    ln.x = ws.y1[l]; ln.ldx = d; ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
+    ln.mean = ws.mean1[l]; ln.rstd = ws.rstd1[l]; ln.yF = ws.x1; ln.ldyF = d; ln.Dpad = d;
+    if (fast) { ln.yB = (bf16_t*)ws.x1b[l]; ln.ldyB = d; }
+    TRY(launch_ln_fwd(ln, s));
+    // FFN: linear1 + GELU, linear2 + DropPath + residual -> y2 ; LN2
+    g = gemm_base(ws.x1b[l], d, fast ? (const void*)w.w1[l] : (const void*)P[m.lay(l, L1W)], d, M, F, d);
+    g.bias = P[m.lay(l, L1B)]; g.act = 2;
+    if (tr) { g.outPre = ws.apre[l]; g.ldpre_out = F; }
+    set_out(g, ws.h[l], F);
+    TRY(run_gemm(g, !fast));
+    g = gemm_base(ws.h[l], F, fast ? (const void*)w.w2[l] : (const void*)P[m.lay(l, L2W)], F, M, d, F);
+    g.bias = P[m.lay(l, L2B)]; g.resid = ws.x1; g.ldr = d; g.outF = ws.y2[l]; g.ldoF = d;
+    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l + 1) * m.c.B; g.rs_seg = S; }
+    TRY(run_gemm(g, !fast));
+    memset(&ln, 0, sizeof(ln));
+    ln.x = ws.y2[l]; ln.ldx = d; ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N2W)]; ln.beta = P[m.lay(l, N2B)]; ln.eps = 1e-5f;
+    ln.mean = ws.mean2[l]; ln.rstd = ws.rstd2[l]; ln.Dpad = d; ln.S = S; ln.Lv = m.c.Lv;
+    if (!last) {
+      ln.yF = ws.xin[l + 1]; ln.ldyF = d; ln.pos = ws.pos; ln.ldyU = d;
+      if (fast) { ln.yB = (bf16_t*)ws.xb[l + 1]; ln.ldyB = d; ln.yU = (bf16_t*)ws.ub[l + 1]; }
+      else ln.yUF = (float*)ws.ub[l + 1];
+    } else {
+      if (memory_out) { ln.yF = memory_out; ln.ldyF = d; }
+      ln.ldyP = d;
+      if (fast) ln.yP = (bf16_t*)ws.vm_pad; else ln.yPF = (float*)ws.vm_pad;
+    }
+    TRY(launch_ln_fwd(ln, s));
+    return 0;
+  }
+
+  int heads(float* pred_logits, float* pred_spans) {
+    const int d = m.c.d, Lv = m.c.Lv, B = m.c.B;
+    const size_t es = fast ? 2 : 4;
+    TRY(zero_frame(ws.vm_pad, B, Lv, (int)(d * es), s));
+    TRY(zero_frame(ws.h1_pad, B, Lv, (int)(2 * d * es), s));
+    TRY(zero_frame(ws.h2_pad, B, Lv, (int)(2 * d * es), s));
+    // conv layer 0 of both heads as one 3-tap GEMM, N = 2d (model/univtg.py:84-85,375-382)
+    GemmArgs g = gemm_base(ws.vm_pad, d, fast ? (const void*)w.wc0 : (const void*)w.wc0F, 3 * d, m.Mv, 2 * d, 3 * d);
+    g.ktap = d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
+    g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1;
+    g.bias = w.bc0; g.act = 1;
+    set_out(g, ws.h1_pad, 2 * d);
+    TRY(run_gemm(g, !fast));
+    // conv layer 1: two groups (span | class), each d -> d
+    g = gemm_base(ws.h1_pad, 2 * d, fast ? (const void*)w.wc1 : (const void*)w.wc1F, 3 * d, m.Mv, d, 3 * d);
+    g.ktap = d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
+    g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1;
+    g.groups = 2; g.gA = d; g.gB = (long long)d * 3 * d; g.gBias = d; g.gOut = d;
+    g.bias = w.bc1; g.act = 1;
+    set_out(g, ws.h2_pad, 2 * d);
+    TRY(run_gemm(g, !fast));
+    HeadsFinalArgs hf; memset(&hf, 0, sizeof(hf));
+    hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.precise = !fast;
+    hf.w_span = P[m.tail(SP2W)]; hf.b_span = P[m.tail(SP2B)]; hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)];
+    hf.B = B; hf.Lv = Lv; hf.d = d; hf.pred_logits = pred_logits; hf.pred_spans = pred_spans;
+    TRY(launch_heads_final_fwd(hf, s));
+    return 0;
+  }
+};
+
+SaliencyArgs sal_args(const Dm& m, const float* const* P, WSpace& ws, const float* x0, const float* tmask, const float* vmask,
+                      float* pooled, float* sal) {
+  SaliencyArgs a; memset(&a, 0, sizeof(a));
+  a.x0 = x0; a.S = m.S; a.Lv = m.c.Lv; a.Lt = m.c.Lt; a.B = m.c.B; a.d = m.c.d; a.txt_mask = tmask; a.vid_mask = vmask;
+  a.w_pool = P[m.tail(POOL)]; a.alpha = ws.alpha; a.pooled = pooled; a.cosv = ws.cosv; a.sal = sal; a.vnorm = ws.vnorm; a.qnorm = ws.qnorm;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const void* wcache,
+                            const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
+                            const float* dim_t, float* x0, float* pred_logits, float* pred_spans, float* txt_mem_proj,
+                            float* saliency, float* memory, void* workspace, uvtg_stream_t stream) {
+  if (int e = check_dims(dm)) return e;
+  if (dm->E > MAXE) return -17;
+  if (!P || !wcache || !src_txt || !src_txt_mask || !src_vid || !src_vid_mask || !dim_t || !x0 || !pred_logits ||
+      !pred_spans || !txt_mem_proj || !saliency || !workspace) return -20;
+  hipStream_t s = (hipStream_t)stream;
+  Dm m(*dm);
+  WCache w(m, (void*)wcache);
+  WSpace ws(m, workspace, x0);
+  Fwd f{m, P, w, ws, s, !m.c.precise, m.c.training != 0, m.c.precise || m.c.proj_precise};
+  TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, s));
+  if (f.tr && m.c.p_path > 0.f) TRY(launch_droppath_scales(ws.dps, 2 * m.c.E, m.c.B, m.c.p_path, m.c.seed, s));
+  TRY(f.project(0, src_vid, x0));
+  TRY(f.project(1, src_txt, x0));
+  for (int l = 0; l < m.c.E; l++) TRY(f.layer(l, memory));
+  TRY(f.heads(pred_logits, pred_spans));
+  SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, txt_mem_proj, saliency);
+  TRY(launch_saliency_fwd(sa, s));
+  return 0;
+}
+
+// =================================================================================================
+// backward
+// =================================================================================================
+extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const void* wcache,
+                             const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
+                             const float* x0, const float* pred_logits, const float* pred_spans, const float* txt_mem_proj,
+                             const float* g_logits, const float* g_spans, const float* g_saliency,
+                             const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
+                             float* grads, void* workspace, uvtg_stream_t stream) {
+  if (int e = check_dims(dm)) return e;
+  if (dm->E > MAXE) return -17;
+  if (dm->precise || !dm->training) return -6;
+  if (!P || !wcache || !x0 || !pred_logits || !pred_spans || !txt_mem_proj || !grads || !workspace || !src_txt || !src_vid ||
+      !src_txt_mask || !src_vid_mask) return -20;
+  hipStream_t s = (hipStream_t)stream;
+  Dm m(*dm);
+  WCache w(m, (void*)wcache);
+  WSpace ws(m, workspace, (float*)x0);
+  const int d = m.c.d, F = m.c.F, M = m.M, S = m.S, Lv = m.c.Lv, B = m.c.B, E = m.c.E;
+  long long off[PER_LAYER * MAXE + N_TAIL + 1];
+  { long long o = 0; for (int i = 0; i < m.np; i++) { off[i] = o; o += (pnumel(m, i) + 3) / 4 * 4; } off[m.np] = o; }
+  auto G = [&](int idx) { return grads + off[idx]; };
+  hipMemsetAsync(grads, 0, (size_t)off[m.np] * sizeof(float), s);
+  const int splits_M = 8, splits_v = 8;
+  auto wgrad = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, int cs,
+                   float* dbias, int q_off, int Mq, int splits) {
+    GemmTNArgs t; memset(&t, 0, sizeof(t));
+    t.P = Pm; t.ldp = ldp; t.Q = Q; t.ldq = ldq; t.M = rows; t.N = N; t.K = K; t.q_row_off = q_off; t.Mq = Mq;
+    t.out = out; t.ldo = ldo; t.col_stride = cs; t.dbias = dbias; t.splits = splits;
+    return launch_gemm_tn_bf16(t, s);
+  };
+
+  // ---------------- heads ----------------
+  TRY(zero_frame(ws.dh2_pad, B, Lv, 2 * d * 2, s));
+  TRY(zero_frame(ws.dh1_pad, B, Lv, 2 * d * 2, s));
+  HeadsFinalArgs hf; memset(&hf, 0, sizeof(hf));
+  hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.w_span = P[m.tail(SP2W)]; hf.b_span = P[m.tail(SP2B)];
+  hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)]; hf.B = B; hf.Lv = Lv; hf.d = d;
+  hf.pred_logits = (float*)pred_logits; hf.pred_spans = (float*)pred_spans; hf.g_logits = g_logits; hf.g_spans = g_spans;
+  hf.dh2 = ws.dh2_pad; hf.lddh = 2 * d;
+  hf.dw_span = G(m.tail(SP2W)); hf.db_span = G(m.tail(SP2B)); hf.dw_cls = G(m.tail(CL2W)); hf.db_cls = G(m.tail(CL2B));
+  TRY(launch_heads_final_bwd(hf, s));
+  const int Rp = m.Rp;
+  for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 1 weight grads: 3 taps x 2 heads
+    float* dW = G(m.tail(hd_ == 0 ? SP1W : CL1W));
+    float* dBi = G(m.tail(hd_ == 0 ? SP1B : CL1B));
+    for (int tap = 0; tap < 3; tap++)
+      TRY(wgrad(ws.dh2_pad + hd_ * d, 2 * d, (const bf16_t*)ws.h1_pad + hd_ * d, 2 * d, Rp, d, d, dW + tap, 3 * d, 3,
+                tap == 1 ? dBi : nullptr, tap - 1, Rp, splits_v));
+  }
+  {                                             // conv layer 1 dgrad (+ relu' of h1) -> dh1_pad
+    GemmArgs g = gemm_base(ws.dh2_pad, 2 * d, w.wc1T, 3 * d, m.Mv, d, 3 * d);
+    g.ktap = d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0; g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1;
+    g.groups = 2; g.gA = d; g.gB = (long long)d * 3 * d; g.gOut = d; g.gPre = d;
+    g.gradPre = (const bf16_t*)ws.h1_pad; g.ldgp = 2 * d; g.actgrad = 1;
+    g.outB = ws.dh1_pad; g.ldoB = 2 * d;
+    TRY(launch_gemm_nt_bf16(g, s));
+  }
+  for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 0 weight grads
+    float* dW = G(m.tail(hd_ == 0 ? SP0W : CL0W));
+    float* dBi = G(m.tail(hd_ == 0 ? SP0B : CL0B));
+    for (int tap = 0; tap < 3; tap++)
+      TRY(wgrad(ws.dh1_pad + hd_ * d, 2 * d, (const bf16_t*)ws.vm_pad, d, Rp, d, d, dW + tap, 3 * d, 3,
+                tap == 1 ? dBi : nullptr, tap - 1, Rp, splits_v));
+  }
+  {                                             // conv layer 0 dgrad -> dvm (fp32, video rows)
+    GemmArgs g = gemm_base(ws.dh1_pad, 2 * d, w.wc0T, 6 * d, m.Mv, d, 6 * d);
+    g.ktap = 2 * d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
+    g.outF = ws.dvm; g.ldoF = d;
+    TRY(launch_gemm_nt_bf16(g, s));
+  }
+  // ---------------- encoder ----------------
+  const float* gin = nullptr;                   // gradient wrt the layer output (fp32 [M, d]); null = zero
+  for (int l = E - 1; l >= 0; l--) {
+    const bool last = l == E - 1;
+    const float* dp_attn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l) * B : nullptr;
+    const float* dp_ffn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l + 1) * B : nullptr;
+    LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
+    lb.g = gin; lb.ldg = d;
+    if (last) { lb.g2 = ws.dvm; lb.ldg2 = d; lb.g2_S = S; lb.g2_Lv = Lv; }
+    lb.x = ws.y2[l]; lb.ldx = d; lb.mean = ws.mean2[l]; lb.rstd = ws.rstd2[l]; lb.gamma = P[m.lay(l, N2W)];
+    lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
+    lb.dxF = ws.dyF; lb.lddxF = d; lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S;
+    TRY(launch_ln_bwd(lb, s));
+    TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, 1, G(m.lay(l, L2B)), 0, M, splits_M));
+    GemmArgs g = gemm_base(ws.dyB, d, w.w2T[l], d, M, F, d);          // d h = dy2 W2 ; da = dh * gelu'(a)
+    g.gradPre = ws.apre[l]; g.ldgp = F; g.actgrad = 2; g.outB = ws.da; g.ldoB = F;
+    TRY(launch_gemm_nt_bf16(g, s));
+    TRY(wgrad(ws.da, F, (const bf16_t*)ws.x1b[l], d, M, F, d, G(m.lay(l, L1W)), d, 1, G(m.lay(l, L1B)), 0, M, splits_M));
+    g = gemm_base(ws.da, F, w.w1T[l], F, M, d, F);                     // dx1 = da W1 + dy2
+    g.resid = ws.dyF; g.ldr = d; g.outF = ws.gx[0]; g.ldoF = d;
+    TRY(launch_gemm_nt_bf16(g, s));
+    memset(&lb, 0, sizeof(lb));
+    lb.g = ws.gx[0]; lb.ldg = d; lb.x = ws.y1[l]; lb.ldx = d; lb.mean = ws.mean1[l]; lb.rstd = ws.rstd1[l];
+    lb.gamma = P[m.lay(l, N1W)]; lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
+    lb.dxF = ws.dyF; lb.lddxF = d; lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S;
+    TRY(launch_ln_bwd(lb, s));
+    TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.o[l], d, M, d, d, G(m.lay(l, OPW)), d, 1, G(m.lay(l, OPB)), 0, M, splits_M));
+    g = gemm_base(ws.dyB, d, w.woT[l], d, M, d, d);                    // dO = dy1 Wo
+    g.outB = ws.dOb; g.ldoB = d;
+    TRY(launch_gemm_nt_bf16(g, s));
+    AttnArgs at; memset(&at, 0, sizeof(at));
+    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = ws.kvalid;
+    at.B = B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = m.c.p_attn; at.seed = m.c.seed; at.layer = l;
+    at.dO = ws.dOb; at.lddo = d; at.delta = ws.delta; at.dqkv = ws.dqkv; at.lddqkv = 3 * d; at.qscale = 1.0f / sqrtf((float)m.hd);
+    TRY(launch_attn_bwd(at, s));
+    TRY(wgrad(ws.dqkv, 3 * d, (const bf16_t*)ws.ub[l], d, M, 2 * d, d, G(m.lay(l, IPW)), d, 1, G(m.lay(l, IPB)), 0, M, splits_M));
+    TRY(wgrad(ws.dqkv + 2 * d, 3 * d, (const bf16_t*)ws.xb[l], d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, 1,
+              G(m.lay(l, IPB)) + 2 * d, 0, M, splits_M));
+    g = gemm_base(ws.dqkv, 3 * d, w.wqkvT[l], 3 * d, M, d, 3 * d);     // dx = dqkv Wqkv + dy1
+    g.resid = ws.dyF; g.ldr = d; g.outF = ws.gx[1]; g.ldoF = d;
+    TRY(launch_gemm_nt_bf16(g, s));
+    gin = ws.gx[1];   // consumed by the next (lower) layer's LN2 backward before gx[0]/gx[1] are rewritten
+  }
+  float* dx0 = ws.gx[1];                         // d loss / d x0 from the encoder, fp32 [M, d]
+  // ---------------- saliency branch ----------------
+  SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
+  sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.dx0 = dx0; sa.dw_pool = G(m.tail(POOL));
+  TRY(launch_saliency_bwd(sa, s));
+  // ---------------- input projections ----------------
+  for (int which = 0; which < 2; which++) {
+    const int R = which == 0 ? m.Mv : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
+    const int L = which == 0 ? Lv : m.c.Lt, roff = which == 0 ? 0 : Lv;
+    const int t0 = which == 0 ? VP0G : TP0G, t1 = which == 0 ? VP1G : TP1G;
+    const unsigned rs = which == 0 ? UVTG_RNG_IN_VID : UVTG_RNG_IN_TXT;
+    const float* src = which == 0 ? src_vid : src_txt;
+    const bool pp = m.c.proj_precise != 0;
+    const bf16_t* a2b = pp ? ws.a2B[which] : (const bf16_t*)ws.a2[which];
+    const bf16_t* a1b = pp ? ws.a1B[which] : (const bf16_t*)ws.a1[which];
+    const long long n4 = (long long)R * d / 4;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dx0, S, roff, L, d, ws.dyP[which], n4);
+    UVTG_CHECK_LAUNCH();
+    TRY(wgrad(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, 1, G(m.tail(t1 + 3)), 0, R, splits_v));
+    hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + (which == 0 ? d : 0), G(m.tail(t1 + 3)), d);
+    UVTG_CHECK_LAUNCH();
+    GemmArgs g = gemm_base(ws.dyP[which], d, which == 0 ? w.vp1T : w.tp1T, d, R, d, d);
+    g.outF = ws.dA2[which]; g.ldoF = d;
+    TRY(launch_gemm_nt_bf16(g, s));
+    LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
+    lb.g = ws.dA2[which]; lb.ldg = d; lb.x = ws.h1[which]; lb.ldx = d; lb.mean = ws.m1[which]; lb.rstd = ws.r1[which];
+    lb.gamma = P[m.tail(t1)]; lb.rows = R; lb.D = d; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs + 1;
+    lb.dgamma = G(m.tail(t1)); lb.dbeta = G(m.tail(t1 + 1)); lb.dxB = ws.dh1b[which]; lb.lddxB = d; lb.rs_seg = 1; lb.relu_from_x = 1;
+    TRY(launch_ln_bwd(lb, s));
+    TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
+    g = gemm_base(ws.dh1b[which], d, which == 0 ? w.vp0T : w.tp0T, d, R, Kp, d);
+    g.outF = ws.dA1[which]; g.ldoF = Kp;
+    TRY(launch_gemm_nt_bf16(g, s));
+    memset(&lb, 0, sizeof(lb));
+    lb.g = ws.dA1[which]; lb.ldg = Kp; lb.x = src; lb.ldx = Din; lb.mean = ws.m0[which]; lb.rstd = ws.r0[which];
+    lb.gamma = P[m.tail(t0)]; lb.rows = R; lb.D = Din; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs;
+    lb.dgamma = G(m.tail(t0)); lb.dbeta = G(m.tail(t0 + 1)); lb.rs_seg = 1;
+    TRY(launch_ln_bwd(lb, s));
+  }
+  return 0;
+}
+
+// =================================================================================================
+// criterion
+// =================================================================================================
+namespace {
+LossArgs loss_args(int B, int Lv, int d, int which, float eos_coef, const float* pred_logits, const float* pred_spans,
+                   const float* vid, long long vid_sb, long long vid_st, const float* txt_mem, const float* timestamp,
+                   const float* ts_mask, const float* ts_window, const float* span_nn, const float* sal, const long long* pos_idx,
+                   float* ws, float* losses) {
+  LossArgs a; memset(&a, 0, sizeof(a));
+  a.B = B; a.Lv = Lv; a.d = d; a.pred_logits = pred_logits; a.pred_spans = pred_spans; a.vid = vid; a.vid_sb = vid_sb; a.vid_st = vid_st;
+  a.txt = txt_mem; a.timestamp = timestamp; a.ts_mask = ts_mask; a.ts_window = ts_window; a.span_nn = span_nn; a.sal_tgt = sal;
+  a.pos_idx = pos_idx; a.eos_coef = eos_coef; a.do_spans = which & 1; a.do_labels = (which >> 1) & 1; a.do_saliency = (which >> 2) & 1;
+  a.ws = ws; a.losses = losses;
+  return a;
+}
+}  // namespace
+
+extern "C" int uvtg_criterion_fwd(int B, int Lv, int d, int which, float eos_coef, const float* pred_logits, const float* pred_spans,
+                                  const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,
+                                  const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
+                                  const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
+                                  float* loss_ws, float* losses_out, uvtg_stream_t stream) {
+  if (B <= 0 || Lv <= 0 || d <= 0) return -11;
+  if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !timestamp_window || !span_labels_nn || !loss_ws || !losses_out) return -20;
+  if ((which & 4) && saliency_scores && pos_idx && (!vid || !txt_mem)) return -20;
+  LossArgs a = loss_args(B, Lv, d, which, eos_coef, pred_logits, pred_spans, vid, vid_sb, vid_st, txt_mem, timestamp, timestamp_mask,
+                         timestamp_window, span_labels_nn, saliency_scores, pos_idx, loss_ws, losses_out);
+  return launch_losses_fwd(a, (hipStream_t)stream);
+}
+
+extern "C" int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coef, const float* pred_logits, const float* pred_spans,
+                                  const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,
+                                  const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
+                                  const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
+                                  float* loss_ws, const float* losses_out, const float* go,
+                                  float* g_logits, float* g_spans, float* g_vid, float* g_txt, uvtg_stream_t stream) {
+  if (B <= 0 || Lv <= 0 || d <= 0) return -11;
+  if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !timestamp_window || !span_labels_nn || !loss_ws ||
+      !losses_out || !go || !g_logits || !g_spans) return -20;
+  LossArgs a = loss_args(B, Lv, d, which, eos_coef, pred_logits, pred_spans, vid, vid_sb, vid_st, txt_mem, timestamp, timestamp_mask,
+                         timestamp_window, span_labels_nn, saliency_scores, pos_idx, loss_ws, (float*)losses_out);
+  a.go = go; a.g_logits = g_logits; a.g_spans = g_spans; a.g_vid = g_vid; a.g_txt = g_txt;
+  hipStream_t s = (hipStream_t)stream;
+  const bool sal = (which & 4) && saliency_scores && pos_idx;
+  if (sal && (!g_vid || !g_txt)) return -20;
+  if (!sal) {
+    if (g_vid) hipMemsetAsync(g_vid, 0, (size_t)B * Lv * d * sizeof(float), s);
+    if (g_txt) hipMemsetAsync(g_txt, 0, (size_t)B * d * sizeof(float), s);
+  }
+  return launch_losses_bwd(a, s);
+}
+
+// =================================================================================================
+// kernel-level entry points
+// =================================================================================================
+extern "C" int uvtg_linear_bf16(const void* A, const void* W, const float* bias, float* C, int M, int N, int K, int act, uvtg_stream_t st) {
+  if (!A || !W || !C) return -20;
+  GemmArgs g = gemm_base(A, K, W, K, M, N, K);
+  g.bias = bias; g.act = act; g.outF = C; g.ldoF = N;
+  return launch_gemm_nt_bf16(g, (hipStream_t)st);
+}
+extern "C" int uvtg_linear_f32x3(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, uvtg_stream_t st) {
+  if (!A || !W || !C) return -20;
+  GemmArgs g = gemm_base(A, K, W, K, M, N, K);
+  g.bias = bias; g.act = act; g.outF = C; g.ldoF = N;
+  return launch_gemm_nt_f32x3(g, (hipStream_t)st);
+}
+extern "C" int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits, uvtg_stream_t st) {
+  if (!dY || !X || !dW) return -20;
+  GemmTNArgs t; memset(&t, 0, sizeof(t));
+  t.P = (const bf16_t*)dY; t.ldp = N; t.Q = (const bf16_t*)X; t.ldq = K; t.M = M; t.N = N; t.K = K; t.Mq = M;
+  t.out = dW; t.ldo = K; t.col_stride = 1; t.dbias = dbias; t.splits = splits;
+  return launch_gemm_tn_bf16(t, (hipStream_t)st);
+}
+extern "C" int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t st) {
+  if (!src || !dst) return -20;
+  return launch_cast_bf16(src, (bf16_t*)dst, n, (hipStream_t)st);
+}
+extern "C" int uvtg_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                  int rows, int D, uvtg_stream_t st) {
+  if (!x || !gamma || !beta || !y) return -20;
+  LnFwdArgs a; memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = D; a.rows = rows; a.D = D; a.gamma = gamma; a.beta = beta; a.eps = 1e-5f; a.mean = mean; a.rstd = rstd;
+  a.yF = y; a.ldyF = D; a.Dpad = D;
+  return launch_ln_fwd(a, (hipStream_t)st);
+}
+extern "C" int uvtg_layernorm_bwd(const float* g, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                  float* dx, float* dgamma, float* dbeta, int rows, int D, uvtg_stream_t st) {
+  if (!g || !x || !mean || !rstd || !gamma) return -20;
+  LnBwdArgs a; memset(&a, 0, sizeof(a));
+  a.g = g; a.ldg = D; a.x = x; a.ldx = D; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.rows = rows; a.D = D;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.dxF = dx; a.lddxF = D; a.rs_seg = 1;
+  return launch_ln_bwd(a, (hipStream_t)st);
+}
+extern "C" int uvtg_attention_fwd(const void* qkv, const unsigned char* kvalid, void* o, float* lse, int B, int S, int H, int hd,
+                                  int precise, uvtg_stream_t st) {
+  if (!qkv || !kvalid || !o) return -20;
+  AttnArgs a; memset(&a, 0, sizeof(a));
+  a.qkv = qkv; a.ldqkv = 3 * H * hd; a.o = o; a.ldo = H * hd; a.lse = lse; a.kvalid = kvalid; a.B = B; a.S = S; a.H = H; a.hd = hd;
+  a.precise = precise;
+  return launch_attn_fwd(a, (hipStream_t)st);
+}
+extern "C" int uvtg_attention_bwd(const void* qkv, const unsigned char* kvalid, const void* o, const float* lse, const void* dO,
+                                  float* delta, void* dqkv, float qscale, int B, int S, int H, int hd, uvtg_stream_t st) {
+  if (!qkv || !kvalid || !o || !lse || !dO || !delta || !dqkv) return -20;
+  AttnArgs a; memset(&a, 0, sizeof(a));
+  a.qkv = qkv; a.ldqkv = 3 * H * hd; a.o = (void*)o; a.ldo = H * hd; a.lse = (float*)lse; a.kvalid = kvalid; a.B = B; a.S = S; a.H = H;
+  a.hd = hd; a.dO = (const bf16_t*)dO; a.lddo = H * hd; a.delta = delta; a.dqkv = (bf16_t*)dqkv; a.lddqkv = 3 * H * hd; a.qscale = qscale;
+  return launch_attn_bwd(a, (hipStream_t)st);
+}
+extern "C" int uvtg_sine_position(const float* vid_mask, const float* txt_mask, const float* dim_t, float* pos, unsigned char* kvalid,
+                                  int B, int Lv, int Lt, int d, uvtg_stream_t st) {
+  if (!vid_mask || !txt_mask || !dim_t || !pos || !kvalid) return -20;
+  return launch_seq_prep(vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, (hipStream_t)st);
+}

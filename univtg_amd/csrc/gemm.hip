@@ -1,0 +1,314 @@
+// MFMA GEMMs for gfx950 (CDNA4): 64-wide waves, v_mfma_f32_32x32x16_bf16, LDS-staged swizzled tiles.
+//
+//  gemm_nt : C[M,N] = A[M,K] * B[N,K]^T  + fused epilogue.  Every Linear / Conv1d(k=3) forward and
+//            every dgrad of the hot path (model/univtg.py:399-406,375-382;
+//            model/transformer_encoder_droppath.py:117-125) runs through it.
+//            bf16 variant: operands bf16, 128x128x64 tiles, ds_read_b128 fragments.
+//            f32x3 variant: operands fp32 in HBM, split on the fly into bf16 hi+lo while staging and
+//            multiplied as hi*hi + hi*lo + lo*hi (~2^-16 relative, fp32-class accuracy at 3 MFMAs).
+//  gemm_tn : C[N,K] += P[M,N]^T * Q[M,K] (weight gradients): both operands are row-major in the
+//            reduction dimension, fragments come from ds_read_b64_tr_b16 transposing LDS reads.
+#include "uvtg_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+
+template <int BK> struct Swz {
+  static constexpr int CPR = BK * 2 / 16;                      // 16-byte chunks per tile row
+  static constexpr int RPB = (256 / (BK * 2)) > 0 ? (256 / (BK * 2)) : 1;   // rows per 256-B bank row
+  __device__ static __forceinline__ int f(int r) { return (r / RPB) % CPR; }
+};
+
+__device__ __forceinline__ int map_row(int m, int seg, int stride, int off) {
+  return seg ? (m / seg) * stride + (m % seg) + off : m + off;
+}
+
+template <bool X3>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
+  constexpr int BK = X3 ? 32 : 64;
+  constexpr int TILE = BM * BK;
+  constexpr int NT = X3 ? 4 : 2;            // operand tiles per stage (A,B[,Alo,Blo])
+  using SW = Swz<BK>;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NT * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gz = blockIdx.z;
+
+  const char* Ab = (const char*)p.A + (size_t)gz * p.gA * (X3 ? 4 : 2);
+  const char* Bb = (const char*)p.B + (size_t)gz * p.gB * (X3 ? 4 : 2);
+
+  // per-thread staging coordinates: 4 x 16-byte pieces of A and of B per K tile
+  int srow[4], sch[4];
+  size_t aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int q = tid + 256 * i;
+    srow[i] = q >> 3; sch[i] = q & 7;
+    int m = min(m0 + srow[i], p.M - 1);
+    int n = min(n0 + srow[i], p.N - 1);
+    aoff[i] = (size_t)map_row(m, p.a_seg, p.a_seg_stride, p.a_off) * p.lda;
+    boff[i] = (size_t)n * p.ldb;
+  }
+  const int nk = (p.K + BK - 1) / BK;
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    const int tap = k0 / p.ktap, kk = k0 - tap * p.ktap;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      constexpr int EPC = X3 ? 4 : 8;       // elements per 16-byte piece
+      const int kc = sch[i] * EPC;
+      const bool ok = (k0 + kc) < p.K;
+      u32x4 z = {0, 0, 0, 0};
+      ra[i] = ok ? *(const u32x4*)(Ab + ((aoff[i] + (size_t)tap * p.lda + kk + kc) * (X3 ? 4 : 2))) : z;
+      rb[i] = ok ? *(const u32x4*)(Bb + ((boff[i] + k0 + kc) * (X3 ? 4 : 2))) : z;
+    }
+  };
+  auto sstore = [&](int stage) {
+    bf16_t* base = smem + stage * NT * TILE;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = srow[i];
+      if constexpr (!X3) {
+        const int off = r * BK + ((sch[i] ^ SW::f(r)) * 8);
+        *(u32x4*)(base + off) = ra[i];
+        *(u32x4*)(base + TILE + off) = rb[i];
+      } else {
+        // piece = 4 floats -> 4 hi + 4 lo bf16 (8 bytes each)
+        const int off = r * BK + (((sch[i] >> 1) ^ SW::f(r)) * 8) + (sch[i] & 1) * 4;
+        float fa[4], fb[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { fa[e] = __uint_as_float(ra[i][e]); fb[e] = __uint_as_float(rb[i][e]); }
+        bf16_t ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          ah[e] = f2bf(fa[e]); al[e] = f2bf(fa[e] - bf2f(ah[e]));
+          bh[e] = f2bf(fb[e]); bl[e] = f2bf(fb[e] - bf2f(bh[e]));
+        }
+        u32x2 v;
+        v[0] = ah[0] | ((unsigned)ah[1] << 16); v[1] = ah[2] | ((unsigned)ah[3] << 16); *(u32x2*)(base + off) = v;
+        v[0] = bh[0] | ((unsigned)bh[1] << 16); v[1] = bh[2] | ((unsigned)bh[3] << 16); *(u32x2*)(base + TILE + off) = v;
+        v[0] = al[0] | ((unsigned)al[1] << 16); v[1] = al[2] | ((unsigned)al[3] << 16); *(u32x2*)(base + 2 * TILE + off) = v;
+        v[0] = bl[0] | ((unsigned)bl[1] << 16); v[1] = bl[2] | ((unsigned)bl[3] << 16); *(u32x2*)(base + 3 * TILE + off) = v;
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk) gload(kt + 1);
+    const bf16_t* base = smem + (kt & 1) * NT * TILE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      s16x8 a[2], b[2], al[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int ra_ = wm * 64 + i * 32 + l31, rb_ = wn * 64 + i * 32 + l31;
+        const int oa = ra_ * BK + (((2 * ks + g) ^ SW::f(ra_)) * 8);
+        const int ob = rb_ * BK + (((2 * ks + g) ^ SW::f(rb_)) * 8);
+        a[i] = *(const s16x8*)(base + oa);
+        b[i] = *(const s16x8*)(base + TILE + ob);
+        if constexpr (X3) { al[i] = *(const s16x8*)(base + 2 * TILE + oa); bl[i] = *(const s16x8*)(base + 3 * TILE + ob); }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if constexpr (X3) {
+            acc[i][j] = mfma32(al[i], b[j], acc[i][j]);
+            acc[i][j] = mfma32(a[i], bl[j], acc[i][j]);
+          }
+          acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        }
+    }
+    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const float* bias = p.bias ? p.bias + (size_t)gz * p.gBias : nullptr;
+  const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (m >= p.M) continue;
+      const size_t orow = (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off);
+      const float rs = p.rowscale ? p.rowscale[m / p.rs_seg] : 1.0f;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        if (bias) v += bias[n];
+        if (p.bias2) v += p.bias2[n];
+        if (n < p.colscale_n) v *= p.colscale;
+        if (p.outPre) p.outPre[go + orow * p.ldpre_out + n] = f2bf(v);
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = gelu_erf(v);
+        if (p.actgrad == 1) v = bf2f(p.gradPre[gp + orow * p.ldgp + n]) > 0.f ? v : 0.f;
+        else if (p.actgrad == 2) v *= gelu_erf_grad(bf2f(p.gradPre[gp + orow * p.ldgp + n]));
+        v *= rs;
+        if (p.resid) v += p.resid[orow * p.ldr + n];
+        if (p.outF) p.outF[go + orow * p.ldoF + n] = v;
+        if (p.outB) p.outB[go + orow * p.ldoB + n] = f2bf(v);
+        if (p.outU || p.outUF) {
+          const float u = v + ((p.pos && m < p.pos_rows) ? p.pos[(size_t)m * p.ldpos + n] : 0.f);
+          if (p.outU) p.outU[orow * p.ldoU + n] = f2bf(u);
+          if (p.outUF) p.outUF[orow * p.ldoU + n] = u;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: out[n][k] += sum_m P[m][n] * Q[m + q_row_off][k]
+// ------------------------------------------------------------------------------------------------
+constexpr int TBM = 64;                 // reduction rows per step
+constexpr int TLD = 128 + 32;           // LDS row stride (elements): 320 B keeps tr-reads conflict-free
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sP[2][TBM * TLD];
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[2][TBM * TLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1, g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  const int tiles_k = (p.K + 127) / 128;
+  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  // rows of this split, in multiples of TBM
+  const int steps_total = (p.M + TBM - 1) / TBM;
+  const int steps_per = (steps_total + p.splits - 1) / p.splits;
+  const int st0 = blockIdx.y * steps_per, st1 = min(steps_total, st0 + steps_per);
+  if (st0 >= st1) return;
+
+  int srow[4], sch[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { int q = tid + 256 * i; srow[i] = q >> 4; sch[i] = q & 15; }
+  u32x4 rp[4], rq[4];
+  auto gload = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int m = st * TBM + srow[i];
+      const int mq = m + p.q_row_off;
+      u32x4 z = {0, 0, 0, 0};
+      const int nc = n0 + sch[i] * 8, kc = k0 + sch[i] * 8;
+      rp[i] = (m < p.M && nc < p.N) ? *(const u32x4*)(p.P + (size_t)m * p.ldp + nc) : z;
+      rq[i] = (m < p.M && mq >= 0 && mq < p.Mq && kc < p.ldq) ? *(const u32x4*)(p.Q + (size_t)mq * p.ldq + kc) : z;
+    }
+  };
+  auto sstore = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      *(u32x4*)(&sP[stage][srow[i] * TLD + sch[i] * 8]) = rp[i];
+      *(u32x4*)(&sQ[stage][srow[i] * TLD + sch[i] * 8]) = rq[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  float bsum = 0.f;   // column sum of P for the bias gradient (threads 0..127 own one column each)
+
+  gload(st0);
+  sstore(0);
+  __syncthreads();
+  for (int st = st0; st < st1; st++) {
+    const int cur = (st - st0) & 1;
+    if (st + 1 < st1) gload(st + 1);
+    const bf16_t* bp = sP[cur];
+    const bf16_t* bq = sQ[cur];
+#pragma unroll
+    for (int ks = 0; ks < TBM / 16; ks++) {
+      s16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int mrow = ks * 16 + 8 * g + (i16 >> 2);
+        const int ca = wn * 64 + i * 32 + 16 * qd + 4 * (i16 & 3);
+        const int cb = wk * 64 + i * 32 + 16 * qd + 4 * (i16 & 3);
+        s16x4 a0 = lds_tr16(bp + mrow * TLD + ca), a1 = lds_tr16(bp + (mrow + 4) * TLD + ca);
+        s16x4 b0 = lds_tr16(bq + mrow * TLD + cb), b1 = lds_tr16(bq + (mrow + 4) * TLD + cb);
+        a[i] = (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        b[i] = (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+    if (p.dbias && tile_k == 0 && tid < 128) {
+#pragma unroll 8
+      for (int r = 0; r < TBM; r++) bsum += bf2f(bp[r * TLD + tid]);
+    }
+    if (st + 1 < st1) sstore(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int k = k0 + wk * 64 + j * 32 + l31;
+        if (k < p.K) atomicAdd(p.out + (size_t)n * p.ldo + (size_t)k * p.col_stride, acc[i][j][r]);
+      }
+    }
+  if (p.dbias && tile_k == 0 && tid < 128 && n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, bsum);
+}
+
+}  // namespace
+
+static int check_nt(const GemmArgs& a, int elem) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
+  const int al = 16 / elem;   // elements per 16 bytes
+  if (a.lda % al || a.ldb % al || a.ktap <= 0) return -2;
+  if (a.ktap < a.K && (a.ktap % (elem == 2 ? 64 : 32))) return -2;
+  if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return -3;
+  return 0;
+}
+
+int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
+  if (int e = check_nt(a, 2)) return e;
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
+  hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s) {
+  if (int e = check_nt(a, 4)) return e;
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
+  hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.splits <= 0) return -1;
+  if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15)) return -2;
+  dim3 grid(cdiv(a.N, 128) * cdiv(a.K, 128), a.splits, 1);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}

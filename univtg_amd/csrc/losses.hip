@@ -1,0 +1,334 @@
+// Dense UniVTG criterion on device (model/univtg.py:195-282): SmoothL1 + paired gIoU on the foreground
+// clips, weighted BCE on the foreground probability, inter-video and intra-video NCE saliency terms.
+// Values and gradients, O(N) paired gIoU instead of the reference's N x N matrix + diag, and no
+// device->host synchronisation (the reference's `saliency_scores.sum() == 0` early-out becomes a
+// device-side flag that zeroes the two saliency terms and their gradients).
+#include "uvtg_kernels.h"
+
+namespace {
+
+constexpr float TAU = 0.07f;          // model/univtg.py:185 (hard-coded)
+constexpr float EPS = 1e-8f;          // sim_matrix / cosine_similarity eps
+
+struct WS {                            // carve-up of LossArgs::ws
+  float *cosv, *vnorm, *qnorm, *sim, *lse_r, *lse_c, *zr, *zc, *cnt, *gz, *vpn;
+  __host__ __device__ WS(float* p, int B, int Lv) {
+    cosv = p; p += (size_t)B * Lv;
+    vnorm = p; p += (size_t)B * Lv;
+    gz = p; p += (size_t)B * Lv;
+    sim = p; p += (size_t)B * B;
+    qnorm = p; p += B;
+    lse_r = p; p += B;
+    lse_c = p; p += B;
+    zr = p; p += B;
+    vpn = p; p += B;
+    zc = p; p += Lv;
+    cnt = p; p += Lv;
+  }
+};
+
+__device__ __forceinline__ const float* vrow(const LossArgs& a, int b, int t) {
+  return a.vid + (size_t)b * a.vid_sb + (size_t)t * a.vid_st;
+}
+__device__ __forceinline__ bool is_neg(const LossArgs& a, int b, int t) {
+  // neg_indices_in & mask (model/univtg.py:266-268)
+  const int p = (int)a.pos_idx[b];
+  const bool n = (a.sal_tgt[b * a.Lv + t] < a.sal_tgt[b * a.Lv + p]) || (t == p);
+  return n && (a.ts_mask[b * a.Lv + t] != 0.f);
+}
+__device__ __forceinline__ float zval(const LossArgs& a, const WS& w, int b, int t) {
+  return w.cosv[b * a.Lv + t] + (is_neg(a, b, t) ? 0.f : UVTG_LOG_TINY);
+}
+
+// per (b, t): |v|, cos(v, q_b);  per b: |q|
+__global__ __launch_bounds__(256) void loss_stats_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B * a.Lv) return;
+  const int b = row / a.Lv, t = row % a.Lv;
+  const float* v = vrow(a, b, t);
+  const float* q = a.txt + (size_t)b * a.d;
+  float vv = 0.f, qq = 0.f, vq = 0.f;
+  for (int c = lane; c < a.d; c += 64) { const float x = v[c], y = q[c]; vv += x * x; qq += y * y; vq += x * y; }
+  vv = wave_sum(vv); qq = wave_sum(qq); vq = wave_sum(vq);
+  if (lane == 0) {
+    const float vn = sqrtf(vv), qn = sqrtf(qq);
+    w.vnorm[row] = vn;
+    w.cosv[row] = vq / (fmaxf(vn, EPS) * fmaxf(qn, EPS));
+    if (t == 0) w.qnorm[b] = qn;
+  }
+}
+
+// sim[i][j] = vhat_i . qhat_j  with v_i = vid[i, pos_i]
+__global__ __launch_bounds__(256) void loss_sim_kernel(const LossArgs a) {
+  extern __shared__ float sv[];
+  const WS w(a.ws, a.B, a.Lv);
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = (int)a.pos_idx[i];
+  const float* v = vrow(a, i, p);
+  const float vn = fmaxf(w.vnorm[i * a.Lv + p], EPS);
+  for (int c = threadIdx.x; c < a.d; c += 256) sv[c] = v[c] / vn;
+  __syncthreads();
+  for (int j = wave; j < a.B; j += 4) {
+    const float* q = a.txt + (size_t)j * a.d;
+    float acc = 0.f;
+    for (int c = lane; c < a.d; c += 64) acc += sv[c] * q[c];
+    acc = wave_sum(acc);
+    if (lane == 0) w.sim[i * a.B + j] = acc / fmaxf(w.qnorm[j], EPS);
+  }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ void giou_terms(float a0, float a1, float b0, float b1, float& I, float& U, float& H) {
+  I = fmaxf(fminf(a1, b1) - fmaxf(a0, b0), 0.f);
+  U = (a1 - a0) + (b1 - b0) - I;
+  H = fmaxf(fmaxf(a1, b1) - fminf(a0, b0), 0.f);
+}
+
+// single block: every scalar of the criterion
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const LossArgs a) {
+  __shared__ float red[16];
+  const WS w(a.ws, a.B, a.Lv);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int n = a.B * a.Lv;
+  float nwin = 0.f, nval = 0.f, ssum = 0.f;
+  for (int i = tid; i < n; i += blockDim.x) {
+    nwin += (a.ts_window[i] != 0.f);
+    nval += (a.ts_mask[i] != 0.f);
+    if (a.sal_tgt) ssum += a.sal_tgt[i];
+  }
+  nwin = block_sum(nwin, red); nval = block_sum(nval, red); ssum = block_sum(ssum, red);
+  const bool sal_on = a.do_saliency && a.sal_tgt && a.pos_idx && ssum != 0.f;
+  float lb = 0.f, lg = 0.f, lf = 0.f;
+  for (int i = tid; i < n; i += blockDim.x) {
+    const float win = a.ts_window[i], msk = a.ts_mask[i];
+    if (a.do_spans && win != 0.f) {
+      const float s0 = a.timestamp[2 * i] + a.pred_spans[2 * i], s1 = a.timestamp[2 * i + 1] + a.pred_spans[2 * i + 1];
+      const float g0 = a.span_nn[2 * i], g1 = a.span_nn[2 * i + 1];
+      const float d0 = fabsf(s0 - g0), d1 = fabsf(s1 - g1);
+      lb += win * ((d0 < 1.f ? 0.5f * d0 * d0 : d0 - 0.5f) + (d1 < 1.f ? 0.5f * d1 * d1 : d1 - 0.5f));
+      float I, U, H;
+      giou_terms(s0, s1, g0, g1, I, U, H);
+      lg += 1.f - (I / U - (H - U) / H);
+    }
+    if (a.do_labels && msk != 0.f) {
+      const float p = a.pred_logits[i], y = win != 0.f ? 1.f : 0.f, wt = win != 0.f ? 1.f : a.eos_coef;
+      lf += -wt * (y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+    }
+  }
+  lb = block_sum(lb, red); lg = block_sum(lg, red); lf = block_sum(lf, red);
+  float inter = 0.f, intra = 0.f;
+  if (sal_on) {
+    const int B = a.B, Lv = a.Lv;
+    // inter-video: row / column log-sum-exp of sim / tau
+    for (int i = wave; i < B; i += nw) {
+      float mr = -INFINITY, mc = -INFINITY;
+      for (int j = lane; j < B; j += 64) { mr = fmaxf(mr, w.sim[i * B + j]); mc = fmaxf(mc, w.sim[j * B + i]); }
+      mr = wave_max(mr); mc = wave_max(mc);
+      float sr = 0.f, sc = 0.f;
+      for (int j = lane; j < B; j += 64) { sr += expf((w.sim[i * B + j] - mr) / TAU); sc += expf((w.sim[j * B + i] - mc) / TAU); }
+      sr = wave_sum(sr); sc = wave_sum(sc);
+      if (lane == 0) { w.lse_r[i] = mr / TAU + logf(sr); w.lse_c[i] = mc / TAU + logf(sc); }
+    }
+    for (int t = tid; t < Lv; t += blockDim.x) w.cnt[t] = 0.f;
+    __syncthreads();
+    // intra-video rows
+    for (int b = wave; b < B; b += nw) {
+      float m = -INFINITY;
+      for (int t = lane; t < Lv; t += 64) m = fmaxf(m, zval(a, w, b, t));
+      m = wave_max(m);
+      float s = 0.f;
+      for (int t = lane; t < Lv; t += 64) s += expf((zval(a, w, b, t) - m) / TAU);
+      s = wave_sum(s);
+      if (lane == 0) { w.zr[b] = m / TAU + logf(s); atomicAdd(&w.cnt[(int)a.pos_idx[b]], 1.f); }
+    }
+    // intra-video columns (softmax over the batch at each clip index)
+    for (int t = wave; t < Lv; t += nw) {
+      float m = -INFINITY;
+      for (int b = lane; b < B; b += 64) m = fmaxf(m, zval(a, w, b, t));
+      m = wave_max(m);
+      float s = 0.f;
+      for (int b = lane; b < B; b += 64) s += expf((zval(a, w, b, t) - m) / TAU);
+      s = wave_sum(s);
+      if (lane == 0) w.zc[t] = m / TAU + logf(s);
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += blockDim.x) {
+      const int p = (int)a.pos_idx[b];
+      const float sd = w.sim[b * B + b] / TAU;
+      inter += -(sd - w.lse_r[b]) - (sd - w.lse_c[b]);
+      const float z = zval(a, w, b, p) / TAU;
+      intra += -(z - w.zr[b]) - (z - w.zc[p]);
+    }
+    inter = block_sum(inter, red) / (float)B;
+    intra = block_sum(intra, red) / (float)B;
+  }
+  if (tid == 0) {
+    a.losses[0] = a.do_spans ? lb / nwin : 0.f;
+    a.losses[1] = a.do_spans ? lg / nwin : 0.f;
+    a.losses[2] = a.do_labels ? lf / nval : 0.f;
+    a.losses[3] = inter;
+    a.losses[4] = intra;
+    a.losses[5] = sal_on ? 1.f : 0.f;
+    a.losses[6] = nwin;
+    a.losses[7] = nval;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradients
+// ------------------------------------------------------------------------------------------------
+__global__ void loss_grad_small_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = a.B * a.Lv;
+  const float nwin = a.losses[6], nval = a.losses[7];
+  const bool sal_on = a.losses[5] != 0.f;
+  if (i < n) {
+    const int b = i / a.Lv, t = i % a.Lv;
+    const float win = a.ts_window[i], msk = a.ts_mask[i];
+    float gs0 = 0.f, gs1 = 0.f, gl = 0.f;
+    if (a.do_spans && win != 0.f) {
+      const float s0 = a.timestamp[2 * i] + a.pred_spans[2 * i], s1 = a.timestamp[2 * i + 1] + a.pred_spans[2 * i + 1];
+      const float g0 = a.span_nn[2 * i], g1 = a.span_nn[2 * i + 1];
+      const float e0 = s0 - g0, e1 = s1 - g1;
+      gs0 = a.go[0] * win * fminf(fmaxf(e0, -1.f), 1.f) / nwin;
+      gs1 = a.go[0] * win * fminf(fmaxf(e1, -1.f), 1.f) / nwin;
+      float I, U, H;
+      giou_terms(s0, s1, g0, g1, I, U, H);
+      const float dI0 = (I > 0.f && s0 > g0) ? -1.f : ((I > 0.f && s0 == g0) ? -0.5f : 0.f);
+      const float dI1 = (I > 0.f && s1 < g1) ? 1.f : ((I > 0.f && s1 == g1) ? 0.5f : 0.f);
+      const float dU0 = -1.f - dI0, dU1 = 1.f - dI1;
+      const float dH0 = (H > 0.f && s0 < g0) ? -1.f : ((H > 0.f && s0 == g0) ? -0.5f : 0.f);
+      const float dH1 = (H > 0.f && s1 > g1) ? 1.f : ((H > 0.f && s1 == g1) ? 0.5f : 0.f);
+      const float dg0 = (dI0 * U - I * dU0) / (U * U) + (dU0 * H - U * dH0) / (H * H);
+      const float dg1 = (dI1 * U - I * dU1) / (U * U) + (dU1 * H - U * dH1) / (H * H);
+      gs0 += -a.go[1] * dg0 / nwin;
+      gs1 += -a.go[1] * dg1 / nwin;
+    }
+    if (a.do_labels && msk != 0.f) {
+      const float p = a.pred_logits[i], y = win != 0.f ? 1.f : 0.f, wt = win != 0.f ? 1.f : a.eos_coef;
+      gl = a.go[2] * wt * (p - y) / fmaxf((1.f - p) * p, 1e-12f) / nval;
+    }
+    a.g_spans[2 * i] = gs0; a.g_spans[2 * i + 1] = gs1; a.g_logits[i] = gl;
+    float gz = 0.f;
+    if (sal_on) {
+      const int p = (int)a.pos_idx[b];
+      const float z = zval(a, w, b, t) / TAU;
+      const float dl = (t == p) ? 1.f : 0.f;
+      gz = a.go[4] / ((float)a.B * TAU) * ((expf(z - w.zr[b]) - dl) + (w.cnt[t] * expf(z - w.zc[t]) - dl));
+    }
+    w.gz[i] = gz;
+  }
+}
+// dsim in place: sim[i][j] <- go_inter / (B tau) * (softmax_row + softmax_col - 2 delta)
+__global__ void loss_grad_sim_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.B * a.B) return;
+  const int i = idx / a.B, j = idx % a.B;
+  float g = 0.f;
+  if (a.losses[5] != 0.f) {
+    const float s = w.sim[idx] / TAU, dl = (i == j) ? 1.f : 0.f;
+    g = a.go[3] / ((float)a.B * TAU) * ((expf(s - w.lse_r[i]) - dl) + (expf(s - w.lse_c[j]) - dl));
+  }
+  w.sim[idx] = g;
+}
+
+// g_vid[b, t, :] = gz * (qhat - cos vhat) / |v|  (+ the inter-video term on the positive clip row)
+__global__ __launch_bounds__(256) void loss_grad_vid_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B * a.Lv) return;
+  const int b = row / a.Lv, t = row % a.Lv, d = a.d;
+  float* out = a.g_vid + (size_t)row * d;
+  const bool sal_on = a.losses[5] != 0.f;
+  if (!sal_on) { for (int c = lane; c < d; c += 64) out[c] = 0.f; return; }
+  const float* v = vrow(a, b, t);
+  const float* q = a.txt + (size_t)b * d;
+  const float vn = fmaxf(w.vnorm[row], EPS), qn = fmaxf(w.qnorm[b], EPS), cs = w.cosv[row], gz = w.gz[row];
+  const bool is_pos = (t == (int)a.pos_idx[b]);
+  float dot = 0.f;                       // vhat . dvhat for the positive row
+  if (is_pos) {
+    for (int c = lane; c < d; c += 64) {
+      float dv = 0.f;
+      for (int j = 0; j < a.B; j++) dv += w.sim[b * a.B + j] * a.txt[(size_t)j * d + c] / fmaxf(w.qnorm[j], EPS);
+      out[c] = dv;                       // stash dvhat
+      dot += dv * v[c] / vn;
+    }
+    dot = wave_sum(dot);
+  }
+  for (int c = lane; c < d; c += 64) {
+    const float vh = v[c] / vn, qh = q[c] / qn;
+    float g = gz * (qh - cs * vh) / vn;
+    if (is_pos) g += (out[c] - vh * dot) / vn;
+    out[c] = g;
+  }
+}
+// g_txt[b, :] = sum_t gz (vhat_t - cos_t qhat)/|q|  +  (dqhat - qhat (qhat.dqhat)) / |q|
+__global__ __launch_bounds__(256) void loss_grad_txt_kernel(const LossArgs a) {
+  extern __shared__ float sh[];          // [d] dqhat, [8] red
+  const WS w(a.ws, a.B, a.Lv);
+  const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
+  float* out = a.g_txt + (size_t)b * d;
+  if (a.losses[5] == 0.f) { for (int c = tid; c < d; c += 256) out[c] = 0.f; return; }
+  const float* q = a.txt + (size_t)b * d;
+  const float qn = fmaxf(w.qnorm[b], EPS);
+  float dot = 0.f;
+  for (int c = tid; c < d; c += 256) {
+    float dq = 0.f;
+    for (int i = 0; i < a.B; i++) {
+      const int p = (int)a.pos_idx[i];
+      dq += w.sim[i * a.B + b] * vrow(a, i, p)[c] / fmaxf(w.vnorm[i * a.Lv + p], EPS);
+    }
+    sh[c] = dq;
+    dot += dq * q[c] / qn;
+  }
+  dot = block_sum(dot, sh + d);
+  for (int c = tid; c < d; c += 256) {
+    const float qh = q[c] / qn;
+    float g = (sh[c] - qh * dot) / qn;
+    for (int t = 0; t < a.Lv; t++) {
+      const float gz = w.gz[b * a.Lv + t];
+      if (gz != 0.f) g += gz * (vrow(a, b, t)[c] / fmaxf(w.vnorm[b * a.Lv + t], EPS) - w.cosv[b * a.Lv + t] * qh) / qn;
+    }
+    out[c] = g;
+  }
+}
+
+}  // namespace
+
+long long loss_ws_floats(int B, int Lv) { return 3LL * B * Lv + (long long)B * B + 5LL * B + 2LL * Lv + 64; }
+
+int launch_losses_fwd(const LossArgs& a, hipStream_t s) {
+  const int n = a.B * a.Lv;
+  if (a.do_saliency && a.sal_tgt && a.pos_idx) {
+    hipLaunchKernelGGL(loss_stats_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_sim_kernel, dim3(a.B), dim3(256), a.d * sizeof(float), s, a);
+  }
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_losses_bwd(const LossArgs& a, hipStream_t s) {
+  const int n = a.B * a.Lv;
+  hipLaunchKernelGGL(loss_grad_small_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a);
+  if (a.do_saliency && a.sal_tgt && a.pos_idx) {
+    hipLaunchKernelGGL(loss_grad_sim_kernel, dim3(cdiv(a.B * a.B, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_grad_vid_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_grad_txt_kernel, dim3(a.B), dim3(256), (a.d + 16) * sizeof(float), s, a);
+  }
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}

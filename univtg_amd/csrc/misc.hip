@@ -1,0 +1,382 @@
+// Small HBM-bound kernels of the UniVTG hot path: sine position table + key mask
+// (model/position_encoding.py:60-83, model/univtg.py:119-124), DropPath factors
+// (model/transformer_encoder_droppath.py:154-167), weight re-layouts, the last Conv1d layer of both heads
+// with sigmoid / sign (model/univtg.py:129-136,375-382), weighted text pooling + cosine saliency
+// (model/univtg.py:36-49,143-147) and their backward passes.
+#include "uvtg_kernels.h"
+
+namespace {
+
+// ---------------- position table + key validity ----------------
+__global__ void seq_prep_kernel(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
+                                const float* dim_t, float* pos, unsigned char* kvalid) {
+  const int row = blockIdx.x;             // (b, t) over B*Lv
+  const int b = row / Lv, t = row % Lv;
+  __shared__ float s_c, s_last;
+  if (threadIdx.x < 64) {
+    float c = 0.f, tot = 0.f;
+    for (int i = threadIdx.x; i < Lv; i += 64) {
+      const float m = vid_mask[b * Lv + i];
+      tot += m;
+      if (i <= t) c += m;
+    }
+    c = wave_sum(c); tot = wave_sum(tot);
+    if (threadIdx.x == 0) { s_c = c; s_last = tot; }
+  }
+  __syncthreads();
+  // x_embed / (x_embed[:, -1:] + eps) * scale, all in fp32 (position_encoding.py:70-73)
+  const float e = s_c / (s_last + 1e-6f) * 6.283185307179586f;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    const float ang = e / dim_t[c];
+    pos[(size_t)row * d + c] = (c & 1) ? cosf(ang) : sinf(ang);
+  }
+  if (t == 0) {
+    const int S = Lv + Lt;
+    for (int s = threadIdx.x; s < S; s += blockDim.x)
+      kvalid[b * S + s] = (s < Lv ? vid_mask[b * Lv + s] : txt_mask[b * Lt + (s - Lv)]) != 0.f;
+  }
+}
+
+__global__ void droppath_kernel(float* scales, int n, int B, float p, unsigned long long seed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * B) return;
+  unsigned r[4];
+  philox4(seed, (unsigned long long)i, UVTG_RNG_PATH, r);
+  const float keep = 1.0f - p;
+  scales[i] = floorf(keep + u01(r[0])) / keep;     // drop_path(): mask = floor(keep + U[0,1)), x / keep * mask
+}
+
+__global__ void cast_bf16_kernel(const float* src, bf16_t* dst, long long n) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 v = *(const f32x4*)(src + i);
+    u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
+    *(u32x2*)(dst + i) = t;
+  } else {
+    for (long long j = i; j < n; j++) dst[j] = f2bf(src[j]);
+  }
+}
+template <typename T> __device__ __forceinline__ T cvt(float v);
+template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float v) { return f2bf(v); }
+
+template <typename T>
+__global__ void cast_pad_kernel(const float* src, int rows, int cols, T* dst, int ld) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * ld) return;
+  const int r = (int)(i / ld), c = (int)(i % ld);
+  dst[i] = cvt<T>(c < cols ? src[(size_t)r * cols + c] : 0.f);
+}
+// dst[c][r] = src[r][c]  (bf16), 32x32 LDS tile
+__global__ void transpose_bf16_kernel(const float* src, int rows, int cols, bf16_t* dst, int ld) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    t[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) dst[(size_t)c * ld + r] = f2bf(t[threadIdx.x][i]);
+  }
+}
+// conv weight (N, C, 3) -> forward operand [n][tap*C + c]
+__global__ void conv_w_fwd_kernel(const float* w, int N, int C, bf16_t* dstB, float* dstF, int ld) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * 3 * C) return;
+  const int n = (int)(i / (3 * C)), rem = (int)(i % (3 * C)), tap = rem / C, c = rem % C;
+  const float v = w[((size_t)n * C + c) * 3 + tap];
+  if (dstB) dstB[(size_t)n * ld + rem] = f2bf(v);
+  if (dstF) dstF[(size_t)n * ld + rem] = v;
+}
+// dgrad operand [c][tap' * Ntot + n_off + n] = w[n][c][2 - tap']
+__global__ void conv_w_bwd_kernel(const float* w, int N, int C, bf16_t* dst, int ld, int Ntot, int n_off) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * 3 * C) return;
+  const int c = (int)(i / (3 * N)), rem = (int)(i % (3 * N)), tp = rem / N, n = rem % N;
+  dst[(size_t)c * ld + tp * Ntot + n_off + n] = f2bf(w[((size_t)n * C + c) * 3 + (2 - tp)]);
+}
+
+// ---------------- heads: last conv layer + activations ----------------
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void heads_final_fwd_kernel(const HeadsFinalArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, t)
+  if (row >= a.B * a.Lv) return;
+  const int b = row / a.Lv, t = row % a.Lv, d = a.d;
+  const T* h2 = (const T*)a.h2;
+  float z0 = 0.f, z1 = 0.f, zc = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 3; tap++) {
+    const T* hr = h2 + (size_t)(b * (a.Lv + 2) + t + tap) * a.ldh;
+    for (int c = lane; c < d; c += 64) {
+      const float hs = ldf<T>(hr + c), hc = ldf<T>(hr + d + c);
+      z0 += hs * a.w_span[(size_t)c * 3 + tap];
+      z1 += hs * a.w_span[((size_t)d + c) * 3 + tap];
+      zc += hc * a.w_cls[(size_t)c * 3 + tap];
+    }
+  }
+  z0 = wave_sum(z0); z1 = wave_sum(z1); zc = wave_sum(zc);
+  if (lane == 0) {
+    a.pred_spans[(size_t)row * 2 + 0] = -1.0f / (1.0f + expf(-(z0 + a.b_span[0])));
+    a.pred_spans[(size_t)row * 2 + 1] = 1.0f / (1.0f + expf(-(z1 + a.b_span[1])));
+    a.pred_logits[row] = 1.0f / (1.0f + expf(-(zc + a.b_cls[0])));
+  }
+}
+
+// pre-activation gradients of the three head outputs for clip (b, t); zero outside [0, Lv)
+__device__ __forceinline__ void head_dz(const HeadsFinalArgs& a, int b, int t, float& d0, float& d1, float& dc) {
+  if (t < 0 || t >= a.Lv) { d0 = d1 = dc = 0.f; return; }
+  const size_t r = (size_t)b * a.Lv + t;
+  const float s0 = -a.pred_spans[r * 2], s1 = a.pred_spans[r * 2 + 1], p = a.pred_logits[r];
+  d0 = a.g_spans ? -a.g_spans[r * 2] * s0 * (1.f - s0) : 0.f;
+  d1 = a.g_spans ? a.g_spans[r * 2 + 1] * s1 * (1.f - s1) : 0.f;
+  dc = a.g_logits ? a.g_logits[r] * p * (1.f - p) : 0.f;
+}
+
+// dh2[b, u, :] (zero-framed, relu' applied) : dh[u][c] = sum_tap sum_j w[j][c][tap] * dz_j[u - tap + 1]
+__global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFinalArgs a) {
+  const int row = blockIdx.x;                               // (b, u)
+  const int b = row / a.Lv, u = row % a.Lv, d = a.d;
+  float dz0[3], dz1[3], dzc[3];
+#pragma unroll
+  for (int tap = 0; tap < 3; tap++) head_dz(a, b, u - tap + 1, dz0[tap], dz1[tap], dzc[tap]);
+  const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(b * (a.Lv + 2) + u + 1) * a.ldh;
+  bf16_t* out = a.dh2 + (size_t)(b * (a.Lv + 2) + u + 1) * a.lddh;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float gs = 0.f, gc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 3; tap++) {
+      gs += a.w_span[(size_t)c * 3 + tap] * dz0[tap] + a.w_span[((size_t)d + c) * 3 + tap] * dz1[tap];
+      gc += a.w_cls[(size_t)c * 3 + tap] * dzc[tap];
+    }
+    out[c] = f2bf(bf2f(h2[c]) > 0.f ? gs : 0.f);
+    out[d + c] = f2bf(bf2f(h2[d + c]) > 0.f ? gc : 0.f);
+  }
+}
+
+// dW[j][c][tap] = sum_{b,t} dz_j[b,t] * h2[b, t + tap - 1][c];  one block per 64-column slab
+__global__ __launch_bounds__(256) void heads_final_bwd_dw_kernel(const HeadsFinalArgs a) {
+  const int d = a.d;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6, nrows = a.B * a.Lv;
+  float ws0[3] = {0, 0, 0}, ws1[3] = {0, 0, 0}, wc[3] = {0, 0, 0}, b0 = 0.f, b1 = 0.f, bc = 0.f;
+  const bf16_t* h2 = (const bf16_t*)a.h2;
+  for (int row = blockIdx.y * 4 + part; row < nrows; row += gridDim.y * 4) {
+    const int b = row / a.Lv, t = row % a.Lv;
+    float d0, d1, dc;
+    head_dz(a, b, t, d0, d1, dc);
+    b0 += d0; b1 += d1; bc += dc;
+    if (c < d) {
+#pragma unroll
+      for (int tap = 0; tap < 3; tap++) {
+        const bf16_t* hr = h2 + (size_t)(b * (a.Lv + 2) + t + tap) * a.ldh;
+        const float hs = bf2f(hr[c]), hc = bf2f(hr[d + c]);
+        ws0[tap] += d0 * hs; ws1[tap] += d1 * hs; wc[tap] += dc * hc;
+      }
+    }
+  }
+  if (c < d) {
+#pragma unroll
+    for (int tap = 0; tap < 3; tap++) {
+      atomicAdd(a.dw_span + (size_t)c * 3 + tap, ws0[tap]);
+      atomicAdd(a.dw_span + ((size_t)d + c) * 3 + tap, ws1[tap]);
+      atomicAdd(a.dw_cls + (size_t)c * 3 + tap, wc[tap]);
+    }
+  }
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+    atomicAdd(a.db_span, b0); atomicAdd(a.db_span + 1, b1); atomicAdd(a.db_cls, bc);
+  }
+}
+
+// ---------------- weighted pooling + cosine saliency ----------------
+__global__ __launch_bounds__(256) void saliency_fwd_kernel(const SaliencyArgs a) {
+  extern __shared__ float sm[];                 // [Lt] logits/alpha | [d] pooled | [8] scratch
+  float* s_alpha = sm;
+  float* s_pool = sm + a.Lt;
+  float* s_red = s_pool + a.d;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
+  const float* xt = a.x0 + ((size_t)b * a.S + a.Lv) * d;      // text rows
+  for (int t = wave; t < a.Lt; t += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < d; c += 64) acc += xt[(size_t)t * d + c] * a.w_pool[c];
+    acc = wave_sum(acc);
+    if (lane == 0) s_alpha[t] = acc + (1.0f - a.txt_mask[b * a.Lt + t]) * (-1e30f);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float mx = -INFINITY;
+    for (int t = lane; t < a.Lt; t += 64) mx = fmaxf(mx, s_alpha[t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < a.Lt; t += 64) sum += expf(s_alpha[t] - mx);
+    sum = wave_sum(sum);
+    for (int t = lane; t < a.Lt; t += 64) {
+      const float al = expf(s_alpha[t] - mx) / sum;
+      s_alpha[t] = al;
+      if (a.alpha) a.alpha[b * a.Lt + t] = al;
+    }
+  }
+  __syncthreads();
+  float nsq = 0.f;
+  for (int c = tid; c < d; c += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < a.Lt; t++) acc += s_alpha[t] * xt[(size_t)t * d + c];
+    s_pool[c] = acc;
+    a.pooled[(size_t)b * d + c] = acc;
+    nsq += acc * acc;
+  }
+  nsq = wave_sum(nsq);
+  if (lane == 0) s_red[wave] = nsq;
+  __syncthreads();
+  const float qn = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+  if (tid == 0 && a.qnorm) a.qnorm[b] = qn;
+  const float qd = fmaxf(qn, 1e-8f);
+  const float* xv = a.x0 + (size_t)b * a.S * d;
+  for (int t = wave; t < a.Lv; t += 4) {
+    float dot = 0.f, vs = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = xv[(size_t)t * d + c]; dot += v * s_pool[c]; vs += v * v; }
+    dot = wave_sum(dot); vs = wave_sum(vs);
+    if (lane == 0) {
+      const float vn = sqrtf(vs);
+      const float cs = dot / (fmaxf(vn, 1e-8f) * qd);
+      if (a.vnorm) a.vnorm[b * a.Lv + t] = vn;
+      if (a.cosv) a.cosv[b * a.Lv + t] = cs;
+      a.sal[b * a.Lv + t] = cs + (a.vid_mask[b * a.Lv + t] != 0.f ? 0.f : UVTG_LOG_TINY);
+    }
+  }
+}
+
+// dx0 += (everything that flows into the pre-encoder tokens from saliency / vid_mem_proj / txt_mem_proj)
+__global__ __launch_bounds__(256) void saliency_bwd_kernel(const SaliencyArgs a) {
+  extern __shared__ float sm[];                 // [d] q | [d] dq | [Lt] dalpha | [8]
+  float* s_q = sm;
+  float* s_dq = sm + a.d;
+  float* s_da = s_dq + a.d;
+  float* s_red = s_da + a.Lt;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
+  const float qn = fmaxf(a.qnorm[b], 1e-8f);
+  for (int c = tid; c < d; c += 256) {
+    s_q[c] = a.pooled[(size_t)b * d + c];
+    s_dq[c] = a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f;
+  }
+  __syncthreads();
+  // video rows: dv = g_sal * (qhat - cos * vhat) / |v| + g_vid ; dq += g_sal * (vhat - cos * qhat) / |q|
+  const float* xv = a.x0 + (size_t)b * a.S * d;
+  float* dxv = a.dx0 + (size_t)b * a.S * d;
+  for (int t = wave; t < a.Lv; t += 4) {
+    const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
+    const float vn = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f), cs = a.cosv[b * a.Lv + t];
+    for (int c = lane; c < d; c += 64) {
+      const float v = xv[(size_t)t * d + c];
+      const float vh = v / vn, qh = s_q[c] / qn;
+      float g = gs * (qh - cs * vh) / vn;
+      if (a.g_vid) g += a.g_vid[(size_t)b * a.gv_sb + (size_t)t * a.gv_st + c];
+      dxv[(size_t)t * d + c] += g;
+      if (gs != 0.f) atomicAdd(&s_dq[c], gs * (vh - cs * qh) / qn);
+    }
+  }
+  __syncthreads();
+  // text rows: q = sum alpha x ; alpha = softmax(x.w + mask)
+  const float* xt = xv + (size_t)a.Lv * d;
+  float* dxt = dxv + (size_t)a.Lv * d;
+  for (int t = wave; t < a.Lt; t += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < d; c += 64) acc += s_dq[c] * xt[(size_t)t * d + c];
+    acc = wave_sum(acc);
+    if (lane == 0) s_da[t] = acc;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int t = 0; t < a.Lt; t++) dot += a.alpha[b * a.Lt + t] * s_da[t];
+  for (int t = wave; t < a.Lt; t += 4) {
+    const float al = a.alpha[b * a.Lt + t];
+    const float dlog = al * (s_da[t] - dot);
+    for (int c = lane; c < d; c += 64) {
+      dxt[(size_t)t * d + c] += al * s_dq[c] + dlog * a.w_pool[c];
+      if (a.dw_pool && dlog != 0.f) atomicAdd(a.dw_pool + c, dlog * xt[(size_t)t * d + c]);
+    }
+  }
+  (void)s_red;
+}
+
+}  // namespace
+
+int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
+                    const float* dim_t, float* pos, unsigned char* kvalid, hipStream_t s) {
+  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_droppath_scales(float* scales, int n, int B, float p, unsigned long long seed, hipStream_t s) {
+  hipLaunchKernelGGL(droppath_kernel, dim3(cdiv(n * B, 256)), dim3(256), 0, s, scales, n, B, p, seed);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, src, dst, n);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s) {
+  const long long n = (long long)rows * ld;
+  hipLaunchKernelGGL(cast_pad_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst, ld);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s) {
+  const long long n = (long long)rows * ld;
+  hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst, ld);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, s, src, rows, cols, dst, ld);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_conv_w_fwd(const float* w, int N, int C, bf16_t* dstB, float* dstF, int ld, hipStream_t s) {
+  const long long n = (long long)N * 3 * C;
+  hipLaunchKernelGGL(conv_w_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, N, C, dstB, dstF, ld);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_conv_w_bwd(const float* w, int N, int C, bf16_t* dst, int ld, int Ntot, int n_off, hipStream_t s) {
+  const long long n = (long long)N * 3 * C;
+  hipLaunchKernelGGL(conv_w_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, N, C, dst, ld, Ntot, n_off);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_heads_final_fwd(const HeadsFinalArgs& a, hipStream_t s) {
+  const int rows = a.B * a.Lv;
+  if (a.precise) hipLaunchKernelGGL(heads_final_fwd_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(heads_final_fwd_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s) {
+  if (a.precise) return -6;
+  hipLaunchKernelGGL(heads_final_bwd_dh_kernel, dim3(a.B * a.Lv), dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(heads_final_bwd_dw_kernel, dim3(cdiv(a.d, 64), 32), dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
+  const size_t sh = (a.Lt + a.d + 8) * sizeof(float);
+  hipLaunchKernelGGL(saliency_fwd_kernel, dim3(a.B), dim3(256), sh, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
+  const size_t sh = (2 * a.d + a.Lt + 8) * sizeof(float);
+  hipLaunchKernelGGL(saliency_bwd_kernel, dim3(a.B), dim3(256), sh, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}

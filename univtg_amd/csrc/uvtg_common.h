@@ -1,0 +1,70 @@
+// Shared device/host helpers for the UniVTG gfx950 kernels (internal; the public C-ABI is include/uvtg.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define UVTG_LOG_TINY (-103.27892990343184f)   // logf(1e-45f) evaluated in fp32 (denormal 2^-149)
+
+__device__ __forceinline__ bf16_t f2bf(float f) {          // round-to-nearest-even
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+__device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: within each 16-lane group the 16 lanes x 4 elements form a [4][16] matrix in
+// lane order (lane i supplies row i>>2, columns 4*(i&3)..+3); lane i receives column i (rows 0..3).
+// Verified on gfx950 by tools/probe_tr.hip.
+__device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// Counter-based RNG (Philox-4x32-10) for dropout / DropPath: stateless, reproducible in backward.
+__device__ __forceinline__ void philox4(unsigned long long seed, unsigned long long ctr_lo, unsigned ctr_hi, unsigned out[4]) {
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = ctr_hi, c3 = 0x5eed5eedu;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (x >> 8) * (1.0f / 16777216.0f); }
+
+// RNG stream ids (ctr_hi) so that every stochastic op draws from its own stream.
+enum { UVTG_RNG_IN_VID = 0x100, UVTG_RNG_IN_TXT = 0x200, UVTG_RNG_ATTN = 0x300, UVTG_RNG_PATH = 0x400 };
+
+#define UVTG_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

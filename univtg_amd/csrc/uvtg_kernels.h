@@ -1,0 +1,185 @@
+// Internal launcher interface shared by the kernel translation units and the engine.
+// (Public C-ABI: include/uvtg.h.)  All launchers enqueue on `stream`, never allocate, return 0/hipError_t.
+#pragma once
+#include "uvtg_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// GEMM  C[M,N] = A[M,K] * B[N,K]^T   (both operands K-contiguous), fused epilogue.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const void* A;      // bf16 (fast) or fp32 (x3) [rows, lda]
+  const void* B;      // bf16 / fp32 [N, ldb]
+  int M, N, K, lda, ldb;
+  // A-row gather: arow(m) = (m / a_seg) * a_seg_stride + (m % a_seg) + a_off   (a_seg == 0: identity)
+  // K is split in taps of `ktap` columns; tap t reads row arow(m) + t, columns k % ktap (3-tap conv).
+  int a_seg, a_seg_stride, a_off, ktap;
+  // output-row scatter, same form
+  int o_seg, o_seg_stride, o_off;
+  // batched groups over blockIdx.z: element offsets added per group
+  long long gA, gB, gBias, gOut, gPre;
+  int groups;
+  // epilogue (applied in this order)
+  const float* bias;       // [N]
+  const float* bias2;      // [N] second bias (token-type embedding row)
+  float colscale; int colscale_n;     // columns < colscale_n are multiplied (q scaling)
+  bf16_t* outPre; int ldpre_out;      // bf16 copy before the activation (pre-GELU, saved for backward)
+  int act;                 // 0 none, 1 relu, 2 gelu(erf)
+  const bf16_t* gradPre; int ldgp; int actgrad;   // 1: zero where gradPre<=0 (relu'), 2: *= gelu'(gradPre)
+  const float* rowscale; int rs_seg;  // per-sample factor rowscale[m / rs_seg] (DropPath)
+  const float* resid; int ldr;        // fp32 residual, indexed by the OUTPUT row
+  float* outF; int ldoF;              // fp32 output
+  bf16_t* outB; int ldoB;             // bf16 output
+  const float* pos; int ldpos; int pos_rows;   // fp32 positional table indexed by m (< pos_rows)
+  bf16_t* outU; float* outUF; int ldoU;        // (value + pos) in bf16 / fp32
+};
+int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s);
+int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s);
+
+// C[N,K] (+)= P[M,N]^T * Q[M,K]  (reduction over rows; fp32 atomic accumulation, split over M)
+struct GemmTNArgs {
+  const bf16_t* P; int ldp;     // [M, ldp]
+  const bf16_t* Q; int ldq;     // [Mq, ldq]
+  int M, N, K;
+  int q_row_off, Mq;            // Q row = m + q_row_off, rows outside [0, Mq) read as zero
+  float* out; int ldo, col_stride;   // out[n * ldo + k * col_stride]
+  float* dbias;                 // optional: dbias[n] += sum_m P[m][n]
+  int splits;
+};
+int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm
+// ---------------------------------------------------------------------------------------------
+struct LnFwdArgs {
+  const float* x; int ldx;      // [rows, D] fp32
+  int rows, D;
+  const float* gamma; const float* beta; float eps;
+  float* mean; float* rstd;     // optional [rows]
+  // dropout on the normalised output (input projections): keep prob 1-p, Philox stream id
+  float p_drop; unsigned long long seed; unsigned stream_id;
+  // outputs (any may be null); Dpad: columns [D, Dpad) of the bf16/f32 GEMM operand are zero-filled
+  float* yF; int ldyF;
+  bf16_t* yB; int ldyB; int Dpad;
+  float* yF2; int ldyF2;        // fp32 GEMM operand with zero padding to Dpad (x3 path)
+  // (y + pos) for rows that are video tokens: row -> (b = row / S, s = row % S), s < Lv
+  const float* pos; int S, Lv;  // pos [B*Lv, D]
+  bf16_t* yU; float* yUF; int ldyU;
+  // copy of the video rows into the zero-framed conv layout [(b*(Lv+2) + s + 1), ldyP]
+  bf16_t* yP; float* yPF; int ldyP;
+};
+int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
+
+struct LnBwdArgs {
+  const float* g; int ldg;      // upstream gradient wrt LN output [rows, D] fp32
+  const float* g2; int ldg2;    // optional second upstream gradient, added (video rows only if g2_Lv>0)
+  int g2_S, g2_Lv;              // g2 row index = b*g2_Lv + s for s < g2_Lv when g2_S > 0; else same row
+  const float* x; int ldx;      // LN input (saved)
+  const float* mean; const float* rstd; const float* gamma;
+  int rows, D;
+  float p_drop; unsigned long long seed; unsigned stream_id;   // same dropout mask as forward
+  float* dgamma; float* dbeta;  // atomically accumulated [D]
+  float* dxF; int lddxF;        // fp32 dx
+  bf16_t* dxB; int lddxB;       // bf16 dx (optionally scaled per sample)
+  const float* rowscale; int rs_seg;
+  int relu_from_x;              // 1: dx is masked by (x > 0): x is the output of a ReLU (input projections)
+};
+int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// attention
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const void* qkv; int ldqkv;   // bf16 (or fp32 when precise) [B*S, 3d]: q | k | v, q pre-scaled
+  void* o; int ldo;             // bf16 / fp32 [B*S, d]
+  float* lse;                   // [B, H, S]
+  const unsigned char* kvalid;  // [B, S] 1 = real key
+  int B, S, H, hd;
+  float p_drop; unsigned long long seed; unsigned layer;
+  int precise;
+  // backward
+  const bf16_t* dO; int lddo;   // [B*S, d]
+  float* delta;                 // [B, H, S] scratch: rowsum(dO * O)
+  bf16_t* dqkv; int lddqkv;     // [B*S, 3d]
+  float qscale;                 // dq is multiplied by the forward q scale
+};
+int launch_attn_fwd(const AttnArgs& a, hipStream_t s);
+int launch_attn_bwd(const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// small fused kernels (misc.hip)
+// ---------------------------------------------------------------------------------------------
+int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
+                    const float* dim_t, float* pos, unsigned char* kvalid, hipStream_t s);
+int launch_droppath_scales(float* scales, int n_layers2, int B, float p, unsigned long long seed, hipStream_t s);
+int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
+int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s);
+int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);
+int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);  // dst[c][r]
+// conv weight (N, C, 3) -> tap-major (N, 3*C) [forward operand]; and its dgrad operand (C, 3*N) with taps flipped
+int launch_conv_w_fwd(const float* w, int N, int C, bf16_t* dstB, float* dstF, int ld, hipStream_t s);
+int launch_conv_w_bwd(const float* w, int N, int C, bf16_t* dst, int ld, int Ntot, int n_off, hipStream_t s);
+
+struct HeadsFinalArgs {           // last conv layer of both heads + sigmoid/sign (model/univtg.py:129-136)
+  const void* h2; int ldh;        // zero-framed [(b*(Lv+2)+t), 2*d]: span half | class half; bf16 or fp32
+  int precise;
+  const float* w_span; const float* b_span;   // (2, d, 3), (2)
+  const float* w_cls; const float* b_cls;     // (1, d, 3), (1)
+  int B, Lv, d;
+  float* pred_logits;  // [B, Lv, 1]
+  float* pred_spans;   // [B, Lv, 2]
+  // backward
+  const float* g_logits; const float* g_spans;   // upstream grads
+  bf16_t* dh2; int lddh;          // zero-framed gradient wrt h2 (pre-activation of layer 3 input), relu' applied
+  float* dw_span; float* db_span; float* dw_cls; float* db_cls;
+};
+int launch_heads_final_fwd(const HeadsFinalArgs& a, hipStream_t s);
+int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s);
+
+struct SaliencyArgs {             // weighted text pooling + cosine saliency (model/univtg.py:36-49,143-147)
+  const float* x0; int S, Lv, Lt, B, d;   // fp32 [B*S, d] projected tokens (video rows then text rows)
+  const float* txt_mask; const float* vid_mask;
+  const float* w_pool;            // [d]
+  float* alpha;                   // [B, Lt] softmax weights (saved)
+  float* pooled;                  // [B, d]  (txt_mem_proj)
+  float* cosv;                    // [B, Lv] raw cosine (saved for the criterion)
+  float* sal;                     // [B, Lv] cosine + log-mask
+  float* vnorm; float* qnorm;     // [B, Lv], [B]
+  // backward
+  const float* g_sal;             // [B, Lv]  d/d saliency_scores
+  const float* g_pooled;          // [B, d]   d/d txt_mem_proj
+  const float* g_vid; long long gv_sb, gv_st;   // d/d vid_mem_proj: g_vid[b*gv_sb + t*gv_st + c], or null
+  float* dx0;                     // [B*S, d] accumulated (+=)
+  float* dw_pool;                 // [d] atomically accumulated
+};
+int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s);
+int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// dense criterion (model/univtg.py:195-282), values + gradients, no host synchronisation
+// ---------------------------------------------------------------------------------------------
+struct LossArgs {
+  int B, Lv, d;
+  const float* pred_logits;   // [B, Lv]
+  const float* pred_spans;    // [B, Lv, 2]
+  const float* vid; long long vid_sb, vid_st;   // vid_mem_proj[b, t, c] = vid[b*vid_sb + t*vid_st + c]
+  const float* txt;           // [B, d] txt_mem_proj
+  const float* timestamp;     // [B, Lv, 2]
+  const float* ts_mask;       // [B, Lv]
+  const float* ts_window;     // [B, Lv]
+  const float* span_nn;       // [B, Lv, 2]
+  const float* sal_tgt;       // [B, Lv] or null
+  const long long* pos_idx;   // [B] or null  (saliency_pos_labels[:, 0])
+  float eos_coef;
+  int do_spans, do_labels, do_saliency;
+  float* ws;                  // workspace, uvtg_loss_ws_floats(B, Lv) floats
+  float* losses;              // [8]: loss_b, loss_g, loss_f, loss_s_inter, loss_s_intra, active, Nwin, Nvalid
+  // backward
+  const float* go;            // [5] upstream gradient per loss (device memory)
+  float* g_logits;            // [B, Lv]
+  float* g_spans;             // [B, Lv, 2]
+  float* g_vid;               // [B, Lv, d] dense
+  float* g_txt;               // [B, d]
+};
+long long loss_ws_floats(int B, int Lv);
+int launch_losses_fwd(const LossArgs& a, hipStream_t s);
+int launch_losses_bwd(const LossArgs& a, hipStream_t s);

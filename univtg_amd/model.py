@@ -1,0 +1,436 @@
+"""Drop-in replacement for the reference's ``model/univtg.py`` boundary on MI355X.
+
+``build_model(args) -> (model, criterion)`` keeps the reference's factory signature
+(model/univtg.py:409-450), ``Model.forward`` its call signature and output dict
+(model/univtg.py:105-155), ``SetCriterion.forward`` its loss dict (model/univtg.py:338-351) and
+``state_dict()`` the reference's checkpoint keys/shapes -- but every FLOP of the hot path
+runs in the hand-written gfx950 kernels of ``libuvtg.so`` through the C ABI of ``include/uvtg.h``.
+PyTorch only owns memory (parameters, activations, gradients), streams and autograd bookkeeping.
+
+There is no CPU / eager fallback: tensors must live on a ROCm device and ``libuvtg.so`` must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+
+__all__ = ["build_model", "Model", "SetCriterion", "HungarianMatcher", "build_matcher"]
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Bag(nn.Module):
+    """Parameter container (no forward): only exists to reproduce the reference's state_dict keys."""
+
+
+def _linear_bag(out_f, in_f):
+    b = _Bag()
+    b.weight = nn.Parameter(torch.empty(out_f, in_f))
+    b.bias = nn.Parameter(torch.empty(out_f))
+    nn.init.kaiming_uniform_(b.weight, a=math.sqrt(5))          # nn.Linear default (LinearLayer, univtg.py:392-395)
+    bound = 1 / math.sqrt(in_f)
+    nn.init.uniform_(b.bias, -bound, bound)
+    return b
+
+
+def _ln_bag(dim):
+    b = _Bag()
+    b.weight = nn.Parameter(torch.ones(dim))
+    b.bias = nn.Parameter(torch.zeros(dim))
+    return b
+
+
+def _conv_bag(out_c, in_c, k=3):
+    b = _Bag()
+    b.weight = nn.Parameter(torch.empty(out_c, in_c, k))
+    b.bias = nn.Parameter(torch.empty(out_c))
+    nn.init.kaiming_uniform_(b.weight, a=math.sqrt(5))          # nn.Conv1d default (Conv, univtg.py:375-377)
+    bound = 1 / math.sqrt(in_c * k)
+    nn.init.uniform_(b.bias, -bound, bound)
+    return b
+
+
+def _proj_bag(in_f, hidden, n_layers):
+    """input_{vid,txt}_proj: Sequential of LinearLayer(LayerNorm, net=[Dropout, Linear]) (univtg.py:91-100)."""
+    seq = nn.ModuleList()
+    for i in range(n_layers):
+        blk = _Bag()
+        blk.LayerNorm = _ln_bag(in_f if i == 0 else hidden)
+        blk.net = nn.ModuleList([_Bag(), _linear_bag(hidden, in_f if i == 0 else hidden)])
+        seq.append(blk)
+    return seq
+
+
+def _encoder_bag(d, F, E):
+    tr = _Bag()
+    tr.encoder = _Bag()
+    layers = nn.ModuleList()
+    for _ in range(E):
+        lay = _Bag()
+        lay.self_attn = _Bag()
+        lay.self_attn.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        lay.self_attn.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        lay.self_attn.out_proj = _Bag()
+        lay.self_attn.out_proj.weight = nn.Parameter(torch.empty(d, d))
+        lay.self_attn.out_proj.bias = nn.Parameter(torch.zeros(d))
+        lay.linear1 = _linear_bag(F, d)
+        lay.linear2 = _linear_bag(d, F)
+        lay.norm1 = _ln_bag(d)
+        lay.norm2 = _ln_bag(d)
+        layers.append(lay)
+    tr.encoder.layers = layers
+    for p in tr.parameters():                                   # Transformer._reset_parameters (droppath.py:32-35)
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+    return tr
+
+
+class _UniVTGFunction(torch.autograd.Function):
+    """Whole-model autograd node: one C call forward, one C call backward."""
+
+    @staticmethod
+    def forward(ctx, model, src_txt, src_txt_mask, src_vid, src_vid_mask, *params):
+        lib = _lib.load()
+        B, Lv, Dv = src_vid.shape
+        Lt, Dt = src_txt.shape[1], src_txt.shape[2]
+        dev = src_vid.device
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        training = bool(model.training or need_grad)
+        if training and model.precision != "bf16":
+            raise RuntimeError("backward is implemented for precision='bf16'; the 'fp32x3' mode is inference-only")
+        dims = model._dims(B, Lv, Lt, Dv, Dt, training)
+        ptrs = model._param_ptrs(params)
+        wcache = model._prepare(dims, ptrs, params)
+        S, d = Lv + Lt, dims.d
+        ws = torch.empty(lib.uvtg_workspace_bytes(C.byref(dims)), dtype=torch.uint8, device=dev)
+        x0 = torch.empty(B, S, d, device=dev)
+        pred_logits = torch.empty(B, Lv, 1, device=dev)
+        pred_spans = torch.empty(B, Lv, 2, device=dev)
+        txt_mem = torch.empty(B, 1, d, device=dev)
+        sal = torch.empty(B, Lv, device=dev)
+        memory = torch.empty(B, S, d, device=dev) if model.return_memory else None
+        _lib.check(lib.uvtg_forward(C.byref(dims), ptrs, _ptr(wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
+                                    _ptr(src_vid_mask), _ptr(model._dim_t(dev)), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans),
+                                    _ptr(txt_mem), _ptr(sal), _ptr(memory), _ptr(ws), _stream()), "uvtg_forward")
+        if training:
+            ctx.model, ctx.dims, ctx.ws, ctx.wcache = model, dims, ws, wcache
+            ctx.save_for_backward(src_txt, src_txt_mask, src_vid, src_vid_mask, x0, pred_logits, pred_spans, txt_mem, *params)
+        ctx.mark_non_differentiable(*([memory] if memory is not None else []))
+        outs = (x0, pred_logits, pred_spans, txt_mem, sal)
+        return outs + ((memory,) if memory is not None else ())
+
+    @staticmethod
+    def backward(ctx, g_x0, g_logits, g_spans, g_txt, g_sal, *unused):
+        lib = _lib.load()
+        model, dims = ctx.model, ctx.dims
+        src_txt, src_txt_mask, src_vid, src_vid_mask, x0, pred_logits, pred_spans, txt_mem, *params = ctx.saved_tensors
+        ptrs = model._param_ptrs(params)
+        offs = model._offsets(dims)
+        grads = torch.empty(offs[-1], device=x0.device)
+        g = [None if t is None else _f32c(t) for t in (g_logits, g_spans, g_sal, g_txt, g_x0)]
+        S, d = x0.shape[1], x0.shape[2]
+        _lib.check(lib.uvtg_backward(C.byref(dims), ptrs, _ptr(ctx.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
+                                     _ptr(src_vid_mask), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans), _ptr(txt_mem),
+                                     _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d,
+                                     _ptr(grads), _ptr(ctx.ws), _stream()), "uvtg_backward")
+        ctx.ws = None
+        out = [None] * 5
+        for i, p in enumerate(params):
+            out.append(grads[offs[i]: offs[i] + p.numel()].view_as(p) if p.requires_grad else None)
+        return tuple(out)
+
+
+class Model(nn.Module):
+    """MI355X UniVTG model.  Same constructor surface as the reference's ``Model`` where it matters
+    (hidden sizes instead of sub-modules) and the same ``forward`` signature / output dict."""
+
+    def __init__(self, hidden_dim, nheads, dim_feedforward, enc_layers, txt_dim, vid_dim, input_dropout, dropout=0.1,
+                 droppath=0.1, max_q_l=75, max_v_l=75, span_loss_type="l1", use_txt_pos=False, n_input_proj=2,
+                 precision="bf16", proj_precise=True):
+        super().__init__()
+        if span_loss_type != "l1":
+            raise NotImplementedError("span_loss_type='ce' is not implemented by the reference forward either (univtg.py:137-138)")
+        if use_txt_pos:
+            raise NotImplementedError("--use_txt_pos is never set by the reference scripts and is not on the accelerated path")
+        if n_input_proj != 2:
+            raise NotImplementedError("only n_input_proj=2 (the value of every reference script) is implemented")
+        if precision not in ("bf16", "fp32x3"):
+            raise ValueError("precision must be 'bf16' or 'fp32x3'")
+        d = hidden_dim
+        self.hidden_dim, self.nheads, self.dim_feedforward, self.enc_layers = d, nheads, dim_feedforward, enc_layers
+        self.txt_dim, self.vid_dim = txt_dim, vid_dim
+        self.input_dropout, self.dropout, self.droppath = float(input_dropout), float(dropout), float(droppath)
+        self.span_loss_type, self.max_v_l, self.use_txt_pos, self.n_input_proj = span_loss_type, max_v_l, use_txt_pos, n_input_proj
+        self.precision, self.proj_precise, self.return_memory = precision, bool(proj_precise), False
+        # ---- parameters, registered in the reference's order / names ----
+        self.transformer = _encoder_bag(d, dim_feedforward, enc_layers)
+        self.txt_position_embed = _Bag()                                    # unused unless use_txt_pos (kept for ckpt parity)
+        self.txt_position_embed.position_embeddings = _Bag()
+        self.txt_position_embed.position_embeddings.weight = nn.Parameter(torch.randn(max_q_l, d))
+        self.txt_position_embed.LayerNorm = _ln_bag(d)
+        self.token_type_embeddings = _Bag()
+        self.token_type_embeddings.weight = nn.Parameter(torch.empty(2, d).normal_(0.0, 0.02))
+        for name, out in (("span_embed", 2), ("class_embed", 1)):
+            head = _Bag()
+            head.layers = nn.ModuleList([_conv_bag(d, d), _conv_bag(d, d), _conv_bag(out, d)])
+            setattr(self, name, head)
+        self.input_txt_proj = _proj_bag(txt_dim, d, n_input_proj)
+        self.input_vid_proj = _proj_bag(vid_dim, d, n_input_proj)
+        self.weightedpool = _Bag()
+        self.weightedpool.weight = nn.Parameter(nn.init.xavier_uniform_(torch.empty(d, 1)))
+        self._step = 0
+        self._seed = 0x5EED
+        self._wcache = {}
+        self._dimt = None
+        self._off_cache = {}
+
+    # ---- parameter table in the C-ABI order (include/uvtg.h) ----
+    def _ordered_params(self):
+        ps = []
+        for lay in self.transformer.encoder.layers:
+            ps += [lay.self_attn.in_proj_weight, lay.self_attn.in_proj_bias, lay.self_attn.out_proj.weight,
+                   lay.self_attn.out_proj.bias, lay.linear1.weight, lay.linear1.bias, lay.linear2.weight, lay.linear2.bias,
+                   lay.norm1.weight, lay.norm1.bias, lay.norm2.weight, lay.norm2.bias]
+        ps.append(self.token_type_embeddings.weight)
+        for head in (self.span_embed, self.class_embed):
+            for c in head.layers:
+                ps += [c.weight, c.bias]
+        for proj in (self.input_txt_proj, self.input_vid_proj):
+            for blk in proj:
+                ps += [blk.LayerNorm.weight, blk.LayerNorm.bias, blk.net[1].weight, blk.net[1].bias]
+        ps.append(self.weightedpool.weight)
+        return ps
+
+    def _dims(self, B, Lv, Lt, Dv, Dt, training):
+        if Dv != self.vid_dim or Dt != self.txt_dim:
+            raise ValueError(f"feature dims ({Dv}, {Dt}) do not match the model ({self.vid_dim}, {self.txt_dim})")
+        if training:
+            self._step += 1
+        return _lib.Dims(B=B, Lv=Lv, Lt=Lt, d=self.hidden_dim, H=self.nheads, F=self.dim_feedforward, E=self.enc_layers,
+                         Dv=Dv, Dt=Dt, n_proj=self.n_input_proj, precise=int(self.precision == "fp32x3"),
+                         training=int(training), proj_precise=int(self.proj_precise),
+                         p_in=self.input_dropout if self.training else 0.0,
+                         p_attn=self.dropout if self.training else 0.0,
+                         p_path=self.droppath if self.training else 0.0,
+                         seed=(self._seed * 1000003 + self._step) & 0xFFFFFFFFFFFFFFFF)
+
+    def _param_ptrs(self, params):
+        arr = (C.c_void_p * len(params))()
+        for i, p in enumerate(params):
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("parameters must be contiguous fp32 tensors")
+            arr[i] = p.data_ptr()
+        return arr
+
+    def _offsets(self, dims):
+        key = (dims.d, dims.F, dims.E, dims.Dv, dims.Dt)
+        if key not in self._off_cache:
+            lib = _lib.load()
+            n = lib.uvtg_param_count(C.byref(dims))
+            buf = (C.c_longlong * (n + 1))()
+            _lib.check(lib.uvtg_param_offsets(C.byref(dims), buf), "uvtg_param_offsets")
+            self._off_cache[key] = list(buf)
+        return self._off_cache[key]
+
+    def _prepare(self, dims, ptrs, params):
+        """(Re)build the MFMA operand cache when any parameter changed (tracked by tensor versions)."""
+        lib = _lib.load()
+        key = (dims.precise, dims.training, dims.proj_precise, dims.Dv, dims.Dt)
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != sig:
+            nbytes = lib.uvtg_wcache_bytes(C.byref(dims))
+            buf = ent[1] if ent is not None and ent[1].numel() == nbytes else torch.empty(nbytes, dtype=torch.uint8, device=params[0].device)
+            _lib.check(lib.uvtg_prepare_weights(C.byref(dims), ptrs, _ptr(buf), _stream()), "uvtg_prepare_weights")
+            self._wcache[key] = (sig, buf)
+            ent = self._wcache[key]
+        return ent[1]
+
+    def _dim_t(self, dev):
+        if self._dimt is None or self._dimt.device != dev:
+            d = self.hidden_dim                                       # position_encoding.py:75-78, evaluated by torch on host
+            i = torch.arange(d, dtype=torch.float32)
+            self._dimt = (10000 ** (2 * torch.div(i, 2).int() / d)).to(dev)
+        return self._dimt
+
+    def set_seed(self, seed: int):
+        self._seed, self._step = int(seed), 0
+
+    def forward(self, src_txt, src_txt_mask, src_vid, src_vid_mask, src_cls=None, src_cls_mask=None):
+        if src_cls is not None:
+            raise NotImplementedError("src_cls (TAL 'saliency_cls' pre-training, main/train_vlp.py) is outside the accelerated path")
+        if not src_vid.is_cuda:
+            raise RuntimeError("univtg_amd runs on MI355X only: inputs must be on a ROCm device (no CPU fallback)")
+        params = self._ordered_params()
+        args = [_f32c(t) for t in (src_txt, src_txt_mask, src_vid, src_vid_mask)]
+        res = _UniVTGFunction.apply(self, *args, *params)
+        x0, pred_logits, pred_spans, txt_mem, sal = res[:5]
+        Lv = src_vid.shape[1]
+        out = {"pred_logits": pred_logits, "pred_spans": pred_spans, "src_vid_mask": src_vid_mask,
+               "vid_mem_proj": x0[:, :Lv], "txt_mem_proj": txt_mem, "saliency_scores": sal}
+        if self.return_memory:
+            out["memory"] = res[5]
+        return out
+
+
+class _CriterionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, which, eos_coef, pred_logits, pred_spans, vid, txt, timestamp, ts_mask, ts_window, span_nn, sal, pos_idx):
+        lib = _lib.load()
+        B, Lv = pred_logits.shape[0], pred_logits.shape[1]
+        d = vid.shape[-1]
+        if vid.stride(2) != 1:
+            vid = vid.contiguous()
+        pl, ps, tx = _f32c(pred_logits), _f32c(pred_spans), _f32c(txt)
+        ws = torch.empty(lib.uvtg_loss_ws_floats(B, Lv), device=pl.device)
+        losses = torch.empty(8, device=pl.device)
+        _lib.check(lib.uvtg_criterion_fwd(B, Lv, d, which, eos_coef, _ptr(pl), _ptr(ps), _ptr(vid), vid.stride(0), vid.stride(1),
+                                          _ptr(tx), _ptr(timestamp), _ptr(ts_mask), _ptr(ts_window), _ptr(span_nn), _ptr(sal),
+                                          _ptr(pos_idx), _ptr(ws), _ptr(losses), _stream()), "uvtg_criterion_fwd")
+        ctx.which, ctx.eos, ctx.ws = which, eos_coef, ws
+        ctx.shapes = (pred_logits.shape, pred_spans.shape, txt.shape)
+        ctx.save_for_backward(pl, ps, vid, tx, timestamp, ts_mask, ts_window, span_nn, sal, pos_idx, losses)
+        return losses[:5].clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        lib = _lib.load()
+        pl, ps, vid, tx, timestamp, ts_mask, ts_window, span_nn, sal, pos_idx, losses = ctx.saved_tensors
+        B, Lv, d = pl.shape[0], pl.shape[1], vid.shape[-1]
+        go = _f32c(go)
+        g_l, g_s = torch.empty(B, Lv, device=pl.device), torch.empty(B, Lv, 2, device=pl.device)
+        g_v, g_t = torch.empty(B, Lv, d, device=pl.device), torch.empty(B, d, device=pl.device)
+        _lib.check(lib.uvtg_criterion_bwd(B, Lv, d, ctx.which, ctx.eos, _ptr(pl), _ptr(ps), _ptr(vid), vid.stride(0), vid.stride(1),
+                                          _ptr(tx), _ptr(timestamp), _ptr(ts_mask), _ptr(ts_window), _ptr(span_nn), _ptr(sal),
+                                          _ptr(pos_idx), _ptr(ctx.ws), _ptr(losses), _ptr(go), _ptr(g_l), _ptr(g_s), _ptr(g_v),
+                                          _ptr(g_t), _stream()), "uvtg_criterion_bwd")
+        sl, ss, st = ctx.shapes
+        return (None, None, g_l.view(sl), g_s.view(ss), g_v, g_t.view(st)) + (None,) * 6
+
+
+class SetCriterion(nn.Module):
+    """Dense UniVTG criterion (model/univtg.py:157-351) on device; same constructor, ``weight_dict`` and loss keys."""
+
+    def __init__(self, matcher, weight_dict, eos_coef, losses, temperature, span_loss_type, max_v_l, saliency_margin=1):
+        super().__init__()
+        self.matcher, self.weight_dict, self.losses = matcher, weight_dict, losses
+        self.span_loss_type, self.max_v_l, self.saliency_margin = span_loss_type, max_v_l, saliency_margin
+        self.temperature = 0.07                       # the reference overwrites --temperature (univtg.py:185)
+        self.foreground_label, self.background_label, self.eos_coef = 0, 1, eos_coef
+        empty_weight = torch.ones(2)
+        empty_weight[-1] = eos_coef
+        self.register_buffer("empty_weight", empty_weight)
+        for name in losses:
+            if name not in ("spans", "labels", "saliency"):
+                raise NotImplementedError(f"loss '{name}' is outside the accelerated path (only spans/labels/saliency)")
+
+    def forward(self, outputs, targets, hl_only=False):
+        which = (1 if "spans" in self.losses else 0) | (2 if "labels" in self.losses else 0) | (4 if "saliency" in self.losses else 0)
+        pl = outputs["pred_logits"]
+        if not pl.is_cuda:
+            raise RuntimeError("univtg_amd criterion runs on MI355X only (no CPU fallback)")
+        f = lambda k: _f32c(targets[k])
+        has_sal = ("saliency_pos_labels" in targets) and ("saliency_scores" in targets)
+        sal = f("saliency_scores") if has_sal else None
+        pos = targets["saliency_pos_labels"][:, 0].long().contiguous() if has_sal else None
+        res = _CriterionFunction.apply(which, float(self.eos_coef), pl, outputs["pred_spans"], outputs["vid_mem_proj"],
+                                       outputs["txt_mem_proj"], f("timestamp"), f("timestamp_mask"), f("timestamp_window"),
+                                       f("span_labels_nn"), sal, pos)
+        out = {}
+        if which & 1:
+            out["loss_b"], out["loss_g"] = res[0], res[1]
+        if which & 2:
+            out["loss_f"] = res[2]
+        if which & 4:
+            out["loss_s_inter"], out["loss_s_intra"] = res[3], res[4]
+        return out
+
+
+class HungarianMatcher(nn.Module):
+    """model/matcher.py:13-100 on device (cost matrix + per-sample LSAP kernels); same call signature/return."""
+
+    def __init__(self, cost_class=1.0, cost_span=1.0, cost_giou=1.0, span_loss_type="l1", max_v_l=75):
+        super().__init__()
+        if span_loss_type != "l1":
+            raise NotImplementedError("only the l1 span cost is implemented")
+        assert cost_class != 0 or cost_span != 0 or cost_giou != 0, "all costs cant be 0"
+        self.cost_class, self.cost_span, self.cost_giou = cost_class, cost_span, cost_giou
+        self.span_loss_type, self.max_v_l, self.foreground_label = span_loss_type, max_v_l, 0
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        lib = _lib.load()
+        logits, spans = _f32c(outputs["pred_logits"]), _f32c(outputs["pred_spans"])
+        if not logits.is_cuda:
+            raise RuntimeError("univtg_amd matcher runs on MI355X only (no CPU fallback)")
+        B, Q = spans.shape[:2]
+        tg = targets["span_labels"]
+        sizes = [len(v["spans"]) for v in tg]
+        max_t = max(1, max(sizes))
+        dev = logits.device
+        tgt = torch.cat([_f32c(v["spans"]).to(dev) for v in tg]) if sum(sizes) else torch.zeros(1, 2, device=dev)
+        off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+        cost = torch.empty(B, Q, max_t, device=dev)
+        op = torch.empty(B, max_t, dtype=torch.int64, device=dev)
+        ot = torch.empty(B, max_t, dtype=torch.int64, device=dev)
+        nm = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.check(lib.uvtg_hungarian(_ptr(logits), logits.shape[-1], _ptr(spans), B, Q, _ptr(tgt), _ptr(off), max_t,
+                                      float(self.cost_class), float(self.cost_span), float(self.cost_giou),
+                                      _ptr(cost), _ptr(op), _ptr(ot), _ptr(nm), _stream()), "uvtg_hungarian")
+        op, ot, nm = op.cpu(), ot.cpu(), nm.cpu().tolist()
+        if any(n < 0 for n in nm):
+            raise RuntimeError("uvtg_hungarian: problem larger than the device LSAP limits (32 x 256)")
+        return [(op[b, :nm[b]].clone(), ot[b, :nm[b]].clone()) for b in range(B)]
+
+
+def build_matcher(args):
+    return HungarianMatcher(cost_span=args.set_cost_span, cost_giou=args.set_cost_giou, cost_class=args.set_cost_class,
+                            span_loss_type=args.span_loss_type, max_v_l=args.max_v_l)
+
+
+def build_model(args):
+    """Same contract as the reference factory (model/univtg.py:409-450): reads the same ``args`` fields and
+    returns ``(model, criterion)``; ``main/config.py:setup_model`` moves the model to the device itself."""
+    device = torch.device(args.device)
+    model = Model(hidden_dim=args.hidden_dim, nheads=args.nheads, dim_feedforward=args.dim_feedforward,
+                  enc_layers=args.enc_layers, txt_dim=args.t_feat_dim, vid_dim=args.v_feat_dim,
+                  input_dropout=args.input_dropout, dropout=args.dropout, droppath=args.droppath,
+                  max_q_l=args.max_q_l, max_v_l=getattr(args, "max_v_l", 75), span_loss_type=args.span_loss_type,
+                  use_txt_pos=args.use_txt_pos, n_input_proj=args.n_input_proj,
+                  precision=getattr(args, "precision", "bf16"), proj_precise=getattr(args, "proj_precise", True))
+    if getattr(args, "pre_norm", False):
+        raise NotImplementedError("--pre_norm crashes in the reference too (forward_pre is undefined, droppath.py:133)")
+    matcher = build_matcher(args)
+    weight_dict = {"loss_b": args.b_loss_coef, "loss_g": args.g_loss_coef, "loss_f": args.f_loss_coef,
+                   "loss_s_intra": args.s_loss_intra_coef, "loss_s_inter": args.s_loss_inter_coef}
+    if args.dset_type in ["mr", "vlp"]:
+        if "tal" not in args.train_path:
+            losses = ["spans", "labels", "saliency"]
+        else:
+            raise NotImplementedError("'saliency_cls' (TAL pre-training) is outside the accelerated path")
+    elif args.dset_type in ["hl", "vs"]:
+        losses = ["labels", "saliency"]
+    else:
+        raise ValueError(args.dset_type)
+    criterion = SetCriterion(matcher=matcher, weight_dict=weight_dict, losses=losses, eos_coef=args.eos_coef,
+                             temperature=args.temperature, span_loss_type=args.span_loss_type, max_v_l=args.max_v_l,
+                             saliency_margin=args.saliency_margin)
+    criterion.to(device)
+    return model, criterion
