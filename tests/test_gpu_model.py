@@ -137,13 +137,17 @@ def test_losses_and_grads_match_reference(dev, golden_dir, name):
         tol = 2e-2 * max(1.0, abs(ref)) if k in ("loss_b", "loss_g", "loss_f") else 2e-4 * max(1.0, abs(ref))
         assert abs(got - ref) < tol, (k, got, ref)
     named = dict(model.named_parameters())
-    worst = {}
+    # bf16 operands vs the fp32 reference: per-parameter direction (cosine) and magnitude (norm ratio) --
+    # element-wise max error is dominated by bf16 rounding noise at these tiny widths (d=64/128)
+    bad = {}
     for k, g in grads_ref.items():
         assert named[k].grad is not None, k
-        scale = float(g.abs().max()) + 1e-12
-        worst[k] = float((named[k].grad.cpu() - g).abs().max()) / scale
-    bad = {k: v for k, v in worst.items() if v > 6e-2}
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+        a, r = named[k].grad.cpu().double().flatten(), g.double().flatten()
+        cos = float((a @ r) / (a.norm() * r.norm() + 1e-30))
+        ratio = float(a.norm() / (r.norm() + 1e-30))
+        if cos < 0.985 or abs(ratio - 1) > 0.05:
+            bad[k] = (cos, ratio)
+    assert not bad, bad
     assert {k for k, p in named.items() if p.grad is None} == set(meta["no_grad_params"])
 
 
@@ -240,9 +244,11 @@ def test_production_width_vs_oracle(dev):
               "input_vid_proj.0.net.1.weight", "input_vid_proj.0.LayerNorm.weight", "span_embed.layers.0.weight",
               "class_embed.layers.2.weight", "weightedpool.weight", "token_type_embeddings.weight",
               "transformer.encoder.layers.0.norm1.bias", "input_txt_proj.1.net.1.bias"):
-        g = p2[k].grad
-        e = float((named[k].grad.cpu() - g).abs().max()) / (float(g.abs().max()) + 1e-12)
-        assert e < 8e-2, (k, e)
+        a, r = named[k].grad.cpu().double().flatten(), p2[k].grad.double().flatten()
+        cos = float((a @ r) / (a.norm() * r.norm() + 1e-30))
+        ratio = float(a.norm() / (r.norm() + 1e-30))
+        e = float((a - r).abs().max() / (r.abs().max() + 1e-30))
+        assert cos > 0.998 and abs(ratio - 1) < 0.01 and e < 0.12, (k, cos, ratio, e)
 
 
 def test_config2_size_properties(dev):

@@ -61,6 +61,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the UniVTG MI355X kernels are not built. Run `python -m univtg_amd.build` "
             "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU / PyTorch fallback.")
+    # torch first: libuvtg.so must share the HIP runtime instance (and its device context / streams) that
+    # PyTorch-ROCm loaded; loading it before torch binds a second runtime that sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -106,13 +106,12 @@ class _UniVTGFunction(torch.autograd.Function):
     """Whole-model autograd node: one C call forward, one C call backward."""
 
     @staticmethod
-    def forward(ctx, model, src_txt, src_txt_mask, src_vid, src_vid_mask, *params):
+    def forward(ctx, model, need_grad, src_txt, src_txt_mask, src_vid, src_vid_mask, *params):
         lib = _lib.load()
         B, Lv, Dv = src_vid.shape
         Lt, Dt = src_txt.shape[1], src_txt.shape[2]
         dev = src_vid.device
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        training = bool(model.training or need_grad)
+        training = bool(need_grad)                     # decided by the caller: Function.forward runs under no_grad
         if training and model.precision != "bf16":
             raise RuntimeError("backward is implemented for precision='bf16'; the 'fp32x3' mode is inference-only")
         dims = model._dims(B, Lv, Lt, Dv, Dt, training)
@@ -129,6 +128,7 @@ class _UniVTGFunction(torch.autograd.Function):
         _lib.check(lib.uvtg_forward(C.byref(dims), ptrs, _ptr(wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                     _ptr(src_vid_mask), _ptr(model._dim_t(dev)), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans),
                                     _ptr(txt_mem), _ptr(sal), _ptr(memory), _ptr(ws), _stream()), "uvtg_forward")
+        ctx.model = None
         if training:
             ctx.model, ctx.dims, ctx.ws, ctx.wcache = model, dims, ws, wcache
             ctx.save_for_backward(src_txt, src_txt_mask, src_vid, src_vid_mask, x0, pred_logits, pred_spans, txt_mem, *params)
@@ -151,7 +151,7 @@ class _UniVTGFunction(torch.autograd.Function):
                                      _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d,
                                      _ptr(grads), _ptr(ctx.ws), _stream()), "uvtg_backward")
         ctx.ws = None
-        out = [None] * 5
+        out = [None] * 6
         for i, p in enumerate(params):
             out.append(grads[offs[i]: offs[i] + p.numel()].view_as(p) if p.requires_grad else None)
         return tuple(out)
@@ -280,7 +280,8 @@ class Model(nn.Module):
             raise RuntimeError("univtg_amd runs on MI355X only: inputs must be on a ROCm device (no CPU fallback)")
         params = self._ordered_params()
         args = [_f32c(t) for t in (src_txt, src_txt_mask, src_vid, src_vid_mask)]
-        res = _UniVTGFunction.apply(self, *args, *params)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        res = _UniVTGFunction.apply(self, need_grad, *args, *params)
         x0, pred_logits, pred_spans, txt_mem, sal = res[:5]
         Lv = src_vid.shape[1]
         out = {"pred_logits": pred_logits, "pred_spans": pred_spans, "src_vid_mask": src_vid_mask,
