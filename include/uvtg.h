@@ -158,6 +158,19 @@ int uvtg_decode_rank_nms(const float* pred_logits, const float* pred_spans, cons
                          float nms_thd, int max_before, int max_after,
                          double* windows_out, int* order, int* keep, int* n_keep, uvtg_stream_t stream);
 
+/* ---- training-step shell: replaces clip_grad_norm_ + AdamW.step (main/train_vlp_ddp.py:66-68,
+ * main/config.py:349-350) over ONE flat fp32 buffer laid out by uvtg_param_offsets.
+ * g' = grads * grad_scale (1/world after an all-reduce-sum), clipped to global norm max_norm (<=0: off);
+ * torch.optim.AdamW semantics (decoupled decay, bias correction with `step` starting at 1).  scratch: 2 floats. */
+int uvtg_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float max_norm, float grad_scale, float* scratch, uvtg_stream_t stream);
+
+/* ---- measurement hooks (bench.py): HIP events around every launch of the three GEMM kernels, recorded on
+ * the launch stream.  index 0: gemm_nt bf16, 1: gemm_nt split-bf16, 2: gemm_tn (wgrad).  host arrays [3]. */
+int uvtg_profile_start(void);
+int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
+
 const char* uvtg_strerror(int code);
 int uvtg_version(void);
 

@@ -142,37 +142,41 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   }
 
   // ---------------- epilogue ----------------
+  // (fully unrolled with compile-time accumulator indices: a rolled loop would force acc[][] into scratch memory)
   const float* bias = p.bias ? p.bias + (size_t)gz * p.gBias : nullptr;
   const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
-#pragma unroll
+  const bool has_u = p.outU || p.outUF;
+#pragma clang loop unroll(full)
   for (int i = 0; i < 2; i++) {
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int r = 0; r < 16; r++) {
       const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (m >= p.M) continue;
-      const size_t orow = (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off);
-      const float rs = p.rowscale ? p.rowscale[m / p.rs_seg] : 1.0f;
-#pragma unroll
+      const bool mok = m < p.M;
+      const int mc = mok ? m : p.M - 1;
+      const size_t orow = (size_t)map_row(mc, p.o_seg, p.o_seg_stride, p.o_off);
+      const float rs = p.rowscale ? p.rowscale[mc / p.rs_seg] : 1.0f;
+#pragma clang loop unroll(full)
       for (int j = 0; j < 2; j++) {
         const int n = n0 + wn * 64 + j * 32 + l31;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r];
-        if (bias) v += bias[n];
-        if (p.bias2) v += p.bias2[n];
-        if (n < p.colscale_n) v *= p.colscale;
-        if (p.outPre) p.outPre[go + orow * p.ldpre_out + n] = f2bf(v);
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = gelu_erf(v);
-        if (p.actgrad == 1) v = bf2f(p.gradPre[gp + orow * p.ldgp + n]) > 0.f ? v : 0.f;
-        else if (p.actgrad == 2) v *= gelu_erf_grad(bf2f(p.gradPre[gp + orow * p.ldgp + n]));
-        v *= rs;
-        if (p.resid) v += p.resid[orow * p.ldr + n];
-        if (p.outF) p.outF[go + orow * p.ldoF + n] = v;
-        if (p.outB) p.outB[go + orow * p.ldoB + n] = f2bf(v);
-        if (p.outU || p.outUF) {
-          const float u = v + ((p.pos && m < p.pos_rows) ? p.pos[(size_t)m * p.ldpos + n] : 0.f);
-          if (p.outU) p.outU[orow * p.ldoU + n] = f2bf(u);
-          if (p.outUF) p.outUF[orow * p.ldoU + n] = u;
+        if (mok && n < p.N) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[n];
+          if (p.bias2) v += p.bias2[n];
+          if (n < p.colscale_n) v *= p.colscale;
+          if (p.outPre) p.outPre[go + orow * p.ldpre_out + n] = f2bf(v);
+          if (p.act == 1) v = fmaxf(v, 0.f);
+          else if (p.act == 2) v = gelu_erf(v);
+          if (p.actgrad == 1) v = bf2f(p.gradPre[gp + orow * p.ldgp + n]) > 0.f ? v : 0.f;
+          else if (p.actgrad == 2) v *= gelu_erf_grad(bf2f(p.gradPre[gp + orow * p.ldgp + n]));
+          v *= rs;
+          if (p.resid) v += p.resid[orow * p.ldr + n];
+          if (p.outF) p.outF[go + orow * p.ldoF + n] = v;
+          if (p.outB) p.outB[go + orow * p.ldoB + n] = f2bf(v);
+          if (has_u) {
+            const float u = v + ((p.pos && m < p.pos_rows) ? p.pos[(size_t)m * p.ldpos + n] : 0.f);
+            if (p.outU) p.outU[orow * p.ldoU + n] = f2bf(u);
+            if (p.outUF) p.outUF[orow * p.ldoU + n] = u;
+          }
         }
       }
     }
@@ -281,6 +285,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs p) {
 
 }  // namespace
 
+void uvtg_prof_begin_launch(int family, double flops, hipStream_t s);
+void uvtg_prof_end_launch(int family, hipStream_t s);
+
 static int check_nt(const GemmArgs& a, int elem) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
   const int al = 16 / elem;   // elements per 16 bytes
@@ -293,14 +300,18 @@ static int check_nt(const GemmArgs& a, int elem) {
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
   if (int e = check_nt(a, 2)) return e;
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
+  uvtg_prof_begin_launch(0, 2.0 * a.M * a.N * a.K * grid.z, s);
   hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, s, a);
+  uvtg_prof_end_launch(0, s);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
 int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s) {
   if (int e = check_nt(a, 4)) return e;
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
+  uvtg_prof_begin_launch(1, 2.0 * a.M * a.N * a.K * grid.z, s);
   hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, s, a);
+  uvtg_prof_end_launch(1, s);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -308,7 +319,9 @@ int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.splits <= 0) return -1;
   if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15)) return -2;
   dim3 grid(cdiv(a.N, 128) * cdiv(a.K, 128), a.splits, 1);
+  uvtg_prof_begin_launch(2, 2.0 * a.M * a.N * a.K, s);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, a);
+  uvtg_prof_end_launch(2, s);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,105 @@
+// Training-step shell on device: global-norm gradient clipping + AdamW over ONE flat fp32 parameter buffer
+// (replaces nn.utils.clip_grad_norm_ + torch.optim.AdamW of main/train_vlp_ddp.py:66-68, main/config.py:349-350:
+// ~100 small launches -> 2 kernels), plus the per-kernel timing hooks bench.py uses for its roofline line.
+#include "uvtg_kernels.h"
+#include "../../include/uvtg.h"
+#include <vector>
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = ((const f32x4*)g)[i];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0) for (long long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) acc += g[i] * g[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2s, float max_norm,
+                                                    float grad_scale, const float* sqn) {
+  // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+  const float total = sqrtf(*sqn) * grad_scale;
+  const float coef = grad_scale * (max_norm > 0.f ? fminf(1.f, max_norm / (total + 1e-6f)) : 1.f);
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+    const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float gr = gv[e] * coef;
+      pv[e] *= 1.f - lr * wd;                                   // decoupled weight decay
+      mv[e] = b1 * mv[e] + (1.f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+      pv[e] -= (lr / bc1) * mv[e] / (sqrtf(vv[e]) / bc2s + eps);
+    }
+    ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+  }
+}
+
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev[3];
+  size_t used[3] = {0, 0, 0};
+  double flops[3] = {0, 0, 0};
+} g_prof;
+
+}  // namespace
+
+extern "C" int uvtg_adamw_clip_step(float* params, const float* grads, float* m, float* v, long long n, float lr, float beta1,
+                                    float beta2, float eps, float wd, int step, float max_norm, float grad_scale, float* scratch,
+                                    uvtg_stream_t stream) {
+  if (!params || !grads || !m || !v || !scratch) return -20;
+  if (n <= 0 || n % 4 || step <= 0) return -11;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float), s)) return (int)e;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(1024), dim3(256), 0, s, grads, n, scratch);
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2s,
+                     max_norm, grad_scale, scratch);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- timing hooks: HIP events around every launch of one kernel family, on the launch stream ----
+void uvtg_prof_begin_launch(int family, double flops, hipStream_t s) {
+  if (!g_prof.on) return;
+  auto& ev = g_prof.ev[family];
+  size_t& u = g_prof.used[family];
+  while (ev.size() < u + 2) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }
+  hipEventRecord(ev[u], s);
+  g_prof.flops[family] += flops;
+}
+void uvtg_prof_end_launch(int family, hipStream_t s) {
+  if (!g_prof.on) return;
+  size_t& u = g_prof.used[family];
+  hipEventRecord(g_prof.ev[family][u + 1], s);
+  u += 2;
+}
+extern "C" int uvtg_profile_start(void) {
+  for (int f = 0; f < 3; f++) { g_prof.used[f] = 0; g_prof.flops[f] = 0; }
+  g_prof.on = true;
+  return 0;
+}
+extern "C" int uvtg_profile_stop(double* ms, double* flops, long long* launches) {
+  g_prof.on = false;
+  if (!ms || !flops || !launches) return -20;
+  if (hipError_t e = hipDeviceSynchronize()) return (int)e;
+  for (int f = 0; f < 3; f++) {
+    double tot = 0;
+    for (size_t i = 0; i + 1 < g_prof.used[f]; i += 2) {
+      float t = 0;
+      hipEventElapsedTime(&t, g_prof.ev[f][i], g_prof.ev[f][i + 1]);
+      tot += t;
+    }
+    ms[f] = tot; flops[f] = g_prof.flops[f]; launches[f] = (long long)(g_prof.used[f] / 2);
+  }
+  return 0;
+}

@@ -1,0 +1,129 @@
+"""Native data-parallel training step for the UniVTG hot path on MI355X.
+
+One step = forward -> criterion -> backward -> (RCCL all-reduce over xGMI) -> global-norm clip + AdamW, i.e. the
+body of ``train_epoch`` in the reference (main/train_vlp_ddp.py:44-75), issued as a handful of C-ABI calls on
+the current HIP stream with every buffer pre-allocated (no autograd graph, no per-step allocation, no host sync:
+the loss values stay on the device until somebody asks for them).
+
+Data parallelism: one process per GPU; parameters, gradients and AdamW moments live in ONE flat fp32 buffer
+each (layout of ``uvtg_param_offsets``), so gradient averaging is a single bucketed ``all_reduce`` on the flat
+buffer (``torch.distributed`` backend "nccl" == RCCL on ROCm).  NCE negatives stay rank-local like the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .dist import allreduce_flat_, broadcast_flat_
+from .model import Model, SetCriterion, _ptr, _stream
+
+LOSS_KEYS = ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")
+
+
+def flatten_parameters(model: Model) -> torch.Tensor:
+    """Re-home every table parameter into one flat fp32 buffer (views keep names/shapes: state_dict is unchanged)."""
+    params = model._ordered_params()
+    dev = params[0].device
+    dims = model._dims(1, 4, 4, model.vid_dim, model.txt_dim, False)
+    offs = model._offsets(dims)
+    flat = torch.zeros(offs[-1], device=dev)
+    for i, p in enumerate(params):
+        flat[offs[i]: offs[i] + p.numel()].copy_(p.data.reshape(-1))
+        p.data = flat[offs[i]: offs[i] + p.numel()].view(p.shape)
+    model._flat = flat
+    return flat
+
+
+class TrainStep:
+    def __init__(self, model: Model, criterion: SetCriterion, lr=1e-4, weight_decay=1e-4, grad_clip=0.1,
+                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64):
+        if model.precision != "bf16":
+            raise RuntimeError("training uses precision='bf16'")
+        self.lib = _lib.load()
+        self.model, self.crit = model, criterion
+        self.flat = getattr(model, "_flat", None)
+        if self.flat is None:
+            self.flat = flatten_parameters(model)
+        dev = self.flat.device
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.grads = torch.zeros_like(self.flat)
+        self.scratch = torch.zeros(2, device=dev)
+        self.lr, self.wd, self.clip, self.betas, self.eps = lr, weight_decay, grad_clip, betas, eps
+        self.t = 0
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+            broadcast_flat_(self.flat, 0, process_group)
+        self.bucket = int(bucket_mb * (1 << 20) // 4)
+        wd = criterion.weight_dict
+        self.go = torch.tensor([wd.get(k, 0.0) for k in LOSS_KEYS], dtype=torch.float32, device=dev)
+        self.which = (1 if "spans" in criterion.losses else 0) | (2 if "labels" in criterion.losses else 0) | \
+                     (4 if "saliency" in criterion.losses else 0)
+        self._shape = None
+        self.params = model._ordered_params()
+        self.ptrs = model._param_ptrs(self.params)
+
+    def _alloc(self, B, Lv, Lt, dims):
+        dev, d = self.flat.device, self.model.hidden_dim
+        S = Lv + Lt
+        self.ws = torch.empty(self.lib.uvtg_workspace_bytes(C.byref(dims)), dtype=torch.uint8, device=dev)
+        self.wcache = torch.empty(self.lib.uvtg_wcache_bytes(C.byref(dims)), dtype=torch.uint8, device=dev)
+        self.x0 = torch.empty(B, S, d, device=dev)
+        self.pred_logits = torch.empty(B, Lv, 1, device=dev)
+        self.pred_spans = torch.empty(B, Lv, 2, device=dev)
+        self.txt_mem = torch.empty(B, 1, d, device=dev)
+        self.sal = torch.empty(B, Lv, device=dev)
+        self.loss_ws = torch.empty(self.lib.uvtg_loss_ws_floats(B, Lv), device=dev)
+        self.losses = torch.zeros(8, device=dev)
+        self.g_logits = torch.empty(B, Lv, device=dev)
+        self.g_spans = torch.empty(B, Lv, 2, device=dev)
+        self.g_vid = torch.empty(B, Lv, d, device=dev)
+        self.g_txt = torch.empty(B, d, device=dev)
+        self._shape = (B, Lv, Lt)
+
+    def step(self, inputs, targets, optimize=True):
+        """One training step; returns the device tensor [loss_b, loss_g, loss_f, loss_s_inter, loss_s_intra] (no sync)."""
+        lib, model = self.lib, self.model
+        src_txt, src_txt_mask = inputs["src_txt"], inputs["src_txt_mask"]
+        src_vid, src_vid_mask = inputs["src_vid"], inputs["src_vid_mask"]
+        B, Lv, Dv = src_vid.shape
+        Lt, Dt = src_txt.shape[1], src_txt.shape[2]
+        dims = model._dims(B, Lv, Lt, Dv, Dt, True)
+        if self._shape != (B, Lv, Lt):
+            self._alloc(B, Lv, Lt, dims)
+        st = _stream()
+        d = model.hidden_dim
+        S = Lv + Lt
+        chk = _lib.check
+        chk(lib.uvtg_prepare_weights(C.byref(dims), self.ptrs, _ptr(self.wcache), st), "uvtg_prepare_weights")
+        chk(lib.uvtg_forward(C.byref(dims), self.ptrs, _ptr(self.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
+                             _ptr(src_vid_mask), _ptr(model._dim_t(src_vid.device)), _ptr(self.x0), _ptr(self.pred_logits),
+                             _ptr(self.pred_spans), _ptr(self.txt_mem), _ptr(self.sal), None, _ptr(self.ws), st), "uvtg_forward")
+        tg = targets
+        sal = tg.get("saliency_scores")
+        pos = tg.get("_pos_idx")
+        if pos is None and "saliency_pos_labels" in tg:
+            pos = tg["saliency_pos_labels"][:, 0].long().contiguous()
+        crit_args = (B, Lv, d, self.which, float(self.crit.eos_coef), _ptr(self.pred_logits), _ptr(self.pred_spans),
+                     _ptr(self.x0), S * d, d, _ptr(self.txt_mem), _ptr(tg["timestamp"]), _ptr(tg["timestamp_mask"]),
+                     _ptr(tg["timestamp_window"]), _ptr(tg["span_labels_nn"]), _ptr(sal), _ptr(pos), _ptr(self.loss_ws),
+                     _ptr(self.losses))
+        chk(lib.uvtg_criterion_fwd(*crit_args, st), "uvtg_criterion_fwd")
+        chk(lib.uvtg_criterion_bwd(*crit_args, _ptr(self.go), _ptr(self.g_logits), _ptr(self.g_spans), _ptr(self.g_vid),
+                                   _ptr(self.g_txt), st), "uvtg_criterion_bwd")
+        chk(lib.uvtg_backward(C.byref(dims), self.ptrs, _ptr(self.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
+                              _ptr(src_vid_mask), _ptr(self.x0), _ptr(self.pred_logits), _ptr(self.pred_spans), _ptr(self.txt_mem),
+                              _ptr(self.g_logits), _ptr(self.g_spans), None, _ptr(self.g_txt), _ptr(self.g_vid), Lv * d, d,
+                              _ptr(self.grads), _ptr(self.ws), st), "uvtg_backward")
+        if self.world > 1:
+            allreduce_flat_(self.grads, self.bucket, self.pg)
+        if optimize:
+            self.t += 1
+            chk(lib.uvtg_adamw_clip_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.flat.numel(),
+                                         self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, float(self.clip),
+                                         1.0 / self.world, _ptr(self.scratch), st), "uvtg_adamw_clip_step")
+        return self.losses[:5]
