@@ -19,6 +19,8 @@ for (M, N, K) in [(27392, 1024, 1024), (27392, 2048, 1024), (27392, 1024, 3072),
     w = torch.randn(N, K, device=dev).to(torch.bfloat16)
     t = timeit(lambda: ops.linear_bf16(a, w, None, 0))
     print(f"NT bf16 {M}x{N}x{K}: {t:8.1f} us  {2*M*N*K/t/1e6:8.1f} TFLOP/s (fp32 out)")
+    t = timeit(lambda: ops.linear_bf16(a, w, None, 100))
+    print(f"NT bf16 {M}x{N}x{K}: {t:8.1f} us  {2*M*N*K/t/1e6:8.1f} TFLOP/s (NO epilogue)")
     af, wf = a.float(), w.float()
     t = timeit(lambda: ops.linear_f32x3(af, wf, None, 0), 5)
     print(f"NT x3   {M}x{N}x{K}: {t:8.1f} us  {2*M*N*K/t/1e6:8.1f} TFLOP/s-equiv")

@@ -256,6 +256,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -4: return "layernorm: unsupported row width";
     case -5: return "attention: head_dim must be 32, 64 or 128";
     case -6: return "backward is only available in bf16 mode (precise == 0)";
+    case -7: return "gemm: N and every epilogue leading dimension must be multiples of 4";
     case -10: return "null dims";
     case -11: return "dims: non-positive size";
     case -12: return "dims: n_proj must be 2";

@@ -142,43 +142,72 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   }
 
   // ---------------- epilogue ----------------
-  // (fully unrolled with compile-time accumulator indices: a rolled loop would force acc[][] into scratch memory)
+  // Each wave parks its 64x64 fp32 accumulator tile in its own 16 KB slice of the (now idle) staging LDS, then
+  // re-reads it row-wise so that every lane owns 4 consecutive columns: bias / residual / positional loads and all
+  // stores become 8-16 byte vector accesses on full 128-256 byte row segments (the MFMA register layout would
+  // give 2-4 byte stores at a row stride).  Accumulator indices stay compile-time constants (no scratch).
+  if (p.act == 100) {   // measurement aid: main loop only (keeps the accumulators live, stores nothing)
+    float t = 0.f;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 2; i++)
+#pragma clang loop unroll(full)
+      for (int j = 0; j < 2; j++)
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; r++) t += acc[i][j][r];
+    if (t == 123.456f) p.outF[0] = t;
+    return;
+  }
+  float* wbuf = (float*)smem + wave * 4096;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < 2; i++)
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 2; j++)
+#pragma clang loop unroll(full)
+      for (int r = 0; r < 16; r++)
+        wbuf[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
   const float* bias = p.bias ? p.bias + (size_t)gz * p.gBias : nullptr;
   const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
-  const bool has_u = p.outU || p.outUF;
-#pragma clang loop unroll(full)
-  for (int i = 0; i < 2; i++) {
-#pragma clang loop unroll(full)
-    for (int r = 0; r < 16; r++) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      const bool mok = m < p.M;
-      const int mc = mok ? m : p.M - 1;
-      const size_t orow = (size_t)map_row(mc, p.o_seg, p.o_seg_stride, p.o_off);
-      const float rs = p.rowscale ? p.rowscale[mc / p.rs_seg] : 1.0f;
-#pragma clang loop unroll(full)
-      for (int j = 0; j < 2; j++) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        if (mok && n < p.N) {
-          float v = acc[i][j][r];
-          if (bias) v += bias[n];
-          if (p.bias2) v += p.bias2[n];
-          if (n < p.colscale_n) v *= p.colscale;
-          if (p.outPre) p.outPre[go + orow * p.ldpre_out + n] = f2bf(v);
-          if (p.act == 1) v = fmaxf(v, 0.f);
-          else if (p.act == 2) v = gelu_erf(v);
-          if (p.actgrad == 1) v = bf2f(p.gradPre[gp + orow * p.ldgp + n]) > 0.f ? v : 0.f;
-          else if (p.actgrad == 2) v *= gelu_erf_grad(bf2f(p.gradPre[gp + orow * p.ldgp + n]));
-          v *= rs;
-          if (p.resid) v += p.resid[orow * p.ldr + n];
-          if (p.outF) p.outF[go + orow * p.ldoF + n] = v;
-          if (p.outB) p.outB[go + orow * p.ldoB + n] = f2bf(v);
-          if (has_u) {
-            const float u = v + ((p.pos && m < p.pos_rows) ? p.pos[(size_t)m * p.ldpos + n] : 0.f);
-            if (p.outU) p.outU[orow * p.ldoU + n] = f2bf(u);
-            if (p.outUF) p.outUF[orow * p.ldoU + n] = u;
-          }
-        }
-      }
+  const int c4 = (lane & 15) * 4;
+  const int n = n0 + wn * 64 + c4;
+  if (n >= p.N) return;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *(const f32x4*)(bias + n);
+  if (p.bias2) { const f32x4 t = *(const f32x4*)(p.bias2 + n); bv += t; }
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const int row = it * 4 + (lane >> 4);
+    const int m = m0 + wm * 64 + row;
+    if (m >= p.M) continue;
+    f32x4 v = *(const f32x4*)(wbuf + row * 64 + c4);
+    const size_t orow = (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off);
+    v += bv;
+    if (n < p.colscale_n) v *= p.colscale;
+    if (p.outPre) {
+      u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
+      *(u32x2*)(p.outPre + go + orow * p.ldpre_out + n) = t;
+    }
+    if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    else if (p.act == 2) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+    if (p.actgrad) {
+      const u32x2 t = *(const u32x2*)(p.gradPre + gp + orow * p.ldgp + n);
+      const float q0 = __uint_as_float(t[0] << 16), q1 = __uint_as_float(t[0] & 0xffff0000u);
+      const float q2 = __uint_as_float(t[1] << 16), q3 = __uint_as_float(t[1] & 0xffff0000u);
+      if (p.actgrad == 1) { v[0] = q0 > 0.f ? v[0] : 0.f; v[1] = q1 > 0.f ? v[1] : 0.f; v[2] = q2 > 0.f ? v[2] : 0.f; v[3] = q3 > 0.f ? v[3] : 0.f; }
+      else { v[0] *= gelu_erf_grad(q0); v[1] *= gelu_erf_grad(q1); v[2] *= gelu_erf_grad(q2); v[3] *= gelu_erf_grad(q3); }
+    }
+    if (p.rowscale) v *= p.rowscale[m / p.rs_seg];
+    if (p.resid) { const f32x4 t = *(const f32x4*)(p.resid + orow * p.ldr + n); v += t; }
+    if (p.outF) *(f32x4*)(p.outF + go + orow * p.ldoF + n) = v;
+    if (p.outB) {
+      u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
+      *(u32x2*)(p.outB + go + orow * p.ldoB + n) = t;
+    }
+    if (p.outU || p.outUF) {
+      f32x4 u = v;
+      if (p.pos && m < p.pos_rows) { const f32x4 t = *(const f32x4*)(p.pos + (size_t)m * p.ldpos + n); u += t; }
+      if (p.outU) { u32x2 t; t[0] = pack_bf2(u[0], u[1]); t[1] = pack_bf2(u[2], u[3]); *(u32x2*)(p.outU + orow * p.ldoU + n) = t; }
+      if (p.outUF) *(f32x4*)(p.outUF + orow * p.ldoU + n) = u;
     }
   }
 }
@@ -294,6 +323,8 @@ static int check_nt(const GemmArgs& a, int elem) {
   if (a.lda % al || a.ldb % al || a.ktap <= 0) return -2;
   if (a.ktap < a.K && (a.ktap % (elem == 2 ? 64 : 32))) return -2;
   if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return -3;
+  if (a.N % 4 || a.ldoF % 4 || a.ldoB % 4 || a.ldoU % 4 || a.ldr % 4 || a.ldgp % 4 || a.ldpre_out % 4 || a.ldpos % 4 ||
+      a.colscale_n % 4) return -7;
   return 0;
 }
 
