@@ -62,7 +62,7 @@ int uvtg_param_offsets(const uvtg_dims* dm, long long* offsets /* host, [count +
 /* ---- sizes -------------------------------------------------------------------------------- */
 size_t uvtg_workspace_bytes(const uvtg_dims* dm);   /* activations + scratch for forward(+backward) */
 size_t uvtg_wcache_bytes(const uvtg_dims* dm);      /* prepared GEMM operands (bf16 copies, transposes) */
-long long uvtg_loss_ws_floats(int B, int Lv);
+long long uvtg_loss_ws_floats(int B, int Lv, int d);
 
 /* Re-layout / down-cast the weights into the MFMA operand cache.  Call after every parameter update
  * (replaces nothing in the reference: ATen reads the fp32 weights directly). */
@@ -85,12 +85,14 @@ int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wc
  * uvtg_forward(training=1) call.  Upstream gradients (any may be
  * NULL = zero): g_logits [B,Lv,1], g_spans [B,Lv,2], g_saliency [B,Lv], g_txt_mem [B,1,d],
  * g_vid_mem addressed as g_vid_mem[b*g_vid_sb + t*g_vid_st + c] (so the gradient of the whole x0
- * buffer, strides S*d and d, can be passed as is).  grads: flat fp32 buffer (uvtg_param_offsets), overwritten. */
+ * buffer, strides S*d and d, can be passed as is).  g_vrow [B,d] + pos_idx [B] (optional pair): extra gradient
+ * on row pos_idx[b] of vid_mem_proj -- the compact form uvtg_criterion_bwd emits instead of a dense g_vid.  grads: flat fp32 buffer (uvtg_param_offsets), overwritten. */
 int uvtg_backward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                   const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                   const float* x0, const float* pred_logits, const float* pred_spans, const float* txt_mem_proj,
                   const float* g_logits, const float* g_spans, const float* g_saliency,
                   const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
+                  const float* g_vrow, const long long* pos_idx,
                   float* grads, void* workspace, uvtg_stream_t stream);
 
 /* ---- criterion: replaces SetCriterion.forward + its autograd (model/univtg.py:195-282,338-351) ---
@@ -103,15 +105,20 @@ int uvtg_criterion_fwd(int B, int Lv, int d, int which, float eos_coef,
                        const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
                        const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
                        float* loss_ws, float* losses_out, uvtg_stream_t stream);
-/* go [5] (device): upstream gradient of each of the five losses.  Outputs: g_logits [B,Lv],
- * g_spans [B,Lv,2], g_vid [B,Lv,d] (dense), g_txt [B,d].  Must follow the matching _fwd call. */
+/* go [5] (device): upstream gradient of each of the five losses.  Must follow the matching _fwd call.
+ * Outputs: g_logits [B,Lv], g_spans [B,Lv,2], g_cos [B,Lv] (gradient wrt cosine(vid_mem_proj, txt_mem_proj), i.e.
+ * wrt saliency_scores), g_vrow [B,d] (inter-video gradient wrt vid_mem_proj[b, pos_b, :]), g_txt [B,d].
+ * Dense mode (g_vid != NULL): also g_vid [B,Lv,d] = full gradient wrt vid_mem_proj and g_txt = full gradient wrt
+ * txt_mem_proj (what autograd needs).  Compact mode (g_vid == NULL): g_txt holds the inter-video part only; feed
+ * g_cos as g_saliency and (g_vrow, pos_idx) to uvtg_backward, which differentiates the cosine itself. */
 int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coef,
                        const float* pred_logits, const float* pred_spans,
                        const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,
                        const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
                        const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
                        float* loss_ws, const float* losses_out, const float* go,
-                       float* g_logits, float* g_spans, float* g_vid, float* g_txt, uvtg_stream_t stream);
+                       float* g_logits, float* g_spans, float* g_vid, float* g_txt, float* g_cos, float* g_vrow,
+                       uvtg_stream_t stream);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels the engine launches) ----- */
 /* C[M,N] = A[M,K] * W[N,K]^T + bias (nn.Linear).  bf16: A,W bf16, C fp32.  f32x3: A,W fp32. act: 0/1 relu/2 gelu */

@@ -228,22 +228,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward: delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
-__global__ void attn_delta_kernel(const AttnArgs a) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)a.B * a.S * a.H;
-  if (idx >= total) return;
-  const int h = (int)(idx % a.H);
-  const long long row = idx / a.H;
-  const int b = (int)(row / a.S), s = (int)(row % a.S);
-  const bf16_t* o = (const bf16_t*)a.o + row * a.ldo + h * a.hd;
-  const bf16_t* d = a.dO + row * a.lddo + h * a.hd;
-  float acc = 0.f;
-  for (int c = 0; c < a.hd; c += 8) {
-    const s16x8 ov = *(const s16x8*)(o + c), dv = *(const s16x8*)(d + c);
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
+  // one wave per token row; lane owns 8 consecutive channels; heads are reduced inside groups of hd/8 lanes
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)a.B * a.S) return;
+  const int b = (int)(row / a.S), s = (int)(row % a.S), d = a.H * a.hd, lph = a.hd / 8;
+  const bf16_t* o = (const bf16_t*)a.o + row * a.ldo;
+  const bf16_t* g = a.dO + row * a.lddo;
+  for (int c = lane * 8; c < d; c += 512) {
+    const s16x8 ov = *(const s16x8*)(o + c), dv = *(const s16x8*)(g + c);
+    float acc = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; e++) acc += bf2f((bf16_t)ov[e]) * bf2f((bf16_t)dv[e]);
+    for (int off = lph >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((lane % lph) == 0) a.delta[((size_t)b * a.H + c / a.hd) * a.S + s] = acc;
   }
-  a.delta[((size_t)b * a.H + h) * a.S + s] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,8 +482,8 @@ int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
 int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
   if (a.precise) return -6;
-  const long long total = (long long)a.B * a.S * a.H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  const long long rows = (long long)a.B * a.S;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
 #define BWD(HD_)                                                                                  \

@@ -297,7 +297,7 @@ extern "C" size_t uvtg_wcache_bytes(const uvtg_dims* dm) {
   Dm m(*dm);
   return WCache(m, nullptr).bytes;
 }
-extern "C" long long uvtg_loss_ws_floats(int B, int Lv) { return loss_ws_floats(B, Lv); }
+extern "C" long long uvtg_loss_ws_floats(int B, int Lv, int d) { return loss_ws_floats(B, Lv, d); }
 
 // =================================================================================================
 // weight preparation
@@ -534,6 +534,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
                              const float* x0, const float* pred_logits, const float* pred_spans, const float* txt_mem_proj,
                              const float* g_logits, const float* g_spans, const float* g_saliency,
                              const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
+                             const float* g_vrow, const long long* pos_idx,
                              float* grads, void* workspace, uvtg_stream_t stream) {
   if (int e = check_dims(dm)) return e;
   if (dm->E > MAXE) return -17;
@@ -643,7 +644,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   float* dx0 = ws.gx[1];                         // d loss / d x0 from the encoder, fp32 [M, d]
   // ---------------- saliency branch ----------------
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
-  sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.dx0 = dx0; sa.dw_pool = G(m.tail(POOL));
+  sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0 = dx0; sa.dw_pool = G(m.tail(POOL));
   TRY(launch_saliency_bwd(sa, s));
   // ---------------- input projections ----------------
   for (int which = 0; which < 2; which++) {
@@ -717,19 +718,20 @@ extern "C" int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coe
                                   const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
                                   const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
                                   float* loss_ws, const float* losses_out, const float* go,
-                                  float* g_logits, float* g_spans, float* g_vid, float* g_txt, uvtg_stream_t stream) {
+                                  float* g_logits, float* g_spans, float* g_vid, float* g_txt, float* g_cos, float* g_vrow,
+                                  uvtg_stream_t stream) {
   if (B <= 0 || Lv <= 0 || d <= 0) return -11;
   if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !timestamp_window || !span_labels_nn || !loss_ws ||
-      !losses_out || !go || !g_logits || !g_spans) return -20;
+      !losses_out || !go || !g_logits || !g_spans || !g_cos || !g_vrow || !g_txt) return -20;
   LossArgs a = loss_args(B, Lv, d, which, eos_coef, pred_logits, pred_spans, vid, vid_sb, vid_st, txt_mem, timestamp, timestamp_mask,
                          timestamp_window, span_labels_nn, saliency_scores, pos_idx, loss_ws, (float*)losses_out);
-  a.go = go; a.g_logits = g_logits; a.g_spans = g_spans; a.g_vid = g_vid; a.g_txt = g_txt;
+  a.go = go; a.g_logits = g_logits; a.g_spans = g_spans; a.g_vid = g_vid; a.g_txt = g_txt; a.g_cos = g_cos; a.g_vrow = g_vrow;
   hipStream_t s = (hipStream_t)stream;
   const bool sal = (which & 4) && saliency_scores && pos_idx;
-  if (sal && (!g_vid || !g_txt)) return -20;
   if (!sal) {
     if (g_vid) hipMemsetAsync(g_vid, 0, (size_t)B * Lv * d * sizeof(float), s);
-    if (g_txt) hipMemsetAsync(g_txt, 0, (size_t)B * d * sizeof(float), s);
+    hipMemsetAsync(g_txt, 0, (size_t)B * d * sizeof(float), s);
+    hipMemsetAsync(g_vrow, 0, (size_t)B * d * sizeof(float), s);
   }
   return launch_losses_bwd(a, s);
 }

@@ -11,8 +11,8 @@ constexpr float TAU = 0.07f;          // model/univtg.py:185 (hard-coded)
 constexpr float EPS = 1e-8f;          // sim_matrix / cosine_similarity eps
 
 struct WS {                            // carve-up of LossArgs::ws
-  float *cosv, *vnorm, *qnorm, *sim, *lse_r, *lse_c, *zr, *zc, *cnt, *gz, *vpn;
-  __host__ __device__ WS(float* p, int B, int Lv) {
+  float *cosv, *vnorm, *qnorm, *sim, *lse_r, *lse_c, *zr, *zc, *cnt, *gz, *vpn, *dvh, *dqh;
+  __host__ __device__ WS(float* p, int B, int Lv, int d = 0) {
     cosv = p; p += (size_t)B * Lv;
     vnorm = p; p += (size_t)B * Lv;
     gz = p; p += (size_t)B * Lv;
@@ -24,6 +24,9 @@ struct WS {                            // carve-up of LossArgs::ws
     vpn = p; p += B;
     zc = p; p += Lv;
     cnt = p; p += Lv;
+    p += (4 - ((size_t)(5 * B + 2 * Lv) & 3)) & 3;
+    dvh = p; p += (size_t)B * d;
+    dqh = p; p += (size_t)B * d;
   }
 };
 
@@ -42,7 +45,7 @@ __device__ __forceinline__ float zval(const LossArgs& a, const WS& w, int b, int
 
 // per (b, t): |v|, cos(v, q_b);  per b: |q|
 __global__ __launch_bounds__(256) void loss_stats_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv);
+  const WS w(a.ws, a.B, a.Lv, a.d);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.B * a.Lv) return;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(const LossArgs a) {
 // sim[i][j] = vhat_i . qhat_j  with v_i = vid[i, pos_i]
 __global__ __launch_bounds__(256) void loss_sim_kernel(const LossArgs a) {
   extern __shared__ float sv[];
-  const WS w(a.ws, a.B, a.Lv);
+  const WS w(a.ws, a.B, a.Lv, a.d);
   const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = (int)a.pos_idx[i];
   const float* v = vrow(a, i, p);
@@ -98,7 +101,7 @@ __device__ __forceinline__ void giou_terms(float a0, float a1, float b0, float b
 // single block: every scalar of the criterion
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(const LossArgs a) {
   __shared__ float red[16];
-  const WS w(a.ws, a.B, a.Lv);
+  const WS w(a.ws, a.B, a.Lv, a.d);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int n = a.B * a.Lv;
   float nwin = 0.f, nval = 0.f, ssum = 0.f;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const LossArgs a) {
 // gradients
 // ------------------------------------------------------------------------------------------------
 __global__ void loss_grad_small_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv);
+  const WS w(a.ws, a.B, a.Lv, a.d);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.B * a.Lv;
   const float nwin = a.losses[6], nval = a.losses[7];
@@ -228,12 +231,12 @@ __global__ void loss_grad_small_kernel(const LossArgs a) {
       const float dl = (t == p) ? 1.f : 0.f;
       gz = a.go[4] / ((float)a.B * TAU) * ((expf(z - w.zr[b]) - dl) + (w.cnt[t] * expf(z - w.zc[t]) - dl));
     }
-    w.gz[i] = gz;
+    a.g_cos[i] = gz;
   }
 }
 // dsim in place: sim[i][j] <- go_inter / (B tau) * (softmax_row + softmax_col - 2 delta)
 __global__ void loss_grad_sim_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv);
+  const WS w(a.ws, a.B, a.Lv, a.d);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.B * a.B) return;
   const int i = idx / a.B, j = idx % a.B;
@@ -245,71 +248,99 @@ __global__ void loss_grad_sim_kernel(const LossArgs a) {
   w.sim[idx] = g;
 }
 
-// g_vid[b, t, :] = gz * (qhat - cos vhat) / |v|  (+ the inter-video term on the positive clip row)
-__global__ __launch_bounds__(256) void loss_grad_vid_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv);
+// dvh[b][c] = sum_j dsim[b][j] qhat_j[c]   (blockIdx.y == 0),   dqh[b][c] = sum_i dsim[i][b] vhat_i[c]   (blockIdx.y == 1)
+__global__ __launch_bounds__(256) void loss_dvq_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv, a.d);
+  const int b = blockIdx.x, d = a.d, B = a.B;
+  if (a.losses[5] == 0.f) return;
+  __shared__ float coef[1024];
+  for (int c0 = 0; c0 < d; c0 += 4 * 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < B; j0 += 1024) {
+      const int nj = min(1024, B - j0);
+      __syncthreads();
+      for (int j = threadIdx.x; j < nj; j += 256) {
+        const int jj = j0 + j;
+        if (blockIdx.y == 0) coef[j] = w.sim[b * B + jj] / fmaxf(w.qnorm[jj], EPS);
+        else coef[j] = w.sim[jj * B + b] / fmaxf(w.vnorm[jj * a.Lv + (int)a.pos_idx[jj]], EPS);
+      }
+      __syncthreads();
+      for (int j = 0; j < nj; j++) {
+        const int jj = j0 + j;
+        const float* src = blockIdx.y == 0 ? a.txt + (size_t)jj * d : vrow(a, jj, (int)a.pos_idx[jj]);
+        const float cf = coef[j];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int c = c0 + e * 256 + threadIdx.x; if (c < d) acc[e] += cf * src[c]; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = c0 + e * 256 + threadIdx.x;
+      if (c < d) (blockIdx.y == 0 ? w.dvh : w.dqh)[(size_t)b * d + c] = acc[e];
+    }
+  }
+}
+// inter-video gradients in input space: g_vrow[b] = (dvh - vhat (vhat.dvh)) / |v_pos|, g_txt[b] = (dqh - qhat (qhat.dqh)) / |q|
+__global__ __launch_bounds__(256) void loss_grad_rows_kernel(const LossArgs a) {
+  __shared__ float red[8];
+  const WS w(a.ws, a.B, a.Lv, a.d);
+  const int b = blockIdx.x, d = a.d, tid = threadIdx.x;
+  float* gv = a.g_vrow + (size_t)b * d;
+  float* gt = a.g_txt + (size_t)b * d;
+  if (a.losses[5] == 0.f) { for (int c = tid; c < d; c += 256) { gv[c] = 0.f; gt[c] = 0.f; } return; }
+  const int p = (int)a.pos_idx[b];
+  const float* v = vrow(a, b, p);
+  const float* q = a.txt + (size_t)b * d;
+  const float vn = fmaxf(w.vnorm[b * a.Lv + p], EPS), qn = fmaxf(w.qnorm[b], EPS);
+  float dv = 0.f, dq = 0.f;
+  for (int c = tid; c < d; c += 256) { dv += w.dvh[(size_t)b * d + c] * v[c] / vn; dq += w.dqh[(size_t)b * d + c] * q[c] / qn; }
+  dv = block_sum(dv, red); dq = block_sum(dq, red);
+  for (int c = tid; c < d; c += 256) {
+    gv[c] = (w.dvh[(size_t)b * d + c] - v[c] / vn * dv) / vn;
+    gt[c] = (w.dqh[(size_t)b * d + c] - q[c] / qn * dq) / qn;
+  }
+}
+// dense expansion for generic autograd callers:
+// g_vid[b, t, :] = gz * (qhat - cos vhat) / |v|  (+ g_vrow on the positive clip row)
+__global__ __launch_bounds__(256) void loss_expand_vid_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv, a.d);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.B * a.Lv) return;
   const int b = row / a.Lv, t = row % a.Lv, d = a.d;
   float* out = a.g_vid + (size_t)row * d;
-  const bool sal_on = a.losses[5] != 0.f;
-  if (!sal_on) { for (int c = lane; c < d; c += 64) out[c] = 0.f; return; }
+  if (a.losses[5] == 0.f) { for (int c = lane; c < d; c += 64) out[c] = 0.f; return; }
   const float* v = vrow(a, b, t);
   const float* q = a.txt + (size_t)b * d;
-  const float vn = fmaxf(w.vnorm[row], EPS), qn = fmaxf(w.qnorm[b], EPS), cs = w.cosv[row], gz = w.gz[row];
+  const float vn = fmaxf(w.vnorm[row], EPS), qn = fmaxf(w.qnorm[b], EPS), cs = w.cosv[row], gz = a.g_cos[row];
   const bool is_pos = (t == (int)a.pos_idx[b]);
-  float dot = 0.f;                       // vhat . dvhat for the positive row
-  if (is_pos) {
-    for (int c = lane; c < d; c += 64) {
-      float dv = 0.f;
-      for (int j = 0; j < a.B; j++) dv += w.sim[b * a.B + j] * a.txt[(size_t)j * d + c] / fmaxf(w.qnorm[j], EPS);
-      out[c] = dv;                       // stash dvhat
-      dot += dv * v[c] / vn;
-    }
-    dot = wave_sum(dot);
-  }
   for (int c = lane; c < d; c += 64) {
-    const float vh = v[c] / vn, qh = q[c] / qn;
-    float g = gz * (qh - cs * vh) / vn;
-    if (is_pos) g += (out[c] - vh * dot) / vn;
+    float g = gz * (q[c] / qn - cs * v[c] / vn) / vn;
+    if (is_pos) g += a.g_vrow[(size_t)b * d + c];
     out[c] = g;
   }
 }
-// g_txt[b, :] = sum_t gz (vhat_t - cos_t qhat)/|q|  +  (dqhat - qhat (qhat.dqhat)) / |q|
-__global__ __launch_bounds__(256) void loss_grad_txt_kernel(const LossArgs a) {
-  extern __shared__ float sh[];          // [d] dqhat, [8] red
-  const WS w(a.ws, a.B, a.Lv);
-  const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
-  float* out = a.g_txt + (size_t)b * d;
-  if (a.losses[5] == 0.f) { for (int c = tid; c < d; c += 256) out[c] = 0.f; return; }
+// g_txt[b, :] += sum_t gz (vhat_t - cos_t qhat) / |q|     (thread per column, loop over clips: no atomics)
+__global__ __launch_bounds__(256) void loss_expand_txt_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv, a.d);
+  const int b = blockIdx.x, d = a.d;
+  if (a.losses[5] == 0.f) return;
   const float* q = a.txt + (size_t)b * d;
   const float qn = fmaxf(w.qnorm[b], EPS);
-  float dot = 0.f;
-  for (int c = tid; c < d; c += 256) {
-    float dq = 0.f;
-    for (int i = 0; i < a.B; i++) {
-      const int p = (int)a.pos_idx[i];
-      dq += w.sim[i * a.B + b] * vrow(a, i, p)[c] / fmaxf(w.vnorm[i * a.Lv + p], EPS);
-    }
-    sh[c] = dq;
-    dot += dq * q[c] / qn;
-  }
-  dot = block_sum(dot, sh + d);
-  for (int c = tid; c < d; c += 256) {
+  for (int c = threadIdx.x; c < d; c += 256) {
     const float qh = q[c] / qn;
-    float g = (sh[c] - qh * dot) / qn;
+    float g = 0.f;
     for (int t = 0; t < a.Lv; t++) {
-      const float gz = w.gz[b * a.Lv + t];
-      if (gz != 0.f) g += gz * (vrow(a, b, t)[c] / fmaxf(w.vnorm[b * a.Lv + t], EPS) - w.cosv[b * a.Lv + t] * qh) / qn;
+      const float gz = a.g_cos[b * a.Lv + t];
+      if (gz != 0.f) g += gz * (vrow(a, b, t)[c] / fmaxf(w.vnorm[b * a.Lv + t], EPS) - w.cosv[b * a.Lv + t] * qh);
     }
-    out[c] = g;
+    a.g_txt[(size_t)b * d + c] += g / qn;
   }
 }
 
 }  // namespace
 
-long long loss_ws_floats(int B, int Lv) { return 3LL * B * Lv + (long long)B * B + 5LL * B + 2LL * Lv + 64; }
+long long loss_ws_floats(int B, int Lv, int d) { return 3LL * B * Lv + (long long)B * B + 5LL * B + 2LL * Lv + 2LL * B * d + 64; }
 
 int launch_losses_fwd(const LossArgs& a, hipStream_t s) {
   const int n = a.B * a.Lv;
@@ -326,8 +357,12 @@ int launch_losses_bwd(const LossArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(loss_grad_small_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a);
   if (a.do_saliency && a.sal_tgt && a.pos_idx) {
     hipLaunchKernelGGL(loss_grad_sim_kernel, dim3(cdiv(a.B * a.B, 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_grad_vid_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_grad_txt_kernel, dim3(a.B), dim3(256), (a.d + 16) * sizeof(float), s, a);
+    hipLaunchKernelGGL(loss_dvq_kernel, dim3(a.B, 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_grad_rows_kernel, dim3(a.B), dim3(256), 0, s, a);
+    if (a.g_vid) {     // dense mode: full gradients wrt vid_mem_proj / txt_mem_proj
+      hipLaunchKernelGGL(loss_expand_vid_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(loss_expand_txt_kernel, dim3(a.B), dim3(256), 0, s, a);
+    }
   }
   UVTG_CHECK_LAUNCH();
   return 0;

@@ -252,34 +252,45 @@ __global__ __launch_bounds__(256) void saliency_fwd_kernel(const SaliencyArgs a)
   }
 }
 
-// dx0 += (everything that flows into the pre-encoder tokens from saliency / vid_mem_proj / txt_mem_proj)
+// dx0 += (everything that flows into the pre-encoder tokens from saliency / vid_mem_proj / txt_mem_proj).
+// One block per sample, one thread per column (loops over clips / tokens): coalesced, no atomics on the hot loops.
 __global__ __launch_bounds__(256) void saliency_bwd_kernel(const SaliencyArgs a) {
-  extern __shared__ float sm[];                 // [d] q | [d] dq | [Lt] dalpha | [8]
-  float* s_q = sm;
-  float* s_dq = sm + a.d;
+  extern __shared__ float sm[];                 // [d] dq | [Lt] dalpha | [Lv] gs,vn,cs | [8]
+  float* s_dq = sm;
   float* s_da = s_dq + a.d;
-  float* s_red = s_da + a.Lt;
+  float* s_gs = s_da + a.Lt;
+  float* s_vn = s_gs + a.Lv;
+  float* s_cs = s_vn + a.Lv;
+  float* s_red = s_cs + a.Lv;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
   const float qn = fmaxf(a.qnorm[b], 1e-8f);
-  for (int c = tid; c < d; c += 256) {
-    s_q[c] = a.pooled[(size_t)b * d + c];
-    s_dq[c] = a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f;
+  for (int t = tid; t < a.Lv; t += 256) {
+    s_gs[t] = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
+    s_vn[t] = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f);
+    s_cs[t] = a.cosv[b * a.Lv + t];
   }
   __syncthreads();
-  // video rows: dv = g_sal * (qhat - cos * vhat) / |v| + g_vid ; dq += g_sal * (vhat - cos * qhat) / |q|
+  const int prow = (a.g_vrow && a.pos_idx) ? (int)a.pos_idx[b] : -1;
+  // video rows: dv = g_sal * (qhat - cos * vhat) / |v| + g_vid (+ g_vrow on the positive row);
+  //             dq = g_pooled + sum_t g_sal * (vhat - cos * qhat) / |q|
   const float* xv = a.x0 + (size_t)b * a.S * d;
   float* dxv = a.dx0 + (size_t)b * a.S * d;
-  for (int t = wave; t < a.Lv; t += 4) {
-    const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
-    const float vn = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f), cs = a.cosv[b * a.Lv + t];
-    for (int c = lane; c < d; c += 64) {
-      const float v = xv[(size_t)t * d + c];
-      const float vh = v / vn, qh = s_q[c] / qn;
-      float g = gs * (qh - cs * vh) / vn;
+  for (int c = tid; c < d; c += 256) {
+    const float qh = a.pooled[(size_t)b * d + c] / qn;
+    float dq = a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f;
+    for (int t = 0; t < a.Lv; t++) {
+      const float gs = s_gs[t];
+      float g = 0.f;
+      if (gs != 0.f) {
+        const float vh = xv[(size_t)t * d + c] / s_vn[t];
+        g = gs * (qh - s_cs[t] * vh) / s_vn[t];
+        dq += gs * (vh - s_cs[t] * qh) / qn;
+      }
       if (a.g_vid) g += a.g_vid[(size_t)b * a.gv_sb + (size_t)t * a.gv_st + c];
-      dxv[(size_t)t * d + c] += g;
-      if (gs != 0.f) atomicAdd(&s_dq[c], gs * (vh - cs * qh) / qn);
+      if (t == prow) g += a.g_vrow[(size_t)b * d + c];
+      if (g != 0.f) dxv[(size_t)t * d + c] += g;
     }
+    s_dq[c] = dq;
   }
   __syncthreads();
   // text rows: q = sum alpha x ; alpha = softmax(x.w + mask)
@@ -294,13 +305,16 @@ __global__ __launch_bounds__(256) void saliency_bwd_kernel(const SaliencyArgs a)
   __syncthreads();
   float dot = 0.f;
   for (int t = 0; t < a.Lt; t++) dot += a.alpha[b * a.Lt + t] * s_da[t];
-  for (int t = wave; t < a.Lt; t += 4) {
-    const float al = a.alpha[b * a.Lt + t];
-    const float dlog = al * (s_da[t] - dot);
-    for (int c = lane; c < d; c += 64) {
-      dxt[(size_t)t * d + c] += al * s_dq[c] + dlog * a.w_pool[c];
-      if (a.dw_pool && dlog != 0.f) atomicAdd(a.dw_pool + c, dlog * xt[(size_t)t * d + c]);
+  for (int c = tid; c < d; c += 256) {
+    const float wp = a.w_pool[c], dqc = s_dq[c];
+    float dw = 0.f;
+    for (int t = 0; t < a.Lt; t++) {
+      const float al = a.alpha[b * a.Lt + t];
+      const float dlog = al * (s_da[t] - dot);
+      dxt[(size_t)t * d + c] += al * dqc + dlog * wp;
+      dw += dlog * xt[(size_t)t * d + c];
     }
+    if (a.dw_pool) atomicAdd(a.dw_pool + c, dw);
   }
   (void)s_red;
 }
@@ -375,7 +389,7 @@ int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
   return 0;
 }
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
-  const size_t sh = (2 * a.d + a.Lt + 8) * sizeof(float);
+  const size_t sh = (a.d + a.Lt + 3 * a.Lv + 8) * sizeof(float);
   hipLaunchKernelGGL(saliency_bwd_kernel, dim3(a.B), dim3(256), sh, s, a);
   UVTG_CHECK_LAUNCH();
   return 0;

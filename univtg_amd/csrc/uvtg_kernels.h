@@ -148,6 +148,7 @@ struct SaliencyArgs {             // weighted text pooling + cosine saliency (mo
   const float* g_sal;             // [B, Lv]  d/d saliency_scores
   const float* g_pooled;          // [B, d]   d/d txt_mem_proj
   const float* g_vid; long long gv_sb, gv_st;   // d/d vid_mem_proj: g_vid[b*gv_sb + t*gv_st + c], or null
+  const float* g_vrow; const long long* pos_idx; // optional compact extra: g_vrow[b, :] is added on row pos_idx[b]
   float* dx0;                     // [B*S, d] accumulated (+=)
   float* dw_pool;                 // [d] atomically accumulated
 };
@@ -177,9 +178,11 @@ struct LossArgs {
   const float* go;            // [5] upstream gradient per loss (device memory)
   float* g_logits;            // [B, Lv]
   float* g_spans;             // [B, Lv, 2]
-  float* g_vid;               // [B, Lv, d] dense
-  float* g_txt;               // [B, d]
+  float* g_vid;               // [B, Lv, d] dense, or NULL = compact mode
+  float* g_txt;               // [B, d]  (compact mode: inter-video part only)
+  float* g_cos;               // [B, Lv] d/d cosine(vid, txt)  (= d/d saliency_scores)
+  float* g_vrow;              // [B, d]  inter-video gradient wrt vid_mem_proj[b, pos_b, :]
 };
-long long loss_ws_floats(int B, int Lv);
+long long loss_ws_floats(int B, int Lv, int d);
 int launch_losses_fwd(const LossArgs& a, hipStream_t s);
 int launch_losses_bwd(const LossArgs& a, hipStream_t s);

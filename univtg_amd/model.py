@@ -148,7 +148,7 @@ class _UniVTGFunction(torch.autograd.Function):
         S, d = x0.shape[1], x0.shape[2]
         _lib.check(lib.uvtg_backward(C.byref(dims), ptrs, _ptr(ctx.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                      _ptr(src_vid_mask), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans), _ptr(txt_mem),
-                                     _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d,
+                                     _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d, None, None,
                                      _ptr(grads), _ptr(ctx.ws), _stream()), "uvtg_backward")
         ctx.ws = None
         out = [None] * 6
@@ -300,7 +300,7 @@ class _CriterionFunction(torch.autograd.Function):
         if vid.stride(2) != 1:
             vid = vid.contiguous()
         pl, ps, tx = _f32c(pred_logits), _f32c(pred_spans), _f32c(txt)
-        ws = torch.empty(lib.uvtg_loss_ws_floats(B, Lv), device=pl.device)
+        ws = torch.empty(lib.uvtg_loss_ws_floats(B, Lv, d), device=pl.device)
         losses = torch.empty(8, device=pl.device)
         _lib.check(lib.uvtg_criterion_fwd(B, Lv, d, which, eos_coef, _ptr(pl), _ptr(ps), _ptr(vid), vid.stride(0), vid.stride(1),
                                           _ptr(tx), _ptr(timestamp), _ptr(ts_mask), _ptr(ts_window), _ptr(span_nn), _ptr(sal),
@@ -318,10 +318,11 @@ class _CriterionFunction(torch.autograd.Function):
         go = _f32c(go)
         g_l, g_s = torch.empty(B, Lv, device=pl.device), torch.empty(B, Lv, 2, device=pl.device)
         g_v, g_t = torch.empty(B, Lv, d, device=pl.device), torch.empty(B, d, device=pl.device)
+        g_c, g_r = torch.empty(B, Lv, device=pl.device), torch.empty(B, d, device=pl.device)
         _lib.check(lib.uvtg_criterion_bwd(B, Lv, d, ctx.which, ctx.eos, _ptr(pl), _ptr(ps), _ptr(vid), vid.stride(0), vid.stride(1),
                                           _ptr(tx), _ptr(timestamp), _ptr(ts_mask), _ptr(ts_window), _ptr(span_nn), _ptr(sal),
                                           _ptr(pos_idx), _ptr(ctx.ws), _ptr(losses), _ptr(go), _ptr(g_l), _ptr(g_s), _ptr(g_v),
-                                          _ptr(g_t), _stream()), "uvtg_criterion_bwd")
+                                          _ptr(g_t), _ptr(g_c), _ptr(g_r), _stream()), "uvtg_criterion_bwd")
         sl, ss, st = ctx.shapes
         return (None, None, g_l.view(sl), g_s.view(ss), g_v, g_t.view(st)) + (None,) * 6
 

@@ -77,11 +77,12 @@ class TrainStep:
         self.pred_spans = torch.empty(B, Lv, 2, device=dev)
         self.txt_mem = torch.empty(B, 1, d, device=dev)
         self.sal = torch.empty(B, Lv, device=dev)
-        self.loss_ws = torch.empty(self.lib.uvtg_loss_ws_floats(B, Lv), device=dev)
+        self.loss_ws = torch.empty(self.lib.uvtg_loss_ws_floats(B, Lv, d), device=dev)
         self.losses = torch.zeros(8, device=dev)
         self.g_logits = torch.empty(B, Lv, device=dev)
         self.g_spans = torch.empty(B, Lv, 2, device=dev)
-        self.g_vid = torch.empty(B, Lv, d, device=dev)
+        self.g_cos = torch.empty(B, Lv, device=dev)
+        self.g_vrow = torch.empty(B, d, device=dev)
         self.g_txt = torch.empty(B, d, device=dev)
         self._shape = (B, Lv, Lt)
 
@@ -113,12 +114,12 @@ class TrainStep:
                      _ptr(tg["timestamp_window"]), _ptr(tg["span_labels_nn"]), _ptr(sal), _ptr(pos), _ptr(self.loss_ws),
                      _ptr(self.losses))
         chk(lib.uvtg_criterion_fwd(*crit_args, st), "uvtg_criterion_fwd")
-        chk(lib.uvtg_criterion_bwd(*crit_args, _ptr(self.go), _ptr(self.g_logits), _ptr(self.g_spans), _ptr(self.g_vid),
-                                   _ptr(self.g_txt), st), "uvtg_criterion_bwd")
+        chk(lib.uvtg_criterion_bwd(*crit_args, _ptr(self.go), _ptr(self.g_logits), _ptr(self.g_spans), None,
+                                   _ptr(self.g_txt), _ptr(self.g_cos), _ptr(self.g_vrow), st), "uvtg_criterion_bwd")
         chk(lib.uvtg_backward(C.byref(dims), self.ptrs, _ptr(self.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                               _ptr(src_vid_mask), _ptr(self.x0), _ptr(self.pred_logits), _ptr(self.pred_spans), _ptr(self.txt_mem),
-                              _ptr(self.g_logits), _ptr(self.g_spans), None, _ptr(self.g_txt), _ptr(self.g_vid), Lv * d, d,
-                              _ptr(self.grads), _ptr(self.ws), st), "uvtg_backward")
+                              _ptr(self.g_logits), _ptr(self.g_spans), _ptr(self.g_cos), _ptr(self.g_txt), None, 0, 0,
+                              _ptr(self.g_vrow), _ptr(pos), _ptr(self.grads), _ptr(self.ws), st), "uvtg_backward")
         if self.world > 1:
             allreduce_flat_(self.grads, self.bucket, self.pg)
         if optimize:
