@@ -164,10 +164,10 @@ def main():
         lib.uvtg_profile_start()
         for i in range(args.profile_steps):
             step.step(*batches[i % 2])
-        ms, fl, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_longlong * 3)()
+        ms, fl, n = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
         _lib.check(lib.uvtg_profile_stop(ms, fl, n), "uvtg_profile_stop")
-        fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel"]
-        dom = max(range(3), key=lambda i: ms[i])
+        fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel", "gemm_nt256_kernel"]
+        dom = max(range(4), key=lambda i: ms[i])
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         roof = dict(bound="mfma", kernel=fam[dom], achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                     traffic=None, launches_per_step=int(n[dom] // max(1, args.profile_steps)),
@@ -175,7 +175,7 @@ def main():
                     algorithmic_gflop_per_launch=round(fl[dom] / max(1, n[dom]) / 1e9, 2),
                     all_gemm_kernels={fam[i]: dict(ms_per_step=round(ms[i] / max(1, args.profile_steps), 3),
                                                    tflops=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else 0.0,
-                                                   launches_per_step=int(n[i] // max(1, args.profile_steps))) for i in range(3)})
+                                                   launches_per_step=int(n[i] // max(1, args.profile_steps))) for i in range(4)})
     if world > 1:
         torch.distributed.barrier()
 

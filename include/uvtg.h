@@ -173,10 +173,15 @@ int uvtg_adamw_clip_step(float* params, const float* grads, float* exp_avg, floa
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float max_norm, float grad_scale, float* scratch, uvtg_stream_t stream);
 
-/* ---- measurement hooks (bench.py): HIP events around every launch of the three GEMM kernels, recorded on
- * the launch stream.  index 0: gemm_nt bf16, 1: gemm_nt split-bf16, 2: gemm_tn (wgrad).  host arrays [3]. */
+/* ---- measurement hooks (bench.py): HIP events around every launch of the GEMM kernels, recorded on the launch
+ * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-bf16, 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,
+ * persistent).  host arrays [4]. */
 int uvtg_profile_start(void);
 int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
+
+/* Test knob: force the NT GEMM tile size (0 = automatic choice, 128, 256) so that both kernels can be compared on
+ * identical inputs.  Process-wide. */
+int uvtg_debug_force_nt_tile(int tile);
 
 const char* uvtg_strerror(int code);
 int uvtg_version(void);

@@ -23,7 +23,7 @@ def relerr(a, b):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(256, 256, 256, 0), (300, 200, 136, 1), (1024, 1024, 1024, 2), (77, 64, 96, 0),
-                                       (27392, 1024, 1024, 0)])
+                                       (27392, 1024, 1024, 0), (8292, 2056, 512, 2), (5000, 3080, 192, 1)])
 def test_linear_bf16(dev, M, N, K, act):
     from univtg_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
@@ -164,3 +164,23 @@ def test_sine_position(dev):
     ref = O.sine_position(vm, d)
     assert float((pos.cpu() - ref).abs().max()) < 5e-6
     assert torch.equal(kvalid.cpu().bool(), torch.cat([vm, tm], 1).bool())
+
+
+def test_nt_tile_sizes_agree(dev):
+    """The persistent 256-tile GEMM and the 128-tile GEMM give the same results (same bf16 products, fp32 accumulation
+    in the same K order) on ragged shapes, with every epilogue the kernel-level entry point exposes."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7)
+    try:
+        for (M, N, K, act) in [(5000, 3080, 192, 1), (700, 520, 1024, 2), (27392, 1024, 1024, 0)]:
+            a = bf(torch.randn(M, K, generator=g).to(dev))
+            w = bf((torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev))
+            b = torch.randn(N, generator=g).to(dev)
+            _lib.check(lib.uvtg_debug_force_nt_tile(128))
+            r128 = ops.linear_bf16(a, w, b, act)
+            _lib.check(lib.uvtg_debug_force_nt_tile(256))
+            r256 = ops.linear_bf16(a, w, b, act)
+            assert float((r128 - r256).abs().max()) <= 1e-6 * float(r128.abs().max()), (M, N, K)
+    finally:
+        lib.uvtg_debug_force_nt_tile(0)

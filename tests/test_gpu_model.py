@@ -330,3 +330,39 @@ def test_native_train_step_matches_autograd_path(dev):
     opt = torch.optim.AdamW([p_ref], lr=1e-4, weight_decay=1e-4)
     opt.step()
     assert float((p_ref.detach() - step.flat).abs().max()) < 1e-6
+
+
+def test_nt256_engine_path_matches_nt128(dev):
+    """Config-2 size (B=256): the whole forward+criterion+backward with the persistent 256-tile GEMM gives the same
+    losses and the same flat gradient as with the 128-tile GEMM forced (identical bf16 products, same K order; only
+    the fp32 atomic order of the weight-gradient kernel differs)."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import _lib
+    from univtg_amd.trainer import TrainStep
+    lib = _lib.load()
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0)
+    params = O.init_params(cfg, seed=21)
+    inputs, tg = O.make_batch(cfg, 256, 75, 32, seed=22, ragged=True)
+    ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    model, crit = build(cfg, params, dev, "bf16")
+    model.eval()
+    step = TrainStep(model, crit, grad_clip=0.1)
+    res = {}
+    try:
+        for tile in (128, 256):
+            _lib.check(lib.uvtg_debug_force_nt_tile(tile))
+            losses = step.step(ind, tgd, optimize=False).clone()
+            torch.cuda.synchronize()
+            res[tile] = (losses, step.grads.clone(), step.pred_logits.clone(), step.pred_spans.clone())
+    finally:
+        lib.uvtg_debug_force_nt_tile(0)
+    l1, g1, pl1, ps1 = res[128]
+    l2, g2, pl2, ps2 = res[256]
+    assert torch.isfinite(g2).all()
+    assert float((pl1 - pl2).abs().max()) < 1e-6 and float((ps1 - ps2).abs().max()) < 1e-6
+    assert float((l1 - l2).abs().max()) < 1e-5 * max(1.0, float(l1.abs().max()))
+    offs = model._offsets(model._dims(256, 75, 32, cfg.v_feat_dim, cfg.t_feat_dim, False))
+    for i, p in enumerate(model._ordered_params()):
+        a, b = g1[offs[i]: offs[i] + p.numel()], g2[offs[i]: offs[i] + p.numel()]
+        err = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
+        assert err < 2e-3, (i, err)

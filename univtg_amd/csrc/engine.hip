@@ -266,6 +266,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -16: return "dims: feature dims must be positive";
     case -17: return "dims: too many encoder layers";
     case -20: return "null pointer argument";
+    case -21: return "force_nt_tile: tile must be 0, 128 or 256";
     default: return "invalid argument";
   }
 }

@@ -213,6 +213,235 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_nt256: the large-shape bf16 path.  256 x 256 x 64 tiles, 8 waves (2 x 4, 128 x 64 each, 128 accumulator
+// registers), operands staged with global_load_lds (16 B per lane, no VGPR round trip) into two 64 KB stages,
+// ONE barrier per K tile.  Persistent: grid = min(tiles, #CU); every workgroup walks tiles bid, bid + G, ... and the
+// K-tile stream never drains at a tile boundary -- the last K step of a tile prefetches K tile 0 of the next tile into
+// the other stage while the epilogue of the finished tile runs out of the stage just consumed (an 8 KB fp32 slab per
+// wave, row-contiguous 16/32-byte global accesses) and its stores stay in flight behind the next tile's main loop.
+// LDS image of a stage: A [256][64] bf16, then B [256][64] bf16; rows are 128 B; the 16-byte chunk c of row r sits at
+// chunk position c ^ ((r >> 1) & 7): global_load_lds writes lane-linearly, so the permutation is applied to the per-lane
+// SOURCE address and again on the ds_read_b128 fragment reads (conflict-free for the 32-row fragments).
+// Tiles are enumerated XCD-aware: the 8 workgroups that run concurrently on one XCD take neighbouring tiles, which
+// share the A row panel through that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// GATHER: row gather / scatter / conv taps / groups present (integer divisions per row); the plain variant has none.
+template <bool GATHER>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
+  constexpr int TB = 256, KB = 64, TM = 4, TN = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + TB - 1) / TB;
+  const int per_group = tiles_m * tiles_n;
+  const int ntiles = per_group * p.groups;
+  const int nk = p.K / KB;
+  const int sr = lane >> 3, sc = lane & 7;
+
+  auto tile_origin = [&](int t, int& gz, int& m0, int& n0) {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
+    int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    gz = l / per_group; l -= gz * per_group;
+    m0 = (l / tiles_n) * TB; n0 = (l % tiles_n) * TB;
+  };
+  unsigned aofs[4], bofs[4];     // byte offsets of this lane's 8 staging pieces for the tile being loaded
+  auto set_offsets = [&](int gz, int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = (wave * 4 + i) * 8 + sr;
+      const int c = (sc ^ ((r >> 1) & 7)) * 8;
+      const int am = GATHER ? map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off) : min(m0 + r, p.M - 1);
+      aofs[i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
+      bofs[i] = (unsigned)(((size_t)min(n0 + r, p.N - 1) * p.ldb + c + (size_t)gz * p.gB) * 2);
+    }
+  };
+  int s_tap = 0, s_kk = 0;        // conv tap / column within the tap of the K tile staged next (GATHER only)
+  auto stage = [&](int s, int kt) {
+    unsigned char* base = smem256 + s * 65536 + wave * 4096;
+    const int k0 = kt * KB;
+    unsigned ka = (unsigned)k0 * 2u;
+    const unsigned kb = (unsigned)k0 * 2u;
+    if constexpr (GATHER) {
+      if (kt == 0) { s_tap = 0; s_kk = 0; }
+      ka = (unsigned)(s_tap * p.lda + s_kk) * 2u;
+      s_kk += KB;
+      if (s_kk >= p.ktap) { s_kk = 0; s_tap++; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.A + (aofs[i] + ka)), (lds_void_t*)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i] + kb)), (lds_void_t*)(base + 32768 + i * 1024), 16, 0, 0);
+    }
+  };
+  int aoff[TM], boff[TN];
+  const int swz = (l31 >> 1) & 7;           // identical for every 32-row fragment of the wave
+#pragma unroll
+  for (int i = 0; i < TM; i++) aoff[i] = (wm * 128 + i * 32 + l31) * 128;
+#pragma unroll
+  for (int j = 0; j < TN; j++) boff[j] = 32768 + (wn * 64 + j * 32 + l31) * 128;
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int gz, m0, n0;
+  tile_origin(tile, gz, m0, n0);
+  set_offsets(gz, m0, n0);
+  stage(0, 0);
+  int it = 0;
+  while (true) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int next = tile + gridDim.x;
+    int ngz = 0, nm0 = 0, nn0 = 0;
+    for (int kt = 0; kt < nk; kt++, it++) {
+      const int cur = it & 1;
+      __syncthreads();                       // vmcnt(0) + barrier: K tile `it` landed, the other stage is free
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      else if (next < ntiles) { tile_origin(next, ngz, nm0, nn0); set_offsets(ngz, nm0, nn0); stage(cur ^ 1, 0); }
+      const unsigned char* base = smem256 + cur * 65536;
+      s16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; j++) fb[0][j] = *(const s16x8*)(base + boff[j] + ((g ^ swz) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        if (ks < 3) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) fa[(ks + 1) & 1][i] = *(const s16x8*)(base + aoff[i] + (((2 * ks + 2 + g) ^ swz) << 4));
+#pragma unroll
+          for (int j = 0; j < TN; j++) fb[(ks + 1) & 1][j] = *(const s16x8*)(base + boff[j] + (((2 * ks + 2 + g) ^ swz) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      }
+    }
+    // ---------------- epilogue of `tile`, out of the stage consumed last ----------------
+    if (p.act == 100) {   // measurement aid: main loop only
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) t += acc[i][j][r];
+      if (t == 123.456f) p.outF[0] = t;
+    } else {
+      __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
+      float* wbuf = (float*)(smem256 + ((it - 1) & 1) * 65536) + wave * 2048;    // [32][64] fp32, wave-private
+      const int c8 = (lane & 7) * 8;
+      const int n = n0 + wn * 64 + c8;
+      const bool ncol = n < p.N;
+      const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) bv[e] = 0.f;
+      if (ncol) {
+        if (p.bias) {
+          const float* bias = p.bias + (size_t)gz * p.gBias + n;
+          const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+        }
+        if (p.bias2) {
+          const f32x4 b0 = *(const f32x4*)(p.bias2 + n), b1 = *(const f32x4*)(p.bias2 + n + 4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+        }
+      }
+      const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            wbuf[((r & 3) + 8 * (r >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+          const int row = q * 8 + (lane >> 3);
+          const int m = m0 + wm * 128 + i * 32 + row;
+          const f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
+          if (m >= p.M || !ncol) continue;
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          const size_t orow = GATHER ? (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off) : (size_t)m;
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = (v[e] + bv[e]) * cs;
+          if (p.outPre) {
+            u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
+            *(u32x4*)(p.outPre + go + orow * p.ldpre_out + n) = t;
+          }
+          if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = gelu_erf(v[e]);
+          }
+          if (p.actgrad) {
+            const u32x4 t = *(const u32x4*)(p.gradPre + gp + orow * p.ldgp + n);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const float q0 = __uint_as_float(t[e] << 16), q1 = __uint_as_float(t[e] & 0xffff0000u);
+              if (p.actgrad == 1) { v[2 * e] = q0 > 0.f ? v[2 * e] : 0.f; v[2 * e + 1] = q1 > 0.f ? v[2 * e + 1] : 0.f; }
+              else { v[2 * e] *= gelu_erf_grad(q0); v[2 * e + 1] *= gelu_erf_grad(q1); }
+            }
+          }
+          if (p.rowscale) {
+            const float rs = p.rowscale[m / p.rs_seg];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] *= rs;
+          }
+          if (p.resid) {
+            const float* rp = p.resid + orow * p.ldr + n;
+            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          if (p.outF) {
+            float* op = p.outF + go + orow * p.ldoF + n;
+            *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+          }
+          if (p.outB) {
+            u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
+            *(u32x4*)(p.outB + go + orow * p.ldoB + n) = t;
+          }
+          if (p.outU || p.outUF) {
+            if (p.pos && m < p.pos_rows) {
+              const float* pp = p.pos + (size_t)m * p.ldpos + n;
+              const f32x4 r0 = *(const f32x4*)pp, r1 = *(const f32x4*)(pp + 4);
+#pragma unroll
+              for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            }
+            if (p.outU) {
+              u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
+              *(u32x4*)(p.outU + orow * p.ldoU + n) = t;
+            }
+            if (p.outUF) {
+              float* op = p.outUF + orow * p.ldoU + n;
+              *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+              *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
+          }
+        }
+      }
+    }
+    if (next >= ntiles) break;
+    tile = next; gz = ngz; m0 = nm0; n0 = nn0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TN: out[n][k] += sum_m P[m][n] * Q[m + q_row_off][k]
 // ------------------------------------------------------------------------------------------------
 constexpr int TBM = 64;                 // reduction rows per step
@@ -328,8 +557,54 @@ static int check_nt(const GemmArgs& a, int elem) {
   return 0;
 }
 
+// eligibility of the 256-tile path: whole 64-wide K tiles (also per conv tap), 16-byte rows everywhere the epilogue
+// touches 8 columns at a time, 32-bit byte offsets, and enough work that 256 x 256 tiles do not waste the chip
+static int g_force_tile = 0;   // 0: automatic, 128 / 256: force that NT tile size where it is legal (parity tests)
+extern "C" int uvtg_debug_force_nt_tile(int tile) { if (tile != 0 && tile != 128 && tile != 256) return -21; g_force_tile = tile; return 0; }
+static bool nt256_ok(const GemmArgs& a) {
+  if (g_force_tile == 128) return false;
+  if (a.K % 64 || a.ktap % 64 || a.lda % 8 || a.ldb % 8 || a.N % 8) return false;
+  if (a.ldoF % 8 || a.ldoB % 8 || a.ldoU % 8 || a.ldr % 8 || a.ldgp % 8 || a.ldpre_out % 8 || a.ldpos % 8 || a.colscale_n % 8) return false;
+  if (a.gA % 8 || a.gB % 8 || a.gBias % 4 || a.gOut % 8 || a.gPre % 8) return false;
+  const int groups = a.groups > 0 ? a.groups : 1;
+  if (g_force_tile != 256) {  // pick the tile size that wastes less of the chip: whole rounds of 256 (one 256-tile per CU) vs 512 (two 128-tiles per CU)
+    const long long t256 = (long long)cdiv(a.M, 256) * cdiv(a.N, 256) * groups, t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128) * groups;
+    const double e256 = (double)t256 / (double)((t256 + 255) / 256 * 256) * 950.0;     // measured in-loop TFLOP/s of the two structures
+    const double e128 = (double)t128 / (double)((t128 + 511) / 512 * 512) * 620.0;
+    if (e256 < e128) return false;
+  }
+  const long long amax = ((long long)(a.a_seg ? (a.M / a.a_seg + 1) * a.a_seg_stride : a.M) + a.a_off + 3) * a.lda + (long long)groups * a.gA;
+  const long long bmax = (long long)a.N * a.ldb + (long long)groups * a.gB;
+  return amax * 2 < (1LL << 32) && bmax * 2 < (1LL << 32);
+}
+static int g_num_cu = 0;
+static int launch_nt256(const GemmArgs& a, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipError_t e = hipGetDevice(&dev)) return (int)e;
+    if (hipError_t e = hipGetDeviceProperties(&pr, dev)) return (int)e;
+    g_num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    attr = true;
+  }
+  GemmArgs b = a;
+  if (b.groups <= 0) b.groups = 1;
+  const int tiles = cdiv(b.M, 256) * cdiv(b.N, 256) * b.groups;
+  const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+  uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
+  const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1;
+  if (gather) hipLaunchKernelGGL(gemm_nt256_kernel<true>, dim3(grid), dim3(512), 131072, s, b);
+  else hipLaunchKernelGGL(gemm_nt256_kernel<false>, dim3(grid), dim3(512), 131072, s, b);
+  uvtg_prof_end_launch(3, s);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
   if (int e = check_nt(a, 2)) return e;
+  if (nt256_ok(a)) return launch_nt256(a, s);
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
   uvtg_prof_begin_launch(0, 2.0 * a.M * a.N * a.K * grid.z, s);
   hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, s, a);

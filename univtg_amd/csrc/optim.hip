@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 
 struct Prof {
   bool on = false;
-  std::vector<hipEvent_t> ev[3];
-  size_t used[3] = {0, 0, 0};
-  double flops[3] = {0, 0, 0};
+  std::vector<hipEvent_t> ev[4];
+  size_t used[4] = {0, 0, 0, 0};
+  double flops[4] = {0, 0, 0, 0};
 } g_prof;
 
 }  // namespace
@@ -84,7 +84,7 @@ void uvtg_prof_end_launch(int family, hipStream_t s) {
   u += 2;
 }
 extern "C" int uvtg_profile_start(void) {
-  for (int f = 0; f < 3; f++) { g_prof.used[f] = 0; g_prof.flops[f] = 0; }
+  for (int f = 0; f < 4; f++) { g_prof.used[f] = 0; g_prof.flops[f] = 0; }
   g_prof.on = true;
   return 0;
 }
@@ -92,7 +92,7 @@ extern "C" int uvtg_profile_stop(double* ms, double* flops, long long* launches)
   g_prof.on = false;
   if (!ms || !flops || !launches) return -20;
   if (hipError_t e = hipDeviceSynchronize()) return (int)e;
-  for (int f = 0; f < 3; f++) {
+  for (int f = 0; f < 4; f++) {
     double tot = 0;
     for (size_t i = 0; i + 1 < g_prof.used[f]; i += 2) {
       float t = 0;
