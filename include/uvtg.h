@@ -129,6 +129,11 @@ int uvtg_linear_f32x3(const float* A, const float* W, const float* bias, float* 
 /* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 operands, fp32 atomic accumulate), dbias[N] += colsum(dY) (may be NULL) */
 int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits,
                     uvtg_stream_t stream);
+/* same, with caller scratch of uvtg_wgrad_scratch_floats(M, N, K) floats: the large shapes then run the 256-tile kernel
+ * (split partial tiles as plain fp32 slabs + a reduce pass instead of fp32 atomics) */
+long long uvtg_wgrad_scratch_floats(int M, int N, int K);
+int uvtg_wgrad_bf16_ws(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, float* scratch,
+                       long long scratch_floats, uvtg_stream_t stream);
 int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t stream);
 /* LayerNorm rows (eps 1e-5): y fp32, optional mean/rstd */
 int uvtg_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -63,6 +63,24 @@ def test_wgrad_tn(dev, M, N, K, splits):
     assert relerr(db, dy.double().sum(0)) < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(27392, 1024, 1024), (4100, 520, 2824), (19200, 1024, 2880), (2050, 256, 264)])
+def test_wgrad_tn256(dev, M, N, K):
+    """256-tile weight-gradient kernel (plain fp32 slabs + reduce): ragged M tail, ragged N / K tiles, bias gradient."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + 3 * N)
+    dy = bf(torch.randn(M, N, generator=g)).to(dev)
+    x = bf(torch.randn(M, K, generator=g)).to(dev)
+    try:
+        _lib.check(lib.uvtg_debug_force_nt_tile(256))
+        dw, db = ops.wgrad_bf16_ws(dy, x)
+    finally:
+        lib.uvtg_debug_force_nt_tile(0)
+    ref = dy.double().t() @ x.double()
+    assert relerr(dw, ref) < 3e-5, relerr(dw, ref)
+    assert relerr(db, dy.double().sum(0)) < 3e-5
+
+
 @pytest.mark.parametrize("rows,D", [(64, 1024), (37, 2818), (50, 512), (9, 514), (33, 64), (5, 2817)])
 def test_layernorm(dev, rows, D):
     from univtg_amd import ops

@@ -29,3 +29,5 @@ for (M, N, K) in [(27392, 1024, 1024), (27392, 2048, 1024), (19200, 1024, 2944)]
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     t = timeit(lambda: ops.wgrad_bf16(dy, x, 8))
     print(f"TN bf16 {M}x{N}x{K}: {t:8.1f} us  {2*M*N*K/t/1e6:8.1f} TFLOP/s (incl. zero-init of dW)")
+    t = timeit(lambda: ops.wgrad_bf16_ws(dy, x))
+    print(f"TN256   {M}x{N}x{K}: {t:8.1f} us  {2*M*N*K/t/1e6:8.1f} TFLOP/s (incl. zero-init of dW, scratch alloc)")

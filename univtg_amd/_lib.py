@@ -39,6 +39,8 @@ SIGNATURES = {
     "uvtg_linear_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uvtg_linear_f32x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uvtg_wgrad_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "uvtg_wgrad_scratch_floats": (_LL, [_I, _I, _I]),
+    "uvtg_wgrad_bf16_ws": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _LL, _P]),
     "uvtg_cast_bf16": (_I, [_P, _P, _LL, _P]),
     "uvtg_layernorm_fwd": (_I, [_P] * 6 + [_I, _I, _P]),
     "uvtg_layernorm_bwd": (_I, [_P] * 8 + [_I, _I, _P]),

@@ -125,7 +125,7 @@ struct WSpace {
   // saliency
   float *alpha, *cosv, *vnorm, *qnorm;
   // backward scratch
-  float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2];
+  float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2], *tn_scratch; long long tn_scratch_floats;
   bf16_t *dh2_pad, *dh1_pad, *dyB, *da, *dOb, *dqkv, *dyP[2], *dh1b[2];
   size_t bytes;
   WSpace(const Dm& m, void* base, float* x0) {
@@ -181,6 +181,13 @@ struct WSpace {
     if (tr) {
       dvm = a.take<float>((size_t)m.Mv * d); gx[0] = a.take<float>(M * d); gx[1] = a.take<float>(M * d);
       dyF = a.take<float>(M * d); delta = a.take<float>(B * m.c.H * m.S);
+      {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
+        long long need = 0;
+        const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d},
+                                 {m.Mv, (int)d, (int)d}, {m.Mt, (int)d, (int)d}, {m.Mv, (int)d, m.c.Dv}, {m.Mt, (int)d, m.c.Dt}};
+        for (auto& sh : shapes) { const long long f = gemm_tn_scratch_floats(sh[0], sh[1], sh[2]); if (f > need) need = f; }
+        tn_scratch_floats = need; tn_scratch = a.take<float>((size_t)need);
+      }
       dh2_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d); dh1_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d);
       dyB = a.take<bf16_t>(M * d); da = a.take<bf16_t>(M * F); dOb = a.take<bf16_t>(M * d); dqkv = a.take<bf16_t>(M * 3 * d);
       for (int i = 0; i < 2; i++) {
@@ -189,7 +196,7 @@ struct WSpace {
         dA2[i] = a.take<float>(R * d); dA1[i] = a.take<float>(R * Kp);
       }
     } else {
-      dvm = gx[0] = gx[1] = dyF = delta = nullptr; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
+      dvm = gx[0] = gx[1] = dyF = delta = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
       for (int i = 0; i < 2; i++) { dyP[i] = dh1b[i] = nullptr; dA2[i] = dA1[i] = nullptr; }
     }
     bytes = a.off + 256;
@@ -557,6 +564,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     GemmTNArgs t; memset(&t, 0, sizeof(t));
     t.P = Pm; t.ldp = ldp; t.Q = Q; t.ldq = ldq; t.M = rows; t.N = N; t.K = K; t.q_row_off = q_off; t.Mq = Mq;
     t.out = out; t.ldo = ldo; t.col_stride = cs; t.dbias = dbias; t.splits = splits;
+    t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
     return launch_gemm_tn_bf16(t, s);
   };
 
@@ -757,6 +765,15 @@ extern "C" int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* 
   GemmTNArgs t; memset(&t, 0, sizeof(t));
   t.P = (const bf16_t*)dY; t.ldp = N; t.Q = (const bf16_t*)X; t.ldq = K; t.M = M; t.N = N; t.K = K; t.Mq = M;
   t.out = dW; t.ldo = K; t.col_stride = 1; t.dbias = dbias; t.splits = splits;
+  return launch_gemm_tn_bf16(t, (hipStream_t)st);
+}
+extern "C" long long uvtg_wgrad_scratch_floats(int M, int N, int K) { return gemm_tn_scratch_floats(M, N, K); }
+extern "C" int uvtg_wgrad_bf16_ws(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, float* scratch,
+                                  long long scratch_floats, uvtg_stream_t st) {
+  if (!dY || !X || !dW) return -20;
+  GemmTNArgs t; memset(&t, 0, sizeof(t));
+  t.P = (const bf16_t*)dY; t.ldp = N; t.Q = (const bf16_t*)X; t.ldq = K; t.M = M; t.N = N; t.K = K; t.Mq = M;
+  t.out = dW; t.ldo = K; t.col_stride = 1; t.dbias = dbias; t.splits = 8; t.scratch = scratch; t.scratch_floats = scratch_floats;
   return launch_gemm_tn_bf16(t, (hipStream_t)st);
 }
 extern "C" int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t st) {

@@ -541,6 +541,166 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs p) {
   if (p.dbias && tile_k == 0 && tid < 128 && n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, bsum);
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_tn256: weight gradients at the large shapes.  out[N,K] += P[M,N]^T Q[M,K] as 256 x 256 output tiles, the M
+// reduction cut into `splits` ranges so that tiles x splits ~ #CU; 8 waves (2 x 4, 128 n x 64 k each).  Both operands
+// are row-major in the reduction dimension: they are staged as [64 m][256] bf16 tiles with buffer_load ... lds
+// (out-of-range rows -- the M tail and the conv taps' row -1 / row Mq -- come back as zeros from the buffer bounds
+// check) and the MFMA fragments are built with ds_read_b64_tr_b16.  The 16-byte chunk c of tile row m is stored at
+// chunk c ^ ((m & 3) << 2), which spreads the four rows one transposing read touches over all 64 banks.
+// fp32 atomics top out at ~0.3 T adds/s on this chip (a 16-way split of a 1024^2 gradient would spend as long in
+// atomics as in MFMAs), so every (tile, split) unit writes its partial tile as a plain fp32 slab and
+// gemm_tn_reduce_kernel folds the slabs (and the bias-gradient partials) into the gradient buffer.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int splits, int steps_per, int tiles_n, int tiles_k,
+                                                         unsigned bytes_p, unsigned bytes_q, int n_pad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31, i16 = lane & 15, qd = (lane >> 4) & 1;
+  const int tiles = tiles_n * tiles_k, units = gridDim.x;
+  int l;
+  {
+    const int q = units / 8, r = units % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int split = l / tiles, tile = l % tiles;
+  const int tile_n = tile / tiles_k, tile_k = tile % tiles_k;
+  const int n0 = tile_n * 256, k0 = tile_k * 256;
+  const int steps_total = (p.M + 63) / 64;
+  const int st0 = split * steps_per, st1 = min(steps_total, st0 + steps_per);
+
+  __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, bytes_p, 0x00020000);
+  __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, bytes_q, 0x00020000);
+  unsigned vp[4], vq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int rr = (wave * 4 + i) * 2 + g;                 // tile row 0..63
+    const int cs = (l31 ^ ((rr & 3) << 2)) * 8;            // source column chunk of this lane (LDS stays lane-linear)
+    vp[i] = (unsigned)(((st0 * 64 + rr) * p.ldp + n0 + cs) * 2);
+    vq[i] = (unsigned)(((st0 * 64 + rr + p.q_row_off) * p.ldq + k0 + cs) * 2);   // negative rows wrap to out-of-range
+  }
+  const unsigned dp = (unsigned)(64 * p.ldp * 2), dq = (unsigned)(64 * p.ldq * 2);
+  auto stage = [&](int s) {
+    unsigned char* base = smem256 + s * 65536 + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void_t*)(base + i * 1024), 16, vp[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)(base + 32768 + i * 1024), 16, vq[i], 0, 0, 0);
+      vp[i] += dp; vq[i] += dq;
+    }
+  };
+  // transposing-read offsets: lane (i16, qd) addresses row m = mb + (i16 >> 2), 4 columns at 16 qd + 4 (i16 & 3)
+  const int mr = i16 >> 2;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int n = wm * 128 + i * 32 + 16 * qd + 4 * (i16 & 3);
+    aoff[i] = (8 * g + mr) * 512 + ((((n >> 3) ^ (mr << 2))) << 4) + (n & 7) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int k = wn * 64 + j * 32 + 16 * qd + 4 * (i16 & 3);
+    boff[j] = 32768 + (8 * g + mr) * 512 + ((((k >> 3) ^ (mr << 2))) << 4) + (k & 7) * 2;
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.dbias && tile_k == 0 && wn == 0;
+
+  if (st0 < st1) stage(0);
+  for (int st = st0; st < st1; st++) {
+    const int cur = (st - st0) & 1;
+    __syncthreads();
+    if (st + 1 < st1) stage(cur ^ 1);
+    const unsigned char* base = smem256 + cur * 65536;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      s16x8 a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const s16x4 a0 = lds_tr16((const bf16_t*)(base + aoff[i] + ks * 8192)), a1 = lds_tr16((const bf16_t*)(base + aoff[i] + ks * 8192 + 2048));
+        a[i] = (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const s16x4 b0 = lds_tr16((const bf16_t*)(base + boff[j] + ks * 8192)), b1 = lds_tr16((const bf16_t*)(base + boff[j] + ks * 8192 + 2048));
+        b[j] = (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) bsum[i] += bf2f((bf16_t)a[i][e]);
+      }
+    }
+  }
+  // ---- partial tile -> fp32 slab [256 n][256 k] of this (split, tile) unit, row-contiguous 16-byte stores ----
+  __syncthreads();
+  float* slab = p.scratch + ((size_t)split * tiles + tile) * 65536;
+  float* wbuf = (float*)smem256 + wave * 2048;        // [32][64] fp32, wave-private
+  const int c8 = (lane & 7) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        wbuf[((r & 3) + 8 * (r >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = q * 8 + (lane >> 3);
+      const f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
+      float* op = slab + (size_t)(wm * 128 + i * 32 + row) * 256 + wn * 64 + c8;
+      *(f32x4*)op = v0;
+      *(f32x4*)(op + 4) = v1;
+    }
+  }
+  if (do_bias) {
+    float* bpart = p.scratch + (size_t)splits * tiles * 65536 + (size_t)split * n_pad;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (g == 0) bpart[n0 + wm * 128 + i * 32 + l31] = t;
+    }
+  }
+}
+
+// out[n * ldo + k * col_stride] += sum over splits of the unit slabs; dbias[n] += sum of the bias partials
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const GemmTNArgs p, int splits, int tiles_n, int tiles_k, int n_pad) {
+  const int tiles = tiles_n * tiles_k;
+  const int kq = (p.K + 3) / 4;
+  const long long total = (long long)p.N * kq;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) {
+    const int n = (int)(idx / kq), k = (int)(idx % kq) * 4;
+    const int tile = (n >> 8) * tiles_k + (k >> 8);
+    const float* sp = p.scratch + (size_t)tile * 65536 + (size_t)(n & 255) * 256 + (k & 255);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sidx = 0; sidx < splits; sidx++) s += *(const f32x4*)(sp + (size_t)sidx * tiles * 65536);
+    float* op = p.out + (size_t)n * p.ldo + (size_t)k * p.col_stride;
+    if (p.col_stride == 1 && k + 3 < p.K && ((((uintptr_t)op) & 15) == 0)) { f32x4 o = *(f32x4*)op; o += s; *(f32x4*)op = o; }
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (k + e < p.K) op[(size_t)e * p.col_stride] += s[e];
+    }
+  }
+  if (p.dbias && idx < p.N) {
+    const float* bp = p.scratch + (size_t)splits * tiles * 65536 + idx;
+    float s = 0.f;
+    for (int sidx = 0; sidx < splits; sidx++) s += bp[(size_t)sidx * n_pad];
+    p.dbias[idx] += s;
+  }
+}
+
 }  // namespace
 
 void uvtg_prof_begin_launch(int family, double flops, hipStream_t s);
@@ -621,8 +781,53 @@ int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s) {
   UVTG_CHECK_LAUNCH();
   return 0;
 }
+// ---- 256-tile weight-gradient path -----------------------------------------------------------------
+static void tn256_plan(int M, int N, int K, int& tiles_n, int& tiles_k, int& splits, int& steps_per) {
+  tiles_n = cdiv(N, 256); tiles_k = cdiv(K, 256);
+  const int tiles = tiles_n * tiles_k, steps_total = cdiv(M, 64);
+  int want = 256 / tiles;                              // tiles x splits ~ one unit per CU
+  if (want < 1) want = 1;
+  if (want > steps_total) want = steps_total;
+  steps_per = cdiv(steps_total, want);
+  splits = cdiv(steps_total, steps_per);               // no empty split
+}
+long long gemm_tn_scratch_floats(int M, int N, int K) {
+  int tn, tk, sp, per;
+  tn256_plan(M, N, K, tn, tk, sp, per);
+  return (long long)sp * tn * tk * 65536 + (long long)sp * tn * 256;
+}
+static int launch_tn256(const GemmTNArgs& a, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    attr = true;
+  }
+  int tn, tk, sp, per;
+  tn256_plan(a.M, a.N, a.K, tn, tk, sp, per);
+  const unsigned bytes_p = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
+  const int kcols = a.ldq < (a.K + 7) / 8 * 8 ? a.ldq : (a.K + 7) / 8 * 8;
+  const unsigned bytes_q = (unsigned)((((long long)a.Mq - 1) * a.ldq + kcols) * 2);
+  uvtg_prof_begin_launch(2, 2.0 * a.M * a.N * a.K, s);
+  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tn * tk * sp), dim3(512), 131072, s, a, sp, per, tn, tk, bytes_p, bytes_q, tn * 256);
+  const long long total = (long long)a.N * ((a.K + 3) / 4);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, sp, tn, tk, tn * 256);
+  uvtg_prof_end_launch(2, s);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+static bool tn256_ok(const GemmTNArgs& a) {
+  if (!a.scratch || g_force_tile == 128) return false;
+  if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15) || ((uintptr_t)a.scratch & 15)) return false;
+  if (((long long)a.M + 64) * a.ldp * 2 >= (1LL << 31) || ((long long)a.Mq + 64) * a.ldq * 2 >= (1LL << 31)) return false;
+  if (a.scratch_floats < gemm_tn_scratch_floats(a.M, a.N, a.K)) return false;
+  if (g_force_tile == 256) return true;
+  // worth it only when 256-wide tiles do not waste much of the output and there is a real reduction to split
+  const double fill = ((double)a.N * a.K) / ((double)cdiv(a.N, 256) * 256 * (double)cdiv(a.K, 256) * 256);
+  return fill >= 0.85 && a.M >= 2048;
+}
 int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.splits <= 0) return -1;
+  if (tn256_ok(a)) return launch_tn256(a, s);
   if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15)) return -2;
   dim3 grid(cdiv(a.N, 128) * cdiv(a.K, 128), a.splits, 1);
   uvtg_prof_begin_launch(2, 2.0 * a.M * a.N * a.K, s);

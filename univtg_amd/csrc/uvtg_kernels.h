@@ -43,8 +43,12 @@ struct GemmTNArgs {
   int q_row_off, Mq;            // Q row = m + q_row_off, rows outside [0, Mq) read as zero
   float* out; int ldo, col_stride;   // out[n * ldo + k * col_stride]
   float* dbias;                 // optional: dbias[n] += sum_m P[m][n]
-  int splits;
+  int splits;                   // M splits of the atomic 128-tile kernel
+  // optional scratch for the 256-tile kernel (split partial tiles as plain fp32 slabs + a reduce pass instead of
+  // fp32 atomics); null / too small -> the atomic kernel is used
+  float* scratch; long long scratch_floats;
 };
+long long gemm_tn_scratch_floats(int M, int N, int K);   // scratch that makes every (M, N, K) eligible for the 256-tile kernel
 int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

@@ -57,6 +57,21 @@ def wgrad_bf16(dy_bf16, x_bf16, splits=4, with_bias=True):
     return dw, db
 
 
+def wgrad_bf16_ws(dy_bf16, x_bf16, with_bias=True):
+    """Same as wgrad_bf16 with the scratch that enables the 256-tile slab + reduce kernel."""
+    _need_cuda(dy_bf16)
+    lib = _lib.load()
+    M, N = dy_bf16.shape
+    K = x_bf16.shape[1]
+    dw = torch.zeros(N, K, device=dy_bf16.device)
+    db = torch.zeros(N, device=dy_bf16.device) if with_bias else None
+    nf = lib.uvtg_wgrad_scratch_floats(M, N, K)
+    scratch = torch.empty(nf, device=dy_bf16.device)
+    _lib.check(lib.uvtg_wgrad_bf16_ws(_ptr(dy_bf16.contiguous()), _ptr(x_bf16.contiguous()), _ptr(dw), _ptr(db), M, N, K,
+                                      _ptr(scratch), nf, _stream()), "uvtg_wgrad_bf16_ws")
+    return dw, db
+
+
 def layernorm_fwd(x, gamma, beta):
     _need_cuda(x)
     x = _f32c(x)
