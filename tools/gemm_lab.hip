@@ -213,9 +213,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const LabArgs p) {
     int nm0 = 0, nn0 = 0;
     for (int kt = 0; kt < nk; kt++, it++) {
       const int cur = it & 1;
-      __syncthreads();
+      if (!(p.mode & 32)) __syncthreads();
+      if (!(p.mode & 16)) {
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
       else if (next < ntiles) { tile_origin(next, nm0, nn0); set_offsets(nm0, nn0); stage(cur ^ 1, 0); }
+      }
       const unsigned char* base = smem + cur * 65536;
       s16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -235,9 +237,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const LabArgs p) {
 #pragma unroll
           for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
       }
+#ifdef SGB
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+      for (int ks = 0; ks < 3; ks++) {
+#pragma unroll
+        for (int n = 0; n < TM + TN; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+#endif
     }
     // ---- epilogue of `tile` out of the stage consumed last ----
-    if (p.mode == 0) {
+    if ((p.mode & 15) == 0) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; i++)
@@ -333,7 +345,18 @@ template <int WM, int WN> void launch256(const LabArgs& a) {
   hipLaunchKernelGGL((gemm256_kernel<WM, WN>), dim3(grid), dim3(512), 131072, 0, a);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc >= 6 && !strcmp(argv[1], "one")) {
+    const int M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]), mode = atoi(argv[5]);
+    bf16_t *A, *B, *Cb; float* C;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&Cb, (size_t)M * N * 2));
+    fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1);
+    fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2);
+    LabArgs a{A, B, M, N, K, K, K, nullptr, C, Cb, N, mode};
+    for (int i = 0; i < 5; i++) launch256p<2, 4>(a);
+    CK(hipDeviceSynchronize());
+    return 0;
+  }
   // ---- correctness at an awkward shape ----
   {
     const int M = 700, N = 520, K = 192;
@@ -380,7 +403,7 @@ int main() {
     fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1);
     fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2);
     const double fl = 2.0 * M * N * K;
-    for (int mode : {0, 1, 2, 9, 10}) {
+    for (int mode : {0, 16, 32, 48, 1, 2}) {
       LabArgs a{A, B, M, N, K, K, K, nullptr, C, Cb, N, mode};
       float t1 = mode >= 4 ? 0.f : time_us([&] { launch256<2, 4>(a); });
       float t3 = time_us([&] { launch256p<2, 4>(a); });

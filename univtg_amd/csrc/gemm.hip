@@ -9,6 +9,7 @@
 //  gemm_tn : C[N,K] += P[M,N]^T * Q[M,K] (weight gradients): both operands are row-major in the
 //            reduction dimension, fragments come from ds_read_b64_tr_b16 transposing LDS reads.
 #include "uvtg_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -324,6 +325,16 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma unroll
           for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
       }
+      // pin the software pipeline the source expresses (hipcc otherwise sinks every fragment read next to its MFMAs):
+      // 6 reads up front, then each k-step's 8 MFMAs cover the 6 reads of the next k-step
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+      for (int ks = 0; ks < 3; ks++) {
+#pragma unroll
+        for (int n = 0; n < TM + TN; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     // ---------------- epilogue of `tile`, out of the stage consumed last ----------------
     if (p.act == 100) {   // measurement aid: main loop only
@@ -613,36 +624,67 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int
   const bool do_bias = p.dbias && tile_k == 0 && wn == 0;
 
   if (st0 < st1) stage(0);
+  auto main_loop = [&](auto with_bias) {
+  constexpr bool BIAS = decltype(with_bias)::value;
   for (int st = st0; st < st1; st++) {
     const int cur = (st - st0) & 1;
     __syncthreads();
     if (st + 1 < st1) stage(cur ^ 1);
     const unsigned char* base = smem256 + cur * 65536;
+    s16x4 ta[2][4][2], tb[2][2][2];       // [buffer][tile][row half]: 4 m-rows each, two halves make one MFMA operand
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ta[0][i][0] = lds_tr16((const bf16_t*)(base + aoff[i])); ta[0][i][1] = lds_tr16((const bf16_t*)(base + aoff[i] + 2048)); }
+#pragma unroll
+    for (int j = 0; j < 2; j++) { tb[0][j][0] = lds_tr16((const bf16_t*)(base + boff[j])); tb[0][j][1] = lds_tr16((const bf16_t*)(base + boff[j] + 2048)); }
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          ta[(ks + 1) & 1][i][0] = lds_tr16((const bf16_t*)(base + aoff[i] + (ks + 1) * 8192));
+          ta[(ks + 1) & 1][i][1] = lds_tr16((const bf16_t*)(base + aoff[i] + (ks + 1) * 8192 + 2048));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          tb[(ks + 1) & 1][j][0] = lds_tr16((const bf16_t*)(base + boff[j] + (ks + 1) * 8192));
+          tb[(ks + 1) & 1][j][1] = lds_tr16((const bf16_t*)(base + boff[j] + (ks + 1) * 8192 + 2048));
+        }
+      }
       s16x8 a[4], b[2];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const s16x4 a0 = lds_tr16((const bf16_t*)(base + aoff[i] + ks * 8192)), a1 = lds_tr16((const bf16_t*)(base + aoff[i] + ks * 8192 + 2048));
+        const s16x4 a0 = ta[ks & 1][i][0], a1 = ta[ks & 1][i][1];
         a[i] = (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
       }
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        const s16x4 b0 = lds_tr16((const bf16_t*)(base + boff[j] + ks * 8192)), b1 = lds_tr16((const bf16_t*)(base + boff[j] + ks * 8192 + 2048));
+        const s16x4 b0 = tb[ks & 1][j][0], b1 = tb[ks & 1][j][1];
         b[j] = (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-      if (do_bias) {
+      if constexpr (BIAS) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int e = 0; e < 8; e++) bsum[i] += bf2f((bf16_t)a[i][e]);
       }
     }
+    {   // pin the fragment prefetch pipeline (12 transposing reads per k-step under the previous k-step's 8 MFMAs)
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+      for (int ks = 0; ks < 3; ks++) {
+#pragma unroll
+        for (int n = 0; n < 6; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
   }
+  };
+  if (do_bias) main_loop(std::true_type{}); else main_loop(std::false_type{});
   // ---- partial tile -> fp32 slab [256 n][256 k] of this (split, tile) unit, row-contiguous 16-byte stores ----
   __syncthreads();
   float* slab = p.scratch + ((size_t)split * tiles + tile) * 65536;
