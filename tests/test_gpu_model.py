@@ -44,9 +44,12 @@ def load_case(golden_dir, name):
         {k[5:]: float(z[k]) for k in z.files if k.startswith("loss/")}
 
 
-def build(cfg, params, dev, precision):
+def build(cfg, params, dev, precision, proj_precise=True):
+    """proj_precise=True keeps the input projections fp32-class even under autograd, so that the saliency losses can be
+    pinned tightly; the default of the product ("auto": plain bf16 projections whenever a backward follows) is covered by
+    test_auto_projection_mode_training."""
     from univtg_amd.model import build_model
-    model, crit = build_model(args_from_cfg(cfg, precision=precision))
+    model, crit = build_model(args_from_cfg(cfg, precision=precision, proj_precise=proj_precise))
     missing = model.load_state_dict(params, strict=True)           # the reference's checkpoint layout loads as is
     assert not missing.missing_keys and not missing.unexpected_keys
     return model.to(dev), crit.to(dev)
@@ -366,3 +369,33 @@ def test_nt256_engine_path_matches_nt128(dev):
         a, b = g1[offs[i]: offs[i] + p.numel()], g2[offs[i]: offs[i] + p.numel()]
         err = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
         assert err < 2e-3, (i, err)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_auto_projection_mode_training(dev, golden_dir, name):
+    """Product default (proj_precise="auto"): inference calls keep saliency within 1e-4; calls that will be differentiated run
+    the input projections on plain bf16 operands -- losses within bf16 tolerance, gradients still aligned with the reference."""
+    meta, cfg, params, inputs, tg, out_ref, eval_ref, grads_ref, losses_ref = load_case(golden_dir, name)
+    model, crit = build(cfg, params, dev, "bf16", proj_precise="auto")
+    model.eval()
+    valid = inputs["src_vid_mask"].bool()
+    with torch.no_grad():
+        out = model(**to_dev(inputs, dev))
+    assert float((out["saliency_scores"].cpu() - eval_ref["saliency_scores"])[valid].abs().max()) < 1e-4
+    out = model(**to_dev(inputs, dev))                      # gradient-enabled call -> bf16 projections
+    assert float((out["saliency_scores"].detach().cpu() - eval_ref["saliency_scores"])[valid].abs().max()) < 3e-2
+    losses = crit(out, to_dev(tg, dev))
+    wd = crit.weight_dict
+    sum(losses[k] * wd[k] for k in losses if k in wd).backward()
+    for k in ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra"):
+        got, ref = float(losses[k]), losses_ref[k]
+        assert abs(got - ref) < 3e-2 * max(1.0, abs(ref)), (k, got, ref)
+    named = dict(model.named_parameters())
+    bad = {}
+    for k, g in grads_ref.items():
+        a, r = named[k].grad.cpu().double().flatten(), g.double().flatten()
+        cos = float((a @ r) / (a.norm() * r.norm() + 1e-30))
+        ratio = float(a.norm() / (r.norm() + 1e-30))
+        if cos < 0.97 or abs(ratio - 1) > 0.08:
+            bad[k] = (cos, ratio)
+    assert not bad, bad

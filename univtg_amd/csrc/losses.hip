@@ -11,7 +11,7 @@ constexpr float TAU = 0.07f;          // model/univtg.py:185 (hard-coded)
 constexpr float EPS = 1e-8f;          // sim_matrix / cosine_similarity eps
 
 struct WS {                            // carve-up of LossArgs::ws
-  float *cosv, *vnorm, *qnorm, *sim, *lse_r, *lse_c, *zr, *zc, *cnt, *gz, *vpn, *dvh, *dqh;
+  float *cosv, *vnorm, *qnorm, *sim, *lse_r, *lse_c, *zr, *zc, *cnt, *gz, *vpn, *dvh, *dqh, *acc;
   __host__ __device__ WS(float* p, int B, int Lv, int d = 0) {
     cosv = p; p += (size_t)B * Lv;
     vnorm = p; p += (size_t)B * Lv;
@@ -27,6 +27,7 @@ struct WS {                            // carve-up of LossArgs::ws
     p += (4 - ((size_t)(5 * B + 2 * Lv) & 3)) & 3;
     dvh = p; p += (size_t)B * d;
     dqh = p; p += (size_t)B * d;
+    acc = p; p += 8;
   }
 };
 
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(const LossArgs a) {
   }
 }
 
-// sim[i][j] = vhat_i . qhat_j  with v_i = vid[i, pos_i]
+// sim[i][j] = vhat_i . qhat_j  with v_i = vid[i, pos_i].  grid (B, ceil(B / 64)): block (i, jc) handles 64 text rows, each of
+// its 4 waves 16 of them, four at a time (independent 16-byte loads in flight; the kernel is pure L2 latency otherwise)
 __global__ __launch_bounds__(256) void loss_sim_kernel(const LossArgs a) {
   extern __shared__ float sv[];
   const WS w(a.ws, a.B, a.Lv, a.d);
@@ -73,12 +75,33 @@ __global__ __launch_bounds__(256) void loss_sim_kernel(const LossArgs a) {
   const float vn = fmaxf(w.vnorm[i * a.Lv + p], EPS);
   for (int c = threadIdx.x; c < a.d; c += 256) sv[c] = v[c] / vn;
   __syncthreads();
-  for (int j = wave; j < a.B; j += 4) {
-    const float* q = a.txt + (size_t)j * a.d;
-    float acc = 0.f;
-    for (int c = lane; c < a.d; c += 64) acc += sv[c] * q[c];
-    acc = wave_sum(acc);
-    if (lane == 0) w.sim[i * a.B + j] = acc / fmaxf(w.qnorm[j], EPS);
+  const int jbase = blockIdx.y * 64 + wave * 16;
+  for (int j0 = jbase; j0 < min(a.B, jbase + 16); j0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* q[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) q[e] = a.txt + (size_t)min(j0 + e, a.B - 1) * a.d;
+    if ((a.d & 255) == 0) {
+      for (int c = lane * 4; c < a.d; c += 256) {
+        const f32x4 s4 = *(const f32x4*)(sv + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const f32x4 q4 = *(const f32x4*)(q[e] + c);
+          acc[e] += s4[0] * q4[0] + s4[1] * q4[1] + s4[2] * q4[2] + s4[3] * q4[3];
+        }
+      }
+    } else {
+      for (int c = lane; c < a.d; c += 64) {
+        const float sc = sv[c];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] += sc * q[e][c];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float t = wave_sum(acc[e]);
+      if (lane == 0 && j0 + e < a.B) w.sim[i * a.B + j0 + e] = t / fmaxf(w.qnorm[j0 + e], EPS);
+    }
   }
 }
 
@@ -98,74 +121,90 @@ __device__ __forceinline__ void giou_terms(float a0, float a1, float b0, float b
   H = fmaxf(fmaxf(a1, b1) - fminf(a0, b0), 0.f);
 }
 
-// single block: every scalar of the criterion
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(const LossArgs a) {
-  __shared__ float red[16];
+// ---- forward scalars, in three small multi-block passes (was one 1024-thread block: ~220 us of pure latency) ----
+// ws.acc[8] (atomic accumulators): nwin, nval, ssum, lb, lg, lf
+__global__ __launch_bounds__(256) void loss_elem_kernel(const LossArgs a, float* acc) {
+  __shared__ float red[4];
   const WS w(a.ws, a.B, a.Lv, a.d);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.B * a.Lv;
-  float nwin = 0.f, nval = 0.f, ssum = 0.f;
-  for (int i = tid; i < n; i += blockDim.x) {
-    nwin += (a.ts_window[i] != 0.f);
-    nval += (a.ts_mask[i] != 0.f);
-    if (a.sal_tgt) ssum += a.sal_tgt[i];
-  }
-  nwin = block_sum(nwin, red); nval = block_sum(nval, red); ssum = block_sum(ssum, red);
-  const bool sal_on = a.do_saliency && a.sal_tgt && a.pos_idx && ssum != 0.f;
-  float lb = 0.f, lg = 0.f, lf = 0.f;
-  for (int i = tid; i < n; i += blockDim.x) {
+  float nwin = 0.f, nval = 0.f, ssum = 0.f, lb = 0.f, lg = 0.f, lf = 0.f;
+  if (i < n) {
     const float win = a.ts_window[i], msk = a.ts_mask[i];
+    nwin = (win != 0.f); nval = (msk != 0.f);
+    if (a.sal_tgt) ssum = a.sal_tgt[i];
     if (a.do_spans && win != 0.f) {
       const float s0 = a.timestamp[2 * i] + a.pred_spans[2 * i], s1 = a.timestamp[2 * i + 1] + a.pred_spans[2 * i + 1];
       const float g0 = a.span_nn[2 * i], g1 = a.span_nn[2 * i + 1];
       const float d0 = fabsf(s0 - g0), d1 = fabsf(s1 - g1);
-      lb += win * ((d0 < 1.f ? 0.5f * d0 * d0 : d0 - 0.5f) + (d1 < 1.f ? 0.5f * d1 * d1 : d1 - 0.5f));
+      lb = win * ((d0 < 1.f ? 0.5f * d0 * d0 : d0 - 0.5f) + (d1 < 1.f ? 0.5f * d1 * d1 : d1 - 0.5f));
       float I, U, H;
       giou_terms(s0, s1, g0, g1, I, U, H);
-      lg += 1.f - (I / U - (H - U) / H);
+      lg = 1.f - (I / U - (H - U) / H);
     }
     if (a.do_labels && msk != 0.f) {
       const float p = a.pred_logits[i], y = win != 0.f ? 1.f : 0.f, wt = win != 0.f ? 1.f : a.eos_coef;
-      lf += -wt * (y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+      lf = -wt * (y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
     }
   }
-  lb = block_sum(lb, red); lg = block_sum(lg, red); lf = block_sum(lf, red);
+  float vals[6] = {nwin, nval, ssum, lb, lg, lf};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float t = block_sum(vals[k], red);
+    if (threadIdx.x == 0) atomicAdd(acc + k, t);
+  }
+  if (i < a.Lv) w.cnt[i] = 0.f;       // (blocks 0.. cover Lv <= n)
+}
+
+// log-sum-exp rows / columns of the two NCE terms: one wave per task
+//   task < B          : inter-video row i and column i of sim / tau          -> lse_r[i], lse_c[i]
+//   task < 2B         : intra-video row b (softmax over the clips of sample b) -> zr[b], cnt[pos_b] += 1
+//   task < 2B + Lv    : intra-video column t (softmax over the batch at clip t) -> zc[t]
+__global__ __launch_bounds__(256) void loss_lse_kernel(const LossArgs a) {
+  const WS w(a.ws, a.B, a.Lv, a.d);
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int B = a.B, Lv = a.Lv;
+  if (task < B) {
+    const int i = task;
+    float mr = -INFINITY, mc = -INFINITY;
+    for (int j = lane; j < B; j += 64) { mr = fmaxf(mr, w.sim[i * B + j]); mc = fmaxf(mc, w.sim[j * B + i]); }
+    mr = wave_max(mr); mc = wave_max(mc);
+    float sr = 0.f, sc = 0.f;
+    for (int j = lane; j < B; j += 64) { sr += expf((w.sim[i * B + j] - mr) / TAU); sc += expf((w.sim[j * B + i] - mc) / TAU); }
+    sr = wave_sum(sr); sc = wave_sum(sc);
+    if (lane == 0) { w.lse_r[i] = mr / TAU + logf(sr); w.lse_c[i] = mc / TAU + logf(sc); }
+  } else if (task < 2 * B) {
+    const int b = task - B;
+    float m = -INFINITY;
+    for (int t = lane; t < Lv; t += 64) m = fmaxf(m, zval(a, w, b, t));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int t = lane; t < Lv; t += 64) s += expf((zval(a, w, b, t) - m) / TAU);
+    s = wave_sum(s);
+    if (lane == 0) { w.zr[b] = m / TAU + logf(s); atomicAdd(&w.cnt[(int)a.pos_idx[b]], 1.f); }
+  } else if (task < 2 * B + Lv) {
+    const int t = task - 2 * B;
+    float m = -INFINITY;
+    for (int b = lane; b < B; b += 64) m = fmaxf(m, zval(a, w, b, t));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int b = lane; b < B; b += 64) s += expf((zval(a, w, b, t) - m) / TAU);
+    s = wave_sum(s);
+    if (lane == 0) w.zc[t] = m / TAU + logf(s);
+  }
+}
+
+// one block: combine
+__global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, const float* acc, int have_sal) {
+  __shared__ float red[4];
+  const WS w(a.ws, a.B, a.Lv, a.d);
+  const int tid = threadIdx.x;
+  const float nwin = acc[0], nval = acc[1], ssum = acc[2];
+  const bool sal_on = have_sal && ssum != 0.f;
   float inter = 0.f, intra = 0.f;
   if (sal_on) {
-    const int B = a.B, Lv = a.Lv;
-    // inter-video: row / column log-sum-exp of sim / tau
-    for (int i = wave; i < B; i += nw) {
-      float mr = -INFINITY, mc = -INFINITY;
-      for (int j = lane; j < B; j += 64) { mr = fmaxf(mr, w.sim[i * B + j]); mc = fmaxf(mc, w.sim[j * B + i]); }
-      mr = wave_max(mr); mc = wave_max(mc);
-      float sr = 0.f, sc = 0.f;
-      for (int j = lane; j < B; j += 64) { sr += expf((w.sim[i * B + j] - mr) / TAU); sc += expf((w.sim[j * B + i] - mc) / TAU); }
-      sr = wave_sum(sr); sc = wave_sum(sc);
-      if (lane == 0) { w.lse_r[i] = mr / TAU + logf(sr); w.lse_c[i] = mc / TAU + logf(sc); }
-    }
-    for (int t = tid; t < Lv; t += blockDim.x) w.cnt[t] = 0.f;
-    __syncthreads();
-    // intra-video rows
-    for (int b = wave; b < B; b += nw) {
-      float m = -INFINITY;
-      for (int t = lane; t < Lv; t += 64) m = fmaxf(m, zval(a, w, b, t));
-      m = wave_max(m);
-      float s = 0.f;
-      for (int t = lane; t < Lv; t += 64) s += expf((zval(a, w, b, t) - m) / TAU);
-      s = wave_sum(s);
-      if (lane == 0) { w.zr[b] = m / TAU + logf(s); atomicAdd(&w.cnt[(int)a.pos_idx[b]], 1.f); }
-    }
-    // intra-video columns (softmax over the batch at each clip index)
-    for (int t = wave; t < Lv; t += nw) {
-      float m = -INFINITY;
-      for (int b = lane; b < B; b += 64) m = fmaxf(m, zval(a, w, b, t));
-      m = wave_max(m);
-      float s = 0.f;
-      for (int b = lane; b < B; b += 64) s += expf((zval(a, w, b, t) - m) / TAU);
-      s = wave_sum(s);
-      if (lane == 0) w.zc[t] = m / TAU + logf(s);
-    }
-    __syncthreads();
+    const int B = a.B;
     for (int b = tid; b < B; b += blockDim.x) {
       const int p = (int)a.pos_idx[b];
       const float sd = w.sim[b * B + b] / TAU;
@@ -173,15 +212,15 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const LossArgs a) {
       const float z = zval(a, w, b, p) / TAU;
       intra += -(z - w.zr[b]) - (z - w.zc[p]);
     }
-    inter = block_sum(inter, red) / (float)B;
-    intra = block_sum(intra, red) / (float)B;
   }
+  inter = block_sum(inter, red) / (float)a.B;
+  intra = block_sum(intra, red) / (float)a.B;
   if (tid == 0) {
-    a.losses[0] = a.do_spans ? lb / nwin : 0.f;
-    a.losses[1] = a.do_spans ? lg / nwin : 0.f;
-    a.losses[2] = a.do_labels ? lf / nval : 0.f;
-    a.losses[3] = inter;
-    a.losses[4] = intra;
+    a.losses[0] = a.do_spans ? acc[3] / nwin : 0.f;
+    a.losses[1] = a.do_spans ? acc[4] / nwin : 0.f;
+    a.losses[2] = a.do_labels ? acc[5] / nval : 0.f;
+    a.losses[3] = sal_on ? inter : 0.f;
+    a.losses[4] = sal_on ? intra : 0.f;
     a.losses[5] = sal_on ? 1.f : 0.f;
     a.losses[6] = nwin;
     a.losses[7] = nval;
@@ -249,35 +288,54 @@ __global__ void loss_grad_sim_kernel(const LossArgs a) {
 }
 
 // dvh[b][c] = sum_j dsim[b][j] qhat_j[c]   (blockIdx.y == 0),   dqh[b][c] = sum_i dsim[i][b] vhat_i[c]   (blockIdx.y == 1)
+// Block = 8 output rows x 256 columns (blockIdx.z): 64 column groups of 4 (16-byte loads) x 4 j-lanes that split the
+// reduction; every source row loaded serves 8 outputs.
 __global__ __launch_bounds__(256) void loss_dvq_kernel(const LossArgs a) {
   const WS w(a.ws, a.B, a.Lv, a.d);
-  const int b = blockIdx.x, d = a.d, B = a.B;
+  const int d = a.d, B = a.B, side = blockIdx.y;
   if (a.losses[5] == 0.f) return;
-  __shared__ float coef[1024];
-  for (int c0 = 0; c0 < d; c0 += 4 * 256) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < B; j0 += 1024) {
-      const int nj = min(1024, B - j0);
-      __syncthreads();
-      for (int j = threadIdx.x; j < nj; j += 256) {
-        const int jj = j0 + j;
-        if (blockIdx.y == 0) coef[j] = w.sim[b * B + jj] / fmaxf(w.qnorm[jj], EPS);
-        else coef[j] = w.sim[jj * B + b] / fmaxf(w.vnorm[jj * a.Lv + (int)a.pos_idx[jj]], EPS);
-      }
-      __syncthreads();
-      for (int j = 0; j < nj; j++) {
-        const int jj = j0 + j;
-        const float* src = blockIdx.y == 0 ? a.txt + (size_t)jj * d : vrow(a, jj, (int)a.pos_idx[jj]);
-        const float cf = coef[j];
+  __shared__ float coef[8][260];
+  __shared__ float part[4][8][256];
+  const int b0 = blockIdx.x * 8, c0 = blockIdx.z * 256;
+  const int cg = threadIdx.x & 63, jl = threadIdx.x >> 6;
+  const int c = c0 + cg * 4;
+  float acc[8][4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { const int c = c0 + e * 256 + threadIdx.x; if (c < d) acc[e] += cf * src[c]; }
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
+  for (int j0 = 0; j0 < B; j0 += 256) {
+    const int nj = min(256, B - j0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 8 * nj; idx += 256) {
+      const int r = idx / nj, j = idx % nj, jj = j0 + j, bb = min(b0 + r, B - 1);
+      coef[r][j] = side == 0 ? w.sim[bb * B + jj] / fmaxf(w.qnorm[jj], EPS)
+                             : w.sim[jj * B + bb] / fmaxf(w.vnorm[jj * a.Lv + (int)a.pos_idx[jj]], EPS);
+    }
+    __syncthreads();
+    if (c < d) {
+#pragma unroll 4
+      for (int j = jl; j < nj; j += 4) {
+        const int jj = j0 + j;
+        const float* src = side == 0 ? a.txt + (size_t)jj * d : vrow(a, jj, (int)a.pos_idx[jj]);
+        const f32x4 x = *(const f32x4*)(src + c);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const float cf = coef[r][j];
+          acc[r][0] += cf * x[0]; acc[r][1] += cf * x[1]; acc[r][2] += cf * x[2]; acc[r][3] += cf * x[3];
+        }
       }
     }
+  }
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int c = c0 + e * 256 + threadIdx.x;
-      if (c < d) (blockIdx.y == 0 ? w.dvh : w.dqh)[(size_t)b * d + c] = acc[e];
-    }
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) part[jl][r][cg * 4 + e] = acc[r][e];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 8 * 256; idx += 256) {
+    const int r = idx >> 8, cc = idx & 255;
+    if (b0 + r < B && c0 + cc < d)
+      (side == 0 ? w.dvh : w.dqh)[(size_t)(b0 + r) * d + c0 + cc] = part[0][r][cc] + part[1][r][cc] + part[2][r][cc] + part[3][r][cc];
   }
 }
 // inter-video gradients in input space: g_vrow[b] = (dvh - vhat (vhat.dvh)) / |v_pos|, g_txt[b] = (dqh - qhat (qhat.dqh)) / |q|
@@ -346,9 +404,14 @@ int launch_losses_fwd(const LossArgs& a, hipStream_t s) {
   const int n = a.B * a.Lv;
   if (a.do_saliency && a.sal_tgt && a.pos_idx) {
     hipLaunchKernelGGL(loss_stats_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_sim_kernel, dim3(a.B), dim3(256), a.d * sizeof(float), s, a);
+    hipLaunchKernelGGL(loss_sim_kernel, dim3(a.B, cdiv(a.B, 64)), dim3(256), a.d * sizeof(float), s, a);
   }
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, a);
+  const WS w(a.ws, a.B, a.Lv, a.d);
+  const bool have_sal = a.do_saliency && a.sal_tgt && a.pos_idx;
+  hipMemsetAsync(w.acc, 0, 8 * sizeof(float), s);
+  hipLaunchKernelGGL(loss_elem_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, w.acc);
+  if (have_sal) hipLaunchKernelGGL(loss_lse_kernel, dim3(cdiv(2 * a.B + a.Lv, 4)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a, w.acc, have_sal ? 1 : 0);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -357,7 +420,7 @@ int launch_losses_bwd(const LossArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(loss_grad_small_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a);
   if (a.do_saliency && a.sal_tgt && a.pos_idx) {
     hipLaunchKernelGGL(loss_grad_sim_kernel, dim3(cdiv(a.B * a.B, 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_dvq_kernel, dim3(a.B, 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_dvq_kernel, dim3(cdiv(a.B, 8), 2, cdiv(a.d, 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_grad_rows_kernel, dim3(a.B), dim3(256), 0, s, a);
     if (a.g_vid) {     // dense mode: full gradients wrt vid_mem_proj / txt_mem_proj
       hipLaunchKernelGGL(loss_expand_vid_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);

@@ -163,7 +163,7 @@ class Model(nn.Module):
 
     def __init__(self, hidden_dim, nheads, dim_feedforward, enc_layers, txt_dim, vid_dim, input_dropout, dropout=0.1,
                  droppath=0.1, max_q_l=75, max_v_l=75, span_loss_type="l1", use_txt_pos=False, n_input_proj=2,
-                 precision="bf16", proj_precise=True):
+                 precision="bf16", proj_precise="auto"):
         super().__init__()
         if span_loss_type != "l1":
             raise NotImplementedError("span_loss_type='ce' is not implemented by the reference forward either (univtg.py:137-138)")
@@ -178,7 +178,12 @@ class Model(nn.Module):
         self.txt_dim, self.vid_dim = txt_dim, vid_dim
         self.input_dropout, self.dropout, self.droppath = float(input_dropout), float(dropout), float(droppath)
         self.span_loss_type, self.max_v_l, self.use_txt_pos, self.n_input_proj = span_loss_type, max_v_l, use_txt_pos, n_input_proj
-        self.precision, self.proj_precise, self.return_memory = precision, bool(proj_precise), False
+        # proj_precise: True  = input projections always in split-bf16 (fp32-class; saliency within 1e-4 of the fp32 reference),
+        #               False = always plain bf16 operands,
+        #               "auto" (default) = split-bf16 for inference calls (no gradient), plain bf16 when a backward will follow
+        if proj_precise not in (True, False, "auto"):
+            raise ValueError("proj_precise must be True, False or 'auto'")
+        self.precision, self.proj_precise, self.return_memory = precision, proj_precise, False
         # ---- parameters, registered in the reference's order / names ----
         self.transformer = _encoder_bag(d, dim_feedforward, enc_layers)
         self.txt_position_embed = _Bag()                                    # unused unless use_txt_pos (kept for ckpt parity)
@@ -225,7 +230,7 @@ class Model(nn.Module):
             self._step += 1
         return _lib.Dims(B=B, Lv=Lv, Lt=Lt, d=self.hidden_dim, H=self.nheads, F=self.dim_feedforward, E=self.enc_layers,
                          Dv=Dv, Dt=Dt, n_proj=self.n_input_proj, precise=int(self.precision == "fp32x3"),
-                         training=int(training), proj_precise=int(self.proj_precise),
+                         training=int(training), proj_precise=int((not training) if self.proj_precise == "auto" else bool(self.proj_precise)),
                          p_in=self.input_dropout if self.training else 0.0,
                          p_attn=self.dropout if self.training else 0.0,
                          p_path=self.droppath if self.training else 0.0,
@@ -416,7 +421,7 @@ def build_model(args):
                   input_dropout=args.input_dropout, dropout=args.dropout, droppath=args.droppath,
                   max_q_l=args.max_q_l, max_v_l=getattr(args, "max_v_l", 75), span_loss_type=args.span_loss_type,
                   use_txt_pos=args.use_txt_pos, n_input_proj=args.n_input_proj,
-                  precision=getattr(args, "precision", "bf16"), proj_precise=getattr(args, "proj_precise", True))
+                  precision=getattr(args, "precision", "bf16"), proj_precise=getattr(args, "proj_precise", "auto"))
     if getattr(args, "pre_norm", False):
         raise NotImplementedError("--pre_norm crashes in the reference too (forward_pre is undefined, droppath.py:133)")
     matcher = build_matcher(args)
