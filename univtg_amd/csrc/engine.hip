@@ -123,7 +123,7 @@ struct WSpace {
   // heads
   void *vm_pad, *h1_pad, *h2_pad;
   // saliency
-  float *alpha, *cosv, *vnorm, *qnorm;
+  float *alpha, *cosv, *vnorm, *qnorm, *sal_dq, *sal_dlog;
   // backward scratch
   float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2], *tn_scratch; long long tn_scratch_floats;
   bf16_t *dh2_pad, *dh1_pad, *dyB, *da, *dOb, *dqkv, *dyP[2], *dh1b[2];
@@ -181,6 +181,7 @@ struct WSpace {
     if (tr) {
       dvm = a.take<float>((size_t)m.Mv * d); gx[0] = a.take<float>(M * d); gx[1] = a.take<float>(M * d);
       dyF = a.take<float>(M * d); delta = a.take<float>(B * m.c.H * m.S);
+      sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
       {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
         long long need = 0;
         const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d},
@@ -196,7 +197,7 @@ struct WSpace {
         dA2[i] = a.take<float>(R * d); dA1[i] = a.take<float>(R * Kp);
       }
     } else {
-      dvm = gx[0] = gx[1] = dyF = delta = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
+      dvm = gx[0] = gx[1] = dyF = delta = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
       for (int i = 0; i < 2; i++) { dyP[i] = dh1b[i] = nullptr; dA2[i] = dA1[i] = nullptr; }
     }
     bytes = a.off + 256;
@@ -654,6 +655,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // ---------------- saliency branch ----------------
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
   sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0 = dx0; sa.dw_pool = G(m.tail(POOL));
+  sa.dq = ws.sal_dq; sa.dlog = ws.sal_dlog; sa.out_vid = ws.dyP[0]; sa.out_txt = ws.dyP[1];
   TRY(launch_saliency_bwd(sa, s));
   // ---------------- input projections ----------------
   for (int which = 0; which < 2; which++) {
@@ -665,9 +667,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     const bool pp = m.c.proj_precise != 0;
     const bf16_t* a2b = pp ? ws.a2B[which] : (const bf16_t*)ws.a2[which];
     const bf16_t* a1b = pp ? ws.a1B[which] : (const bf16_t*)ws.a1[which];
-    const long long n4 = (long long)R * d / 4;
-    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dx0, S, roff, L, d, ws.dyP[which], n4);
-    UVTG_CHECK_LAUNCH();
+    // (ws.dyP[which] = bf16(dx0 + saliency-branch gradients), packed per modality by launch_saliency_bwd)
     TRY(wgrad(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, 1, G(m.tail(t1 + 3)), 0, R, splits_v));
     hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + (which == 0 ? d : 0), G(m.tail(t1 + 3)), d);
     UVTG_CHECK_LAUNCH();

@@ -195,14 +195,15 @@ __global__ __launch_bounds__(256) void heads_final_bwd_dw_kernel(const HeadsFina
 }
 
 // ---------------- weighted pooling + cosine saliency ----------------
-__global__ __launch_bounds__(256) void saliency_fwd_kernel(const SaliencyArgs a) {
-  extern __shared__ float sm[];                 // [Lt] logits/alpha | [d] pooled | [8] scratch
+// forward, pass 1: one 1024-thread block per sample -- pooling logits (one wave per text row), masked softmax,
+// pooled text vector (one thread per column) and its norm
+__global__ __launch_bounds__(1024) void saliency_pool_kernel(const SaliencyArgs a) {
+  extern __shared__ float sm[];                 // [Lt] logits/alpha | [16] scratch
   float* s_alpha = sm;
-  float* s_pool = sm + a.Lt;
-  float* s_red = s_pool + a.d;
+  float* s_red = sm + a.Lt;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
   const float* xt = a.x0 + ((size_t)b * a.S + a.Lv) * d;      // text rows
-  for (int t = wave; t < a.Lt; t += 4) {
+  for (int t = wave; t < a.Lt; t += 16) {
     float acc = 0.f;
     for (int c = lane; c < d; c += 64) acc += xt[(size_t)t * d + c] * a.w_pool[c];
     acc = wave_sum(acc);
@@ -224,45 +225,59 @@ __global__ __launch_bounds__(256) void saliency_fwd_kernel(const SaliencyArgs a)
   }
   __syncthreads();
   float nsq = 0.f;
-  for (int c = tid; c < d; c += 256) {
+  for (int c = tid; c < d; c += 1024) {
     float acc = 0.f;
+#pragma unroll 8
     for (int t = 0; t < a.Lt; t++) acc += s_alpha[t] * xt[(size_t)t * d + c];
-    s_pool[c] = acc;
     a.pooled[(size_t)b * d + c] = acc;
     nsq += acc * acc;
   }
   nsq = wave_sum(nsq);
   if (lane == 0) s_red[wave] = nsq;
   __syncthreads();
-  const float qn = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
-  if (tid == 0 && a.qnorm) a.qnorm[b] = qn;
-  const float qd = fmaxf(qn, 1e-8f);
-  const float* xv = a.x0 + (size_t)b * a.S * d;
-  for (int t = wave; t < a.Lv; t += 4) {
-    float dot = 0.f, vs = 0.f;
-    for (int c = lane; c < d; c += 64) { const float v = xv[(size_t)t * d + c]; dot += v * s_pool[c]; vs += v * v; }
-    dot = wave_sum(dot); vs = wave_sum(vs);
-    if (lane == 0) {
-      const float vn = sqrtf(vs);
-      const float cs = dot / (fmaxf(vn, 1e-8f) * qd);
-      if (a.vnorm) a.vnorm[b * a.Lv + t] = vn;
-      if (a.cosv) a.cosv[b * a.Lv + t] = cs;
-      a.sal[b * a.Lv + t] = cs + (a.vid_mask[b * a.Lv + t] != 0.f ? 0.f : UVTG_LOG_TINY);
-    }
+  if (tid == 0 && a.qnorm) {
+    float t = 0.f;
+    for (int i = 0; i < 16; i++) t += s_red[i];
+    a.qnorm[b] = sqrtf(t);
+  }
+}
+// forward, pass 2: one wave per video row -- |v|, cos(v, pooled), saliency = cos + log-mask
+__global__ __launch_bounds__(256) void saliency_cos_kernel(const SaliencyArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B * a.Lv) return;
+  const int b = row / a.Lv, t = row % a.Lv, d = a.d;
+  const float* v = a.x0 + ((size_t)b * a.S + t) * d;
+  const float* q = a.pooled + (size_t)b * d;
+  float dot = 0.f, vs = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 x = *(const f32x4*)(v + c), y = *(const f32x4*)(q + c);
+    dot += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    vs += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+  }
+  dot = wave_sum(dot); vs = wave_sum(vs);
+  if (lane == 0) {
+    const float vn = sqrtf(vs);
+    const float cs = dot / (fmaxf(vn, 1e-8f) * fmaxf(a.qnorm[b], 1e-8f));
+    if (a.vnorm) a.vnorm[row] = vn;
+    if (a.cosv) a.cosv[row] = cs;
+    a.sal[row] = cs + (a.vid_mask[row] != 0.f ? 0.f : UVTG_LOG_TINY);
   }
 }
 
-// dx0 += (everything that flows into the pre-encoder tokens from saliency / vid_mem_proj / txt_mem_proj).
-// One block per sample, one thread per column (loops over clips / tokens): coalesced, no atomics on the hot loops.
-__global__ __launch_bounds__(256) void saliency_bwd_kernel(const SaliencyArgs a) {
-  extern __shared__ float sm[];                 // [d] dq | [Lt] dalpha | [Lv] gs,vn,cs | [8]
-  float* s_dq = sm;
-  float* s_da = s_dq + a.d;
-  float* s_gs = s_da + a.Lt;
+// backward.  Everything that flows into the pre-encoder tokens x0 from saliency / vid_mem_proj / txt_mem_proj is added
+// to the encoder's gradient dx0 while the rows are re-packed per modality in bf16 for the input-projection backward
+// (three passes: dq per sample and column; softmax gradient per sample; then one wave per token row).
+//   video row t: g = dx0 + g_sal (qhat - cos vhat) / |v| + g_vid (+ g_vrow on the positive row)
+//   dq           = g_pooled + sum_t g_sal (vhat - cos qhat) / |q|
+//   text row s : g = dx0 + alpha dq + dlog w_pool,  dlog = alpha (dq.x_s - sum alpha dq.x);  dw_pool += sum dlog x_s
+__global__ __launch_bounds__(256) void saliency_dq_kernel(const SaliencyArgs a) {
+  extern __shared__ float sm[];                 // [Lv] gs / |v| | [Lv] gs cos / |v|... kept as three arrays
+  float* s_gs = sm;
   float* s_vn = s_gs + a.Lv;
   float* s_cs = s_vn + a.Lv;
-  float* s_red = s_cs + a.Lv;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
+  const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
+  const int c = blockIdx.y * 256 + tid;
   const float qn = fmaxf(a.qnorm[b], 1e-8f);
   for (int t = tid; t < a.Lv; t += 256) {
     s_gs[t] = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
@@ -270,53 +285,130 @@ __global__ __launch_bounds__(256) void saliency_bwd_kernel(const SaliencyArgs a)
     s_cs[t] = a.cosv[b * a.Lv + t];
   }
   __syncthreads();
-  const int prow = (a.g_vrow && a.pos_idx) ? (int)a.pos_idx[b] : -1;
-  // video rows: dv = g_sal * (qhat - cos * vhat) / |v| + g_vid (+ g_vrow on the positive row);
-  //             dq = g_pooled + sum_t g_sal * (vhat - cos * qhat) / |q|
+  if (c >= d) return;
   const float* xv = a.x0 + (size_t)b * a.S * d;
-  float* dxv = a.dx0 + (size_t)b * a.S * d;
-  for (int c = tid; c < d; c += 256) {
-    const float qh = a.pooled[(size_t)b * d + c] / qn;
-    float dq = a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f;
-    for (int t = 0; t < a.Lv; t++) {
-      const float gs = s_gs[t];
-      float g = 0.f;
-      if (gs != 0.f) {
-        const float vh = xv[(size_t)t * d + c] / s_vn[t];
-        g = gs * (qh - s_cs[t] * vh) / s_vn[t];
-        dq += gs * (vh - s_cs[t] * qh) / qn;
-      }
-      if (a.g_vid) g += a.g_vid[(size_t)b * a.gv_sb + (size_t)t * a.gv_st + c];
-      if (t == prow) g += a.g_vrow[(size_t)b * d + c];
-      if (g != 0.f) dxv[(size_t)t * d + c] += g;
-    }
-    s_dq[c] = dq;
+  const float qh = a.pooled[(size_t)b * d + c] / qn;
+  float dq = a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f;
+  for (int t = 0; t < a.Lv; t++) {
+    const float gs = s_gs[t];
+    if (gs != 0.f) dq += gs * (xv[(size_t)t * d + c] / s_vn[t] - s_cs[t] * qh) / qn;
   }
-  __syncthreads();
-  // text rows: q = sum alpha x ; alpha = softmax(x.w + mask)
-  const float* xt = xv + (size_t)a.Lv * d;
-  float* dxt = dxv + (size_t)a.Lv * d;
-  for (int t = wave; t < a.Lt; t += 4) {
+  a.dq[(size_t)b * d + c] = dq;
+}
+__global__ __launch_bounds__(1024) void saliency_dlog_kernel(const SaliencyArgs a) {
+  extern __shared__ float sm[];                 // [Lt] da
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
+  const float* xt = a.x0 + ((size_t)b * a.S + a.Lv) * d;
+  const float* dq = a.dq + (size_t)b * d;
+  for (int t = wave; t < a.Lt; t += 16) {
     float acc = 0.f;
-    for (int c = lane; c < d; c += 64) acc += s_dq[c] * xt[(size_t)t * d + c];
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 x = *(const f32x4*)(xt + (size_t)t * d + c), y = *(const f32x4*)(dq + c);
+      acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
     acc = wave_sum(acc);
-    if (lane == 0) s_da[t] = acc;
+    if (lane == 0) sm[t] = acc;
   }
   __syncthreads();
   float dot = 0.f;
-  for (int t = 0; t < a.Lt; t++) dot += a.alpha[b * a.Lt + t] * s_da[t];
-  for (int c = tid; c < d; c += 256) {
-    const float wp = a.w_pool[c], dqc = s_dq[c];
-    float dw = 0.f;
-    for (int t = 0; t < a.Lt; t++) {
-      const float al = a.alpha[b * a.Lt + t];
-      const float dlog = al * (s_da[t] - dot);
-      dxt[(size_t)t * d + c] += al * dqc + dlog * wp;
-      dw += dlog * xt[(size_t)t * d + c];
+  for (int t = 0; t < a.Lt; t++) dot += a.alpha[b * a.Lt + t] * sm[t];
+  for (int t = tid; t < a.Lt; t += 1024) a.dlog[b * a.Lt + t] = a.alpha[b * a.Lt + t] * (sm[t] - dot);
+}
+// one block per (sample, 32-row chunk); 4 waves, each walks rows chunk*32 + wave, +4, ...; lane owns columns 4*lane + 256*k
+template <int KC>    // d = 256 * KC
+__global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a) {
+  __shared__ float s_dw[4][256 * KC];
+  const int b = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = a.d;
+  const float qn = fmaxf(a.qnorm[b], 1e-8f);
+  const int prow = (a.g_vrow && a.pos_idx) ? (int)a.pos_idx[b] : -1;
+  float dw[KC][4];
+#pragma unroll
+  for (int k = 0; k < KC; k++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) dw[k][e] = 0.f;
+  bool any_txt = false;
+  const int s_end = min(a.S, chunk * 32 + 32);
+  for (int srow = chunk * 32 + wave; srow < s_end; srow += 4) {
+    const size_t row = (size_t)b * a.S + srow;
+    const float* x = a.x0 + row * d;
+    const float* g0 = a.dx0 + row * d;
+    if (srow < a.Lv) {
+      const int t = srow;
+      const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
+      const float vn = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f), cs = a.cosv[b * a.Lv + t];
+      bf16_t* out = a.out_vid + ((size_t)b * a.Lv + t) * d;
+#pragma unroll
+      for (int k = 0; k < KC; k++) {
+        const int c = k * 256 + lane * 4;
+        f32x4 g = *(const f32x4*)(g0 + c);
+        if (gs != 0.f) {
+          const f32x4 xv = *(const f32x4*)(x + c), q = *(const f32x4*)(a.pooled + (size_t)b * d + c);
+#pragma unroll
+          for (int e = 0; e < 4; e++) g[e] += gs * (q[e] / qn - cs * (xv[e] / vn)) / vn;
+        }
+        if (a.g_vid) { const f32x4 t4 = *(const f32x4*)(a.g_vid + (size_t)b * a.gv_sb + (size_t)t * a.gv_st + c); g += t4; }
+        if (t == prow) { const f32x4 t4 = *(const f32x4*)(a.g_vrow + (size_t)b * d + c); g += t4; }
+        u32x2 o; o[0] = pack_bf2(g[0], g[1]); o[1] = pack_bf2(g[2], g[3]);
+        *(u32x2*)(out + c) = o;
+      }
+    } else {
+      const int t = srow - a.Lv;
+      const float al = a.alpha[b * a.Lt + t], dl = a.dlog[b * a.Lt + t];
+      bf16_t* out = a.out_txt + ((size_t)b * a.Lt + t) * d;
+      any_txt = true;
+#pragma unroll
+      for (int k = 0; k < KC; k++) {
+        const int c = k * 256 + lane * 4;
+        f32x4 g = *(const f32x4*)(g0 + c);
+        const f32x4 xt = *(const f32x4*)(x + c), dq = *(const f32x4*)(a.dq + (size_t)b * d + c), wp = *(const f32x4*)(a.w_pool + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { g[e] += al * dq[e] + dl * wp[e]; dw[k][e] += dl * xt[e]; }
+        u32x2 o; o[0] = pack_bf2(g[0], g[1]); o[1] = pack_bf2(g[2], g[3]);
+        *(u32x2*)(out + c) = o;
+      }
     }
-    if (a.dw_pool) atomicAdd(a.dw_pool + c, dw);
   }
-  (void)s_red;
+  if (!a.dw_pool) return;
+  const bool blk_txt = s_end > a.Lv;          // block-uniform: does this chunk contain text rows
+  if (!blk_txt) return;
+#pragma unroll
+  for (int k = 0; k < KC; k++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) s_dw[wave][k * 256 + lane * 4 + e] = any_txt ? dw[k][e] : 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(a.dw_pool + c, s_dw[0][c] + s_dw[1][c] + s_dw[2][c] + s_dw[3][c]);
+}
+// generic width fallback of the row pass (one wave per row, scalar columns)
+__global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const SaliencyArgs a) {
+  const int lane = threadIdx.x & 63, d = a.d;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)a.B * a.S) return;
+  const int b = (int)(row / a.S), srow = (int)(row % a.S);
+  const float qn = fmaxf(a.qnorm[b], 1e-8f);
+  const int prow = (a.g_vrow && a.pos_idx) ? (int)a.pos_idx[b] : -1;
+  const float* x = a.x0 + (size_t)row * d;
+  const float* g0 = a.dx0 + (size_t)row * d;
+  if (srow < a.Lv) {
+    const int t = srow;
+    const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
+    const float vn = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f), cs = a.cosv[b * a.Lv + t];
+    bf16_t* out = a.out_vid + ((size_t)b * a.Lv + t) * d;
+    for (int c = lane; c < d; c += 64) {
+      float g = g0[c];
+      if (gs != 0.f) g += gs * (a.pooled[(size_t)b * d + c] / qn - cs * (x[c] / vn)) / vn;
+      if (a.g_vid) g += a.g_vid[(size_t)b * a.gv_sb + (size_t)t * a.gv_st + c];
+      if (t == prow) g += a.g_vrow[(size_t)b * d + c];
+      out[c] = f2bf(g);
+    }
+  } else {
+    const int t = srow - a.Lv;
+    const float al = a.alpha[b * a.Lt + t], dl = a.dlog[b * a.Lt + t];
+    bf16_t* out = a.out_txt + ((size_t)b * a.Lt + t) * d;
+    for (int c = lane; c < d; c += 64) {
+      out[c] = f2bf(g0[c] + al * a.dq[(size_t)b * d + c] + dl * a.w_pool[c]);
+      if (a.dw_pool) atomicAdd(a.dw_pool + c, dl * x[c]);
+    }
+  }
 }
 
 }  // namespace
@@ -383,14 +475,19 @@ int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s) {
   return 0;
 }
 int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
-  const size_t sh = (a.Lt + a.d + 8) * sizeof(float);
-  hipLaunchKernelGGL(saliency_fwd_kernel, dim3(a.B), dim3(256), sh, s, a);
+  hipLaunchKernelGGL(saliency_pool_kernel, dim3(a.B), dim3(1024), (a.Lt + 16) * sizeof(float), s, a);
+  hipLaunchKernelGGL(saliency_cos_kernel, dim3(cdiv(a.B * a.Lv, 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
-  const size_t sh = (a.d + a.Lt + 3 * a.Lv + 8) * sizeof(float);
-  hipLaunchKernelGGL(saliency_bwd_kernel, dim3(a.B), dim3(256), sh, s, a);
+  hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 256)), dim3(256), 3 * a.Lv * sizeof(float), s, a);
+  hipLaunchKernelGGL(saliency_dlog_kernel, dim3(a.B), dim3(1024), a.Lt * sizeof(float), s, a);
+  const dim3 grid(a.B, cdiv(a.S, 32));
+  if (a.d == 1024) hipLaunchKernelGGL(saliency_rows_kernel<4>, grid, dim3(256), 0, s, a);
+  else if (a.d == 512) hipLaunchKernelGGL(saliency_rows_kernel<2>, grid, dim3(256), 0, s, a);
+  else if (a.d == 256) hipLaunchKernelGGL(saliency_rows_kernel<1>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(saliency_rows_generic_kernel, dim3((unsigned)(((long long)a.B * a.S + 3) / 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -153,7 +153,9 @@ struct SaliencyArgs {             // weighted text pooling + cosine saliency (mo
   const float* g_pooled;          // [B, d]   d/d txt_mem_proj
   const float* g_vid; long long gv_sb, gv_st;   // d/d vid_mem_proj: g_vid[b*gv_sb + t*gv_st + c], or null
   const float* g_vrow; const long long* pos_idx; // optional compact extra: g_vrow[b, :] is added on row pos_idx[b]
-  float* dx0;                     // [B*S, d] accumulated (+=)
+  const float* dx0;               // [B*S, d] encoder gradient wrt x0 (read only)
+  float* dq; float* dlog;         // scratch [B, d], [B, Lt]
+  bf16_t* out_vid; bf16_t* out_txt;   // bf16 [B*Lv, d] / [B*Lt, d]: dx0 + saliency-branch gradients, re-packed per modality
   float* dw_pool;                 // [d] atomically accumulated
 };
 int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s);
