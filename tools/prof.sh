@@ -7,4 +7,4 @@ rocprofv3 --kernel-trace -d $R/gpurun_out/prof_$N -o $N -- "$@" > $R/gpurun_out/
 DB=$(find $R/gpurun_out/prof_$N -name '*.db' | head -1)
 python $R/tools/rocpd_stats.py $DB $S > $R/gpurun_out/${N}_stats.md
 rm -rf $R/gpurun_out/prof_$N
-head -30 $R/gpurun_out/${N}_stats.md
+head -60 $R/gpurun_out/${N}_stats.md

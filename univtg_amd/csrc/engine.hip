@@ -578,6 +578,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   hf.pred_logits = (float*)pred_logits; hf.pred_spans = (float*)pred_spans; hf.g_logits = g_logits; hf.g_spans = g_spans;
   hf.dh2 = ws.dh2_pad; hf.lddh = 2 * d;
   hf.dw_span = G(m.tail(SP2W)); hf.db_span = G(m.tail(SP2B)); hf.dw_cls = G(m.tail(CL2W)); hf.db_cls = G(m.tail(CL2B));
+  hf.scratch = ws.tn_scratch; hf.scratch_floats = ws.tn_scratch_floats;
   TRY(launch_heads_final_bwd(hf, s));
   const int Rp = m.Rp;
   for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 1 weight grads: 3 taps x 2 heads

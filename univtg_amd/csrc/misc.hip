@@ -103,6 +103,24 @@ template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
+// 8 consecutive channels of a hidden row as floats (16-byte load in bf16 mode, 2 x 16 bytes in fp32 mode)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const u32x4 t = *(const u32x4*)p;
+#pragma unroll
+  for (int e = 0; e < 4; e++) { v[2 * e] = __uint_as_float(t[e] << 16); v[2 * e + 1] = __uint_as_float(t[e] & 0xffff0000u); }
+}
+// the 24 weights w[c..c+7][tap 0..2] of one output channel (contiguous: (d, 3) layout)
+__device__ __forceinline__ void ldw24(const float* w, float (&o)[24]) {
+#pragma unroll
+  for (int q = 0; q < 6; q++) { const f32x4 t = *(const f32x4*)(w + 4 * q); o[4 * q] = t[0]; o[4 * q + 1] = t[1]; o[4 * q + 2] = t[2]; o[4 * q + 3] = t[3]; }
+}
+
+// one wave per clip (b, t); lane owns 8 consecutive channels per pass (d % 8 == 0)
 template <typename T>
 __global__ __launch_bounds__(256) void heads_final_fwd_kernel(const HeadsFinalArgs a) {
   const int lane = threadIdx.x & 63;
@@ -111,14 +129,16 @@ __global__ __launch_bounds__(256) void heads_final_fwd_kernel(const HeadsFinalAr
   const int b = row / a.Lv, t = row % a.Lv, d = a.d;
   const T* h2 = (const T*)a.h2;
   float z0 = 0.f, z1 = 0.f, zc = 0.f;
+  for (int c = lane * 8; c < d; c += 512) {
+    float w0[24], w1[24], wc[24];
+    ldw24(a.w_span + (size_t)c * 3, w0); ldw24(a.w_span + ((size_t)d + c) * 3, w1); ldw24(a.w_cls + (size_t)c * 3, wc);
 #pragma unroll
-  for (int tap = 0; tap < 3; tap++) {
-    const T* hr = h2 + (size_t)(b * (a.Lv + 2) + t + tap) * a.ldh;
-    for (int c = lane; c < d; c += 64) {
-      const float hs = ldf<T>(hr + c), hc = ldf<T>(hr + d + c);
-      z0 += hs * a.w_span[(size_t)c * 3 + tap];
-      z1 += hs * a.w_span[((size_t)d + c) * 3 + tap];
-      zc += hc * a.w_cls[(size_t)c * 3 + tap];
+    for (int tap = 0; tap < 3; tap++) {
+      const T* hr = h2 + (size_t)(b * (a.Lv + 2) + t + tap) * a.ldh;
+      float hs[8], hc[8];
+      ld8<T>(hr + c, hs); ld8<T>(hr + d + c, hc);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { z0 += hs[e] * w0[e * 3 + tap]; z1 += hs[e] * w1[e * 3 + tap]; zc += hc[e] * wc[e * 3 + tap]; }
     }
   }
   z0 = wave_sum(z0); z1 = wave_sum(z1); zc = wave_sum(zc);
@@ -140,57 +160,144 @@ __device__ __forceinline__ void head_dz(const HeadsFinalArgs& a, int b, int t, f
 }
 
 // dh2[b, u, :] (zero-framed, relu' applied) : dh[u][c] = sum_tap sum_j w[j][c][tap] * dz_j[u - tap + 1]
+// one wave per (b, u) row, lane owns 8 channels of the 2d-wide row per pass
 __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFinalArgs a) {
-  const int row = blockIdx.x;                               // (b, u)
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, u)
+  if (row >= a.B * a.Lv) return;
   const int b = row / a.Lv, u = row % a.Lv, d = a.d;
   float dz0[3], dz1[3], dzc[3];
 #pragma unroll
   for (int tap = 0; tap < 3; tap++) head_dz(a, b, u - tap + 1, dz0[tap], dz1[tap], dzc[tap]);
   const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(b * (a.Lv + 2) + u + 1) * a.ldh;
   bf16_t* out = a.dh2 + (size_t)(b * (a.Lv + 2) + u + 1) * a.lddh;
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    float gs = 0.f, gc = 0.f;
+  for (int c2 = lane * 8; c2 < 2 * d; c2 += 512) {
+    const bool cls = c2 >= d;
+    const int c = cls ? c2 - d : c2;
+    float h[8], g[8];
+    ld8<bf16_t>(h2 + c2, h);
+    if (!cls) {
+      float w0[24], w1[24];
+      ldw24(a.w_span + (size_t)c * 3, w0); ldw24(a.w_span + ((size_t)d + c) * 3, w1);
 #pragma unroll
-    for (int tap = 0; tap < 3; tap++) {
-      gs += a.w_span[(size_t)c * 3 + tap] * dz0[tap] + a.w_span[((size_t)d + c) * 3 + tap] * dz1[tap];
-      gc += a.w_cls[(size_t)c * 3 + tap] * dzc[tap];
+      for (int e = 0; e < 8; e++) {
+        float t = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 3; tap++) t += w0[e * 3 + tap] * dz0[tap] + w1[e * 3 + tap] * dz1[tap];
+        g[e] = h[e] > 0.f ? t : 0.f;
+      }
+    } else {
+      float wc[24];
+      ldw24(a.w_cls + (size_t)c * 3, wc);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float t = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 3; tap++) t += wc[e * 3 + tap] * dzc[tap];
+        g[e] = h[e] > 0.f ? t : 0.f;
+      }
     }
-    out[c] = f2bf(bf2f(h2[c]) > 0.f ? gs : 0.f);
-    out[d + c] = f2bf(bf2f(h2[d + c]) > 0.f ? gc : 0.f);
+    u32x4 o; o[0] = pack_bf2(g[0], g[1]); o[1] = pack_bf2(g[2], g[3]); o[2] = pack_bf2(g[4], g[5]); o[3] = pack_bf2(g[6], g[7]);
+    *(u32x4*)(out + c2) = o;
   }
 }
 
-// dW[j][c][tap] = sum_{b,t} dz_j[b,t] * h2[b, t + tap - 1][c];  one block per 64-column slab
-__global__ __launch_bounds__(256) void heads_final_bwd_dw_kernel(const HeadsFinalArgs a) {
-  const int d = a.d;
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6, nrows = a.B * a.Lv;
-  float ws0[3] = {0, 0, 0}, ws1[3] = {0, 0, 0}, wc[3] = {0, 0, 0}, b0 = 0.f, b1 = 0.f, bc = 0.f;
+// dW[j][c][tap] = sum_{b,t} dz_j[b,t] * h2[b, t + tap - 1][c] = sum over hidden rows u of h2[b, u][c] * dz_j[b, u - tap + 1].
+// One 1024-thread block per sample: 4 row groups x 256 threads, a thread owns 8 channels of the 2d-wide hidden row
+// (16-byte loads; every hidden row is loaded once and feeds all three taps), the 4 groups' partial sums are folded
+// through LDS and leave as one set of atomics per sample.
+__global__ __launch_bounds__(1024) void heads_final_bwd_dw_kernel(const HeadsFinalArgs a) {
+  extern __shared__ float sm[];                 // [3][Lv + 2] dz (zero at both ends) | [2][256][49] partial sums
+  const int b = blockIdx.x, d = a.d, tid = threadIdx.x, Lv = a.Lv, grp = tid >> 8, t8 = tid & 255;
+  float* s_dz = sm;
+  float* s_part = sm + 3 * (Lv + 2);
   const bf16_t* h2 = (const bf16_t*)a.h2;
-  for (int row = blockIdx.y * 4 + part; row < nrows; row += gridDim.y * 4) {
-    const int b = row / a.Lv, t = row % a.Lv;
+  float bs0 = 0.f, bs1 = 0.f, bsc = 0.f;
+  for (int i = tid; i < Lv + 2; i += 1024) {
     float d0, d1, dc;
-    head_dz(a, b, t, d0, d1, dc);
-    b0 += d0; b1 += d1; bc += dc;
-    if (c < d) {
+    head_dz(a, b, i - 1, d0, d1, dc);
+    s_dz[i] = d0; s_dz[(Lv + 2) + i] = d1; s_dz[2 * (Lv + 2) + i] = dc;
+    bs0 += d0; bs1 += d1; bsc += dc;
+  }
+  bs0 = wave_sum(bs0); bs1 = wave_sum(bs1); bsc = wave_sum(bsc);
+  if ((tid & 63) == 0 && (bs0 != 0.f || bs1 != 0.f || bsc != 0.f)) { atomicAdd(a.db_span, bs0); atomicAdd(a.db_span + 1, bs1); atomicAdd(a.db_cls, bsc); }
+  __syncthreads();
+  const int per = (Lv + 3) / 4, u0 = grp * per, u1 = min(Lv, u0 + per);
+  for (int c2 = t8 * 8; c2 < 2 * d + 2047; c2 += 2048) {        // block-uniform trip count; inactive threads only join the barriers
+    const bool live = c2 < 2 * d;
+    const bool cls = c2 >= d;
+    const int c = cls ? c2 - d : c2;
+    float acc0[24], acc1[24];
 #pragma unroll
-      for (int tap = 0; tap < 3; tap++) {
-        const bf16_t* hr = h2 + (size_t)(b * (a.Lv + 2) + t + tap) * a.ldh;
-        const float hs = bf2f(hr[c]), hc = bf2f(hr[d + c]);
-        ws0[tap] += d0 * hs; ws1[tap] += d1 * hs; wc[tap] += dc * hc;
+    for (int i = 0; i < 24; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    if (live) {
+      const float* z0 = s_dz + (cls ? 2 * (Lv + 2) : 0);
+      const float* z1 = s_dz + (Lv + 2);
+#pragma unroll 4
+      for (int u = u0; u < u1; u++) {
+        float h[8];
+        ld8<bf16_t>(h2 + (size_t)(b * (Lv + 2) + u + 1) * a.ldh + c2, h);
+#pragma unroll
+        for (int tap = 0; tap < 3; tap++) {
+          const float g0 = z0[u - tap + 2], g1 = z1[u - tap + 2];      // clip t = u - tap + 1 -> index 1 + t
+#pragma unroll
+          for (int e = 0; e < 8; e++) { acc0[e * 3 + tap] += g0 * h[e]; acc1[e * 3 + tap] += g1 * h[e]; }
+        }
       }
     }
-  }
-  if (c < d) {
+    // fold groups 2,3 into 0,1, then 1 into 0
+    if (grp >= 2) {
 #pragma unroll
-    for (int tap = 0; tap < 3; tap++) {
-      atomicAdd(a.dw_span + (size_t)c * 3 + tap, ws0[tap]);
-      atomicAdd(a.dw_span + ((size_t)d + c) * 3 + tap, ws1[tap]);
-      atomicAdd(a.dw_cls + (size_t)c * 3 + tap, wc[tap]);
+      for (int i = 0; i < 24; i++) { s_part[((grp - 2) * 256 + t8) * 49 + i] = acc0[i]; s_part[((grp - 2) * 256 + t8) * 49 + 24 + i] = acc1[i]; }
     }
+    __syncthreads();
+    if (grp < 2) {
+#pragma unroll
+      for (int i = 0; i < 24; i++) { acc0[i] += s_part[(grp * 256 + t8) * 49 + i]; acc1[i] += s_part[(grp * 256 + t8) * 49 + 24 + i]; }
+    }
+    __syncthreads();
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < 24; i++) { s_part[t8 * 49 + i] = acc0[i]; s_part[t8 * 49 + 24 + i] = acc1[i]; }
+    }
+    __syncthreads();
+    if (grp == 0 && live) {
+#pragma unroll
+      for (int i = 0; i < 24; i++) { acc0[i] += s_part[t8 * 49 + i]; acc1[i] += s_part[t8 * 49 + 24 + i]; }
+      if (a.scratch) {        // per-sample partial in the final (j, c, tap) order; heads_final_dw_reduce_kernel sums over samples
+        float* part = a.scratch + (size_t)b * 9 * d;
+        float* p0 = part + (cls ? (size_t)6 * d : 0) + (size_t)c * 3;
+#pragma unroll
+        for (int q = 0; q < 6; q++) *(f32x4*)(p0 + 4 * q) = (f32x4){acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
+        if (!cls) {
+          float* p1 = part + ((size_t)d + c) * 3;
+#pragma unroll
+          for (int q = 0; q < 6; q++) *(f32x4*)(p1 + 4 * q) = (f32x4){acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+        }
+      } else if (!cls) {      // (256 same-address atomics per element serialise in L2: only the fallback without scratch)
+#pragma unroll
+        for (int i = 0; i < 24; i++) { atomicAdd(a.dw_span + (size_t)c * 3 + i, acc0[i]); atomicAdd(a.dw_span + ((size_t)d + c) * 3 + i, acc1[i]); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 24; i++) atomicAdd(a.dw_cls + (size_t)c * 3 + i, acc0[i]);
+      }
+    }
+    __syncthreads();
   }
-  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-    atomicAdd(a.db_span, b0); atomicAdd(a.db_span + 1, b1); atomicAdd(a.db_cls, bc);
+}
+__global__ __launch_bounds__(256) void heads_final_dw_reduce_kernel(const HeadsFinalArgs a) {
+  __shared__ float red[16][17];
+  const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;        // 16 outputs x 16 sample lanes per block
+  const int idx = blockIdx.x * 16 + il, n = 9 * a.d;
+  float s = 0.f;
+  if (idx < n) for (int b = bl; b < a.B; b += 16) s += a.scratch[(size_t)b * n + idx];
+  red[bl][il] = s;
+  __syncthreads();
+  if (bl == 0 && idx < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][il];
+    if (idx < 6 * a.d) a.dw_span[idx] += t; else a.dw_cls[idx - 6 * a.d] += t;
   }
 }
 
@@ -468,9 +575,19 @@ int launch_heads_final_fwd(const HeadsFinalArgs& a, hipStream_t s) {
 }
 int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s) {
   if (a.precise) return -6;
-  hipLaunchKernelGGL(heads_final_bwd_dh_kernel, dim3(a.B * a.Lv), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(heads_final_bwd_dh_kernel, dim3(cdiv(a.B * a.Lv, 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(heads_final_bwd_dw_kernel, dim3(cdiv(a.d, 64), 32), dim3(256), 0, s, a);
+  static bool attr = false;
+  if (!attr) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)heads_final_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return (int)e;
+    attr = true;
+  }
+  const size_t sh = (3 * (size_t)(a.Lv + 2) + 2 * 256 * 49) * sizeof(float);
+  if (sh > 160 * 1024) return -11;
+  HeadsFinalArgs b = a;
+  if (b.scratch && b.scratch_floats < (long long)b.B * 9 * b.d) b.scratch = nullptr;
+  hipLaunchKernelGGL(heads_final_bwd_dw_kernel, dim3(b.B), dim3(1024), sh, s, b);
+  if (b.scratch) hipLaunchKernelGGL(heads_final_dw_reduce_kernel, dim3(cdiv(9 * b.d, 16)), dim3(256), 0, s, b);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -135,6 +135,7 @@ struct HeadsFinalArgs {           // last conv layer of both heads + sigmoid/sig
   const float* g_logits; const float* g_spans;   // upstream grads
   bf16_t* dh2; int lddh;          // zero-framed gradient wrt h2 (pre-activation of layer 3 input), relu' applied
   float* dw_span; float* db_span; float* dw_cls; float* db_cls;
+  float* scratch; long long scratch_floats;   // optional [B, 9 d] per-sample weight-gradient partials (else atomics)
 };
 int launch_heads_final_fwd(const HeadsFinalArgs& a, hipStream_t s);
 int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s);
