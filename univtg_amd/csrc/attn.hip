@@ -463,6 +463,158 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, S <= 128: dQ, dK, dV of one (sample, head) in ONE pass over the operands (the split dK/dV + dQ kernels
+// above read q, k, v, dO twice and recompute the scores twice).  wave w owns keys 32w .. 32w+31: it keeps its V rows in
+// registers, accumulates dK / dV for them over the 32-query blocks exactly like attn_bwd_dkdv_kernel, and publishes its
+// dS tile (bf16) to LDS; after a barrier wave w computes the head-dim tile 32w .. 32w+31 of dQ^T = K^T dS^T for the
+// query block from the full K (LDS resident, padded rows: row reads and transposing reads are both conflict-free).
+// No attention dropout in this kernel (the counter-based RNG per element costs ~150 registers when unrolled, which would
+// halve the occupancy); with p_drop > 0 -- never the case in the reference scripts, scripts/pretrain.sh:34 -- the split
+// kernels run instead.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a) {
+  constexpr int KSTR = HD + 8, QSTR = HD + 8, DSTR = 128 + 8, CH = HD / 8;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[128 * KSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * QSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[32 * QSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sDS[32 * DSTR];
+  __shared__ float sL[32], sD[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.S, d = a.H * HD;
+  const size_t rowbase = (size_t)b * S;
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  // K (all keys) -> LDS, zero rows beyond S
+#pragma unroll
+  for (int i = 0; i < (128 * CH) / 256; i++) {
+    const int q = tid + 256 * i, r = q / CH, c = q % CH;
+    u32x4 kv = {0, 0, 0, 0};
+    if (r < S) kv = *(const u32x4*)(qkv + (rowbase + r) * a.ldqkv + d + h * HD + c * 8);
+    *(u32x4*)(&sK[r * KSTR + c * 8]) = kv;
+  }
+  const int key = wave * 32 + l31;
+  const int krow = min(key, S - 1);
+  const bool kok = key < S && a.kvalid[rowbase + krow];
+  const bf16_t* vrow = qkv + (rowbase + krow) * a.ldqkv + 2 * d + h * HD + 8 * g;   // this lane's V row (A operand of dP = dO V^T)
+  f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+  constexpr int NP = (32 * CH + 255) / 256;          // staging pieces per thread per operand
+  u32x4 pq[NP], po[NP];
+  auto prefetch = [&](int qb) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const int q = tid + 256 * i, r = q / CH, c = q % CH, qi = qb * 32 + r;
+      pq[i] = (u32x4){0, 0, 0, 0}; po[i] = (u32x4){0, 0, 0, 0};
+      if (q < 32 * CH && qi < S) {
+        pq[i] = *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8);
+        po[i] = *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8);
+      }
+    }
+  };
+  const int nqb = (S + 31) / 32;
+  prefetch(0);
+  for (int qb = 0; qb < nqb; qb++) {
+    __syncthreads();                                 // previous block's readers of sQ / sO / sDS are done
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const int q = tid + 256 * i, r = q / CH, c = q % CH;
+      if (q < 32 * CH) { *(u32x4*)(&sQ[r * QSTR + c * 8]) = pq[i]; *(u32x4*)(&sO[r * QSTR + c * 8]) = po[i]; }
+    }
+    if (tid < 32) {
+      const int qi = qb * 32 + tid;
+      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * S + qi] : 0.f;
+      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * S + qi] : 0.f;
+    }
+    if (qb + 1 < nqb) prefetch(qb + 1);
+    // V fragments are re-fetched (L2 hits) per query block instead of living in 32 registers across the whole loop:
+    // with the 128 dK / dV accumulators that keeps the kernel at two workgroups per CU without spilling
+    s16x8 vf[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ks++) vf[ks] = *(const s16x8*)(vrow + 16 * ks);
+    __syncthreads();
+    // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ks++) {
+      const s16x8 qf = *(const s16x8*)(&sQ[l31 * QSTR + 16 * ks + 8 * g]);
+      const s16x8 of = *(const s16x8*)(&sO[l31 * QSTR + 16 * ks + 8 * g]);
+      const s16x8 kf = *(const s16x8*)(&sK[key * KSTR + 16 * ks + 8 * g]);
+      sc = mfma32(qf, kf, sc);
+      dp = mfma32(of, vf[ks], dp);
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int ql = (r & 3) + 8 * (r >> 2) + 4 * g, qi = qb * 32 + ql;
+      float p = (kok && qi < S) ? __expf(sc[r] - sL[ql]) : 0.f;
+      pd[r] = p;
+      ds[r] = p * (dp[r] - sD[ql]);
+      sDS[ql * DSTR + key] = f2bf(ds[r]);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      const s16x8 pb = pack8(&pd[8 * hf]);
+      const s16x8 db = pack8(&ds[8 * hf]);
+      const int qr = 16 * hf + 4 * g + (i16 >> 2);
+#pragma unroll
+      for (int blk = 0; blk < HD / 32; blk++) {
+        const int col = blk * 32 + 16 * qd + 4 * (i16 & 3);
+        const s16x8 ot = cat4(lds_tr16(&sO[qr * QSTR + col]), lds_tr16(&sO[(qr + 8) * QSTR + col]));
+        const s16x8 qt = cat4(lds_tr16(&sQ[qr * QSTR + col]), lds_tr16(&sQ[(qr + 8) * QSTR + col]));
+        dv[blk] = mfma32(ot, pb, dv[blk]);
+        dk[blk] = mfma32(qt, db, dk[blk]);
+      }
+    }
+    __syncthreads();                                 // every wave's dS tile of this query block is in sDS
+    // dQ^T tile (head dims 32 wave .. +31) x (32 queries) = sum over all 128 keys of K^T dS^T
+    if (wave * 32 < HD) {
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; r++) dq[r] = 0.f;
+      const int col = wave * 32 + 16 * qd + 4 * (i16 & 3);
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        const int kr = 16 * kk + 8 * g + (i16 >> 2);
+        const s16x8 kt_ = cat4(lds_tr16(&sK[kr * KSTR + col]), lds_tr16(&sK[(kr + 4) * KSTR + col]));
+        const s16x8 db = *(const s16x8*)(&sDS[l31 * DSTR + 16 * kk + 8 * g]);
+        dq = mfma32(kt_, db, dq);
+      }
+      const int qi = qb * 32 + l31;
+      if (qi < S) {
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+          const int c = wave * 32 + 8 * rq + 4 * g;
+          u32x2 t;
+          t[0] = pack_bf2(dq[4 * rq] * a.qscale, dq[4 * rq + 1] * a.qscale);
+          t[1] = pack_bf2(dq[4 * rq + 2] * a.qscale, dq[4 * rq + 3] * a.qscale);
+          *(u32x2*)(a.dqkv + (rowbase + qi) * a.lddqkv + h * HD + c) = t;
+        }
+      }
+    }
+  }
+  if (key < S) {
+#pragma unroll
+    for (int blk = 0; blk < HD / 32; blk++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const int c = blk * 32 + 8 * rq + 4 * g;
+        bf16_t* base = a.dqkv + (rowbase + key) * a.lddqkv + h * HD + c;
+        u32x2 t;
+        t[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); t[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]);
+        *(u32x2*)(base + d) = t;
+        t[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); t[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]);
+        *(u32x2*)(base + 2 * d) = t;
+      }
+  }
+}
+
 }  // namespace
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
@@ -486,6 +638,13 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
+  if (a.S <= 128 && a.p_drop <= 0.f) {   // whole (sample, head) problem in one workgroup: one pass over q, k, v, dO
+    if (a.hd == 128) hipLaunchKernelGGL((attn_bwd_fused_kernel<128>), grid, blk, 0, s, a);
+    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32>), grid, blk, 0, s, a);
+    UVTG_CHECK_LAUNCH();
+    return 0;
+  }
 #define BWD(HD_)                                                                                  \
   if (a.hd == HD_) {                                                                              \
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_>), grid, blk, 0, s, a);                          \
