@@ -120,13 +120,14 @@ struct WSpace {
   float* xin[MAXE + 1]; void *xb[MAXE + 1], *ub[MAXE + 1];
   void *qkv[MAXE], *o[MAXE], *x1b[MAXE], *h[MAXE]; bf16_t* apre[MAXE];
   float *lse[MAXE], *y1[MAXE], *mean1[MAXE], *rstd1[MAXE], *y2[MAXE], *mean2[MAXE], *rstd2[MAXE], *x1;
+  bf16_t *y1b[MAXE], *y2b[MAXE];        // fast mode: the pre-LayerNorm sums live in bf16 (the fp32 y1 / y2 / xin / x1 are precise-mode only)
   // heads
   void *vm_pad, *h1_pad, *h2_pad;
   // saliency
   float *alpha, *cosv, *vnorm, *qnorm, *sal_dq, *sal_dlog;
   // backward scratch
   float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2], *tn_scratch; long long tn_scratch_floats;
-  bf16_t *dh2_pad, *dh1_pad, *dyB, *da, *dOb, *dqkv, *dyP[2], *dh1b[2];
+  bf16_t *dh2_pad, *dh1_pad, *dyB, *dyR, *dvmB, *gxb[2], *da, *dOb, *dqkv, *dyP[2], *dh1b[2];
   size_t bytes;
   WSpace(const Dm& m, void* base, float* x0) {
     Arena a(base);
@@ -145,16 +146,17 @@ struct WSpace {
       a2B[i] = (tr && pp) ? a.take<bf16_t>(R * d) : nullptr;
       m1[i] = a.take<float>(R); r1[i] = a.take<float>(R);
     }
-    x1 = a.take<float>(M * d);
+    x1 = fast ? nullptr : a.take<float>(M * d);
     float* xpp[2] = {nullptr, nullptr}; void* xbpp[2] = {nullptr, nullptr}; void* ubpp[2] = {nullptr, nullptr};
     for (size_t l = 0; l <= E; l++) {       // layer l reads slot l, writes slot l + 1
       if (tr) {
-        xin[l] = l == 0 ? x0 : a.take<float>(M * d);
+        xin[l] = l == 0 ? x0 : (fast ? nullptr : a.take<float>(M * d));
         xb[l] = fast ? (void*)a.take<char>(M * d * es) : (void*)xin[l];
         ub[l] = a.take<char>(M * d * es);
       } else {                              // eval: ping-pong
         if (l == 0) xin[0] = x0;
-        else { if (l <= 2) xpp[l - 1] = a.take<float>(M * d); xin[l] = xpp[(l - 1) % 2]; }
+        else if (!fast) { if (l <= 2) xpp[l - 1] = a.take<float>(M * d); xin[l] = xpp[(l - 1) % 2]; }
+        else xin[l] = nullptr;
         if (fast) { if (l <= 1) xbpp[l] = a.take<char>(M * d * es); xb[l] = xbpp[l % 2]; }
         else xb[l] = xin[l];
         if (l <= 1) ubpp[l] = a.take<char>(M * d * es);
@@ -166,12 +168,14 @@ struct WSpace {
       qkv[l] = own ? (void*)a.take<char>(M * 3 * d * es) : qkv[0];
       o[l] = own ? (void*)a.take<char>(M * d * es) : o[0];
       lse[l] = own ? a.take<float>(B * m.c.H * m.S) : lse[0];
-      y1[l] = own ? a.take<float>(M * d) : y1[0];
+      y1[l] = fast ? nullptr : (own ? a.take<float>(M * d) : y1[0]);
+      y1b[l] = fast ? (own ? a.take<bf16_t>(M * d) : y1b[0]) : nullptr;
       mean1[l] = own ? a.take<float>(M) : mean1[0]; rstd1[l] = own ? a.take<float>(M) : rstd1[0];
       x1b[l] = fast ? (own ? (void*)a.take<char>(M * d * es) : x1b[0]) : (void*)x1;
       apre[l] = tr ? a.take<bf16_t>(M * F) : nullptr;
       h[l] = own ? (void*)a.take<char>(M * F * es) : h[0];
-      y2[l] = own ? a.take<float>(M * d) : y2[0];
+      y2[l] = fast ? nullptr : (own ? a.take<float>(M * d) : y2[0]);
+      y2b[l] = fast ? (own ? a.take<bf16_t>(M * d) : y2b[0]) : nullptr;
       mean2[l] = own ? a.take<float>(M) : mean2[0]; rstd2[l] = own ? a.take<float>(M) : rstd2[0];
     }
     vm_pad = a.take<char>((size_t)(m.Rp + 1) * d * es);
@@ -179,8 +183,9 @@ struct WSpace {
     h2_pad = a.take<char>((size_t)(m.Rp + 1) * 2 * d * es);
     alpha = a.take<float>((size_t)B * m.c.Lt); cosv = a.take<float>(m.Mv); vnorm = a.take<float>(m.Mv); qnorm = a.take<float>(B);
     if (tr) {
-      dvm = a.take<float>((size_t)m.Mv * d); gx[0] = a.take<float>(M * d); gx[1] = a.take<float>(M * d);
-      dyF = a.take<float>(M * d); delta = a.take<float>(B * m.c.H * m.S);
+      dvm = nullptr; gx[0] = gx[1] = nullptr; dyF = nullptr;       // (fp32 gradient stream: not used by the bf16 training path)
+      dvmB = a.take<bf16_t>((size_t)m.Mv * d); gxb[0] = a.take<bf16_t>(M * d); gxb[1] = a.take<bf16_t>(M * d);
+      dyR = a.take<bf16_t>(M * d); delta = a.take<float>(B * m.c.H * m.S);
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
       {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
         long long need = 0;
@@ -197,7 +202,7 @@ struct WSpace {
         dA2[i] = a.take<float>(R * d); dA1[i] = a.take<float>(R * Kp);
       }
     } else {
-      dvm = gx[0] = gx[1] = dyF = delta = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
+      dvm = gx[0] = gx[1] = dyF = delta = nullptr; dyR = dvmB = gxb[0] = gxb[1] = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
       for (int i = 0; i < 2; i++) { dyP[i] = dh1b[i] = nullptr; dA2[i] = dA1[i] = nullptr; }
     }
     bytes = a.off + 256;
@@ -437,13 +442,16 @@ struct Fwd {
     TRY(launch_attn_fwd(at, s));
     // out-proj + DropPath + residual -> y1 ; LN1
     g = gemm_base(ws.o[l], d, fast ? (const void*)w.wo[l] : (const void*)P[m.lay(l, OPW)], d, M, d, d);
-    g.bias = P[m.lay(l, OPB)]; g.resid = ws.xin[l]; g.ldr = d; g.outF = ws.y1[l]; g.ldoF = d;
+    g.bias = P[m.lay(l, OPB)];
+    if (fast) { g.residB = (const bf16_t*)ws.xb[l]; g.ldrB = d; g.outB = ws.y1b[l]; g.ldoB = d; }
+    else { g.resid = ws.xin[l]; g.ldr = d; g.outF = ws.y1[l]; g.ldoF = d; }
     if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l) * m.c.B; g.rs_seg = S; }
     TRY(run_gemm(g, !fast));
     LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
-    ln.x = ws.y1[l]; ln.ldx = d; ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
-    ln.mean = ws.mean1[l]; ln.rstd = ws.rstd1[l]; ln.yF = ws.x1; ln.ldyF = d; ln.Dpad = d;
-    if (fast) { ln.yB = (bf16_t*)ws.x1b[l]; ln.ldyB = d; }
+    ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
+    ln.mean = ws.mean1[l]; ln.rstd = ws.rstd1[l]; ln.Dpad = d;
+    if (fast) { ln.xB = ws.y1b[l]; ln.ldxB = d; ln.yB = (bf16_t*)ws.x1b[l]; ln.ldyB = d; }
+    else { ln.x = ws.y1[l]; ln.ldx = d; ln.yF = ws.x1; ln.ldyF = d; }
     TRY(launch_ln_fwd(ln, s));
     // FFN: linear1 + GELU, linear2 + DropPath + residual -> y2 ; LN2
     g = gemm_base(ws.x1b[l], d, fast ? (const void*)w.w1[l] : (const void*)P[m.lay(l, L1W)], d, M, F, d);
@@ -452,14 +460,18 @@ struct Fwd {
     set_out(g, ws.h[l], F);
     TRY(run_gemm(g, !fast));
     g = gemm_base(ws.h[l], F, fast ? (const void*)w.w2[l] : (const void*)P[m.lay(l, L2W)], F, M, d, F);
-    g.bias = P[m.lay(l, L2B)]; g.resid = ws.x1; g.ldr = d; g.outF = ws.y2[l]; g.ldoF = d;
+    g.bias = P[m.lay(l, L2B)];
+    if (fast) { g.residB = (const bf16_t*)ws.x1b[l]; g.ldrB = d; g.outB = ws.y2b[l]; g.ldoB = d; }
+    else { g.resid = ws.x1; g.ldr = d; g.outF = ws.y2[l]; g.ldoF = d; }
     if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l + 1) * m.c.B; g.rs_seg = S; }
     TRY(run_gemm(g, !fast));
     memset(&ln, 0, sizeof(ln));
-    ln.x = ws.y2[l]; ln.ldx = d; ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N2W)]; ln.beta = P[m.lay(l, N2B)]; ln.eps = 1e-5f;
+    ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N2W)]; ln.beta = P[m.lay(l, N2B)]; ln.eps = 1e-5f;
     ln.mean = ws.mean2[l]; ln.rstd = ws.rstd2[l]; ln.Dpad = d; ln.S = S; ln.Lv = m.c.Lv;
+    if (fast) { ln.xB = ws.y2b[l]; ln.ldxB = d; } else { ln.x = ws.y2[l]; ln.ldx = d; }
     if (!last) {
-      ln.yF = ws.xin[l + 1]; ln.ldyF = d; ln.pos = ws.pos; ln.ldyU = d;
+      if (!fast) { ln.yF = ws.xin[l + 1]; ln.ldyF = d; }
+      ln.pos = ws.pos; ln.ldyU = d;
       if (fast) { ln.yB = (bf16_t*)ws.xb[l + 1]; ln.ldyB = d; ln.yU = (bf16_t*)ws.ub[l + 1]; }
       else ln.yUF = (float*)ws.ub[l + 1];
     } else {
@@ -606,21 +618,25 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   {                                             // conv layer 0 dgrad -> dvm (fp32, video rows)
     GemmArgs g = gemm_base(ws.dh1_pad, 2 * d, w.wc0T, 6 * d, m.Mv, d, 6 * d);
     g.ktap = 2 * d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
-    g.outF = ws.dvm; g.ldoF = d;
+    g.outB = ws.dvmB; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
   }
   // ---------------- encoder ----------------
-  const float* gin = nullptr;                   // gradient wrt the layer output (fp32 [M, d]); null = zero
+  // The gradient stream is bf16 (like the activation stream): gin = gradient wrt the layer output; dyB = LayerNorm input
+  // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
+  const bf16_t* gin = nullptr;                  // null = zero
   for (int l = E - 1; l >= 0; l--) {
     const bool last = l == E - 1;
     const float* dp_attn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l) * B : nullptr;
     const float* dp_ffn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l + 1) * B : nullptr;
+    const bf16_t* dyRes = dp_ffn ? ws.dyR : ws.dyB;
     LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
-    lb.g = gin; lb.ldg = d;
-    if (last) { lb.g2 = ws.dvm; lb.ldg2 = d; lb.g2_S = S; lb.g2_Lv = Lv; }
-    lb.x = ws.y2[l]; lb.ldx = d; lb.mean = ws.mean2[l]; lb.rstd = ws.rstd2[l]; lb.gamma = P[m.lay(l, N2W)];
+    lb.gB = gin; lb.ldgB = d;
+    if (last) { lb.g2B = ws.dvmB; lb.ldg2B = d; lb.g2_S = S; lb.g2_Lv = Lv; }
+    lb.xB = ws.y2b[l]; lb.ldxB = d; lb.mean = ws.mean2[l]; lb.rstd = ws.rstd2[l]; lb.gamma = P[m.lay(l, N2W)];
     lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
-    lb.dxF = ws.dyF; lb.lddxF = d; lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S;
+    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S;
+    if (dp_ffn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     TRY(launch_ln_bwd(lb, s));
     TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, 1, G(m.lay(l, L2B)), 0, M, splits_M));
     GemmArgs g = gemm_base(ws.dyB, d, w.w2T[l], d, M, F, d);          // d h = dy2 W2 ; da = dh * gelu'(a)
@@ -628,12 +644,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     TRY(launch_gemm_nt_bf16(g, s));
     TRY(wgrad(ws.da, F, (const bf16_t*)ws.x1b[l], d, M, F, d, G(m.lay(l, L1W)), d, 1, G(m.lay(l, L1B)), 0, M, splits_M));
     g = gemm_base(ws.da, F, w.w1T[l], F, M, d, F);                     // dx1 = da W1 + dy2
-    g.resid = ws.dyF; g.ldr = d; g.outF = ws.gx[0]; g.ldoF = d;
+    g.residB = dyRes; g.ldrB = d; g.outB = ws.gxb[0]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
     memset(&lb, 0, sizeof(lb));
-    lb.g = ws.gx[0]; lb.ldg = d; lb.x = ws.y1[l]; lb.ldx = d; lb.mean = ws.mean1[l]; lb.rstd = ws.rstd1[l];
+    lb.gB = ws.gxb[0]; lb.ldgB = d; lb.xB = ws.y1b[l]; lb.ldxB = d; lb.mean = ws.mean1[l]; lb.rstd = ws.rstd1[l];
     lb.gamma = P[m.lay(l, N1W)]; lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
-    lb.dxF = ws.dyF; lb.lddxF = d; lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S;
+    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S;
+    if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     TRY(launch_ln_bwd(lb, s));
     TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.o[l], d, M, d, d, G(m.lay(l, OPW)), d, 1, G(m.lay(l, OPB)), 0, M, splits_M));
     g = gemm_base(ws.dyB, d, w.woT[l], d, M, d, d);                    // dO = dy1 Wo
@@ -648,14 +665,14 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     TRY(wgrad(ws.dqkv + 2 * d, 3 * d, (const bf16_t*)ws.xb[l], d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, 1,
               G(m.lay(l, IPB)) + 2 * d, 0, M, splits_M));
     g = gemm_base(ws.dqkv, 3 * d, w.wqkvT[l], 3 * d, M, d, 3 * d);     // dx = dqkv Wqkv + dy1
-    g.resid = ws.dyF; g.ldr = d; g.outF = ws.gx[1]; g.ldoF = d;
+    g.residB = dp_attn ? ws.dyR : ws.dyB; g.ldrB = d; g.outB = ws.gxb[1]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
-    gin = ws.gx[1];   // consumed by the next (lower) layer's LN2 backward before gx[0]/gx[1] are rewritten
+    gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
   }
-  float* dx0 = ws.gx[1];                         // d loss / d x0 from the encoder, fp32 [M, d]
+  const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]
   // ---------------- saliency branch ----------------
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
-  sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0 = dx0; sa.dw_pool = G(m.tail(POOL));
+  sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0B = dx0; sa.dw_pool = G(m.tail(POOL));
   sa.dq = ws.sal_dq; sa.dlog = ws.sal_dlog; sa.out_vid = ws.dyP[0]; sa.out_txt = ws.dyP[1];
   TRY(launch_saliency_bwd(sa, s));
   // ---------------- input projections ----------------

@@ -199,6 +199,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     }
     if (p.rowscale) v *= p.rowscale[m / p.rs_seg];
     if (p.resid) { const f32x4 t = *(const f32x4*)(p.resid + orow * p.ldr + n); v += t; }
+    if (p.residB) {
+      const u32x2 t = *(const u32x2*)(p.residB + orow * p.ldrB + n);
+      v[0] += __uint_as_float(t[0] << 16); v[1] += __uint_as_float(t[0] & 0xffff0000u);
+      v[2] += __uint_as_float(t[1] << 16); v[3] += __uint_as_float(t[1] & 0xffff0000u);
+    }
     if (p.outF) *(f32x4*)(p.outF + go + orow * p.ldoF + n) = v;
     if (p.outB) {
       u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
@@ -417,6 +422,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
             const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
             for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          if (p.residB) {
+            const u32x4 t = *(const u32x4*)(p.residB + orow * p.ldrB + n);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
           }
           if (p.outF) {
             float* op = p.outF + go + orow * p.ldoF + n;
@@ -754,7 +764,7 @@ static int check_nt(const GemmArgs& a, int elem) {
   if (a.lda % al || a.ldb % al || a.ktap <= 0) return -2;
   if (a.ktap < a.K && (a.ktap % (elem == 2 ? 64 : 32))) return -2;
   if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return -3;
-  if (a.N % 4 || a.ldoF % 4 || a.ldoB % 4 || a.ldoU % 4 || a.ldr % 4 || a.ldgp % 4 || a.ldpre_out % 4 || a.ldpos % 4 ||
+  if (a.N % 4 || a.ldoF % 4 || a.ldoB % 4 || a.ldoU % 4 || a.ldr % 4 || a.ldrB % 4 || a.ldgp % 4 || a.ldpre_out % 4 || a.ldpos % 4 ||
       a.colscale_n % 4) return -7;
   return 0;
 }
@@ -766,7 +776,7 @@ extern "C" int uvtg_debug_force_nt_tile(int tile) { if (tile != 0 && tile != 128
 static bool nt256_ok(const GemmArgs& a) {
   if (g_force_tile == 128) return false;
   if (a.K % 64 || a.ktap % 64 || a.lda % 8 || a.ldb % 8 || a.N % 8) return false;
-  if (a.ldoF % 8 || a.ldoB % 8 || a.ldoU % 8 || a.ldr % 8 || a.ldgp % 8 || a.ldpre_out % 8 || a.ldpos % 8 || a.colscale_n % 8) return false;
+  if (a.ldoF % 8 || a.ldoB % 8 || a.ldoU % 8 || a.ldr % 8 || a.ldrB % 8 || a.ldgp % 8 || a.ldpre_out % 8 || a.ldpos % 8 || a.colscale_n % 8) return false;
   if (a.gA % 8 || a.gB % 8 || a.gBias % 4 || a.gOut % 8 || a.gPre % 8) return false;
   const int groups = a.groups > 0 ? a.groups : 1;
   if (g_force_tile != 256) {  // pick the tile size that wastes less of the chip: whole rounds of 256 (one 256-tile per CU) vs 512 (two 128-tiles per CU)

@@ -438,7 +438,13 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
   for (int srow = chunk * 32 + wave; srow < s_end; srow += 4) {
     const size_t row = (size_t)b * a.S + srow;
     const float* x = a.x0 + row * d;
-    const float* g0 = a.dx0 + row * d;
+    const float* g0 = a.dx0 ? a.dx0 + row * d : nullptr;
+    const bf16_t* g0b = a.dx0 ? nullptr : a.dx0B + row * d;
+    auto ldg = [&](int c) -> f32x4 {
+      if (g0) return *(const f32x4*)(g0 + c);
+      const u32x2 t = *(const u32x2*)(g0b + c);
+      return (f32x4){__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u), __uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
+    };
     if (srow < a.Lv) {
       const int t = srow;
       const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
 #pragma unroll
       for (int k = 0; k < KC; k++) {
         const int c = k * 256 + lane * 4;
-        f32x4 g = *(const f32x4*)(g0 + c);
+        f32x4 g = ldg(c);
         if (gs != 0.f) {
           const f32x4 xv = *(const f32x4*)(x + c), q = *(const f32x4*)(a.pooled + (size_t)b * d + c);
 #pragma unroll
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
 #pragma unroll
       for (int k = 0; k < KC; k++) {
         const int c = k * 256 + lane * 4;
-        f32x4 g = *(const f32x4*)(g0 + c);
+        f32x4 g = ldg(c);
         const f32x4 xt = *(const f32x4*)(x + c), dq = *(const f32x4*)(a.dq + (size_t)b * d + c), wp = *(const f32x4*)(a.w_pool + c);
 #pragma unroll
         for (int e = 0; e < 4; e++) { g[e] += al * dq[e] + dl * wp[e]; dw[k][e] += dl * xt[e]; }
@@ -494,14 +500,16 @@ __global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const Salien
   const float qn = fmaxf(a.qnorm[b], 1e-8f);
   const int prow = (a.g_vrow && a.pos_idx) ? (int)a.pos_idx[b] : -1;
   const float* x = a.x0 + (size_t)row * d;
-  const float* g0 = a.dx0 + (size_t)row * d;
+  const float* g0f = a.dx0 ? a.dx0 + (size_t)row * d : nullptr;
+  const bf16_t* g0b = a.dx0 ? nullptr : a.dx0B + (size_t)row * d;
+  auto g0 = [&](int c) -> float { return g0f ? g0f[c] : bf2f(g0b[c]); };
   if (srow < a.Lv) {
     const int t = srow;
     const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
     const float vn = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f), cs = a.cosv[b * a.Lv + t];
     bf16_t* out = a.out_vid + ((size_t)b * a.Lv + t) * d;
     for (int c = lane; c < d; c += 64) {
-      float g = g0[c];
+      float g = g0(c);
       if (gs != 0.f) g += gs * (a.pooled[(size_t)b * d + c] / qn - cs * (x[c] / vn)) / vn;
       if (a.g_vid) g += a.g_vid[(size_t)b * a.gv_sb + (size_t)t * a.gv_st + c];
       if (t == prow) g += a.g_vrow[(size_t)b * d + c];
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const Salien
     const float al = a.alpha[b * a.Lt + t], dl = a.dlog[b * a.Lt + t];
     bf16_t* out = a.out_txt + ((size_t)b * a.Lt + t) * d;
     for (int c = lane; c < d; c += 64) {
-      out[c] = f2bf(g0[c] + al * a.dq[(size_t)b * d + c] + dl * a.w_pool[c]);
+      out[c] = f2bf(g0(c) + al * a.dq[(size_t)b * d + c] + dl * a.w_pool[c]);
       if (a.dw_pool) atomicAdd(a.dw_pool + c, dl * x[c]);
     }
   }

@@ -23,6 +23,16 @@ template <int VEC> __device__ __forceinline__ void storev(float* p, const float 
   else if constexpr (VEC == 2) { f32x2 t = {v[0], v[1]}; *(f32x2*)p = t; }
   else *p = v[0];
 }
+template <int VEC> __device__ __forceinline__ void loadb(const bf16_t* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const u32x2 t = *(const u32x2*)p;
+    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+  } else if constexpr (VEC == 2) {
+    const unsigned t = *(const unsigned*)p;
+    v[0] = __uint_as_float(t << 16); v[1] = __uint_as_float(t & 0xffff0000u);
+  } else v[0] = bf2f(*p);
+}
 template <int VEC> __device__ __forceinline__ void storeb(bf16_t* p, const float (&v)[VEC]) {
   if constexpr (VEC == 4) { u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); *(u32x2*)p = t; }
   else if constexpr (VEC == 2) { *(unsigned*)p = pack_bf2(v[0], v[1]); }
@@ -49,13 +59,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
   const int wpb = blockDim.x >> 6;
   const int D = a.D, D4 = (D + 3) >> 2;
   for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < a.rows; row += gridDim.x * wpb) {
-    const float* xr = a.x + (size_t)row * a.ldx;
+    const float* xr = a.x ? a.x + (size_t)row * a.ldx : nullptr;
+    const bf16_t* xbr = a.x ? nullptr : a.xB + (size_t)row * a.ldxB;
     float v[NV][VEC];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * VEC;
-      if (c < D) loadv<VEC>(xr + c, v[i]);
+      if (c < D) { if (xr) loadv<VEC>(xr + c, v[i]); else loadb<VEC>(xbr + c, v[i]); }
       else {
 #pragma unroll
         for (int e = 0; e < VEC; e++) v[i][e] = 0.f;
@@ -145,14 +156,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   __syncthreads();
 
   for (int row = blockIdx.x * wpb + wave; row < a.rows; row += gridDim.x * wpb) {
-    const float* xr = a.x + (size_t)row * a.ldx;
+    const float* xr = a.x ? a.x + (size_t)row * a.ldx : nullptr;
+    const bf16_t* xbr = a.x ? nullptr : a.xB + (size_t)row * a.ldxB;
     const float* gr = a.g ? a.g + (size_t)row * a.ldg : nullptr;
+    const bf16_t* gbr = (!a.g && a.gB) ? a.gB + (size_t)row * a.ldgB : nullptr;
     const float* g2r = nullptr;
-    if (a.g2) {
+    const bf16_t* g2br = nullptr;
+    if (a.g2 || a.g2B) {
+      size_t r2 = (size_t)row;
+      bool on = true;
       if (a.g2_S > 0) {
         const int b = row / a.g2_S, s = row - b * a.g2_S;
-        if (s < a.g2_Lv) g2r = a.g2 + (size_t)(b * a.g2_Lv + s) * a.ldg2;
-      } else g2r = a.g2 + (size_t)row * a.ldg2;
+        on = s < a.g2_Lv;
+        r2 = (size_t)(b * a.g2_Lv + s);
+      }
+      if (on) { if (a.g2) g2r = a.g2 + r2 * a.ldg2; else g2br = a.g2B + r2 * a.ldg2B; }
     }
     const float mean = a.mean[row], rstd = a.rstd[row];
     float xh[NV][VEC], gh[NV][VEC];
@@ -163,8 +181,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
       const int c = (i * 64 + lane) * VEC;
       if (c < D) {
         float xv[VEC], gv[VEC], gm[VEC];
-        loadv<VEC>(xr + c, xv);
+        if (xr) loadv<VEC>(xr + c, xv); else loadb<VEC>(xbr + c, xv);
         if (gr) loadv<VEC>(gr + c, gv);
+        else if (gbr) loadb<VEC>(gbr + c, gv);
         else {
 #pragma unroll
           for (int e = 0; e < VEC; e++) gv[e] = 0.f;
@@ -173,9 +192,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
         pm[i] = 0;
 #pragma unroll
         for (int e = 0; e < VEC; e++) pm[i] |= (xv[e] > 0.f ? 1u : 0u) << e;
-        if (g2r) {
+        if (g2r || g2br) {
           float t[VEC];
-          loadv<VEC>(g2r + c, t);
+          if (g2r) loadv<VEC>(g2r + c, t); else loadb<VEC>(g2br + c, t);
 #pragma unroll
           for (int e = 0; e < VEC; e++) gv[e] += t[e];
         }
@@ -212,6 +231,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
           for (int e = 0; e < VEC; e++) dx[e] = ((pm[i] >> e) & 1u) ? dx[e] : 0.f;
         }
         if (a.dxF) storev<VEC>(a.dxF + (size_t)row * a.lddxF + c, dx);
+        if (a.dxB2) storeb<VEC>(a.dxB2 + (size_t)row * a.lddxB2 + c, dx);
         if (a.dxB) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) dx[e] *= rs;
@@ -275,11 +295,11 @@ static bool al(const void* p, int ld_elems, int bytes_per, int want) {
 
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
-  const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.yF, a.ldyF, 4, 16) && al(a.yF2, a.ldyF2, 4, 16) &&
+  const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.xB, a.ldxB, 2, 8) && al(a.yF, a.ldyF, 4, 16) && al(a.yF2, a.ldyF2, 4, 16) &&
                        al(a.yB, a.ldyB, 2, 8) && al(a.yU, a.ldyU, 2, 8) && al(a.yUF, a.ldyU, 4, 16) &&
                        al(a.yP, a.ldyP, 2, 8) && al(a.yPF, a.ldyP, 4, 16) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16) &&
                        al(a.pos, a.D, 4, 16);
-  const bool align8 = al(a.x, a.ldx, 4, 8) && al(a.yF, a.ldyF, 4, 8) && al(a.yF2, a.ldyF2, 4, 8) &&
+  const bool align8 = al(a.x, a.ldx, 4, 8) && al(a.xB, a.ldxB, 2, 4) && al(a.yF, a.ldyF, 4, 8) && al(a.yF2, a.ldyF2, 4, 8) &&
                       al(a.yB, a.ldyB, 2, 4) && al(a.yU, a.ldyU, 2, 4) && al(a.yUF, a.ldyU, 4, 8) &&
                       al(a.yP, a.ldyP, 2, 4) && al(a.yPF, a.ldyP, 4, 8) && al(a.gamma, 0, 4, 8) && al(a.beta, 0, 4, 8) &&
                       al(a.pos, a.D, 4, 8);
@@ -288,9 +308,11 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
 
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
-  const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.g, a.ldg, 4, 16) && al(a.g2, a.ldg2, 4, 16) &&
+  const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.g, a.ldg, 4, 16) && al(a.g2, a.ldg2, 4, 16) && al(a.xB, a.ldxB, 2, 8) &&
+                       al(a.gB, a.ldgB, 2, 8) && al(a.g2B, a.ldg2B, 2, 8) && al(a.dxB2, a.lddxB2, 2, 8) &&
                        al(a.dxF, a.lddxF, 4, 16) && al(a.dxB, a.lddxB, 2, 8) && al(a.gamma, 0, 4, 16);
-  const bool align8 = al(a.x, a.ldx, 4, 8) && al(a.g, a.ldg, 4, 8) && al(a.g2, a.ldg2, 4, 8) &&
+  const bool align8 = al(a.x, a.ldx, 4, 8) && al(a.g, a.ldg, 4, 8) && al(a.g2, a.ldg2, 4, 8) && al(a.xB, a.ldxB, 2, 4) &&
+                      al(a.gB, a.ldgB, 2, 4) && al(a.g2B, a.ldg2B, 2, 4) && al(a.dxB2, a.lddxB2, 2, 4) &&
                       al(a.dxF, a.lddxF, 4, 8) && al(a.dxB, a.lddxB, 2, 4) && al(a.gamma, 0, 4, 8);
   LN_DISPATCH(run_bwd, a)
 }

@@ -27,6 +27,7 @@ struct GemmArgs {
   const bf16_t* gradPre; int ldgp; int actgrad;   // 1: zero where gradPre<=0 (relu'), 2: *= gelu'(gradPre)
   const float* rowscale; int rs_seg;  // per-sample factor rowscale[m / rs_seg] (DropPath)
   const float* resid; int ldr;        // fp32 residual, indexed by the OUTPUT row
+  const bf16_t* residB; int ldrB;     // bf16 residual (the bf16 activation stream of the fast mode), same indexing
   float* outF; int ldoF;              // fp32 output
   bf16_t* outB; int ldoB;             // bf16 output
   const float* pos; int ldpos; int pos_rows;   // fp32 positional table indexed by m (< pos_rows)
@@ -56,6 +57,7 @@ int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 struct LnFwdArgs {
   const float* x; int ldx;      // [rows, D] fp32
+  const bf16_t* xB; int ldxB;   // alternative bf16 input (used when x == nullptr)
   int rows, D;
   const float* gamma; const float* beta; float eps;
   float* mean; float* rstd;     // optional [rows]
@@ -75,15 +77,19 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
 
 struct LnBwdArgs {
   const float* g; int ldg;      // upstream gradient wrt LN output [rows, D] fp32
+  const bf16_t* gB; int ldgB;   // ... or bf16 (used when g == nullptr)
   const float* g2; int ldg2;    // optional second upstream gradient, added (video rows only if g2_Lv>0)
+  const bf16_t* g2B; int ldg2B; // ... or bf16
   int g2_S, g2_Lv;              // g2 row index = b*g2_Lv + s for s < g2_Lv when g2_S > 0; else same row
   const float* x; int ldx;      // LN input (saved)
+  const bf16_t* xB; int ldxB;   // ... or bf16 (used when x == nullptr)
   const float* mean; const float* rstd; const float* gamma;
   int rows, D;
   float p_drop; unsigned long long seed; unsigned stream_id;   // same dropout mask as forward
   float* dgamma; float* dbeta;  // atomically accumulated [D]
   float* dxF; int lddxF;        // fp32 dx
   bf16_t* dxB; int lddxB;       // bf16 dx (optionally scaled per sample)
+  bf16_t* dxB2; int lddxB2;     // bf16 dx, never scaled (the residual branch of the gradient stream)
   const float* rowscale; int rs_seg;
   int relu_from_x;              // 1: dx is masked by (x > 0): x is the output of a ReLU (input projections)
 };
@@ -154,7 +160,8 @@ struct SaliencyArgs {             // weighted text pooling + cosine saliency (mo
   const float* g_pooled;          // [B, d]   d/d txt_mem_proj
   const float* g_vid; long long gv_sb, gv_st;   // d/d vid_mem_proj: g_vid[b*gv_sb + t*gv_st + c], or null
   const float* g_vrow; const long long* pos_idx; // optional compact extra: g_vrow[b, :] is added on row pos_idx[b]
-  const float* dx0;               // [B*S, d] encoder gradient wrt x0 (read only)
+  const float* dx0;               // [B*S, d] encoder gradient wrt x0 (read only), fp32 ...
+  const bf16_t* dx0B;             // ... or bf16 (used when dx0 == nullptr)
   float* dq; float* dlog;         // scratch [B, d], [B, Lt]
   bf16_t* out_vid; bf16_t* out_txt;   // bf16 [B*Lv, d] / [B*Lt, d]: dx0 + saliency-branch gradients, re-packed per modality
   float* dw_pool;                 // [d] atomically accumulated
