@@ -7,7 +7,7 @@ cd /tmp; export TMPDIR=/tmp
 i=0
 for P in "${PASSES[@]}"; do
   rm -rf /tmp/pmc_$N_$i
-  rocprofv3 --pmc $P --output-format csv -d /tmp/pmc_${N}_$i -o p -- "$@" > $R/gpurun_out/pmc_${N}_$i.log 2>&1
+  rocprofv3 --pmc $P $PMC_EXTRA --output-format csv -d /tmp/pmc_${N}_$i -o p -- "$@" > $R/gpurun_out/pmc_${N}_$i.log 2>&1
   F=$(find /tmp/pmc_${N}_$i -name '*counter_collection.csv' | head -1)
   python - "$F" <<'PY' | tee $R/gpurun_out/pmc_${N}_$i.txt
 import csv, sys, collections

@@ -637,6 +637,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
     lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S;
     if (dp_ffn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
+    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
     TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, 1, G(m.lay(l, L2B)), 0, M, splits_M));
     GemmArgs g = gemm_base(ws.dyB, d, w.w2T[l], d, M, F, d);          // d h = dy2 W2 ; da = dh * gelu'(a)
@@ -651,6 +652,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.gamma = P[m.lay(l, N1W)]; lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
     lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S;
     if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
+    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
     TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.o[l], d, M, d, d, G(m.lay(l, OPW)), d, 1, G(m.lay(l, OPB)), 0, M, splits_M));
     g = gemm_base(ws.dyB, d, w.woT[l], d, M, d, d);                    // dO = dy1 Wo
@@ -696,6 +698,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.g = ws.dA2[which]; lb.ldg = d; lb.x = ws.h1[which]; lb.ldx = d; lb.mean = ws.m1[which]; lb.rstd = ws.r1[which];
     lb.gamma = P[m.tail(t1)]; lb.rows = R; lb.D = d; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs + 1;
     lb.dgamma = G(m.tail(t1)); lb.dbeta = G(m.tail(t1 + 1)); lb.dxB = ws.dh1b[which]; lb.lddxB = d; lb.rs_seg = 1; lb.relu_from_x = 1;
+    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
     TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
     g = gemm_base(ws.dh1b[which], d, which == 0 ? w.vp0T : w.tp0T, d, R, Kp, d);
@@ -705,6 +708,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.g = ws.dA1[which]; lb.ldg = Kp; lb.x = src; lb.ldx = Din; lb.mean = ws.m0[which]; lb.rstd = ws.r0[which];
     lb.gamma = P[m.tail(t0)]; lb.rows = R; lb.D = Din; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs;
     lb.dgamma = G(m.tail(t0)); lb.dbeta = G(m.tail(t0 + 1)); lb.rs_seg = 1;
+    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
   }
   return 0;

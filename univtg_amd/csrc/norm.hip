@@ -8,23 +8,33 @@
 
 namespace {
 
-template <int VEC> struct VecT;
+template <int VEC> struct VecT;   // (VEC == 8: two 16-byte accesses in fp32, one in bf16)
 template <> struct VecT<4> { typedef f32x4 T; };
 template <> struct VecT<2> { typedef f32x2 T; };
 template <> struct VecT<1> { typedef float T; };
 
 template <int VEC> __device__ __forceinline__ void loadv(const float* p, float (&v)[VEC]) {
-  if constexpr (VEC == 4) { f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+  if constexpr (VEC == 8) {
+    const f32x4 t = *(const f32x4*)p, u = *(const f32x4*)(p + 4);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; v[4] = u[0]; v[5] = u[1]; v[6] = u[2]; v[7] = u[3];
+  } else if constexpr (VEC == 4) { f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
   else if constexpr (VEC == 2) { f32x2 t = *(const f32x2*)p; v[0] = t[0]; v[1] = t[1]; }
   else v[0] = *p;
 }
 template <int VEC> __device__ __forceinline__ void storev(float* p, const float (&v)[VEC]) {
-  if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = t; }
+  if constexpr (VEC == 8) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  } else if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = t; }
   else if constexpr (VEC == 2) { f32x2 t = {v[0], v[1]}; *(f32x2*)p = t; }
   else *p = v[0];
 }
 template <int VEC> __device__ __forceinline__ void loadb(const bf16_t* p, float (&v)[VEC]) {
-  if constexpr (VEC == 4) {
+  if constexpr (VEC == 8) {
+    const u32x4 t = *(const u32x4*)p;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[2 * e] = __uint_as_float(t[e] << 16); v[2 * e + 1] = __uint_as_float(t[e] & 0xffff0000u); }
+  } else if constexpr (VEC == 4) {
     const u32x2 t = *(const u32x2*)p;
     v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
     v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
@@ -34,7 +44,10 @@ template <int VEC> __device__ __forceinline__ void loadb(const bf16_t* p, float 
   } else v[0] = bf2f(*p);
 }
 template <int VEC> __device__ __forceinline__ void storeb(bf16_t* p, const float (&v)[VEC]) {
-  if constexpr (VEC == 4) { u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); *(u32x2*)p = t; }
+  if constexpr (VEC == 8) {
+    u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
+    *(u32x4*)p = t;
+  } else if constexpr (VEC == 4) { u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); *(u32x2*)p = t; }
   else if constexpr (VEC == 2) { *(unsigned*)p = pack_bf2(v[0], v[1]); }
   else *p = f2bf(v[0]);
 }
@@ -142,130 +155,213 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
 }
 
 // dx = rstd * (gh - mean(gh) - xhat * mean(gh * xhat)),  gh = g * gamma;  dgamma += g * xhat; dbeta += g
-template <int VEC, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
-  extern __shared__ float red[];       // [2][D] block-level dgamma / dbeta
+// RPW rows per wave are in flight together (the row loop is a chain load -> two wave reductions -> store: one row at a time
+// leaves the kernel latency-bound at half the HBM rate).
+template <int VEC, int NV, bool BF>     // BF: x, g, g2 are bf16 (the fast mode's streams); else fp32
+__global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512) void ln_bwd_kernel(const LnBwdArgs a) {
+  constexpr int RPW = (NV * VEC > 32) ? 1 : 2;
+  extern __shared__ float red[];       // [waves][2][D] per-wave dgamma / dbeta partials
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int D = a.D, D4 = (D + 3) >> 2;
-  float dgam[NV][VEC], dbet[NV][VEC];
+  float dgam[NV][VEC], dbet[NV][VEC], gm[NV][VEC];
 #pragma unroll
-  for (int i = 0; i < NV; i++)
+  for (int i = 0; i < NV; i++) {
+    const int c = (i * 64 + lane) * VEC;
 #pragma unroll
-    for (int e = 0; e < VEC; e++) { dgam[i][e] = 0.f; dbet[i][e] = 0.f; }
-  for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) red[c] = 0.f;
-  __syncthreads();
+    for (int e = 0; e < VEC; e++) { dgam[i][e] = 0.f; dbet[i][e] = 0.f; gm[i][e] = 0.f; }
+    if (c < D) loadv<VEC>(a.gamma + c, gm[i]);
+  }
+  const int stride = gridDim.x * wpb;
+  const bool have_g = BF ? (a.gB != nullptr) : (a.g != nullptr);
+  const bool have_g2 = BF ? (a.g2B != nullptr) : (a.g2 != nullptr);
 
-  for (int row = blockIdx.x * wpb + wave; row < a.rows; row += gridDim.x * wpb) {
-    const float* xr = a.x ? a.x + (size_t)row * a.ldx : nullptr;
-    const bf16_t* xbr = a.x ? nullptr : a.xB + (size_t)row * a.ldxB;
-    const float* gr = a.g ? a.g + (size_t)row * a.ldg : nullptr;
-    const bf16_t* gbr = (!a.g && a.gB) ? a.gB + (size_t)row * a.ldgB : nullptr;
-    const float* g2r = nullptr;
-    const bf16_t* g2br = nullptr;
-    if (a.g2 || a.g2B) {
-      size_t r2 = (size_t)row;
-      bool on = true;
-      if (a.g2_S > 0) {
-        const int b = row / a.g2_S, s = row - b * a.g2_S;
-        on = s < a.g2_Lv;
-        r2 = (size_t)(b * a.g2_Lv + s);
+  for (int row0 = blockIdx.x * wpb + wave; row0 < a.rows; row0 += stride * RPW) {
+    // ---- all loads of the RPW rows first, no control flow between them (so they are all in flight together) ----
+    float xv[RPW][NV][VEC], gv[RPW][NV][VEC];
+    float mean[RPW], rstd[RPW];
+    int rowi[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) {
+      rowi[rr] = min(row0 + rr * stride, a.rows - 1);      // clamped duplicate row: loaded, never stored / accumulated
+      const size_t row = (size_t)rowi[rr];
+      mean[rr] = a.mean[row]; rstd[rr] = a.rstd[row];
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * VEC;
+        if (c < D) {
+          if constexpr (BF) loadb<VEC>(a.xB + row * a.ldxB + c, xv[rr][i]);
+          else loadv<VEC>(a.x + row * a.ldx + c, xv[rr][i]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) xv[rr][i][e] = 0.f;
+        }
       }
-      if (on) { if (a.g2) g2r = a.g2 + r2 * a.ldg2; else g2br = a.g2B + r2 * a.ldg2B; }
     }
-    const float mean = a.mean[row], rstd = a.rstd[row];
-    float xh[NV][VEC], gh[NV][VEC];
-    unsigned pm[NV];                    // bit e set: x > 0 (ReLU mask of the producing layer)
-    float s1 = 0.f, s2 = 0.f;
+    if (have_g) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const int c = (i * 64 + lane) * VEC;
-      if (c < D) {
-        float xv[VEC], gv[VEC], gm[VEC];
-        if (xr) loadv<VEC>(xr + c, xv); else loadb<VEC>(xbr + c, xv);
-        if (gr) loadv<VEC>(gr + c, gv);
-        else if (gbr) loadb<VEC>(gbr + c, gv);
-        else {
+      for (int rr = 0; rr < RPW; rr++) {
+        const size_t row = (size_t)rowi[rr];
 #pragma unroll
-          for (int e = 0; e < VEC; e++) gv[e] = 0.f;
+        for (int i = 0; i < NV; i++) {
+          const int c = (i * 64 + lane) * VEC;
+          if (c < D) {
+            if constexpr (BF) loadb<VEC>(a.gB + row * a.ldgB + c, gv[rr][i]);
+            else loadv<VEC>(a.g + row * a.ldg + c, gv[rr][i]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; e++) gv[rr][i][e] = 0.f;
+          }
         }
-        loadv<VEC>(a.gamma + c, gm);
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < RPW; rr++)
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+#pragma unroll
+          for (int e = 0; e < VEC; e++) gv[rr][i][e] = 0.f;
+    }
+    if (have_g2) {
+#pragma unroll
+      for (int rr = 0; rr < RPW; rr++) {
+        size_t r2 = (size_t)rowi[rr];
+        bool on = true;
+        if (a.g2_S > 0) {
+          const int b = rowi[rr] / a.g2_S, s = rowi[rr] - b * a.g2_S;
+          on = s < a.g2_Lv;
+          r2 = (size_t)(b * a.g2_Lv + s);
+        }
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < NV; i++) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < D) {
+              float t[VEC];
+              if constexpr (BF) loadb<VEC>(a.g2B + r2 * a.ldg2B + c, t);
+              else loadv<VEC>(a.g2 + r2 * a.ldg2 + c, t);
+#pragma unroll
+              for (int e = 0; e < VEC; e++) gv[rr][i][e] += t[e];
+            }
+          }
+        }
+      }
+    }
+    // ---- math ----
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) {
+      const int row = row0 + rr * stride;
+      const bool live = row < a.rows;
+      unsigned pm[NV];                  // bit e set: x > 0 (ReLU mask of the producing layer)
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * VEC;
         pm[i] = 0;
+        if (a.relu_from_x) {
 #pragma unroll
-        for (int e = 0; e < VEC; e++) pm[i] |= (xv[e] > 0.f ? 1u : 0u) << e;
-        if (g2r || g2br) {
-          float t[VEC];
-          if (g2r) loadv<VEC>(g2r + c, t); else loadb<VEC>(g2br + c, t);
-#pragma unroll
-          for (int e = 0; e < VEC; e++) gv[e] += t[e];
+          for (int e = 0; e < VEC; e++) pm[i] |= (xv[rr][i][e] > 0.f ? 1u : 0u) << e;
         }
-        if (a.p_drop > 0.f) {
+        if (a.p_drop > 0.f && c < D) {
 #pragma unroll
-          for (int e = 0; e < VEC; e++) gv[e] *= drop_scale(a.seed, a.stream_id, row, c + e, D4, a.p_drop);
+          for (int e = 0; e < VEC; e++) gv[rr][i][e] *= drop_scale(a.seed, a.stream_id, rowi[rr], c + e, D4, a.p_drop);
         }
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
-          xh[i][e] = (xv[e] - mean) * rstd;
-          dgam[i][e] += gv[e] * xh[i][e];
-          dbet[i][e] += gv[e];
-          gh[i][e] = gv[e] * gm[e];
-          s1 += gh[i][e];
-          s2 += gh[i][e] * xh[i][e];
+          const float xh = (c < D) ? (xv[rr][i][e] - mean[rr]) * rstd[rr] : 0.f;
+          const float g = live ? gv[rr][i][e] : 0.f;
+          dgam[i][e] += g * xh;
+          dbet[i][e] += g;
+          xv[rr][i][e] = xh;                      // reuse: xhat
+          gv[rr][i][e] = g * gm[i][e];            // reuse: g * gamma
+          s1 += gv[rr][i][e];
+          s2 += gv[rr][i][e] * xh;
         }
-      } else {
-        pm[i] = 0;
-#pragma unroll
-        for (int e = 0; e < VEC; e++) { xh[i][e] = 0.f; gh[i][e] = 0.f; }
       }
-    }
-    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
-    const float rs = a.rowscale ? a.rowscale[row / a.rs_seg] : 1.0f;
+      const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+      if (!live) continue;
+      const float rs = a.rowscale ? a.rowscale[row / a.rs_seg] : 1.0f;
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const int c = (i * 64 + lane) * VEC;
-      if (c < D) {
-        float dx[VEC];
+      for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * VEC;
+        if (c < D) {
+          float dx[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; e++) dx[e] = rstd * (gh[i][e] - c1 - xh[i][e] * c2);
-        if (a.relu_from_x) {
+          for (int e = 0; e < VEC; e++) dx[e] = rstd[rr] * (gv[rr][i][e] - c1 - xv[rr][i][e] * c2);
+          if (a.relu_from_x) {
 #pragma unroll
-          for (int e = 0; e < VEC; e++) dx[e] = ((pm[i] >> e) & 1u) ? dx[e] : 0.f;
-        }
-        if (a.dxF) storev<VEC>(a.dxF + (size_t)row * a.lddxF + c, dx);
-        if (a.dxB2) storeb<VEC>(a.dxB2 + (size_t)row * a.lddxB2 + c, dx);
-        if (a.dxB) {
+            for (int e = 0; e < VEC; e++) dx[e] = ((pm[i] >> e) & 1u) ? dx[e] : 0.f;
+          }
+          if (a.dxF) storev<VEC>(a.dxF + (size_t)row * a.lddxF + c, dx);
+          if (a.dxB2) storeb<VEC>(a.dxB2 + (size_t)row * a.lddxB2 + c, dx);
+          if (a.dxB) {
 #pragma unroll
-          for (int e = 0; e < VEC; e++) dx[e] *= rs;
-          storeb<VEC>(a.dxB + (size_t)row * a.lddxB + c, dx);
+            for (int e = 0; e < VEC; e++) dx[e] *= rs;
+            storeb<VEC>(a.dxB + (size_t)row * a.lddxB + c, dx);
+          }
         }
       }
     }
   }
   if (a.dgamma) {
+    // cross-wave reduction through wave-private LDS slabs (LDS float atomics from 8 waves on the same 2 D addresses were
+    // ~55 % of this kernel's time), then one coalesced global atomic pass per block
+    float* mine = red + (size_t)wave * 2 * D;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * VEC;
       if (c < D) {
 #pragma unroll
-        for (int e = 0; e < VEC; e++) { atomicAdd(&red[c + e], dgam[i][e]); atomicAdd(&red[D + c + e], dbet[i][e]); }
+        for (int e = 0; e < VEC; e++) { mine[c + e] = dgam[i][e]; mine[D + c + e] = dbet[i][e]; }
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += blockDim.x) {
-      atomicAdd(a.dgamma + c, red[c]);
-      atomicAdd(a.dbeta + c, red[D + c]);
+    // Hundreds of blocks adding into the same 2 D floats serialise in L2 (same-line atomics ~0.1 us each): with caller
+    // scratch the block partials go out as plain stores and ln_bwd_reduce_kernel folds them; atomics only as fallback.
+    for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
+      float t = 0.f;
+      for (int w = 0; w < wpb; w++) t += red[(size_t)w * 2 * D + c];
+      if (a.partial) a.partial[(size_t)blockIdx.x * 2 * D + c] = t;
+      else atomicAdd((c < D ? a.dgamma + c : a.dbeta + (c - D)), t);
     }
+  }
+}
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const LnBwdArgs a, int nblocks) {
+  __shared__ float red2[16][17];
+  const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;        // 16 columns x 16 block lanes
+  const int c = blockIdx.x * 16 + il, n = 2 * a.D;
+  float s = 0.f;
+  if (c < n) for (int b = bl; b < nblocks; b += 16) s += a.partial[(size_t)b * n + c];
+  red2[bl][il] = s;
+  __syncthreads();
+  if (bl == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red2[k][il];
+    if (c < a.D) a.dgamma[c] += t; else a.dbeta[c - a.D] += t;
   }
 }
 
 template <int VEC, int NV> int run_fwd(const LnFwdArgs& a, hipStream_t s) {
-  const int blocks = min(cdiv(a.rows, 4), 4096);
+  const int blocks = min(cdiv(a.rows, 4), 8192);
   hipLaunchKernelGGL((ln_fwd_kernel<VEC, NV>), dim3(blocks), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
+#ifndef UVTG_LN_BLOCKS
+#define UVTG_LN_BLOCKS 512
+#endif
 template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
-  const int blocks = min(cdiv(a.rows, 4), 512);
-  hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV>), dim3(blocks), dim3(256), 2 * a.D * sizeof(float), s, a);
+  const bool bf = a.x == nullptr;
+  if (bf ? ((a.g != nullptr) || (a.g2 != nullptr) || !a.xB) : ((a.gB != nullptr) || (a.g2B != nullptr))) return -4;   // streams are all bf16 or all fp32
+  // waves per block: as many as fit 64 KB of per-wave partial slabs (8 at D <= 1024, 2 at D = 2818); ~12 rows per wave
+  int wpb = (int)(65536 / (2 * (size_t)a.D * sizeof(float)));
+  wpb = wpb >= 8 ? 8 : (wpb >= 4 ? 4 : (wpb >= 2 ? 2 : 1));
+  const int blocks = min(cdiv(a.rows, wpb), max(1, (UVTG_LN_BLOCKS) * 8 / wpb));
+  LnBwdArgs b = a;
+  if (!b.dgamma || b.partial_floats < (long long)blocks * 2 * b.D) b.partial = nullptr;
+  if (bf) hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, true>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
+  else hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, false>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
+  if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 16)), dim3(256), 0, s, b, blocks);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -274,6 +370,12 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
 
 #define LN_DISPATCH(FN, ARGS)                                                          \
   const int D = ARGS.D;                                                                 \
+  if (D % 8 == 0 && alignv8 && D >= 512) {                                              \
+    if (D <= 512) return FN<8, 1>(ARGS, s);                                             \
+    if (D <= 1024) return FN<8, 2>(ARGS, s);                                            \
+    if (D <= 2048) return FN<8, 4>(ARGS, s);                                            \
+    if (D <= 4096) return FN<8, 8>(ARGS, s);                                            \
+  }                                                                                     \
   if (D % 4 == 0 && align16) {                                                          \
     if (D <= 256) return FN<4, 1>(ARGS, s);                                             \
     if (D <= 1024) return FN<4, 4>(ARGS, s);                                            \
@@ -303,6 +405,7 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
                       al(a.yB, a.ldyB, 2, 4) && al(a.yU, a.ldyU, 2, 4) && al(a.yUF, a.ldyU, 4, 8) &&
                       al(a.yP, a.ldyP, 2, 4) && al(a.yPF, a.ldyP, 4, 8) && al(a.gamma, 0, 4, 8) && al(a.beta, 0, 4, 8) &&
                       al(a.pos, a.D, 4, 8);
+  const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.yB, a.ldyB, 2, 16) && al(a.yU, a.ldyU, 2, 16) && al(a.yP, a.ldyP, 2, 16);
   LN_DISPATCH(run_fwd, a)
 }
 
@@ -314,5 +417,7 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
   const bool align8 = al(a.x, a.ldx, 4, 8) && al(a.g, a.ldg, 4, 8) && al(a.g2, a.ldg2, 4, 8) && al(a.xB, a.ldxB, 2, 4) &&
                       al(a.gB, a.ldgB, 2, 4) && al(a.g2B, a.ldg2B, 2, 4) && al(a.dxB2, a.lddxB2, 2, 4) &&
                       al(a.dxF, a.lddxF, 4, 8) && al(a.dxB, a.lddxB, 2, 4) && al(a.gamma, 0, 4, 8);
+  const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.gB, a.ldgB, 2, 16) && al(a.g2B, a.ldg2B, 2, 16) &&
+                       al(a.dxB, a.lddxB, 2, 16) && al(a.dxB2, a.lddxB2, 2, 16);
   LN_DISPATCH(run_bwd, a)
 }

@@ -15,14 +15,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define UVTG_LOG_TINY (-103.27892990343184f)   // logf(1e-45f) evaluated in fp32 (denormal 2^-149)
 
-__device__ __forceinline__ bf16_t f2bf(float f) {          // round-to-nearest-even
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even, on the gfx950 converter (v_cvt_pk_bf16_f32: one instruction per pair instead of
+// ~6 integer ops per element)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 
 __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);

@@ -92,6 +92,7 @@ struct LnBwdArgs {
   bf16_t* dxB2; int lddxB2;     // bf16 dx, never scaled (the residual branch of the gradient stream)
   const float* rowscale; int rs_seg;
   int relu_from_x;              // 1: dx is masked by (x > 0): x is the output of a ReLU (input projections)
+  float* partial; long long partial_floats;   // optional scratch for per-block dgamma / dbeta partials (else atomics)
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
 
