@@ -77,7 +77,7 @@ def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev):
     return inputs, targets
 
 
-def cpu_baseline(sample_B=16, steps=2):
+def cpu_baseline(sample_B=32, steps=3):
     """The oracle (CPU restatement of the reference, same torch CPU ops) timed on the host cores: fwd + criterion +
     bwd at the config-2 shape, bounded sample of `sample_B` samples per step."""
     from oracle import univtg_oracle as O
@@ -169,8 +169,16 @@ def main():
         fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel", "gemm_nt256_kernel"]
         dom = max(range(4), key=lambda i: ms[i])
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        traffic, traffic_note = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_nt256.json")       # separate rocprofv3 --pmc passes of this same command
+        if fam[dom] == "gemm_nt256_kernel" and os.path.exists(pmc):
+            with open(pmc) as f:
+                pj = json.load(f)
+            traffic = pj["traffic_bytes_per_launch"]
+            traffic_note = ("HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed in "
+                            "profiles/r01_pmc_nt256.json; measured MFMA-busy fraction %.3f" % pj["mfma_busy_frac"])
         roof = dict(bound="mfma", kernel=fam[dom], achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
-                    traffic=None, launches_per_step=int(n[dom] // max(1, args.profile_steps)),
+                    traffic=traffic, traffic_note=traffic_note, launches_per_step=int(n[dom] // max(1, args.profile_steps)),
                     avg_launch_us=round(ms[dom] * 1e3 / max(1, n[dom]), 2),
                     algorithmic_gflop_per_launch=round(fl[dom] / max(1, n[dom]) / 1e9, 2),
                     all_gemm_kernels={fam[i]: dict(ms_per_step=round(ms[i] / max(1, args.profile_steps), 3),
