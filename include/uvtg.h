@@ -86,14 +86,18 @@ int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wc
  * NULL = zero): g_logits [B,Lv,1], g_spans [B,Lv,2], g_saliency [B,Lv], g_txt_mem [B,1,d],
  * g_vid_mem addressed as g_vid_mem[b*g_vid_sb + t*g_vid_st + c] (so the gradient of the whole x0
  * buffer, strides S*d and d, can be passed as is).  g_vrow [B,d] + pos_idx [B] (optional pair): extra gradient
- * on row pos_idx[b] of vid_mem_proj -- the compact form uvtg_criterion_bwd emits instead of a dense g_vid.  grads: flat fp32 buffer (uvtg_param_offsets), overwritten. */
+ * on row pos_idx[b] of vid_mem_proj -- the compact form uvtg_criterion_bwd emits instead of a dense g_vid.  grads: flat fp32 buffer (uvtg_param_offsets), overwritten.
+ * ready_events (optional, for overlapping the data-parallel gradient exchange with the rest of backward): event 0 is recorded
+ * on `stream` once the span_embed / class_embed gradients (table entries 12E+1 .. 12E+12) are final, event 1 + i once those of
+ * encoder layer E-1-i are; everything else is final when the call's work completes. */
 int uvtg_backward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                   const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                   const float* x0, const float* pred_logits, const float* pred_spans, const float* txt_mem_proj,
                   const float* g_logits, const float* g_spans, const float* g_saliency,
                   const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
                   const float* g_vrow, const long long* pos_idx,
-                  float* grads, void* workspace, uvtg_stream_t stream);
+                  float* grads, void* workspace, uvtg_stream_t stream,
+                  void* const* ready_events /* hipEvent_t[E + 1] or NULL */, int n_events /* E + 1 or 0 */);
 
 /* ---- criterion: replaces SetCriterion.forward + its autograd (model/univtg.py:195-282,338-351) ---
  * vid_mem_proj is addressed as vid[b*vid_sb + t*vid_st + c] so that the strided view of x0 works.

@@ -66,3 +66,36 @@ def test_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(all(r[1:]) for r in res), res
+
+
+def test_gradient_bucket_ranges_partition_flat_buffer():
+    """The overlap schedule of TrainStep (conv heads, then encoder layers last-to-first, then the rest) covers every element
+    of the flat gradient buffer exactly once and matches the parameter table of include/uvtg.h."""
+    sys.path.insert(0, ROOT)
+    from types import SimpleNamespace
+    from univtg_amd.model import build_model
+    from univtg_amd.trainer import TrainStep
+    a = SimpleNamespace(device="cpu", hidden_dim=64, dropout=0.0, droppath=0.0, nheads=2, dim_feedforward=96, enc_layers=3,
+                        dec_layers=2, pre_norm=False, position_embedding="sine", max_q_l=16, input_dropout=0.0, t_feat_dim=24,
+                        v_feat_dim=34, span_loss_type="l1", use_txt_pos=False, n_input_proj=2, set_cost_span=10, set_cost_giou=1,
+                        set_cost_class=4, max_v_l=75, b_loss_coef=10, g_loss_coef=1, f_loss_coef=10, s_loss_intra_coef=0.1,
+                        s_loss_inter_coef=0.1, dset_type="vlp", train_path=["synthetic"], eos_coef=0.1, temperature=0.07,
+                        saliency_margin=0.2)
+    model, crit = build_model(a)
+    step = TrainStep(model, crit)
+    dims = model._dims(2, 5, 3, 34, 24, False)
+    ranged, rest = step.bucket_ranges(dims)
+    assert len(ranged) == model.enc_layers + 1
+    cover = sorted(ranged + [r for r in rest if r[1] > r[0]])
+    assert cover[0][0] == 0 and cover[-1][1] == step.flat.numel()
+    assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+    # the first range is exactly span_embed + class_embed, the next ones whole encoder layers from the last to the first
+    params = model._ordered_params()
+    offs = model._offsets(dims)
+    names = {id(p): k for k, p in model.named_parameters()}
+    E = model.enc_layers
+    head_ids = [i for i, p in enumerate(params) if names[id(p)].startswith(("span_embed", "class_embed"))]
+    assert ranged[0] == (offs[min(head_ids)], offs[max(head_ids) + 1])
+    for k, l in enumerate(range(E - 1, -1, -1)):
+        ids = [i for i, p in enumerate(params) if names[id(p)].startswith(f"transformer.encoder.layers.{l}.")]
+        assert ranged[1 + k] == (offs[min(ids)], offs[max(ids) + 1])

@@ -280,6 +280,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -17: return "dims: too many encoder layers";
     case -20: return "null pointer argument";
     case -21: return "force_nt_tile: tile must be 0, 128 or 256";
+    case -22: return "backward: ready_events must hold enc_layers + 1 events (or n_events = 0)";
     default: return "invalid argument";
   }
 }
@@ -556,10 +557,11 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
                              const float* g_logits, const float* g_spans, const float* g_saliency,
                              const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
                              const float* g_vrow, const long long* pos_idx,
-                             float* grads, void* workspace, uvtg_stream_t stream) {
+                             float* grads, void* workspace, uvtg_stream_t stream, void* const* ready_events, int n_events) {
   if (int e = check_dims(dm)) return e;
   if (dm->E > MAXE) return -17;
   if (dm->precise || !dm->training) return -6;
+  if (n_events != 0 && (n_events != dm->E + 1 || !ready_events)) return -22;
   if (!P || !wcache || !x0 || !pred_logits || !pred_spans || !txt_mem_proj || !grads || !workspace || !src_txt || !src_vid ||
       !src_txt_mask || !src_vid_mask) return -20;
   hipStream_t s = (hipStream_t)stream;
@@ -621,6 +623,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     g.outB = ws.dvmB; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
   }
+  if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[0], s)) return (int)e; }   // span_embed / class_embed gradients final
   // ---------------- encoder ----------------
   // The gradient stream is bf16 (like the activation stream): gin = gradient wrt the layer output; dyB = LayerNorm input
   // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
@@ -670,6 +673,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     g.residB = dp_attn ? ws.dyR : ws.dyB; g.ldrB = d; g.outB = ws.gxb[1]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
+    if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
   }
   const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]
   // ---------------- saliency branch ----------------

@@ -149,7 +149,7 @@ class _UniVTGFunction(torch.autograd.Function):
         _lib.check(lib.uvtg_backward(C.byref(dims), ptrs, _ptr(ctx.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                      _ptr(src_vid_mask), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans), _ptr(txt_mem),
                                      _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d, None, None,
-                                     _ptr(grads), _ptr(ctx.ws), _stream()), "uvtg_backward")
+                                     _ptr(grads), _ptr(ctx.ws), _stream(), None, 0), "uvtg_backward")
         ctx.ws = None
         out = [None] * 6
         for i, p in enumerate(params):

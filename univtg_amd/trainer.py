@@ -38,7 +38,7 @@ def flatten_parameters(model: Model) -> torch.Tensor:
 
 class TrainStep:
     def __init__(self, model: Model, criterion: SetCriterion, lr=1e-4, weight_decay=1e-4, grad_clip=0.1,
-                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64):
+                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64, overlap_comm=True):
         if model.precision != "bf16":
             raise RuntimeError("training uses precision='bf16'")
         self.lib = _lib.load()
@@ -59,6 +59,12 @@ class TrainStep:
             self.world = torch.distributed.get_world_size(process_group)
             broadcast_flat_(self.flat, 0, process_group)
         self.bucket = int(bucket_mb * (1 << 20) // 4)
+        # Overlap of the gradient exchange with backward: uvtg_backward records an event when the conv-head gradients and then
+        # each encoder layer's gradients are final; every such range is all-reduced on a side stream while the remaining
+        # backward kernels keep running (the reference gets the same effect from DDP's bucketed autograd hooks).
+        # overlap_comm="force" runs the bucketed side-stream exchange even at world size 1 (single-GPU test of the plumbing)
+        self.overlap = bool(overlap_comm) and (self.world > 1 or overlap_comm == "force") and dev.type == "cuda"
+        self._events = self._ev_arr = self._comm_stream = None
         wd = criterion.weight_dict
         self.go = torch.tensor([wd.get(k, 0.0) for k in LOSS_KEYS], dtype=torch.float32, device=dev)
         self.which = (1 if "spans" in criterion.losses else 0) | (2 if "labels" in criterion.losses else 0) | \
@@ -119,12 +125,52 @@ class TrainStep:
         chk(lib.uvtg_backward(C.byref(dims), self.ptrs, _ptr(self.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                               _ptr(src_vid_mask), _ptr(self.x0), _ptr(self.pred_logits), _ptr(self.pred_spans), _ptr(self.txt_mem),
                               _ptr(self.g_logits), _ptr(self.g_spans), _ptr(self.g_cos), _ptr(self.g_txt), None, 0, 0,
-                              _ptr(self.g_vrow), _ptr(pos), _ptr(self.grads), _ptr(self.ws), st), "uvtg_backward")
-        if self.world > 1:
-            allreduce_flat_(self.grads, self.bucket, self.pg)
+                              _ptr(self.g_vrow), _ptr(pos), _ptr(self.grads), _ptr(self.ws), st,
+                              *self._event_args(dims)), "uvtg_backward")
+        if self.world > 1 or self.overlap:
+            self._exchange_gradients(dims)
         if optimize:
             self.t += 1
             chk(lib.uvtg_adamw_clip_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.flat.numel(),
                                          self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, float(self.clip),
                                          1.0 / self.world, _ptr(self.scratch), st), "uvtg_adamw_clip_step")
         return self.losses[:5]
+
+
+    # ---- data-parallel gradient exchange -------------------------------------------------------------------------
+    def bucket_ranges(self, dims):
+        """Element ranges of the flat gradient buffer in the order they become final during uvtg_backward:
+        [conv heads] + [layer E-1, ..., layer 0] (one event each) and the rest (token-type, input projections, pool)."""
+        offs = self.model._offsets(dims)
+        E = self.model.enc_layers
+        ranged = [(offs[12 * E + 1], offs[12 * E + 13])] + [(offs[12 * l], offs[12 * (l + 1)]) for l in range(E - 1, -1, -1)]
+        rest = [(offs[12 * E], offs[12 * E + 1]), (offs[12 * E + 13], offs[-1])]
+        return ranged, rest
+
+    def _event_args(self, dims):
+        if not self.overlap:
+            return None, 0
+        if self._events is None:
+            n = self.model.enc_layers + 1
+            self._events = [torch.cuda.Event() for _ in range(n)]
+            for ev in self._events:
+                ev.record()                                  # materialise the hipEvent_t
+            self._ev_arr = (C.c_void_p * n)(*[ev.cuda_event for ev in self._events])
+            self._comm_stream = torch.cuda.Stream()
+        return self._ev_arr, len(self._events)
+
+    def _exchange_gradients(self, dims):
+        if not self.overlap:
+            allreduce_flat_(self.grads, self.bucket, self.pg)
+            return
+        ranged, rest = self.bucket_ranges(dims)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self._comm_stream):
+            for ev, (lo, hi) in zip(self._events, ranged):
+                self._comm_stream.wait_event(ev)             # that range is final on the compute stream
+                allreduce_flat_(self.grads[lo:hi], self.bucket, self.pg)
+            self._comm_stream.wait_stream(main)              # end of backward: everything else is final
+            for lo, hi in rest:
+                if hi > lo:
+                    allreduce_flat_(self.grads[lo:hi], self.bucket, self.pg)
+        main.wait_stream(self._comm_stream)                  # the optimizer step needs every reduced range
