@@ -440,3 +440,45 @@ def test_overlapped_gradient_exchange_single_rank(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,Lv,Lt,d,H,ragged", [(1, 1, 1, 64, 2, False), (2, 3, 2, 64, 2, True), (3, 129, 5, 128, 1, True),
+                                                (2, 300, 20, 256, 4, True), (2, 128, 1, 128, 4, False)])
+def test_edge_shapes_vs_oracle(dev, B, Lv, Lt, d, H, ragged):
+    """Degenerate and boundary shapes against the CPU oracle: a single clip / token, S just over the single-tile attention
+    limit (129 + 5 with head_dim 128), a long video (S = 320, the tiled attention kernels), S = 129 exactly one text token."""
+    from oracle import univtg_oracle as O
+    cfg = O.make_cfg(hidden_dim=d, nheads=H, dim_feedforward=d, enc_layers=2, v_feat_dim=66, t_feat_dim=40, max_q_l=max(Lt, 4),
+                     input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=B + Lv)
+    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=Lv + Lt, ragged=ragged)
+    with torch.no_grad():
+        ref = O.forward(params, cfg, **inputs)
+    model, _ = build(cfg, params, dev, "fp32x3")
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(inputs, dev))
+    valid = inputs["src_vid_mask"].bool()
+    assert float((out["saliency_scores"].cpu() - ref["saliency_scores"])[valid].abs().max()) < 1e-4
+    for k in ("pred_logits", "pred_spans"):
+        assert float((out[k].cpu() - ref[k]).abs().max()) < 3e-4, k
+    # training path (bf16 operands) against oracle autograd
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    l2 = O.criterion(O.forward(p2, cfg, **inputs), tg, cfg)
+    O.total_loss(l2, cfg).backward()
+    model, crit = build(cfg, params, dev, "bf16")
+    model.eval()
+    ld = crit(model(**to_dev(inputs, dev)), to_dev(tg, dev))
+    sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
+    for k in ("loss_b", "loss_g", "loss_f"):
+        assert abs(float(ld[k]) - float(l2[k])) < 3e-2 * max(1.0, abs(float(l2[k]))), k
+    named = dict(model.named_parameters())
+    worst = 1.0
+    for k, p in p2.items():
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            continue
+        a, r = named[k].grad.cpu().double().flatten(), p.grad.double().flatten()
+        assert torch.isfinite(a).all(), k
+        if float(r.norm()) > 1e-6 * r.numel() ** 0.5:
+            worst = min(worst, float((a @ r) / (a.norm() * r.norm() + 1e-30)))
+    assert worst > 0.95, worst
