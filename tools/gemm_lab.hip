@@ -18,6 +18,7 @@ struct LabArgs {
   const float* bias;
   float* outF; bf16_t* outB; int ldo;
   int mode;   // 0: no epilogue (sink), 1: bf16 out, 2: fp32 out, 3: both
+  int* counter;   // dynamic tile counter (mode bit 64)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -25,9 +26,9 @@ struct LabArgs {
 // barrier per K tile.  LDS image of a stage: A [256][64] bf16 then B [256][64] bf16, rows 128 B,
 // 16-byte chunk c of row r stored at chunk position c ^ ((r >> 1) & 7) (source-side permutation).
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN>   // wave grid (WM x WN = 8), tile 256 x 256
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm256_kernel(const LabArgs p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
+template <int WM, int WN>   // wave grid (WM x WN = 8 or 16), tile 256 x 256
+__global__ __launch_bounds__(64 * WM * WN) void gemm256_kernel(const LabArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64, NW = WM * WN, PPW = 32 / NW;   // staging pieces (1 KB) per wave per operand
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * 64 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,20 +43,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tiles_n = (p.N + BN - 1) / BN;
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
 
-  // staging: each wave issues 4 A pieces + 4 B pieces of 1 KB (8 rows x 128 B) per K tile
+  // staging: each wave issues PPW A pieces + PPW B pieces of 1 KB (8 rows x 128 B) per K tile
   const int sr = lane >> 3, sc = lane & 7;
-  const bf16_t* ag[4]; const bf16_t* bg[4];
+  const bf16_t* ag[PPW]; const bf16_t* bg[PPW];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int r = (wave * 4 + i) * 8 + sr;
+  for (int i = 0; i < PPW; i++) {
+    const int r = (wave * PPW + i) * 8 + sr;
     const int c = (sc ^ ((r >> 1) & 7)) * 8;
     ag[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c;
     bg[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c;
   }
   auto stage = [&](int s, int kt) {
-    unsigned char* base = smem + s * 65536 + wave * 4096;
+    unsigned char* base = smem + s * 65536 + wave * (PPW * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < PPW; i++) {
       __builtin_amdgcn_global_load_lds((gbl_void*)(ag[i] + kt * BK), (lds_void*)(base + i * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)(bg[i] + kt * BK), (lds_void*)(base + 32768 + i * 1024), 16, 0, 0);
     }
@@ -101,6 +102,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
     }
+#ifdef SGB
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++) {
+#pragma unroll
+      for (int n = 0; n < (TM + TN < TM * TN ? TM + TN : TM * TN); n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      if (TM * TN > TM + TN) __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+#endif
   }
   if (p.mode == 0) {
     float t = 0.f;
@@ -194,6 +205,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const LabArgs p) {
 #pragma unroll
   for (int j = 0; j < TN; j++) boff[j] = 32768 + (wn * (BN / WN) + j * 32 + l31) * 128;
 
+  __shared__ int s_next;
+  const bool dyn = (p.mode & 64) != 0;
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
   int m0, n0;
@@ -209,11 +222,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const LabArgs p) {
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int next = tile + gridDim.x;
+    int next = tile + gridDim.x;
     int nm0 = 0, nn0 = 0;
     for (int kt = 0; kt < nk; kt++, it++) {
       const int cur = it & 1;
       if (!(p.mode & 32)) __syncthreads();
+      if (dyn) {
+        if (kt == nk - 2 && tid == 0) s_next = gridDim.x + atomicAdd(p.counter, 1);
+        if (kt == nk - 1) next = s_next;
+      }
       if (!(p.mode & 16)) {
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
       else if (next < ntiles) { tile_origin(next, nm0, nn0); set_offsets(nm0, nn0); stage(cur ^ 1, 0); }
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const LabArgs p) {
 #endif
     }
     // ---- epilogue of `tile` out of the stage consumed last ----
-    if ((p.mode & 15) == 0) {
+    if ((p.mode & 7) == 0) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; i++)
@@ -340,9 +357,10 @@ template <typename F> float time_us(F f, int n = 20) {
 
 template <int WM, int WN> void launch256(const LabArgs& a) {
   static bool once = false;
+  if (WM * WN > 8 && a.mode != 0) return;
   if (!once) { CK(hipFuncSetAttribute((const void*)gemm256_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); once = true; }
   const int grid = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL((gemm256_kernel<WM, WN>), dim3(grid), dim3(512), 131072, 0, a);
+  hipLaunchKernelGGL((gemm256_kernel<WM, WN>), dim3(grid), dim3(64 * WM * WN), 131072, 0, a);
 }
 
 int main(int argc, char** argv) {
@@ -352,7 +370,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&Cb, (size_t)M * N * 2));
     fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1);
     fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2);
-    LabArgs a{A, B, M, N, K, K, K, nullptr, C, Cb, N, mode};
+    LabArgs a{A, B, M, N, K, K, K, nullptr, C, Cb, N, mode, nullptr};
     for (int i = 0; i < 5; i++) launch256p<2, 4>(a);
     CK(hipDeviceSynchronize());
     return 0;
@@ -367,7 +385,7 @@ int main(int argc, char** argv) {
     std::vector<float> hb(N); for (int i = 0; i < N; i++) hb[i] = 0.01f * i;
     CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
     ref_kernel<<<dim3((N + 15) / 16, (M + 15) / 16), dim3(16, 16)>>>(A, B, bias, R, M, N, K);
-    LabArgs a{A, B, M, N, K, K, K, bias, C, Cb, N, 3};
+    LabArgs a{A, B, M, N, K, K, K, bias, C, Cb, N, 3, nullptr};
     CK(hipMemset(C, 0, (size_t)M * N * 4));
     launch256<2, 4>(a);
     CK(hipDeviceSynchronize());
@@ -403,11 +421,13 @@ int main(int argc, char** argv) {
     fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1);
     fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2);
     const double fl = 2.0 * M * N * K;
-    for (int mode : {0, 16, 32, 48, 1, 2}) {
-      LabArgs a{A, B, M, N, K, K, K, nullptr, C, Cb, N, mode};
-      float t1 = mode >= 4 ? 0.f : time_us([&] { launch256<2, 4>(a); });
-      float t3 = time_us([&] { launch256p<2, 4>(a); });
-      float t4 = time_us([&] { launch256p<4, 2>(a); });
+    int* counter; CK(hipMalloc(&counter, 4));
+    for (int mode : {0, 64, 1, 65, 2, 66}) {
+      LabArgs a{A, B, M, N, K, K, K, nullptr, C, Cb, N, mode, counter};
+      float t1 = mode >= 3 ? 0.f : time_us([&] { launch256<2, 4>(a); });
+      if (mode == 0) { float t16 = time_us([&] { launch256<4, 4>(a); }); printf("%5dx%4dx%4d mode 0: V1 4x4 (16 waves) %8.1f us %7.1f TF\n", M, N, K, t16, fl / t16 / 1e6); }
+      float t3 = time_us([&] { if (a.mode & 64) hipMemsetAsync(counter, 0, 4, 0); launch256p<2, 4>(a); });
+      float t4 = time_us([&] { if (a.mode & 64) hipMemsetAsync(counter, 0, 4, 0); launch256p<4, 2>(a); });
       printf("%5dx%4dx%4d mode %d: V1 2x4 %8.1f us %7.1f TF | P 2x4 %8.1f us %7.1f TF | P 4x2 %8.1f us %7.1f TF\n", M, N, K, mode, t1, fl / t1 / 1e6, t3, fl / t3 / 1e6, t4, fl / t4 / 1e6);
     }
     hipFree(A); hipFree(B); hipFree(C); hipFree(Cb);

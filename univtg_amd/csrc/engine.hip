@@ -189,7 +189,7 @@ struct WSpace {
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
       {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
         long long need = 0;
-        const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d},
+        const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d}, {m.Rp, (int)d, 3 * (int)d},
                                  {m.Mv, (int)d, (int)d}, {m.Mt, (int)d, (int)d}, {m.Mv, (int)d, m.c.Dv}, {m.Mt, (int)d, m.c.Dt}};
         for (auto& sh : shapes) { const long long f = gemm_tn_scratch_floats(sh[0], sh[1], sh[2]); if (f > need) need = f; }
         tn_scratch_floats = need; tn_scratch = a.take<float>((size_t)need);
@@ -583,6 +583,18 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     return launch_gemm_tn_bf16(t, s);
   };
 
+  // weight gradient of one Conv1d(k=3): dW[n][c][tap] = sum_rows dY[row][n] * X[row + tap - 1][c] over the zero-framed rows.
+  // One launch over K = 3 d (the k tiles pick their tap's row offset) when the 256-tile kernel takes it, else one per tap.
+  auto conv_wgrad = [&](const bf16_t* dY, int ldp, const bf16_t* X, int ldq, float* dW, float* dBi) -> int {
+    GemmTNArgs t; memset(&t, 0, sizeof(t));
+    t.P = dY; t.ldp = ldp; t.Q = X; t.ldq = ldq; t.M = m.Rp; t.N = d; t.K = 3 * d; t.q_row_off = -1; t.Mq = m.Rp;
+    t.out = dW; t.ldo = 3 * d; t.col_stride = 3; t.dbias = dBi; t.splits = splits_v; t.ktap = d;
+    t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
+    if (gemm_tn_taps_ok(t)) return launch_gemm_tn_bf16(t, s);
+    for (int tap = 0; tap < 3; tap++)
+      TRY(wgrad(dY, ldp, X, ldq, m.Rp, d, d, dW + tap, 3 * d, 3, tap == 1 ? dBi : nullptr, tap - 1, m.Rp, splits_v));
+    return 0;
+  };
   // ---------------- heads ----------------
   TRY(zero_frame(ws.dh2_pad, B, Lv, 2 * d * 2, s));
   TRY(zero_frame(ws.dh1_pad, B, Lv, 2 * d * 2, s));
@@ -598,9 +610,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 1 weight grads: 3 taps x 2 heads
     float* dW = G(m.tail(hd_ == 0 ? SP1W : CL1W));
     float* dBi = G(m.tail(hd_ == 0 ? SP1B : CL1B));
-    for (int tap = 0; tap < 3; tap++)
-      TRY(wgrad(ws.dh2_pad + hd_ * d, 2 * d, (const bf16_t*)ws.h1_pad + hd_ * d, 2 * d, Rp, d, d, dW + tap, 3 * d, 3,
-                tap == 1 ? dBi : nullptr, tap - 1, Rp, splits_v));
+    TRY(conv_wgrad(ws.dh2_pad + hd_ * d, 2 * d, (const bf16_t*)ws.h1_pad + hd_ * d, 2 * d, dW, dBi));
   }
   {                                             // conv layer 1 dgrad (+ relu' of h1) -> dh1_pad
     GemmArgs g = gemm_base(ws.dh2_pad, 2 * d, w.wc1T, 3 * d, m.Mv, d, 3 * d);
@@ -613,9 +623,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 0 weight grads
     float* dW = G(m.tail(hd_ == 0 ? SP0W : CL0W));
     float* dBi = G(m.tail(hd_ == 0 ? SP0B : CL0B));
-    for (int tap = 0; tap < 3; tap++)
-      TRY(wgrad(ws.dh1_pad + hd_ * d, 2 * d, (const bf16_t*)ws.vm_pad, d, Rp, d, d, dW + tap, 3 * d, 3,
-                tap == 1 ? dBi : nullptr, tap - 1, Rp, splits_v));
+    TRY(conv_wgrad(ws.dh1_pad + hd_ * d, 2 * d, (const bf16_t*)ws.vm_pad, d, dW, dBi));
   }
   {                                             // conv layer 0 dgrad -> dvm (fp32, video rows)
     GemmArgs g = gemm_base(ws.dh1_pad, 2 * d, w.wc0T, 6 * d, m.Mv, d, 6 * d);

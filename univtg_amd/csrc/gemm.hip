@@ -590,6 +590,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int
   const int steps_total = (p.M + 63) / 64;
   const int st0 = split * steps_per, st1 = min(steps_total, st0 + steps_per);
 
+  const int q_tap = p.ktap > 0 ? k0 / p.ktap : 0, kq0 = k0 - q_tap * (p.ktap > 0 ? p.ktap : 0);   // conv tap of this k tile
   __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, bytes_p, 0x00020000);
   __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, bytes_q, 0x00020000);
   unsigned vp[4], vq[4];
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int
     const int rr = (wave * 4 + i) * 2 + g;                 // tile row 0..63
     const int cs = (l31 ^ ((rr & 3) << 2)) * 8;            // source column chunk of this lane (LDS stays lane-linear)
     vp[i] = (unsigned)(((st0 * 64 + rr) * p.ldp + n0 + cs) * 2);
-    vq[i] = (unsigned)(((st0 * 64 + rr + p.q_row_off) * p.ldq + k0 + cs) * 2);   // negative rows wrap to out-of-range
+    vq[i] = (unsigned)(((st0 * 64 + rr + p.q_row_off + q_tap) * p.ldq + kq0 + cs) * 2);   // negative rows wrap to out-of-range
   }
   const unsigned dp = (unsigned)(64 * p.ldp * 2), dq = (unsigned)(64 * p.ldq * 2);
   auto stage = [&](int s) {
@@ -738,8 +739,9 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const GemmTNArgs p,
     const float* sp = p.scratch + (size_t)tile * 65536 + (size_t)(n & 255) * 256 + (k & 255);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int sidx = 0; sidx < splits; sidx++) s += *(const f32x4*)(sp + (size_t)sidx * tiles * 65536);
-    float* op = p.out + (size_t)n * p.ldo + (size_t)k * p.col_stride;
-    if (p.col_stride == 1 && k + 3 < p.K && ((((uintptr_t)op) & 15) == 0)) { f32x4 o = *(f32x4*)op; o += s; *(f32x4*)op = o; }
+    const int tap = p.ktap > 0 ? k / p.ktap : 0;
+    float* op = p.out + (size_t)n * p.ldo + (size_t)(k - tap * (p.ktap > 0 ? p.ktap : 0)) * p.col_stride + tap;
+    if (p.col_stride == 1 && p.ktap == 0 && k + 3 < p.K && ((((uintptr_t)op) & 15) == 0)) { f32x4 o = *(f32x4*)op; o += s; *(f32x4*)op = o; }
     else {
 #pragma unroll
       for (int e = 0; e < 4; e++) if (k + e < p.K) op[(size_t)e * p.col_stride] += s[e];
@@ -869,6 +871,7 @@ static int launch_tn256(const GemmTNArgs& a, hipStream_t s) {
 }
 static bool tn256_ok(const GemmTNArgs& a) {
   if (!a.scratch || g_force_tile == 128) return false;
+  if (a.ktap < 0 || (a.ktap > 0 && (a.ktap % 256 || a.K % a.ktap))) return false;
   if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15) || ((uintptr_t)a.scratch & 15)) return false;
   if (((long long)a.M + 64) * a.ldp * 2 >= (1LL << 31) || ((long long)a.Mq + 64) * a.ldq * 2 >= (1LL << 31)) return false;
   if (a.scratch_floats < gemm_tn_scratch_floats(a.M, a.N, a.K)) return false;
@@ -877,9 +880,11 @@ static bool tn256_ok(const GemmTNArgs& a) {
   const double fill = ((double)a.N * a.K) / ((double)cdiv(a.N, 256) * 256 * (double)cdiv(a.K, 256) * 256);
   return fill >= 0.85 && a.M >= 2048;
 }
+bool gemm_tn_taps_ok(const GemmTNArgs& a) { return a.ktap > 0 && tn256_ok(a); }
 int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.splits <= 0) return -1;
   if (tn256_ok(a)) return launch_tn256(a, s);
+  if (a.ktap > 0) return -2;      // taps exist only in the 256-tile kernel: callers check gemm_tn_taps_ok() first
   if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15)) return -2;
   dim3 grid(cdiv(a.N, 128) * cdiv(a.K, 128), a.splits, 1);
   uvtg_prof_begin_launch(2, 2.0 * a.M * a.N * a.K, s);

@@ -48,7 +48,11 @@ struct GemmTNArgs {
   // optional scratch for the 256-tile kernel (split partial tiles as plain fp32 slabs + a reduce pass instead of
   // fp32 atomics); null / too small -> the atomic kernel is used
   float* scratch; long long scratch_floats;
+  // 256-tile kernel only: K is `K / ktap` conv taps of ktap columns; tap t reads Q rows m + q_row_off + t, columns k % ktap,
+  // and lands at out[n * ldo + (k % ktap) * col_stride + t]   (0: no taps)
+  int ktap;
 };
+bool gemm_tn_taps_ok(const GemmTNArgs& a);   // can this call (with ktap set) run as ONE launch?
 long long gemm_tn_scratch_floats(int M, int N, int K);   // scratch that makes every (M, N, K) eligible for the 256-tile kernel
 int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s);
 
