@@ -326,33 +326,53 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   WCache w(m, wcache);
   const int d = m.c.d, F = m.c.F;
   const bool fast = !m.c.precise, tr = fast && m.c.training;
+  // every cast / transpose / conv re-layout of the step goes out in ONE launch per kind (the rebuild runs after each
+  // optimizer step: ~45 five-microsecond launches otherwise)
+  CastOps co; co.count = 0;
+  TransposeOps to; to.count = 0;
+  ConvWOps cv; cv.count = 0; cv.N = d; cv.C = d;
+  auto cast = [&](const float* src, bf16_t* dst, long long n) { co.src[co.count] = src; co.dst[co.count] = dst; co.n[co.count] = n; co.count++; };
+  auto transp = [&](const float* src, int rows, int cols, bf16_t* dst, int ld) {
+    to.src[to.count] = src; to.dst[to.count] = dst; to.rows[to.count] = rows; to.cols[to.count] = cols; to.ld[to.count] = ld; to.count++;
+  };
+  auto convw = [&](const float* wsrc, bf16_t* dst, int ld, int ntot, int n_off, int kind) {
+    cv.w[cv.count] = wsrc; cv.dst[cv.count] = dst; cv.ld[cv.count] = ld; cv.ntot[cv.count] = ntot; cv.n_off[cv.count] = n_off; cv.kind[cv.count] = kind; cv.count++;
+  };
+  if (4 * m.c.E + 4 > UVTG_MAX_PREP_OPS) return -17;
   for (int l = 0; l < m.c.E && fast; l++) {
-    TRY(launch_cast_bf16(P[m.lay(l, IPW)], w.wqkv[l], 3LL * d * d, s));
-    TRY(launch_cast_bf16(P[m.lay(l, OPW)], w.wo[l], (long long)d * d, s));
-    TRY(launch_cast_bf16(P[m.lay(l, L1W)], w.w1[l], (long long)F * d, s));
-    TRY(launch_cast_bf16(P[m.lay(l, L2W)], w.w2[l], (long long)d * F, s));
+    cast(P[m.lay(l, IPW)], w.wqkv[l], 3LL * d * d);
+    cast(P[m.lay(l, OPW)], w.wo[l], (long long)d * d);
+    cast(P[m.lay(l, L1W)], w.w1[l], (long long)F * d);
+    cast(P[m.lay(l, L2W)], w.w2[l], (long long)d * F);
     if (tr) {
-      TRY(launch_transpose_bf16(P[m.lay(l, IPW)], 3 * d, d, w.wqkvT[l], 3 * d, s));
-      TRY(launch_transpose_bf16(P[m.lay(l, OPW)], d, d, w.woT[l], d, s));
-      TRY(launch_transpose_bf16(P[m.lay(l, L1W)], F, d, w.w1T[l], F, s));
-      TRY(launch_transpose_bf16(P[m.lay(l, L2W)], d, F, w.w2T[l], d, s));
+      transp(P[m.lay(l, IPW)], 3 * d, d, w.wqkvT[l], 3 * d);
+      transp(P[m.lay(l, OPW)], d, d, w.woT[l], d);
+      transp(P[m.lay(l, L1W)], F, d, w.w1T[l], F);
+      transp(P[m.lay(l, L2W)], d, F, w.w2T[l], d);
     }
   }
   // conv heads: layer 0 of both heads merged along N (span rows then class rows), layer 1 grouped
   const size_t cw = (size_t)d * 3 * d;
-  TRY(launch_conv_w_fwd(P[m.tail(SP0W)], d, d, fast ? w.wc0 : nullptr, fast ? nullptr : w.wc0F, 3 * d, s));
-  TRY(launch_conv_w_fwd(P[m.tail(CL0W)], d, d, fast ? w.wc0 + cw : nullptr, fast ? nullptr : w.wc0F + cw, 3 * d, s));
-  TRY(launch_conv_w_fwd(P[m.tail(SP1W)], d, d, fast ? w.wc1 : nullptr, fast ? nullptr : w.wc1F, 3 * d, s));
-  TRY(launch_conv_w_fwd(P[m.tail(CL1W)], d, d, fast ? w.wc1 + cw : nullptr, fast ? nullptr : w.wc1F + cw, 3 * d, s));
+  if (fast) {
+    convw(P[m.tail(SP0W)], w.wc0, 3 * d, 0, 0, 0);
+    convw(P[m.tail(CL0W)], w.wc0 + cw, 3 * d, 0, 0, 0);
+    convw(P[m.tail(SP1W)], w.wc1, 3 * d, 0, 0, 0);
+    convw(P[m.tail(CL1W)], w.wc1 + cw, 3 * d, 0, 0, 0);
+  } else {
+    TRY(launch_conv_w_fwd(P[m.tail(SP0W)], d, d, nullptr, w.wc0F, 3 * d, s));
+    TRY(launch_conv_w_fwd(P[m.tail(CL0W)], d, d, nullptr, w.wc0F + cw, 3 * d, s));
+    TRY(launch_conv_w_fwd(P[m.tail(SP1W)], d, d, nullptr, w.wc1F, 3 * d, s));
+    TRY(launch_conv_w_fwd(P[m.tail(CL1W)], d, d, nullptr, w.wc1F + cw, 3 * d, s));
+  }
   hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP0B)], P[m.tail(CL0B)], w.bc0, d);
   hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP1B)], P[m.tail(CL1B)], w.bc1, d);
   UVTG_CHECK_LAUNCH();
   if (tr) {
     // dgrad operands: conv0 merged [d, 3 * 2d] (taps flipped), conv1 per head [d, 3d]
-    TRY(launch_conv_w_bwd(P[m.tail(SP0W)], d, d, w.wc0T, 6 * d, 2 * d, 0, s));
-    TRY(launch_conv_w_bwd(P[m.tail(CL0W)], d, d, w.wc0T, 6 * d, 2 * d, d, s));
-    TRY(launch_conv_w_bwd(P[m.tail(SP1W)], d, d, w.wc1T, 3 * d, d, 0, s));
-    TRY(launch_conv_w_bwd(P[m.tail(CL1W)], d, d, w.wc1T + cw, 3 * d, d, 0, s));
+    convw(P[m.tail(SP0W)], w.wc0T, 6 * d, 2 * d, 0, 1);
+    convw(P[m.tail(CL0W)], w.wc0T, 6 * d, 2 * d, d, 1);
+    convw(P[m.tail(SP1W)], w.wc1T, 3 * d, d, 0, 1);
+    convw(P[m.tail(CL1W)], w.wc1T + cw, 3 * d, d, 0, 1);
   }
   // input projections
   if (w.vp0F) {
@@ -361,17 +381,20 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   } else {
     TRY(launch_cast_pad_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0B, m.Kpv, s));
     TRY(launch_cast_pad_bf16(P[m.tail(TP0W)], d, m.c.Dt, w.tp0B, m.Kpt, s));
-    TRY(launch_cast_bf16(P[m.tail(VP1W)], w.vp1B, (long long)d * d, s));
-    TRY(launch_cast_bf16(P[m.tail(TP1W)], w.tp1B, (long long)d * d, s));
+    cast(P[m.tail(VP1W)], w.vp1B, (long long)d * d);
+    cast(P[m.tail(TP1W)], w.tp1B, (long long)d * d);
   }
   if (tr) {
-    TRY(launch_transpose_bf16(P[m.tail(VP1W)], d, d, w.vp1T, d, s));
-    TRY(launch_transpose_bf16(P[m.tail(TP1W)], d, d, w.tp1T, d, s));
+    transp(P[m.tail(VP1W)], d, d, w.vp1T, d);
+    transp(P[m.tail(TP1W)], d, d, w.tp1T, d);
     hipMemsetAsync(w.vp0T, 0, (size_t)m.Kpv * d * 2, s);
     hipMemsetAsync(w.tp0T, 0, (size_t)m.Kpt * d * 2, s);
-    TRY(launch_transpose_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0T, d, s));
-    TRY(launch_transpose_bf16(P[m.tail(TP0W)], d, m.c.Dt, w.tp0T, d, s));
+    transp(P[m.tail(VP0W)], d, m.c.Dv, w.vp0T, d);
+    transp(P[m.tail(TP0W)], d, m.c.Dt, w.tp0T, d);
   }
+  TRY(launch_cast_bf16_multi(co, s));
+  TRY(launch_transpose_bf16_multi(to, s));
+  TRY(launch_conv_w_multi(cv, s));
   return 0;
 }
 

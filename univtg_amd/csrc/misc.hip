@@ -98,6 +98,55 @@ __global__ void conv_w_bwd_kernel(const float* w, int N, int C, bf16_t* dst, int
   dst[(size_t)c * ld + tp * Ntot + n_off + n] = f2bf(w[((size_t)n * C + c) * 3 + (2 - tp)]);
 }
 
+// ---- batched operand-cache rebuild: blockIdx.y (z for transposes) selects the op ----
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastOps ops) {
+  const int op = blockIdx.y;
+  const long long n = ops.n[op];
+  const float* src = ops.src[op];
+  bf16_t* dst = ops.dst[op];
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long long)gridDim.x * 2048) {
+    if (i + 7 < n) {
+      const f32x4 a = *(const f32x4*)(src + i), b = *(const f32x4*)(src + i + 4);
+      u32x4 t; t[0] = pack_bf2(a[0], a[1]); t[1] = pack_bf2(a[2], a[3]); t[2] = pack_bf2(b[0], b[1]); t[3] = pack_bf2(b[2], b[3]);
+      *(u32x4*)(dst + i) = t;
+    } else {
+      for (long long j = i; j < n; j++) dst[j] = f2bf(src[j]);
+    }
+  }
+}
+__global__ void transpose_bf16_multi_kernel(const TransposeOps ops) {
+  __shared__ float t[32][33];
+  const int op = blockIdx.z;
+  const int rows = ops.rows[op], cols = ops.cols[op], ld = ops.ld[op];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  if (c0 >= cols || r0 >= rows) return;
+  const float* src = ops.src[op];
+  bf16_t* dst = ops.dst[op];
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    t[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) dst[(size_t)c * ld + r] = f2bf(t[threadIdx.x][i]);
+  }
+}
+__global__ __launch_bounds__(256) void conv_w_multi_kernel(const ConvWOps ops) {
+  const int op = blockIdx.y, N = ops.N, C = ops.C;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)N * 3 * C) return;
+  const float* w = ops.w[op];
+  bf16_t* dst = ops.dst[op];
+  if (ops.kind[op] == 0) {
+    const int n = (int)(i / (3 * C)), rem = (int)(i % (3 * C)), tap = rem / C, c = rem % C;
+    dst[(size_t)n * ops.ld[op] + rem] = f2bf(w[((size_t)n * C + c) * 3 + tap]);
+  } else {
+    const int c = (int)(i / (3 * N)), rem = (int)(i % (3 * N)), tp = rem / N, n = rem % N;
+    dst[(size_t)c * ops.ld[op] + tp * ops.ntot[op] + ops.n_off[op] + n] = f2bf(w[((size_t)n * C + c) * 3 + (2 - tp)]);
+  }
+}
+
 // ---------------- heads: last conv layer + activations ----------------
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
@@ -559,6 +608,30 @@ int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int 
 }
 int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s) {
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, s, src, rows, cols, dst, ld);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_cast_bf16_multi(const CastOps& ops, hipStream_t s) {
+  if (ops.count <= 0) return 0;
+  long long mx = 0;
+  for (int i = 0; i < ops.count; i++) mx = ops.n[i] > mx ? ops.n[i] : mx;
+  const unsigned bx = (unsigned)((mx + 2047) / 2048);
+  hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(bx < 512 ? bx : 512, ops.count), dim3(256), 0, s, ops);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_transpose_bf16_multi(const TransposeOps& ops, hipStream_t s) {
+  if (ops.count <= 0) return 0;
+  int mr = 0, mc = 0;
+  for (int i = 0; i < ops.count; i++) { mr = ops.rows[i] > mr ? ops.rows[i] : mr; mc = ops.cols[i] > mc ? ops.cols[i] : mc; }
+  hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3(cdiv(mc, 32), cdiv(mr, 32), ops.count), dim3(32, 8), 0, s, ops);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_conv_w_multi(const ConvWOps& ops, hipStream_t s) {
+  if (ops.count <= 0) return 0;
+  const long long n = (long long)ops.N * 3 * ops.C;
+  hipLaunchKernelGGL(conv_w_multi_kernel, dim3((unsigned)((n + 255) / 256), ops.count), dim3(256), 0, s, ops);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -130,6 +130,16 @@ int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
 int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s);
 int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);
 int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);  // dst[c][r]
+// batched forms for the per-step operand-cache rebuild: all casts / transposes / conv re-layouts of a step in one launch each
+constexpr int UVTG_MAX_PREP_OPS = 80;
+struct CastOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; long long n[UVTG_MAX_PREP_OPS]; int count; };
+struct TransposeOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; int rows[UVTG_MAX_PREP_OPS], cols[UVTG_MAX_PREP_OPS], ld[UVTG_MAX_PREP_OPS]; int count; };
+struct ConvWOps {     // kind 0: forward operand (dst[n][tap*C + c]), 1: dgrad operand (dst[c][tap'*Ntot + n_off + n] = w[n][c][2 - tap'])
+  const float* w[16]; bf16_t* dst[16]; int ld[16], ntot[16], n_off[16], kind[16]; int N, C, count;
+};
+int launch_cast_bf16_multi(const CastOps& ops, hipStream_t s);
+int launch_transpose_bf16_multi(const TransposeOps& ops, hipStream_t s);
+int launch_conv_w_multi(const ConvWOps& ops, hipStream_t s);
 // conv weight (N, C, 3) -> tap-major (N, 3*C) [forward operand]; and its dgrad operand (C, 3*N) with taps flipped
 int launch_conv_w_fwd(const float* w, int N, int C, bf16_t* dstB, float* dstF, int ld, hipStream_t s);
 int launch_conv_w_bwd(const float* w, int N, int C, bf16_t* dst, int ld, int Ntot, int n_off, hipStream_t s);
