@@ -180,6 +180,7 @@ def main():
         roof = dict(bound="mfma", kernel=fam[dom], achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                     traffic=traffic, traffic_note=traffic_note, launches_per_step=int(n[dom] // max(1, args.profile_steps)),
                     avg_launch_us=round(ms[dom] * 1e3 / max(1, n[dom]), 2),
+                    event_pair_floor_us=round(lib.uvtg_profile_event_floor_ms() * 1e3, 2),
                     algorithmic_gflop_per_launch=round(fl[dom] / max(1, n[dom]) / 1e9, 2),
                     all_gemm_kernels={fam[i]: dict(ms_per_step=round(ms[i] / max(1, args.profile_steps), 3),
                                                    tflops=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else 0.0,

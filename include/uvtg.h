@@ -187,6 +187,8 @@ int uvtg_adamw_clip_step(float* params, const float* grads, float* exp_avg, floa
  * persistent).  host arrays [4]. */
 int uvtg_profile_start(void);
 int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
+/* the empty-event-pair floor (ms) that uvtg_profile_stop measured on the launch stream and subtracted from every launch */
+double uvtg_profile_event_floor_ms(void);
 
 /* Test knob: force the NT GEMM tile size (0 = automatic choice, 128, 256) so that both kernels can be compared on
  * identical inputs.  Process-wide. */

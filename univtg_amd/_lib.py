@@ -51,6 +51,7 @@ SIGNATURES = {
     "uvtg_debug_force_nt_tile": (_I, [_I]),
     "uvtg_profile_start": (_I, []),
     "uvtg_profile_stop": (_I, [_P, _P, _P]),
+    "uvtg_profile_event_floor_ms": (C.c_double, []),
     "uvtg_hungarian": (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
     "uvtg_decode_rank_nms": (_I, [_P] * 5 + [_I, _I, _F, _I, _I] + [_P] * 4 + [_P]),
 }
