@@ -74,6 +74,9 @@ def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev):
                    timestamp_window=inside.contiguous(), span_labels_nn=span_nn.contiguous(),
                    saliency_scores=inside.clone(), saliency_pos_labels=pos, _pos_idx=pos[:, 0].contiguous())
     inputs = dict(src_txt=txt.contiguous(), src_txt_mask=tm.contiguous(), src_vid=vid.contiguous(), src_vid_mask=vm.contiguous())
+    # the valid lengths a collate knows on the host anyway (utils/tensor_utils.py:34-53 computes them to build the masks):
+    # handing them over lets the engine run the packed (ragged) encoder stream without a device->host sync
+    inputs["_lens_host"] = (lens_v.cpu().tolist(), lens_t.cpu().tolist())
     return inputs, targets
 
 

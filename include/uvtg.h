@@ -73,12 +73,18 @@ int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* params, void* 
  *          dim_t [d]: the sine-embedding denominators 10000^(2*(i/2)/d) (model/position_encoding.py:75-78)
  * outputs: x0 [B,S,d]   projected tokens (vid rows then txt rows); vid_mem_proj = x0[:, :Lv]
  *          pred_logits [B,Lv,1], pred_spans [B,Lv,2], txt_mem_proj [B,1,d], saliency [B,Lv]
- *          memory [B,S,d] encoder output (optional, may be NULL) */
+ *          memory [B,S,d] encoder output (optional, may be NULL)
+ * lens_host (optional): the per-sample valid lengths the caller's collate already knows on the host (the reference's
+ *          pad_sequences_1d computes them, utils/tensor_utils.py:34-53); masks must be the matching prefix masks.  When given (bf16
+ *          mode, memory == NULL) the encoder runs on the packed rows -- valid clips, ONE representative padded clip per sample,
+ *          valid text tokens -- which reproduces the padded computation exactly (see misc.hip) at ~25 % fewer rows on ragged
+ *          batches.  uvtg_backward must get the same array. */
 int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                  const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                  const float* dim_t,
                  float* x0, float* pred_logits, float* pred_spans, float* txt_mem_proj, float* saliency,
-                 float* memory, void* workspace, uvtg_stream_t stream);
+                 float* memory, void* workspace, uvtg_stream_t stream,
+                 const int* lens_host /* optional, HOST memory [2B]: clips then text tokens per sample */);
 
 /* ---- model backward: replaces autograd through Model.forward ------------------------------------
  * Needs the workspace, inputs and outputs (x0, pred_*, txt_mem_proj) of the matching
@@ -97,7 +103,8 @@ int uvtg_backward(const uvtg_dims* dm, const float* const* params, const void* w
                   const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
                   const float* g_vrow, const long long* pos_idx,
                   float* grads, void* workspace, uvtg_stream_t stream,
-                  void* const* ready_events /* hipEvent_t[E + 1] or NULL */, int n_events /* E + 1 or 0 */);
+                  void* const* ready_events /* hipEvent_t[E + 1] or NULL */, int n_events /* E + 1 or 0 */,
+                  const int* lens_host /* as passed to the matching uvtg_forward, or NULL */);
 
 /* ---- criterion: replaces SetCriterion.forward + its autograd (model/univtg.py:195-282,338-351) ---
  * vid_mem_proj is addressed as vid[b*vid_sb + t*vid_st + c] so that the strided view of x0 works.
@@ -193,6 +200,8 @@ double uvtg_profile_event_floor_ms(void);
 /* Test knob: force the NT GEMM tile size (0 = automatic choice, 128, 256) so that both kernels can be compared on
  * identical inputs.  Process-wide. */
 int uvtg_debug_force_nt_tile(int tile);
+/* ... and the tile HEIGHT of the persistent 256-wide kernel (0 = automatic per launch, 128, 192, 256) */
+int uvtg_debug_force_nt_bm(int bm);
 
 const char* uvtg_strerror(int code);
 int uvtg_version(void);

@@ -202,3 +202,28 @@ def test_nt_tile_sizes_agree(dev):
             assert float((r128 - r256).abs().max()) <= 1e-6 * float(r128.abs().max()), (M, N, K)
     finally:
         lib.uvtg_debug_force_nt_tile(0)
+
+
+def test_nt256_tile_heights_agree(dev):
+    """The 256-, 192- and 128-row instantiations of the persistent GEMM give identical results (same products, same K order)."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    try:
+        _lib.check(lib.uvtg_debug_force_nt_tile(256))
+        for (M, N, K, act) in [(19850, 1024, 1024, 0), (5000, 3080, 192, 1), (700, 520, 1024, 2)]:
+            a = bf(torch.randn(M, K, generator=g).to(dev))
+            w = bf((torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev))
+            b = torch.randn(N, generator=g).to(dev)
+            outs = []
+            for bm in (256, 192, 128):
+                _lib.check(lib.uvtg_debug_force_nt_bm(bm))
+                outs.append(ops.linear_bf16(a, w, b, act))
+            ref = a.double() @ w.double().t() + b.double()
+            ref = torch.relu(ref) if act == 1 else (torch.nn.functional.gelu(ref) if act == 2 else ref)
+            assert relerr(outs[0], ref) < 2e-5
+            for o in outs[1:]:
+                assert float((o - outs[0]).abs().max()) <= 1e-6 * float(outs[0].abs().max()), (M, N, K)
+    finally:
+        lib.uvtg_debug_force_nt_bm(0)
+        lib.uvtg_debug_force_nt_tile(0)

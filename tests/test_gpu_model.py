@@ -482,3 +482,54 @@ def test_edge_shapes_vs_oracle(dev, B, Lv, Lt, d, H, ragged):
         if float(r.norm()) > 1e-6 * r.numel() ** 0.5:
             worst = min(worst, float((a @ r) / (a.norm() * r.norm() + 1e-30)))
     assert worst > 0.95, worst
+
+
+@pytest.mark.parametrize("B,Lv,Lt,d,H,E", [(6, 30, 10, 256, 4, 2), (256, 75, 32, 1024, 8, 4), (3, 150, 12, 128, 2, 2)])
+def test_packed_ragged_stream_matches_padded(dev, B, Lv, Lt, d, H, E):
+    """Packed encoder stream (valid clips + ONE representative padded clip + valid text per sample, include/uvtg.h lens_host)
+    against the padded execution of the same ragged batch: same outputs at every clip position (padded ones included), same
+    losses, same parameter gradients up to bf16 rounding of the re-associated sums."""
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    cfg = O.make_cfg(hidden_dim=d, nheads=H, dim_feedforward=d, enc_layers=E, v_feat_dim=66 if d < 1024 else 2818,
+                     t_feat_dim=40 if d < 1024 else 512, max_q_l=max(Lt, 4), input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=41)
+    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=42, ragged=True)
+    ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    lens = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+    assert min(lens[0]) < Lv, "the batch must contain padded clips"
+    res = {}
+    for mode in (False, True):
+        model, crit = build(cfg, params, dev, "bf16")
+        model.eval()
+        step = TrainStep(model, crit, grad_clip=0.1, packed=mode)
+        batch = dict(ind)
+        if mode:
+            batch["_lens_host"] = lens
+        losses = step.step(batch, tgd, optimize=False).clone()
+        torch.cuda.synchronize()
+        res[mode] = (losses, step.grads.clone(), step.pred_logits.clone(), step.pred_spans.clone(), step.sal.clone())
+    (l0, g0, pl0, ps0, s0), (l1, g1, pl1, ps1, s1) = res[False], res[True]
+    assert torch.isfinite(g1).all()
+    assert float((s0 - s1).abs().max()) < 1e-6                       # saliency never touches the encoder
+    # all clip positions (padded ones too).  The two executions sum in different orders (attention key tiles, GEMM row tiles), so they
+    # differ by bf16 rounding noise; both must be equally close to the fp32-class forward of the same weights
+    m32, _ = build(cfg, params, dev, "fp32x3")
+    m32.eval()
+    with torch.no_grad():
+        ref = m32(**ind)
+    for a, b, r in ((pl0, pl1, ref["pred_logits"]), (ps0, ps1, ref["pred_spans"])):
+        e0, e1 = float((a - r).abs().max()), float((b - r).abs().max())
+        assert e1 <= 1.5 * e0 + 1e-3, (e0, e1)
+        assert float((a - b).abs().max()) <= 2.0 * max(e0, e1) + 1e-4
+    assert float((l0 - l1).abs().max()) < 2e-3 * max(1.0, float(l0.abs().max()))
+    offs = model._offsets(model._dims(B, Lv, Lt, cfg.v_feat_dim, cfg.t_feat_dim, False))
+    names = {id(p): k for k, p in model.named_parameters()}
+    for i, p in enumerate(model._ordered_params()):
+        a, b = g0[offs[i]: offs[i] + p.numel()].double(), g1[offs[i]: offs[i] + p.numel()].double()
+        if float(a.norm()) == 0.0:
+            assert float(b.norm()) == 0.0
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        ratio = float(b.norm() / a.norm())
+        assert cos > 0.999 and abs(ratio - 1) < 1e-2, (names[id(p)], cos, ratio)

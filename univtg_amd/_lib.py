@@ -32,8 +32,8 @@ SIGNATURES = {
     "uvtg_wcache_bytes": (C.c_size_t, [_DP]),
     "uvtg_loss_ws_floats": (_LL, [_I, _I, _I]),
     "uvtg_prepare_weights": (_I, [_DP, _P, _P, _P]),
-    "uvtg_forward": (_I, [_DP, _P, _P] + [_P] * 5 + [_P] * 6 + [_P, _P]),
-    "uvtg_backward": (_I, [_DP, _P, _P] + [_P] * 4 + [_P] * 4 + [_P] * 5 + [_LL, _LL] + [_P, _P] + [_P, _P, _P] + [_P, _I]),
+    "uvtg_forward": (_I, [_DP, _P, _P] + [_P] * 5 + [_P] * 6 + [_P, _P] + [_P]),
+    "uvtg_backward": (_I, [_DP, _P, _P] + [_P] * 4 + [_P] * 4 + [_P] * 5 + [_LL, _LL] + [_P, _P] + [_P, _P, _P] + [_P, _I] + [_P]),
     "uvtg_criterion_fwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P]),
     "uvtg_criterion_bwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P] + [_P] * 6 + [_P]),
     "uvtg_linear_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -49,6 +49,7 @@ SIGNATURES = {
     "uvtg_sine_position": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "uvtg_adamw_clip_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
     "uvtg_debug_force_nt_tile": (_I, [_I]),
+    "uvtg_debug_force_nt_bm": (_I, [_I]),
     "uvtg_profile_start": (_I, []),
     "uvtg_profile_stop": (_I, [_P, _P, _P]),
     "uvtg_profile_event_floor_ms": (C.c_double, []),

@@ -54,10 +54,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   using KS = KSwz<HD>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int b = blockIdx.z, h = blockIdx.y, S = a.S;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S;
+  if ((int)blockIdx.x * 128 >= S) return;
   const int q_raw = blockIdx.x * 128 + wave * 32 + l31;
   const int qrow = min(q_raw, S - 1);
-  const size_t rowbase = (size_t)b * S;
+  const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
 
   // Q fragments (B operand of S^T = K Q^T): lane (query, g) holds q[16ks + 8g .. +7]
   s16x8 qh[HD / 16], ql[PRECISE ? HD / 16 : 1];
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
           *(f32x4*)((float*)a.o + off) = t;
         }
       }
-    if (a.lse && g == 0) a.lse[((size_t)b * a.H + h) * S + q_raw] = m_run + __logf(l_run);
+    if (a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run + __logf(l_run);
   }
 }
 
@@ -232,8 +233,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
   // one wave per token row; lane owns 8 consecutive channels; heads are reduced inside groups of hd/8 lanes
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long long)a.B * a.S) return;
-  const int b = (int)(row / a.S), s = (int)(row % a.S), d = a.H * a.hd, lph = a.hd / 8;
+  if (row >= (a.row_sample ? (long long)a.total_rows : (long long)a.B * a.S)) return;
+  const int b = a.row_sample ? a.row_sample[row] : (int)(row / a.S);
+  const int s = a.row_sample ? (int)(row - a.seq_start[b]) : (int)(row % a.S);
+  const int d = a.H * a.hd, lph = a.hd / 8;
   const bf16_t* o = (const bf16_t*)a.o + row * a.ldo;
   const bf16_t* g = a.dO + row * a.lddo;
   for (int c = lane * 8; c < d; c += 512) {
@@ -260,8 +263,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   using KS = KSwz<HD>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int b = blockIdx.z, h = blockIdx.y, S = a.S, d = a.H * HD;
-  const size_t rowbase = (size_t)b * S;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  if ((int)blockIdx.x * 128 >= S) return;
+  const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
   const int key0 = blockIdx.x * 128;
   const bf16_t* qkv = (const bf16_t*)a.qkv;
   constexpr int CH = HD / 8;
@@ -308,8 +312,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
     }
     if (tid < 32) {
       const int qi = qb * 32 + tid;
-      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * S + qi] : 0.f;
-      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * S + qi] : 0.f;
+      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * a.S + qi] : 0.f;
+      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * a.S + qi] : 0.f;
     }
     __syncthreads();
     // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
@@ -378,8 +382,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   __shared__ unsigned char sValid[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int b = blockIdx.z, h = blockIdx.y, S = a.S, d = a.H * HD;
-  const size_t rowbase = (size_t)b * S;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  if ((int)blockIdx.x * 128 >= S) return;
+  const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
   const int q_raw = blockIdx.x * 128 + wave * 32 + l31;
   const int qrow = min(q_raw, S - 1);
   const bf16_t* qkv = (const bf16_t*)a.qkv;
@@ -389,8 +394,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     qf[ks] = *(const s16x8*)(qkv + (rowbase + qrow) * a.ldqkv + h * HD + 16 * ks + 8 * g);
     of[ks] = *(const s16x8*)(a.dO + (rowbase + qrow) * a.lddo + h * HD + 16 * ks + 8 * g);
   }
-  const float lse = a.lse[((size_t)b * a.H + h) * S + qrow];
-  const float dl = a.delta[((size_t)b * a.H + h) * S + qrow];
+  const float lse = a.lse[((size_t)b * a.H + h) * a.S + qrow];
+  const float dl = a.delta[((size_t)b * a.H + h) * a.S + qrow];
   f32x16 dq[HD / 32];
 #pragma unroll
   for (int i = 0; i < HD / 32; i++)
@@ -483,8 +488,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
   __shared__ float sL[32], sD[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int b = blockIdx.z, h = blockIdx.y, S = a.S, d = a.H * HD;
-  const size_t rowbase = (size_t)b * S;
+  const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
   const bf16_t* qkv = (const bf16_t*)a.qkv;
   // K (all keys) -> LDS, zero rows beyond S
 #pragma unroll
@@ -527,8 +532,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
     }
     if (tid < 32) {
       const int qi = qb * 32 + tid;
-      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * S + qi] : 0.f;
-      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * S + qi] : 0.f;
+      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * a.S + qi] : 0.f;
+      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * a.S + qi] : 0.f;
     }
     if (qb + 1 < nqb) prefetch(qb + 1);
     // V fragments are re-fetched (L2 hits) per query block instead of living in 32 registers across the whole loop:
@@ -634,7 +639,7 @@ int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
 int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
   if (a.precise) return -6;
-  const long long rows = (long long)a.B * a.S;
+  const long long rows = a.row_sample ? (long long)a.total_rows : (long long)a.B * a.S;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);

@@ -114,6 +114,8 @@ struct WCache {
 // ---- workspace -------------------------------------------------------------------------------
 struct WSpace {
   float* pos; unsigned char* kvalid; float* dps;
+  // packed (ragged) execution: tables, packed layer-0 operands, packed conv-head gradient
+  PackTables pk; int* lens_dev; bf16_t *xb0p, *ub0p, *g2p;
   // projections (index 0 = video, 1 = text)
   void* a1[2]; bf16_t* a1B[2]; float *m0[2], *r0[2], *h1[2]; void* a2[2]; bf16_t* a2B[2]; float *m1[2], *r1[2];
   // encoder
@@ -136,6 +138,12 @@ struct WSpace {
     const size_t es = fast ? 2 : 4;                       // compute-dtype element size
     const bool pp = m.c.precise || m.c.proj_precise;
     pos = a.take<float>((size_t)m.Mv * d); kvalid = a.take<unsigned char>(M); dps = a.take<float>(2 * E * B);
+    lens_dev = a.take<int>(2 * B);
+    pk.seq_start = a.take<int>(B); pk.seq_count = a.take<int>(B);
+    pk.row_sample = a.take<int>(M); pk.row_src = a.take<int>(M); pk.row_pos = a.take<int>(M);
+    pk.pad2pack = a.take<int>(M); pk.grad_map = a.take<int>(M); pk.kvalid = a.take<unsigned char>(M);
+    xb0p = fast ? a.take<bf16_t>(M * d) : nullptr; ub0p = fast ? a.take<bf16_t>(M * d) : nullptr;
+    g2p = (fast && tr) ? a.take<bf16_t>(M * d) : nullptr;
     for (int i = 0; i < 2; i++) {
       const size_t R = i == 0 ? m.Mv : m.Mt, Kp = i == 0 ? m.Kpv : m.Kpt;
       a1[i] = a.take<char>(R * Kp * (pp ? 4 : 2));
@@ -245,6 +253,18 @@ __global__ void add_vec_kernel(float* dst, const float* src, int n) {
 
 #define TRY(x) do { int e__ = (x); if (e__) return e__; } while (0)
 
+// rows of the packed encoder stream for these host-side lengths (lens[0..B) clips, lens[B..2B) text tokens per sample)
+int packed_rows(const Dm& m, const int* lens, int* out) {
+  long long n = 0;
+  for (int b = 0; b < m.c.B; b++) {
+    const int lv = lens[b], lt = lens[m.c.B + b];
+    if (lv < 1 || lv > m.c.Lv || lt < 1 || lt > m.c.Lt) return -23;
+    n += lv + (lv < m.c.Lv ? 1 : 0) + lt;
+  }
+  *out = (int)n;
+  return 0;
+}
+
 GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N, int K) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -281,6 +301,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -20: return "null pointer argument";
     case -21: return "force_nt_tile: tile must be 0, 128 or 256";
     case -22: return "backward: ready_events must hold enc_layers + 1 events (or n_events = 0)";
+    case -23: return "lens_host: every sample needs 1 <= len_v <= Lv clips and 1 <= len_t <= Lt text tokens";
     default: return "invalid argument";
   }
 }
@@ -406,6 +427,7 @@ namespace {
 struct Fwd {
   const Dm& m; const float* const* P; WCache& w; WSpace& ws; hipStream_t s;
   bool fast, tr, pp;
+  bool packed = false; int Mrows = 0;     // packed (ragged) encoder stream: Mrows <= B * S rows (see misc.hip)
   int run_gemm(GemmArgs& g, bool x3) { return x3 ? launch_gemm_nt_f32x3(g, s) : launch_gemm_nt_bf16(g, s); }
   void set_out(GemmArgs& g, void* p, int ld) { if (fast) { g.outB = (bf16_t*)p; g.ldoB = ld; } else { g.outF = (float*)p; g.ldoF = ld; } }
 
@@ -446,30 +468,33 @@ struct Fwd {
   }
 
   int layer(int l, float* memory_out) {
-    const int d = m.c.d, F = m.c.F, M = m.M, S = m.S;
+    const int d = m.c.d, F = m.c.F, M = packed ? Mrows : m.M, S = m.S;
+    const void* xb_in = (packed && l == 0) ? (const void*)ws.xb0p : ws.xb[l];
+    const void* ub_in = (packed && l == 0) ? (const void*)ws.ub0p : ws.ub[l];
     const bool last = l == m.c.E - 1;
     const void* Wqkv = fast ? (const void*)w.wqkv[l] : (const void*)P[m.lay(l, IPW)];
     const size_t es = fast ? 2 : 4;
     // q,k from (x + pos); v from x  (transformer_encoder_droppath.py:116-117)
-    GemmArgs g = gemm_base(ws.ub[l], d, Wqkv, d, M, 2 * d, d);
+    GemmArgs g = gemm_base(ub_in, d, Wqkv, d, M, 2 * d, d);
     g.bias = P[m.lay(l, IPB)]; g.colscale = 1.0f / sqrtf((float)m.hd); g.colscale_n = d;
     set_out(g, ws.qkv[l], 3 * d);
     TRY(run_gemm(g, !fast));
-    g = gemm_base(ws.xb[l], d, (const char*)Wqkv + (size_t)2 * d * d * es, d, M, d, d);
+    g = gemm_base(xb_in, d, (const char*)Wqkv + (size_t)2 * d * d * es, d, M, d, d);
     g.bias = P[m.lay(l, IPB)] + 2 * d;
     set_out(g, (char*)ws.qkv[l] + (size_t)2 * d * es, 3 * d);
     TRY(run_gemm(g, !fast));
     AttnArgs at; memset(&at, 0, sizeof(at));
-    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = ws.kvalid;
+    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
+    if (packed) { at.seq_start = ws.pk.seq_start; at.seq_count = ws.pk.seq_count; at.row_sample = ws.pk.row_sample; at.total_rows = M; }
     at.B = m.c.B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = tr ? m.c.p_attn : 0.f; at.seed = m.c.seed; at.layer = l;
     at.precise = !fast;
     TRY(launch_attn_fwd(at, s));
     // out-proj + DropPath + residual -> y1 ; LN1
     g = gemm_base(ws.o[l], d, fast ? (const void*)w.wo[l] : (const void*)P[m.lay(l, OPW)], d, M, d, d);
     g.bias = P[m.lay(l, OPB)];
-    if (fast) { g.residB = (const bf16_t*)ws.xb[l]; g.ldrB = d; g.outB = ws.y1b[l]; g.ldoB = d; }
+    if (fast) { g.residB = (const bf16_t*)xb_in; g.ldrB = d; g.outB = ws.y1b[l]; g.ldoB = d; }
     else { g.resid = ws.xin[l]; g.ldr = d; g.outF = ws.y1[l]; g.ldoF = d; }
-    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l) * m.c.B; g.rs_seg = S; }
+    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l) * m.c.B; g.rs_seg = S; if (packed) g.row_sample = ws.pk.row_sample; }
     TRY(run_gemm(g, !fast));
     LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
     ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
@@ -487,23 +512,27 @@ struct Fwd {
     g.bias = P[m.lay(l, L2B)];
     if (fast) { g.residB = (const bf16_t*)ws.x1b[l]; g.ldrB = d; g.outB = ws.y2b[l]; g.ldoB = d; }
     else { g.resid = ws.x1; g.ldr = d; g.outF = ws.y2[l]; g.ldoF = d; }
-    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l + 1) * m.c.B; g.rs_seg = S; }
+    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l + 1) * m.c.B; g.rs_seg = S; if (packed) g.row_sample = ws.pk.row_sample; }
     TRY(run_gemm(g, !fast));
     memset(&ln, 0, sizeof(ln));
     ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N2W)]; ln.beta = P[m.lay(l, N2B)]; ln.eps = 1e-5f;
     ln.mean = ws.mean2[l]; ln.rstd = ws.rstd2[l]; ln.Dpad = d; ln.S = S; ln.Lv = m.c.Lv;
     if (fast) { ln.xB = ws.y2b[l]; ln.ldxB = d; } else { ln.x = ws.y2[l]; ln.ldx = d; }
+    if (packed) ln.pos_row = ws.pk.row_pos;
     if (!last) {
       if (!fast) { ln.yF = ws.xin[l + 1]; ln.ldyF = d; }
       ln.pos = ws.pos; ln.ldyU = d;
       if (fast) { ln.yB = (bf16_t*)ws.xb[l + 1]; ln.ldyB = d; ln.yU = (bf16_t*)ws.ub[l + 1]; }
       else ln.yUF = (float*)ws.ub[l + 1];
+    } else if (packed) {
+      ln.yB = (bf16_t*)ws.xb[l + 1]; ln.ldyB = d;             // packed encoder output; expanded into the conv frame below
     } else {
       if (memory_out) { ln.yF = memory_out; ln.ldyF = d; }
       ln.ldyP = d;
       if (fast) ln.yP = (bf16_t*)ws.vm_pad; else ln.yPF = (float*)ws.vm_pad;
     }
     TRY(launch_ln_fwd(ln, s));
+    if (last && packed) TRY(launch_unpack_vm((const bf16_t*)ws.xb[l + 1], ws.pk.pad2pack, m.c.B, S, m.c.Lv, d, (bf16_t*)ws.vm_pad, s));
     return 0;
   }
 
@@ -550,7 +579,7 @@ SaliencyArgs sal_args(const Dm& m, const float* const* P, WSpace& ws, const floa
 extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const void* wcache,
                             const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                             const float* dim_t, float* x0, float* pred_logits, float* pred_spans, float* txt_mem_proj,
-                            float* saliency, float* memory, void* workspace, uvtg_stream_t stream) {
+                            float* saliency, float* memory, void* workspace, uvtg_stream_t stream, const int* lens_host) {
   if (int e = check_dims(dm)) return e;
   if (dm->E > MAXE) return -17;
   if (!P || !wcache || !src_txt || !src_txt_mask || !src_vid || !src_vid_mask || !dim_t || !x0 || !pred_logits ||
@@ -560,10 +589,18 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   WCache w(m, (void*)wcache);
   WSpace ws(m, workspace, x0);
   Fwd f{m, P, w, ws, s, !m.c.precise, m.c.training != 0, m.c.precise || m.c.proj_precise};
+  if (lens_host && f.fast && !memory) {         // packed (ragged) encoder stream
+    int mp = 0;
+    TRY(packed_rows(m, lens_host, &mp));
+    f.packed = true; f.Mrows = mp;
+    if (hipError_t e = hipMemcpyAsync(ws.lens_dev, lens_host, 2 * (size_t)m.c.B * sizeof(int), hipMemcpyHostToDevice, s)) return (int)e;
+    TRY(launch_pack_tables(ws.lens_dev, m.c.B, m.c.Lv, m.c.Lt, ws.pk, s));
+  }
   TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, s));
   if (f.tr && m.c.p_path > 0.f) TRY(launch_droppath_scales(ws.dps, 2 * m.c.E, m.c.B, m.c.p_path, m.c.seed, s));
   TRY(f.project(0, src_vid, x0));
   TRY(f.project(1, src_txt, x0));
+  if (f.packed) TRY(launch_pack_rows((const bf16_t*)ws.xb[0], (const bf16_t*)ws.ub[0], ws.pk.row_src, f.Mrows, m.c.d, ws.xb0p, ws.ub0p, s));
   for (int l = 0; l < m.c.E; l++) TRY(f.layer(l, memory));
   TRY(f.heads(pred_logits, pred_spans));
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, txt_mem_proj, saliency);
@@ -580,7 +617,8 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
                              const float* g_logits, const float* g_spans, const float* g_saliency,
                              const float* g_txt_mem, const float* g_vid_mem, long long g_vid_sb, long long g_vid_st,
                              const float* g_vrow, const long long* pos_idx,
-                             float* grads, void* workspace, uvtg_stream_t stream, void* const* ready_events, int n_events) {
+                             float* grads, void* workspace, uvtg_stream_t stream, void* const* ready_events, int n_events,
+                             const int* lens_host) {
   if (int e = check_dims(dm)) return e;
   if (dm->E > MAXE) return -17;
   if (dm->precise || !dm->training) return -6;
@@ -591,7 +629,11 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   Dm m(*dm);
   WCache w(m, (void*)wcache);
   WSpace ws(m, workspace, (float*)x0);
-  const int d = m.c.d, F = m.c.F, M = m.M, S = m.S, Lv = m.c.Lv, B = m.c.B, E = m.c.E;
+  const int d = m.c.d, F = m.c.F, S = m.S, Lv = m.c.Lv, B = m.c.B, E = m.c.E;
+  // packed (ragged) encoder stream: must match the forward call (same lens_host); the tables are still in the workspace
+  const bool packed = lens_host != nullptr;
+  int M = m.M;
+  if (packed) TRY(packed_rows(m, lens_host, &M));
   long long off[PER_LAYER * MAXE + N_TAIL + 1];
   { long long o = 0; for (int i = 0; i < m.np; i++) { off[i] = o; o += (pnumel(m, i) + 3) / 4 * 4; } off[m.np] = o; }
   auto G = [&](int idx) { return grads + off[idx]; };
@@ -659,17 +701,22 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // The gradient stream is bf16 (like the activation stream): gin = gradient wrt the layer output; dyB = LayerNorm input
   // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
   const bf16_t* gin = nullptr;                  // null = zero
+  if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, ws.g2p, s));   // conv-head gradient onto the packed rows
+  const int* row_sample = packed ? ws.pk.row_sample : nullptr;
   for (int l = E - 1; l >= 0; l--) {
+    const bf16_t* xb_in = (packed && l == 0) ? ws.xb0p : (const bf16_t*)ws.xb[l];
+    const bf16_t* ub_in = (packed && l == 0) ? ws.ub0p : (const bf16_t*)ws.ub[l];
     const bool last = l == E - 1;
     const float* dp_attn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l) * B : nullptr;
     const float* dp_ffn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l + 1) * B : nullptr;
     const bf16_t* dyRes = dp_ffn ? ws.dyR : ws.dyB;
     LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
     lb.gB = gin; lb.ldgB = d;
-    if (last) { lb.g2B = ws.dvmB; lb.ldg2B = d; lb.g2_S = S; lb.g2_Lv = Lv; }
+    if (last && packed) { lb.g2B = ws.g2p; lb.ldg2B = d; }
+    else if (last) { lb.g2B = ws.dvmB; lb.ldg2B = d; lb.g2_S = S; lb.g2_Lv = Lv; }
     lb.xB = ws.y2b[l]; lb.ldxB = d; lb.mean = ws.mean2[l]; lb.rstd = ws.rstd2[l]; lb.gamma = P[m.lay(l, N2W)];
     lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
-    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S;
+    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S; lb.row_sample = row_sample;
     if (dp_ffn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
@@ -684,7 +731,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     memset(&lb, 0, sizeof(lb));
     lb.gB = ws.gxb[0]; lb.ldgB = d; lb.xB = ws.y1b[l]; lb.ldxB = d; lb.mean = ws.mean1[l]; lb.rstd = ws.rstd1[l];
     lb.gamma = P[m.lay(l, N1W)]; lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
-    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S;
+    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S; lb.row_sample = row_sample;
     if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
@@ -693,12 +740,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     g.outB = ws.dOb; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
     AttnArgs at; memset(&at, 0, sizeof(at));
-    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = ws.kvalid;
+    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
+    if (packed) { at.seq_start = ws.pk.seq_start; at.seq_count = ws.pk.seq_count; at.row_sample = ws.pk.row_sample; at.total_rows = M; }
     at.B = B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = m.c.p_attn; at.seed = m.c.seed; at.layer = l;
     at.dO = ws.dOb; at.lddo = d; at.delta = ws.delta; at.dqkv = ws.dqkv; at.lddqkv = 3 * d; at.qscale = 1.0f / sqrtf((float)m.hd);
     TRY(launch_attn_bwd(at, s));
-    TRY(wgrad(ws.dqkv, 3 * d, (const bf16_t*)ws.ub[l], d, M, 2 * d, d, G(m.lay(l, IPW)), d, 1, G(m.lay(l, IPB)), 0, M, splits_M));
-    TRY(wgrad(ws.dqkv + 2 * d, 3 * d, (const bf16_t*)ws.xb[l], d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, 1,
+    TRY(wgrad(ws.dqkv, 3 * d, ub_in, d, M, 2 * d, d, G(m.lay(l, IPW)), d, 1, G(m.lay(l, IPB)), 0, M, splits_M));
+    TRY(wgrad(ws.dqkv + 2 * d, 3 * d, xb_in, d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, 1,
               G(m.lay(l, IPB)) + 2 * d, 0, M, splits_M));
     g = gemm_base(ws.dqkv, 3 * d, w.wqkvT[l], 3 * d, M, d, 3 * d);     // dx = dqkv Wqkv + dy1
     g.residB = dp_attn ? ws.dyR : ws.dyB; g.ldrB = d; g.outB = ws.gxb[1]; g.ldoB = d;
@@ -710,6 +758,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // ---------------- saliency branch ----------------
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
   sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0B = dx0; sa.dw_pool = G(m.tail(POOL));
+  if (packed) sa.dx0_map = ws.pk.grad_map;
   sa.dq = ws.sal_dq; sa.dlog = ws.sal_dlog; sa.out_vid = ws.dyP[0]; sa.out_txt = ws.dyP[1];
   TRY(launch_saliency_bwd(sa, s));
   // ---------------- input projections ----------------

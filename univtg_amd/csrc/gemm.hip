@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       if (p.actgrad == 1) { v[0] = q0 > 0.f ? v[0] : 0.f; v[1] = q1 > 0.f ? v[1] : 0.f; v[2] = q2 > 0.f ? v[2] : 0.f; v[3] = q3 > 0.f ? v[3] : 0.f; }
       else { v[0] *= gelu_erf_grad(q0); v[1] *= gelu_erf_grad(q1); v[2] *= gelu_erf_grad(q2); v[3] *= gelu_erf_grad(q3); }
     }
-    if (p.rowscale) v *= p.rowscale[m / p.rs_seg];
+    if (p.rowscale) v *= p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg];
     if (p.resid) { const f32x4 t = *(const f32x4*)(p.resid + orow * p.ldr + n); v += t; }
     if (p.residB) {
       const u32x2 t = *(const u32x2*)(p.residB + orow * p.ldrB + n);
@@ -235,13 +235,15 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 // GATHER: row gather / scatter / conv taps / groups present (integer divisions per row); the plain variant has none.
-template <bool GATHER>
+// TM: 32-row fragments per wave along M -> tile height BM = 64 TM (256 / 192 / 128): the launcher picks the height that
+// wastes the fewest CU-rounds for the launch's tile count (ragged batches give awkward row counts).
+template <bool GATHER, int TM>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
-  constexpr int TB = 256, KB = 64, TM = 4, TN = 2;
+  constexpr int TB = 256, KB = 64, TN = 2, BM = 64 * TM;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
-  const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + TB - 1) / TB;
+  const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + BM - 1) / BM;
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
   const int nk = p.K / KB;
@@ -251,22 +253,27 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
     int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     gz = l / per_group; l -= gz * per_group;
-    m0 = (l / tiles_n) * TB; n0 = (l % tiles_n) * TB;
+    m0 = (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
   };
-  unsigned aofs[4], bofs[4];     // byte offsets of this lane's 8 staging pieces for the tile being loaded
+  unsigned aofs[TM], bofs[4];    // byte offsets of this lane's TM + 4 staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
   auto set_offsets = [&](int gz, int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      const int r = (wave * TM + i) * 8 + sr;
+      const int c = (sc ^ ((r >> 1) & 7)) * 8;
+      const int am = GATHER ? map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off) : min(m0 + r, p.M - 1);
+      aofs[i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = (wave * 4 + i) * 8 + sr;
       const int c = (sc ^ ((r >> 1) & 7)) * 8;
-      const int am = GATHER ? map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off) : min(m0 + r, p.M - 1);
-      aofs[i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
       bofs[i] = (unsigned)(((size_t)min(n0 + r, p.N - 1) * p.ldb + c + (size_t)gz * p.gB) * 2);
     }
   };
   int s_tap = 0, s_kk = 0;        // conv tap / column within the tap of the K tile staged next (GATHER only)
   auto stage = [&](int s, int kt) {
-    unsigned char* base = smem256 + s * 65536 + wave * 4096;
+    unsigned char* base = smem256 + s * 65536;
     const int k0 = kt * KB;
     unsigned ka = (unsigned)k0 * 2u;
     const unsigned kb = (unsigned)k0 * 2u;
@@ -277,15 +284,16 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
       if (s_kk >= p.ktap) { s_kk = 0; s_tap++; }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.A + (aofs[i] + ka)), (lds_void_t*)(base + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i] + kb)), (lds_void_t*)(base + 32768 + i * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < TM; i++)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.A + (aofs[i] + ka)), (lds_void_t*)(base + (wave * TM + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i] + kb)), (lds_void_t*)(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
   };
   int aoff[TM], boff[TN];
   const int swz = (l31 >> 1) & 7;           // identical for every 32-row fragment of the wave
 #pragma unroll
-  for (int i = 0; i < TM; i++) aoff[i] = (wm * 128 + i * 32 + l31) * 128;
+  for (int i = 0; i < TM; i++) aoff[i] = (wm * (32 * TM) + i * 32 + l31) * 128;
 #pragma unroll
   for (int j = 0; j < TN; j++) boff[j] = 32768 + (wn * 64 + j * 32 + l31) * 128;
 
@@ -336,8 +344,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int ks = 0; ks < 3; ks++) {
 #pragma unroll
-        for (int n = 0; n < TM + TN; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+        for (int n = 0; n < (TM + TN < TM * TN ? TM + TN : TM * TN); n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        if (TM * TN > TM + TN) __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+        if (TM * TN < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN - TM * TN, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma unroll 1
         for (int q = 0; q < 4; q++) {
           const int row = q * 8 + (lane >> 3);
-          const int m = m0 + wm * 128 + i * 32 + row;
+          const int m = m0 + wm * (32 * TM) + i * 32 + row;
           const f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
           if (m >= p.M || !ncol) continue;
           float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
             }
           }
           if (p.rowscale) {
-            const float rs = p.rowscale[m / p.rs_seg];
+            const float rs = p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg];
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] *= rs;
           }
@@ -774,6 +783,8 @@ static int check_nt(const GemmArgs& a, int elem) {
 // eligibility of the 256-tile path: whole 64-wide K tiles (also per conv tap), 16-byte rows everywhere the epilogue
 // touches 8 columns at a time, 32-bit byte offsets, and enough work that 256 x 256 tiles do not waste the chip
 static int g_force_tile = 0;   // 0: automatic, 128 / 256: force that NT tile size where it is legal (parity tests)
+static int g_force_bm = 0;     // 0: automatic, 128 / 192 / 256: force the tile height of the 256-wide persistent kernel
+extern "C" int uvtg_debug_force_nt_bm(int bm) { if (bm != 0 && bm != 128 && bm != 192 && bm != 256) return -21; g_force_bm = bm; return 0; }
 extern "C" int uvtg_debug_force_nt_tile(int tile) { if (tile != 0 && tile != 128 && tile != 256) return -21; g_force_tile = tile; return 0; }
 static bool nt256_ok(const GemmArgs& a) {
   if (g_force_tile == 128) return false;
@@ -792,26 +803,42 @@ static bool nt256_ok(const GemmArgs& a) {
   return amax * 2 < (1LL << 32) && bmax * 2 < (1LL << 32);
 }
 static int g_num_cu = 0;
-static int launch_nt256(const GemmArgs& a, hipStream_t s) {
+template <int TM> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    attr = true;
+  }
+  if (gather) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM>), dim3(grid), dim3(512), 131072, s, b);
+  else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM>), dim3(grid), dim3(512), 131072, s, b);
+  return 0;
+}
+static int launch_nt256(const GemmArgs& a, hipStream_t s) {
+  if (!g_num_cu) {
     int dev = 0; hipDeviceProp_t pr;
     if (hipError_t e = hipGetDevice(&dev)) return (int)e;
     if (hipError_t e = hipGetDeviceProperties(&pr, dev)) return (int)e;
     g_num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    attr = true;
   }
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
-  const int tiles = cdiv(b.M, 256) * cdiv(b.N, 256) * b.groups;
+  // tile height: whole rounds of one tile per CU cost rounds x BM; the 192- and 128-row tiles run the same loop a little less
+  // efficiently per row (more B traffic per MFMA), hence the small penalties
+  int best_tm = 4; double best = 1e30;
+  for (int tm = 4; tm >= 2; tm--) {
+    const long long tiles = (long long)cdiv(b.M, 64 * tm) * cdiv(b.N, 256) * b.groups;
+    const double cost = (double)((tiles + g_num_cu - 1) / g_num_cu) * (64.0 * tm) * (tm == 4 ? 1.0 : (tm == 3 ? 1.04 : 1.10));
+    if (cost < best) { best = cost; best_tm = tm; }
+  }
+  if (g_force_bm) best_tm = g_force_bm / 64;
+  const int tiles = cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
   const int grid = tiles < g_num_cu ? tiles : g_num_cu;
-  uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1;
-  if (gather) hipLaunchKernelGGL(gemm_nt256_kernel<true>, dim3(grid), dim3(512), 131072, s, b);
-  else hipLaunchKernelGGL(gemm_nt256_kernel<false>, dim3(grid), dim3(512), 131072, s, b);
+  uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
+  int rc = best_tm == 4 ? launch_nt256_tm<4>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3>(b, grid, gather, s) : launch_nt256_tm<2>(b, grid, gather, s));
   uvtg_prof_end_launch(3, s);
+  if (rc) return rc;
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -147,6 +147,87 @@ __global__ __launch_bounds__(256) void conv_w_multi_kernel(const ConvWOps ops) {
   }
 }
 
+// ---------------- packed (ragged) encoder stream ----------------
+// Every padded clip of a sample enters the encoder with the same value (LN(0) projected + type embedding, and the sine PE
+// is constant beyond the last valid clip), is masked as a key, and only ever acts as a query.  Its encoder output is
+// therefore identical for all padded clips of the sample, and -- backward being linear in the upstream gradient -- the sum of
+// their gradients equals the gradient of ONE such row fed with the summed upstream gradient.  Padded text tokens influence
+// nothing (masked keys, outputs never read).  So the encoder runs on: the valid clips, one representative padded clip (when
+// the sample is shorter than the batch), the valid text tokens -- exactly the reference's results with ~25 % fewer rows on
+// ragged batches.  Row order inside a sample: valid clips, representative, valid text.
+__global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B, int Lv, int Lt, PackTables t) {
+  const int b = blockIdx.x, S = Lv + Lt;
+  __shared__ int s_start;
+  if (threadIdx.x == 0) {
+    int st = 0;
+    for (int i = 0; i < b; i++) { const int lv = lens[i], lt = lens[B + i]; st += lv + (lv < Lv ? 1 : 0) + lt; }
+    s_start = st;
+  }
+  __syncthreads();
+  const int lv = lens[b], lt = lens[B + b], rep = lv < Lv ? 1 : 0, n = lv + rep + lt, st = s_start;
+  if (threadIdx.x == 0) { t.seq_start[b] = st; t.seq_count[b] = n; }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = st + i;
+    int ps;                                            // position in the padded layout
+    if (i < lv) ps = i; else if (i < lv + rep) ps = lv; else ps = Lv + (i - lv - rep);
+    t.row_sample[r] = b;
+    t.row_src[r] = b * S + ps;
+    t.row_pos[r] = ps < Lv ? b * Lv + ps : -1;
+    t.kvalid[r] = (i >= lv && i < lv + rep) ? 0 : 1;   // the representative is a padded position: never a key
+  }
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    int pk, gm;
+    if (s < lv) { pk = st + s; gm = pk; }
+    else if (s < Lv) { pk = st + lv; gm = (s == lv) ? pk : -1; }      // padded clip -> representative; its gradient on the first one
+    else if (s - Lv < lt) { pk = st + lv + rep + (s - Lv); gm = pk; }
+    else { pk = -1; gm = -1; }
+    t.pad2pack[b * S + s] = pk; t.grad_map[b * S + s] = gm;
+  }
+}
+// gather rows of the padded bf16 operands into the packed order (both x and x + pos)
+__global__ __launch_bounds__(256) void pack_rows_kernel(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= Mp) return;
+  const size_t src = (size_t)row_src[r] * d, dst = (size_t)r * d;
+  for (int c = lane * 8; c < d; c += 512) {
+    *(u32x4*)(xbp + dst + c) = *(const u32x4*)(xb + src + c);
+    *(u32x4*)(ubp + dst + c) = *(const u32x4*)(ub + src + c);
+  }
+}
+// encoder output (packed) -> zero-framed conv input: every clip position of the padded layout, padded clips from the representative
+__global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, s) over B * Lv
+  if (row >= B * Lv) return;
+  const int b = row / Lv, s = row % Lv;
+  const size_t src = (size_t)pad2pack[b * S + s] * d, dst = (size_t)(b * (Lv + 2) + s + 1) * d;
+  for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + dst + c) = *(const u32x4*)(packed + src + c);
+}
+// conv-head gradient wrt the clip rows (padded layout) -> packed rows: valid clips copy, the representative gets the SUM over the
+// sample's padded clips, text rows zero
+__global__ __launch_bounds__(256) void pack_reduce_dvm_kernel(const bf16_t* dvm, PackTables t, int B, int S, int Lv, int Mp, int d, bf16_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= Mp) return;
+  const int b = t.row_sample[r], src = t.row_src[r], ps = src - b * S;
+  bf16_t* o = out + (size_t)r * d;
+  const bool rep = t.kvalid[r] == 0;
+  for (int c = lane * 8; c < d; c += 512) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ps < Lv) {
+      const int s1 = rep ? Lv : ps + 1;
+      for (int sv = ps; sv < s1; sv++) {
+        const u32x4 v = *(const u32x4*)(dvm + (size_t)(b * Lv + sv) * d + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { acc[2 * e] += __uint_as_float(v[e] << 16); acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+      }
+    }
+    u32x4 w; w[0] = pack_bf2(acc[0], acc[1]); w[1] = pack_bf2(acc[2], acc[3]); w[2] = pack_bf2(acc[4], acc[5]); w[3] = pack_bf2(acc[6], acc[7]);
+    *(u32x4*)(o + c) = w;
+  }
+}
+
 // ---------------- heads: last conv layer + activations ----------------
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
@@ -487,9 +568,11 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
   for (int srow = chunk * 32 + wave; srow < s_end; srow += 4) {
     const size_t row = (size_t)b * a.S + srow;
     const float* x = a.x0 + row * d;
-    const float* g0 = a.dx0 ? a.dx0 + row * d : nullptr;
-    const bf16_t* g0b = a.dx0 ? nullptr : a.dx0B + row * d;
+    const long long grow = a.dx0_map ? (long long)a.dx0_map[row] : (long long)row;      // row of the (possibly packed) encoder gradient
+    const float* g0 = a.dx0 ? a.dx0 + grow * d : nullptr;
+    const bf16_t* g0b = a.dx0 ? nullptr : a.dx0B + grow * d;
     auto ldg = [&](int c) -> f32x4 {
+      if (grow < 0) return (f32x4){0.f, 0.f, 0.f, 0.f};
       if (g0) return *(const f32x4*)(g0 + c);
       const u32x2 t = *(const u32x2*)(g0b + c);
       return (f32x4){__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u), __uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
@@ -549,9 +632,10 @@ __global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const Salien
   const float qn = fmaxf(a.qnorm[b], 1e-8f);
   const int prow = (a.g_vrow && a.pos_idx) ? (int)a.pos_idx[b] : -1;
   const float* x = a.x0 + (size_t)row * d;
-  const float* g0f = a.dx0 ? a.dx0 + (size_t)row * d : nullptr;
-  const bf16_t* g0b = a.dx0 ? nullptr : a.dx0B + (size_t)row * d;
-  auto g0 = [&](int c) -> float { return g0f ? g0f[c] : bf2f(g0b[c]); };
+  const long long grow = a.dx0_map ? (long long)a.dx0_map[row] : row;
+  const float* g0f = a.dx0 ? a.dx0 + grow * d : nullptr;
+  const bf16_t* g0b = a.dx0 ? nullptr : a.dx0B + grow * d;
+  auto g0 = [&](int c) -> float { return grow < 0 ? 0.f : (g0f ? g0f[c] : bf2f(g0b[c])); };
   if (srow < a.Lv) {
     const int t = srow;
     const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
@@ -577,6 +661,29 @@ __global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const Salien
 
 }  // namespace
 
+int launch_pack_tables(const int* lens_dev, int B, int Lv, int Lt, const PackTables& t, hipStream_t s) {
+  hipLaunchKernelGGL(pack_tables_kernel, dim3(B), dim3(128), 0, s, lens_dev, B, Lv, Lt, t);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp, hipStream_t s) {
+  if (d % 8) return -2;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(cdiv(Mp, 4)), dim3(256), 0, s, xb, ub, row_src, Mp, d, xbp, ubp);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_unpack_vm(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s) {
+  if (d % 8) return -2;
+  hipLaunchKernelGGL(unpack_vm_kernel, dim3(cdiv(B * Lv, 4)), dim3(256), 0, s, packed, pad2pack, B, S, Lv, d, vm_pad);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bf16_t* out, hipStream_t s) {
+  if (d % 8) return -2;
+  hipLaunchKernelGGL(pack_reduce_dvm_kernel, dim3(cdiv(Mp, 4)), dim3(256), 0, s, dvm, t, B, S, Lv, Mp, d, out);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
                     const float* dim_t, float* pos, unsigned char* kvalid, hipStream_t s) {
   hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid);

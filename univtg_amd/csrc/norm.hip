@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     // row classification for the positional / conv-frame copies
     int b = 0, s = 0;
     bool is_vid = false;
-    if (a.S > 0) { b = row / a.S; s = row - b * a.S; is_vid = s < a.Lv; }
+    if (a.S > 0 && !a.pos_row) { b = row / a.S; s = row - b * a.S; is_vid = s < a.Lv; }
     const float* posr = (a.pos && is_vid) ? a.pos + (size_t)(b * a.Lv + s) * D : nullptr;
+    if (a.pos_row) { const int pr = a.pos_row[row]; posr = (a.pos && pr >= 0) ? a.pos + (size_t)pr * D : nullptr; }
     const size_t prow = is_vid ? (size_t)(b * (a.Lv + 2) + s + 1) : 0;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512) void ln_bwd_kernel(const
       }
       const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
       if (!live) continue;
-      const float rs = a.rowscale ? a.rowscale[row / a.rs_seg] : 1.0f;
+      const float rs = a.rowscale ? a.rowscale[a.row_sample ? a.row_sample[row] : row / a.rs_seg] : 1.0f;
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         const int c = (i * 64 + lane) * VEC;

@@ -26,6 +26,7 @@ struct GemmArgs {
   int act;                 // 0 none, 1 relu, 2 gelu(erf)
   const bf16_t* gradPre; int ldgp; int actgrad;   // 1: zero where gradPre<=0 (relu'), 2: *= gelu'(gradPre)
   const float* rowscale; int rs_seg;  // per-sample factor rowscale[m / rs_seg] (DropPath)
+  const int* row_sample;              // packed rows: rowscale[row_sample[m]] instead
   const float* resid; int ldr;        // fp32 residual, indexed by the OUTPUT row
   const bf16_t* residB; int ldrB;     // bf16 residual (the bf16 activation stream of the fast mode), same indexing
   float* outF; int ldoF;              // fp32 output
@@ -73,6 +74,7 @@ struct LnFwdArgs {
   float* yF2; int ldyF2;        // fp32 GEMM operand with zero padding to Dpad (x3 path)
   // (y + pos) for rows that are video tokens: row -> (b = row / S, s = row % S), s < Lv
   const float* pos; int S, Lv;  // pos [B*Lv, D]
+  const int* pos_row;           // packed rows: row -> row of the pos table (or -1); replaces the (S, Lv) arithmetic, no yP / yPF
   bf16_t* yU; float* yUF; int ldyU;
   // copy of the video rows into the zero-framed conv layout [(b*(Lv+2) + s + 1), ldyP]
   bf16_t* yP; float* yPF; int ldyP;
@@ -95,6 +97,7 @@ struct LnBwdArgs {
   bf16_t* dxB; int lddxB;       // bf16 dx (optionally scaled per sample)
   bf16_t* dxB2; int lddxB2;     // bf16 dx, never scaled (the residual branch of the gradient stream)
   const float* rowscale; int rs_seg;
+  const int* row_sample;        // packed rows: rowscale[row_sample[row]]
   int relu_from_x;              // 1: dx is masked by (x > 0): x is the output of a ReLU (input projections)
   float* partial; long long partial_floats;   // optional scratch for per-block dgamma / dbeta partials (else atomics)
 };
@@ -109,6 +112,9 @@ struct AttnArgs {
   float* lse;                   // [B, H, S]
   const unsigned char* kvalid;  // [B, S] 1 = real key
   int B, S, H, hd;
+  // packed (ragged) batches: sample b owns rows seq_start[b] .. + seq_count[b] (<= S); lse / delta keep the stride S.
+  // row_sample [total_rows]: sample of each packed row (attn_delta).  All null: sample b owns rows b*S .. b*S + S.
+  const int* seq_start; const int* seq_count; const int* row_sample; int total_rows;
   float p_drop; unsigned long long seed; unsigned layer;
   int precise;
   // backward
@@ -123,6 +129,19 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 // small fused kernels (misc.hip)
 // ---------------------------------------------------------------------------------------------
+// ---- packed (ragged) execution of the encoder: valid rows of every sample + ONE representative padded clip per sample ----
+struct PackTables {
+  int* seq_start; int* seq_count;     // [B]
+  int* row_sample; int* row_src; int* row_pos;   // [Mp]: sample, padded-layout source row (b*S + s), pos-table row or -1
+  int* pad2pack;                      // [B*S]: token row -> packed row (padded clips -> the representative, padded text -> -1)
+  int* grad_map;                      // [B*S]: token row -> packed row carrying its gradient (valid rows, first padded clip), else -1
+  unsigned char* kvalid;              // [Mp]
+};
+int launch_pack_tables(const int* lens_dev /* [2B] */, int B, int Lv, int Lt, const PackTables& t, hipStream_t s);
+int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp, hipStream_t s);
+int launch_unpack_vm(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s);
+int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bf16_t* out, hipStream_t s);
+
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
                     const float* dim_t, float* pos, unsigned char* kvalid, hipStream_t s);
 int launch_droppath_scales(float* scales, int n_layers2, int B, float p, unsigned long long seed, hipStream_t s);
@@ -177,6 +196,7 @@ struct SaliencyArgs {             // weighted text pooling + cosine saliency (mo
   const float* g_vrow; const long long* pos_idx; // optional compact extra: g_vrow[b, :] is added on row pos_idx[b]
   const float* dx0;               // [B*S, d] encoder gradient wrt x0 (read only), fp32 ...
   const bf16_t* dx0B;             // ... or bf16 (used when dx0 == nullptr)
+  const int* dx0_map;             // packed encoder stream: token row (b*S + s) -> row of dx0 / dx0B, or -1 (no gradient)
   float* dq; float* dlog;         // scratch [B, d], [B, Lt]
   bf16_t* out_vid; bf16_t* out_txt;   // bf16 [B*Lv, d] / [B*Lt, d]: dx0 + saliency-branch gradients, re-packed per modality
   float* dw_pool;                 // [d] atomically accumulated

@@ -127,7 +127,7 @@ class _UniVTGFunction(torch.autograd.Function):
         memory = torch.empty(B, S, d, device=dev) if model.return_memory else None
         _lib.check(lib.uvtg_forward(C.byref(dims), ptrs, _ptr(wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                     _ptr(src_vid_mask), _ptr(model._dim_t(dev)), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans),
-                                    _ptr(txt_mem), _ptr(sal), _ptr(memory), _ptr(ws), _stream()), "uvtg_forward")
+                                    _ptr(txt_mem), _ptr(sal), _ptr(memory), _ptr(ws), _stream(), None), "uvtg_forward")
         ctx.model = None
         if training:
             ctx.model, ctx.dims, ctx.ws, ctx.wcache = model, dims, ws, wcache
@@ -149,7 +149,7 @@ class _UniVTGFunction(torch.autograd.Function):
         _lib.check(lib.uvtg_backward(C.byref(dims), ptrs, _ptr(ctx.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                      _ptr(src_vid_mask), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans), _ptr(txt_mem),
                                      _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d, None, None,
-                                     _ptr(grads), _ptr(ctx.ws), _stream(), None, 0), "uvtg_backward")
+                                     _ptr(grads), _ptr(ctx.ws), _stream(), None, 0, None), "uvtg_backward")
         ctx.ws = None
         out = [None] * 6
         for i, p in enumerate(params):

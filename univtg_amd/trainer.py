@@ -38,7 +38,7 @@ def flatten_parameters(model: Model) -> torch.Tensor:
 
 class TrainStep:
     def __init__(self, model: Model, criterion: SetCriterion, lr=1e-4, weight_decay=1e-4, grad_clip=0.1,
-                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64, overlap_comm=True):
+                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64, overlap_comm=True, packed="auto"):
         if model.precision != "bf16":
             raise RuntimeError("training uses precision='bf16'")
         self.lib = _lib.load()
@@ -69,6 +69,11 @@ class TrainStep:
         self.go = torch.tensor([wd.get(k, 0.0) for k in LOSS_KEYS], dtype=torch.float32, device=dev)
         self.which = (1 if "spans" in criterion.losses else 0) | (2 if "labels" in criterion.losses else 0) | \
                      (4 if "saliency" in criterion.losses else 0)
+        # packed (ragged) encoder stream (include/uvtg.h, lens_host): "auto" = when the batch carries the host-side lengths the
+        # collate already knows (inputs["_lens_host"] = (lens_v, lens_t)); True = always (lengths read back from the masks: one
+        # device->host sync per step); False = padded execution
+        self.packed = packed
+        self._lens_arr = None
         self._shape = None
         self.params = model._ordered_params()
         self.ptrs = model._param_ptrs(self.params)
@@ -106,10 +111,11 @@ class TrainStep:
         d = model.hidden_dim
         S = Lv + Lt
         chk = _lib.check
+        lens = self._host_lens(inputs, B)
         chk(lib.uvtg_prepare_weights(C.byref(dims), self.ptrs, _ptr(self.wcache), st), "uvtg_prepare_weights")
         chk(lib.uvtg_forward(C.byref(dims), self.ptrs, _ptr(self.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                              _ptr(src_vid_mask), _ptr(model._dim_t(src_vid.device)), _ptr(self.x0), _ptr(self.pred_logits),
-                             _ptr(self.pred_spans), _ptr(self.txt_mem), _ptr(self.sal), None, _ptr(self.ws), st), "uvtg_forward")
+                             _ptr(self.pred_spans), _ptr(self.txt_mem), _ptr(self.sal), None, _ptr(self.ws), st, lens), "uvtg_forward")
         tg = targets
         sal = tg.get("saliency_scores")
         pos = tg.get("_pos_idx")
@@ -126,7 +132,7 @@ class TrainStep:
                               _ptr(src_vid_mask), _ptr(self.x0), _ptr(self.pred_logits), _ptr(self.pred_spans), _ptr(self.txt_mem),
                               _ptr(self.g_logits), _ptr(self.g_spans), _ptr(self.g_cos), _ptr(self.g_txt), None, 0, 0,
                               _ptr(self.g_vrow), _ptr(pos), _ptr(self.grads), _ptr(self.ws), st,
-                              *self._event_args(dims)), "uvtg_backward")
+                              *self._event_args(dims), lens), "uvtg_backward")
         if self.world > 1 or self.overlap:
             self._exchange_gradients(dims)
         if optimize:
@@ -136,6 +142,22 @@ class TrainStep:
                                          1.0 / self.world, _ptr(self.scratch), st), "uvtg_adamw_clip_step")
         return self.losses[:5]
 
+
+    def _host_lens(self, inputs, B):
+        """ctypes int[2B] (clips then text tokens per sample) for the packed encoder stream, or None for padded execution."""
+        if self.packed is False:
+            return None
+        lens = inputs.get("_lens_host")
+        if lens is None:
+            if self.packed != True:      # noqa: E712  ("auto": only with caller-provided lengths)
+                return None
+            lens = torch.stack([inputs["src_vid_mask"].sum(1), inputs["src_txt_mask"].sum(1)]).to(torch.int32).cpu()   # sync
+        lv, lt = lens[0], lens[1]
+        vals = [int(x) for x in lv] + [int(x) for x in lt]
+        if len(vals) != 2 * B:
+            raise ValueError("_lens_host must hold B clip counts and B token counts")
+        self._lens_arr = (C.c_int * (2 * B))(*vals)     # kept alive: the engine copies it to the device asynchronously
+        return self._lens_arr
 
     # ---- data-parallel gradient exchange -------------------------------------------------------------------------
     def bucket_ranges(self, dims):
