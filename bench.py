@@ -202,7 +202,8 @@ def main():
                                         "H=8 E=4, full train step (fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1",
                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
                    samples_per_sec=round(B * world * args.steps / elapsed, 1),
-                   encoder_mfma_frac_of_step=round(enc_flops / (elapsed / args.steps) / 2.5e15, 4),
+                   encoder_mfma_frac_of_step=round(enc_flops / (elapsed / args.steps) / 2.5e15, 4),      # reference-algorithmic (padded) encoder FLOPs / step time / peak
+                   packed_rows_fraction=round(sum(sum(a) + sum(b) + sum(1 for x in a if x < Lv) for a, b in (bt[0]["_lens_host"] for bt in batches)) / (len(batches) * B * (Lv + Lt)), 4),
                    losses=[round(x, 5) for x in losses], roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:

@@ -533,3 +533,28 @@ def test_packed_ragged_stream_matches_padded(dev, B, Lv, Lt, d, H, E):
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         ratio = float(b.norm() / a.norm())
         assert cos > 0.999 and abs(ratio - 1) < 1e-2, (names[id(p)], cos, ratio)
+
+
+def test_drop_in_model_packed_option(dev):
+    """build_model(args with packed=True): the autograd path runs the packed stream (lengths read back from the masks) and matches
+    the padded autograd path."""
+    from oracle import univtg_oracle as O
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                     input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=51)
+    inputs, tg = O.make_batch(cfg, 5, 40, 12, seed=52, ragged=True)
+    ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    grads, outs = [], []
+    for packed in (False, True):
+        from univtg_amd.model import build_model
+        model, crit = build_model(args_from_cfg(cfg, precision="bf16", proj_precise=True, packed=packed))
+        model.load_state_dict(params, strict=True)
+        model.to(dev).eval(); crit.to(dev)
+        out = model(**ind)
+        ld = crit(out, tgd)
+        sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
+        grads.append(torch.cat([p.grad.flatten() for p in model._ordered_params()]).double())
+        outs.append(out["pred_logits"].detach())
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-2
+    cos = float((grads[0] @ grads[1]) / (grads[0].norm() * grads[1].norm()))
+    assert cos > 0.999 and abs(float(grads[1].norm() / grads[0].norm()) - 1) < 1e-2, cos

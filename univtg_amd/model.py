@@ -117,6 +117,12 @@ class _UniVTGFunction(torch.autograd.Function):
         dims = model._dims(B, Lv, Lt, Dv, Dt, training)
         ptrs = model._param_ptrs(params)
         wcache = model._prepare(dims, ptrs, params)
+        lens = None
+        if model.packed and model.precision == "bf16" and not model.return_memory:
+            # packed (ragged) encoder stream: the valid lengths come back from the masks (one device->host sync; the reference's
+            # own loop synchronises every step too, main/train_vlp_ddp.py:71-73)
+            hl = torch.stack([src_vid_mask.sum(1), src_txt_mask.sum(1)]).to(torch.int32).cpu().reshape(-1).tolist()
+            lens = (C.c_int * (2 * B))(*hl)
         S, d = Lv + Lt, dims.d
         ws = torch.empty(lib.uvtg_workspace_bytes(C.byref(dims)), dtype=torch.uint8, device=dev)
         x0 = torch.empty(B, S, d, device=dev)
@@ -127,10 +133,10 @@ class _UniVTGFunction(torch.autograd.Function):
         memory = torch.empty(B, S, d, device=dev) if model.return_memory else None
         _lib.check(lib.uvtg_forward(C.byref(dims), ptrs, _ptr(wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                     _ptr(src_vid_mask), _ptr(model._dim_t(dev)), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans),
-                                    _ptr(txt_mem), _ptr(sal), _ptr(memory), _ptr(ws), _stream(), None), "uvtg_forward")
+                                    _ptr(txt_mem), _ptr(sal), _ptr(memory), _ptr(ws), _stream(), lens), "uvtg_forward")
         ctx.model = None
         if training:
-            ctx.model, ctx.dims, ctx.ws, ctx.wcache = model, dims, ws, wcache
+            ctx.model, ctx.dims, ctx.ws, ctx.wcache, ctx.lens = model, dims, ws, wcache, lens
             ctx.save_for_backward(src_txt, src_txt_mask, src_vid, src_vid_mask, x0, pred_logits, pred_spans, txt_mem, *params)
         ctx.mark_non_differentiable(*([memory] if memory is not None else []))
         outs = (x0, pred_logits, pred_spans, txt_mem, sal)
@@ -149,7 +155,7 @@ class _UniVTGFunction(torch.autograd.Function):
         _lib.check(lib.uvtg_backward(C.byref(dims), ptrs, _ptr(ctx.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                      _ptr(src_vid_mask), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans), _ptr(txt_mem),
                                      _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d, None, None,
-                                     _ptr(grads), _ptr(ctx.ws), _stream(), None, 0, None), "uvtg_backward")
+                                     _ptr(grads), _ptr(ctx.ws), _stream(), None, 0, ctx.lens), "uvtg_backward")
         ctx.ws = None
         out = [None] * 6
         for i, p in enumerate(params):
@@ -163,7 +169,7 @@ class Model(nn.Module):
 
     def __init__(self, hidden_dim, nheads, dim_feedforward, enc_layers, txt_dim, vid_dim, input_dropout, dropout=0.1,
                  droppath=0.1, max_q_l=75, max_v_l=75, span_loss_type="l1", use_txt_pos=False, n_input_proj=2,
-                 precision="bf16", proj_precise="auto"):
+                 precision="bf16", proj_precise="auto", packed=False):
         super().__init__()
         if span_loss_type != "l1":
             raise NotImplementedError("span_loss_type='ce' is not implemented by the reference forward either (univtg.py:137-138)")
@@ -184,6 +190,9 @@ class Model(nn.Module):
         if proj_precise not in (True, False, "auto"):
             raise ValueError("proj_precise must be True, False or 'auto'")
         self.precision, self.proj_precise, self.return_memory = precision, proj_precise, False
+        # packed=True: run the encoder on the valid rows only (+ one representative padded clip per sample) -- identical results,
+        # fewer rows on ragged batches; costs one device->host read of the mask sums per call (see include/uvtg.h, lens_host)
+        self.packed = bool(packed)
         # ---- parameters, registered in the reference's order / names ----
         self.transformer = _encoder_bag(d, dim_feedforward, enc_layers)
         self.txt_position_embed = _Bag()                                    # unused unless use_txt_pos (kept for ckpt parity)
@@ -421,7 +430,7 @@ def build_model(args):
                   input_dropout=args.input_dropout, dropout=args.dropout, droppath=args.droppath,
                   max_q_l=args.max_q_l, max_v_l=getattr(args, "max_v_l", 75), span_loss_type=args.span_loss_type,
                   use_txt_pos=args.use_txt_pos, n_input_proj=args.n_input_proj,
-                  precision=getattr(args, "precision", "bf16"), proj_precise=getattr(args, "proj_precise", "auto"))
+                  precision=getattr(args, "precision", "bf16"), proj_precise=getattr(args, "proj_precise", "auto"), packed=getattr(args, "packed", False))
     if getattr(args, "pre_norm", False):
         raise NotImplementedError("--pre_norm crashes in the reference too (forward_pre is undefined, droppath.py:133)")
     matcher = build_matcher(args)
