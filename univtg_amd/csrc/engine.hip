@@ -200,6 +200,7 @@ struct WSpace {
         const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d}, {m.Rp, (int)d, 3 * (int)d},
                                  {m.Mv, (int)d, (int)d}, {m.Mt, (int)d, (int)d}, {m.Mv, (int)d, m.c.Dv}, {m.Mt, (int)d, m.c.Dt}};
         for (auto& sh : shapes) { const long long f = gemm_tn_scratch_floats(sh[0], sh[1], sh[2]); if (f > need) need = f; }
+        { const long long grouped = 320LL * 65536 + 64LL * 8 * (2 * (long long)d + (long long)F + 256); if (grouped > need) need = grouped; }   // grouped launches: <= ~1 unit per CU + bias partials
         tn_scratch_floats = need; tn_scratch = a.take<float>((size_t)need);
       }
       dh2_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d); dh1_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d);
@@ -648,6 +649,19 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     return launch_gemm_tn_bf16(t, s);
   };
 
+  // several weight gradients over the same rows in one launch (more tiles per launch -> fewer M splits -> less partial traffic)
+  auto tn_group = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, float* dbias) {
+    GemmTNArgs t; memset(&t, 0, sizeof(t));
+    t.P = Pm; t.ldp = ldp; t.Q = Q; t.ldq = ldq; t.M = rows; t.N = N; t.K = K; t.Mq = rows;
+    t.out = out; t.ldo = ldo; t.col_stride = 1; t.dbias = dbias; t.splits = splits_M;
+    t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
+    return t;
+  };
+  auto tn_batch = [&](const GemmTNBatch& b) -> int {
+    if (gemm_tn_batch_ok(b)) return launch_gemm_tn_batch(b, s);
+    for (int i = 0; i < b.count; i++) TRY(launch_gemm_tn_bf16(b.g[i], s));      // small / odd shapes: one launch each
+    return 0;
+  };
   // weight gradient of one Conv1d(k=3): dW[n][c][tap] = sum_rows dY[row][n] * X[row + tap - 1][c] over the zero-framed rows.
   // One launch over K = 3 d (the k tiles pick their tap's row offset) when the 256-tile kernel takes it, else one per tap.
   auto conv_wgrad = [&](const bf16_t* dY, int ldp, const bf16_t* X, int ldq, float* dW, float* dBi) -> int {
@@ -720,11 +734,15 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     if (dp_ffn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
-    TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, 1, G(m.lay(l, L2B)), 0, M, splits_M));
     GemmArgs g = gemm_base(ws.dyB, d, w.w2T[l], d, M, F, d);          // d h = dy2 W2 ; da = dh * gelu'(a)
     g.gradPre = ws.apre[l]; g.ldgp = F; g.actgrad = 2; g.outB = ws.da; g.ldoB = F;
     TRY(launch_gemm_nt_bf16(g, s));
-    TRY(wgrad(ws.da, F, (const bf16_t*)ws.x1b[l], d, M, F, d, G(m.lay(l, L1W)), d, 1, G(m.lay(l, L1B)), 0, M, splits_M));
+    {   // FFN weight gradients, one launch: dW2 = dy2^T h, dW1 = da^T x1
+      GemmTNBatch tb; tb.count = 2;
+      tb.g[0] = tn_group(ws.dyB, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, G(m.lay(l, L2B)));
+      tb.g[1] = tn_group(ws.da, F, (const bf16_t*)ws.x1b[l], d, M, F, d, G(m.lay(l, L1W)), d, G(m.lay(l, L1B)));
+      TRY(tn_batch(tb));
+    }
     g = gemm_base(ws.da, F, w.w1T[l], F, M, d, F);                     // dx1 = da W1 + dy2
     g.residB = dyRes; g.ldrB = d; g.outB = ws.gxb[0]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
@@ -735,7 +753,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
-    TRY(wgrad(ws.dyB, d, (const bf16_t*)ws.o[l], d, M, d, d, G(m.lay(l, OPW)), d, 1, G(m.lay(l, OPB)), 0, M, splits_M));
     g = gemm_base(ws.dyB, d, w.woT[l], d, M, d, d);                    // dO = dy1 Wo
     g.outB = ws.dOb; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
@@ -745,9 +762,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     at.B = B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = m.c.p_attn; at.seed = m.c.seed; at.layer = l;
     at.dO = ws.dOb; at.lddo = d; at.delta = ws.delta; at.dqkv = ws.dqkv; at.lddqkv = 3 * d; at.qscale = 1.0f / sqrtf((float)m.hd);
     TRY(launch_attn_bwd(at, s));
-    TRY(wgrad(ws.dqkv, 3 * d, ub_in, d, M, 2 * d, d, G(m.lay(l, IPW)), d, 1, G(m.lay(l, IPB)), 0, M, splits_M));
-    TRY(wgrad(ws.dqkv + 2 * d, 3 * d, xb_in, d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, 1,
-              G(m.lay(l, IPB)) + 2 * d, 0, M, splits_M));
+    {   // attention-block weight gradients, one launch: dWo = dy1^T o, dWq|dWk = dqk^T (x + pos), dWv = dv^T x
+      GemmTNBatch tb; tb.count = 3;
+      tb.g[0] = tn_group(ws.dyB, d, (const bf16_t*)ws.o[l], d, M, d, d, G(m.lay(l, OPW)), d, G(m.lay(l, OPB)));
+      tb.g[1] = tn_group(ws.dqkv, 3 * d, ub_in, d, M, 2 * d, d, G(m.lay(l, IPW)), d, G(m.lay(l, IPB)));
+      tb.g[2] = tn_group(ws.dqkv + 2 * d, 3 * d, xb_in, d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, G(m.lay(l, IPB)) + 2 * d);
+      TRY(tn_batch(tb));
+    }
     g = gemm_base(ws.dqkv, 3 * d, w.wqkvT[l], 3 * d, M, d, 3 * d);     // dx = dqkv Wqkv + dy1
     g.residB = dp_attn ? ws.dyR : ws.dyB; g.ldrB = d; g.outB = ws.gxb[1]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));

@@ -582,18 +582,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs p) {
 // atomics as in MFMAs), so every (tile, split) unit writes its partial tile as a plain fp32 slab and
 // gemm_tn_reduce_kernel folds the slabs (and the bias-gradient partials) into the gradient buffer.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int splits, int steps_per, int tiles_n, int tiles_k,
-                                                         unsigned bytes_p, unsigned bytes_q, int n_pad) {
+struct TNPlan {              // per-launch plan of the grouped 256-tile weight-gradient kernel (host-computed, passed by value)
+  GemmTNArgs g[UVTG_TN_MAX_GROUPS];
+  int tiles_k[UVTG_TN_MAX_GROUPS], tile_base[UVTG_TN_MAX_GROUPS + 1], n_pad[UVTG_TN_MAX_GROUPS];
+  unsigned bytes_p[UVTG_TN_MAX_GROUPS], bytes_q[UVTG_TN_MAX_GROUPS];
+  long long bias_base[UVTG_TN_MAX_GROUPS];      // float offset of the group's bias partials in scratch
+  int count, splits, steps_per, total_tiles;
+  float* scratch;
+};
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31, i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int tiles = tiles_n * tiles_k, units = gridDim.x;
+  const int tiles = plan.total_tiles, units = gridDim.x, splits = plan.splits, steps_per = plan.steps_per;
   int l;
   {
     const int q = units / 8, r = units % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
     l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int split = l / tiles, tile = l % tiles;
+  const int split = l / tiles, tile_g = l % tiles;
+  int gi = 0;
+  while (gi + 1 < plan.count && tile_g >= plan.tile_base[gi + 1]) gi++;
+  const GemmTNArgs p = plan.g[gi];
+  const int tile = tile_g - plan.tile_base[gi], tiles_k = plan.tiles_k[gi], n_pad = plan.n_pad[gi];
+  const unsigned bytes_p = plan.bytes_p[gi], bytes_q = plan.bytes_q[gi];
   const int tile_n = tile / tiles_k, tile_k = tile % tiles_k;
   const int n0 = tile_n * 256, k0 = tile_k * 256;
   const int steps_total = (p.M + 63) / 64;
@@ -707,7 +719,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int
   if (do_bias) main_loop(std::true_type{}); else main_loop(std::false_type{});
   // ---- partial tile -> fp32 slab [256 n][256 k] of this (split, tile) unit, row-contiguous 16-byte stores ----
   __syncthreads();
-  float* slab = p.scratch + ((size_t)split * tiles + tile) * 65536;
+  float* slab = plan.scratch + ((size_t)split * tiles + tile_g) * 65536;
   float* wbuf = (float*)smem256 + wave * 2048;        // [32][64] fp32, wave-private
   const int c8 = (lane & 7) * 8;
 #pragma unroll
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int
     }
   }
   if (do_bias) {
-    float* bpart = p.scratch + (size_t)splits * tiles * 65536 + (size_t)split * n_pad;
+    float* bpart = plan.scratch + plan.bias_base[gi] + (size_t)split * n_pad;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
@@ -737,15 +749,17 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const GemmTNArgs p, int
 }
 
 // out[n * ldo + k * col_stride] += sum over splits of the unit slabs; dbias[n] += sum of the bias partials
-__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const GemmTNArgs p, int splits, int tiles_n, int tiles_k, int n_pad) {
-  const int tiles = tiles_n * tiles_k;
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) {
+  const int gi = blockIdx.y;
+  const GemmTNArgs p = plan.g[gi];
+  const int tiles = plan.total_tiles, tiles_k = plan.tiles_k[gi], splits = plan.splits, n_pad = plan.n_pad[gi];
   const int kq = (p.K + 3) / 4;
   const long long total = (long long)p.N * kq;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < total) {
     const int n = (int)(idx / kq), k = (int)(idx % kq) * 4;
-    const int tile = (n >> 8) * tiles_k + (k >> 8);
-    const float* sp = p.scratch + (size_t)tile * 65536 + (size_t)(n & 255) * 256 + (k & 255);
+    const int tile = plan.tile_base[gi] + (n >> 8) * tiles_k + (k >> 8);
+    const float* sp = plan.scratch + (size_t)tile * 65536 + (size_t)(n & 255) * 256 + (k & 255);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int sidx = 0; sidx < splits; sidx++) s += *(const f32x4*)(sp + (size_t)sidx * tiles * 65536);
     const int tap = p.ktap > 0 ? k / p.ktap : 0;
@@ -757,7 +771,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const GemmTNArgs p,
     }
   }
   if (p.dbias && idx < p.N) {
-    const float* bp = p.scratch + (size_t)splits * tiles * 65536 + idx;
+    const float* bp = plan.scratch + plan.bias_base[gi] + idx;
     float s = 0.f;
     for (int sidx = 0; sidx < splits; sidx++) s += bp[(size_t)sidx * n_pad];
     p.dbias[idx] += s;
@@ -863,45 +877,97 @@ int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s) {
   return 0;
 }
 // ---- 256-tile weight-gradient path -----------------------------------------------------------------
-static void tn256_plan(int M, int N, int K, int& tiles_n, int& tiles_k, int& splits, int& steps_per) {
-  tiles_n = cdiv(N, 256); tiles_k = cdiv(K, 256);
-  const int tiles = tiles_n * tiles_k, steps_total = cdiv(M, 64);
-  int want = 256 / tiles;                              // tiles x splits ~ one unit per CU
+static int g_tn_cus = 256;
+static void tn256_splits(int M, int total_tiles, int& splits, int& steps_per) {
+  const int steps_total = cdiv(M, 64);
+  int want = g_tn_cus / total_tiles;                   // tiles x splits ~ one unit per CU
   if (want < 1) want = 1;
   if (want > steps_total) want = steps_total;
   steps_per = cdiv(steps_total, want);
   splits = cdiv(steps_total, steps_per);               // no empty split
+}
+static void tn256_plan(int M, int N, int K, int& tiles_n, int& tiles_k, int& splits, int& steps_per) {
+  tiles_n = cdiv(N, 256); tiles_k = cdiv(K, 256);
+  tn256_splits(M, tiles_n * tiles_k, splits, steps_per);
 }
 long long gemm_tn_scratch_floats(int M, int N, int K) {
   int tn, tk, sp, per;
   tn256_plan(M, N, K, tn, tk, sp, per);
   return (long long)sp * tn * tk * 65536 + (long long)sp * tn * 256;
 }
-static int launch_tn256(const GemmTNArgs& a, hipStream_t s) {
+static bool tn256_group_ok(const GemmTNArgs& a) {
+  if (g_force_tile == 128) return false;
+  if (a.ktap < 0 || (a.ktap > 0 && (a.ktap % 256 || a.K % a.ktap))) return false;
+  if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15)) return false;
+  if (((long long)a.M + 64) * a.ldp * 2 >= (1LL << 31) || ((long long)a.Mq + 64) * a.ldq * 2 >= (1LL << 31)) return false;
+  return a.M > 0 && a.N > 0 && a.K > 0;
+}
+static int tn_fill_plan(const GemmTNBatch& b, float* scratch, TNPlan& pl) {
+  pl.count = b.count; pl.scratch = scratch;
+  int tiles = 0;
+  for (int i = 0; i < b.count; i++) {
+    const GemmTNArgs& a = b.g[i];
+    pl.g[i] = a;
+    const int tn = cdiv(a.N, 256), tk = cdiv(a.K, 256);
+    pl.tiles_k[i] = tk; pl.tile_base[i] = tiles; pl.n_pad[i] = tn * 256;
+    pl.bytes_p[i] = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
+    const int kq = a.ktap > 0 ? a.ktap : a.K;
+    const int kcols = a.ldq < (kq + 7) / 8 * 8 ? a.ldq : (kq + 7) / 8 * 8;
+    pl.bytes_q[i] = (unsigned)((((long long)a.Mq - 1) * a.ldq + kcols) * 2);
+    tiles += tn * tk;
+  }
+  pl.tile_base[b.count] = tiles; pl.total_tiles = tiles;
+  tn256_splits(b.g[0].M, tiles, pl.splits, pl.steps_per);
+  long long off = (long long)pl.splits * tiles * 65536;
+  for (int i = 0; i < b.count; i++) { pl.bias_base[i] = off; off += (long long)pl.splits * pl.n_pad[i]; }
+  return 0;
+}
+long long gemm_tn_batch_scratch_floats(const GemmTNBatch& b) {
+  TNPlan pl;
+  tn_fill_plan(b, nullptr, pl);
+  return pl.bias_base[b.count - 1] + (long long)pl.splits * pl.n_pad[b.count - 1];
+}
+bool gemm_tn_batch_ok(const GemmTNBatch& b) {
+  if (b.count < 1 || b.count > UVTG_TN_MAX_GROUPS) return false;
+  for (int i = 0; i < b.count; i++) {
+    if (!tn256_group_ok(b.g[i]) || b.g[i].M != b.g[0].M) return false;
+  }
+  const GemmTNArgs& a0 = b.g[0];
+  if (!a0.scratch || ((uintptr_t)a0.scratch & 15)) return false;
+  return a0.scratch_floats >= gemm_tn_batch_scratch_floats(b);
+}
+int launch_gemm_tn_batch(const GemmTNBatch& b, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) g_tn_cus = pr.multiProcessorCount;
     attr = true;
   }
-  int tn, tk, sp, per;
-  tn256_plan(a.M, a.N, a.K, tn, tk, sp, per);
-  const unsigned bytes_p = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
-  const int kcols = a.ldq < (a.K + 7) / 8 * 8 ? a.ldq : (a.K + 7) / 8 * 8;
-  const unsigned bytes_q = (unsigned)((((long long)a.Mq - 1) * a.ldq + kcols) * 2);
-  uvtg_prof_begin_launch(2, 2.0 * a.M * a.N * a.K, s);
-  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tn * tk * sp), dim3(512), 131072, s, a, sp, per, tn, tk, bytes_p, bytes_q, tn * 256);
-  const long long total = (long long)a.N * ((a.K + 3) / 4);
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, sp, tn, tk, tn * 256);
+  if (!gemm_tn_batch_ok(b)) return -2;
+  TNPlan pl;
+  tn_fill_plan(b, b.g[0].scratch, pl);
+  double flops = 0; long long mx = 0;
+  for (int i = 0; i < b.count; i++) {
+    flops += 2.0 * b.g[i].M * b.g[i].N * b.g[i].K;
+    const long long tot = (long long)b.g[i].N * ((b.g[i].K + 3) / 4);
+    mx = tot > mx ? tot : mx;
+  }
+  uvtg_prof_begin_launch(2, flops, s);
+  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(pl.total_tiles * pl.splits), dim3(512), 131072, s, pl);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mx + 255) / 256), b.count), dim3(256), 0, s, pl);
   uvtg_prof_end_launch(2, s);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
+static int launch_tn256(const GemmTNArgs& a, hipStream_t s) {
+  GemmTNBatch b; b.count = 1; b.g[0] = a;
+  return launch_gemm_tn_batch(b, s);
+}
 static bool tn256_ok(const GemmTNArgs& a) {
-  if (!a.scratch || g_force_tile == 128) return false;
-  if (a.ktap < 0 || (a.ktap > 0 && (a.ktap % 256 || a.K % a.ktap))) return false;
-  if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15) || ((uintptr_t)a.scratch & 15)) return false;
-  if (((long long)a.M + 64) * a.ldp * 2 >= (1LL << 31) || ((long long)a.Mq + 64) * a.ldq * 2 >= (1LL << 31)) return false;
-  if (a.scratch_floats < gemm_tn_scratch_floats(a.M, a.N, a.K)) return false;
+  if (!a.scratch) return false;
+  GemmTNBatch b; b.count = 1; b.g[0] = a;
+  if (!gemm_tn_batch_ok(b)) return false;
   if (g_force_tile == 256) return true;
   // worth it only when 256-wide tiles do not waste much of the output and there is a real reduction to split
   const double fill = ((double)a.N * a.K) / ((double)cdiv(a.N, 256) * 256 * (double)cdiv(a.K, 256) * 256);

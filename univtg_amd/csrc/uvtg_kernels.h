@@ -53,6 +53,13 @@ struct GemmTNArgs {
   // and lands at out[n * ldo + (k % ktap) * col_stride + t]   (0: no taps)
   int ktap;
 };
+// several weight gradients over the SAME reduction rows (M, splits plan) in one launch: the tiles of all groups share the M splits,
+// so there are more tiles per launch, fewer splits, and far less split-partial traffic than one launch per gradient
+constexpr int UVTG_TN_MAX_GROUPS = 8;
+struct GemmTNBatch { GemmTNArgs g[UVTG_TN_MAX_GROUPS]; int count; };
+bool gemm_tn_batch_ok(const GemmTNBatch& b);       // all groups eligible for the 256-tile kernel, same M, scratch large enough
+long long gemm_tn_batch_scratch_floats(const GemmTNBatch& b);
+int launch_gemm_tn_batch(const GemmTNBatch& b, hipStream_t s);
 bool gemm_tn_taps_ok(const GemmTNArgs& a);   // can this call (with ktap set) run as ONE launch?
 long long gemm_tn_scratch_floats(int M, int N, int K);   // scratch that makes every (M, N, K) eligible for the 256-tile kernel
 int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s);
