@@ -160,6 +160,13 @@ int uvtg_attention_bwd(const void* qkv, const unsigned char* kvalid, const void*
 int uvtg_sine_position(const float* vid_mask, const float* txt_mask, const float* dim_t, float* pos,
                        unsigned char* kvalid, int B, int Lv, int Lt, int d, uvtg_stream_t stream);
 
+/* ---- wire format: replaces pad_sequences_1d (utils/tensor_utils.py:5-53) + the padded H2D copies of
+ * prepare_batch_inputs_mr (main/dataset.py:1071-1100) for one key: only the VALID rows cross PCIe.
+ * packed [sum(len), D]: the samples' rows back to back (fp32, or bf16 when src_bf16), offsets [B + 1] row offsets (device int),
+ * out [B, Lmax, D] fp32 zero-padded, mask [B, Lmax] fp32 0/1 (may be NULL). */
+int uvtg_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask,
+                          uvtg_stream_t stream);
+
 /* ---- Hungarian matcher: replaces HungarianMatcher.forward (model/matcher.py:36-100) ------------
  * cost[b*Q + q, j] = w_span*L1(cxw) + w_giou*(-gIoU(xx)) + w_class*(-softmax(logits)[.,0]) for the targets
  * of sample b (tgt_off[b] .. tgt_off[b+1]); then a per-sample rectangular LSAP on device.

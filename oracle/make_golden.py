@@ -318,6 +318,45 @@ def run_dense_targets(ref):
     print("dense_targets: ok", len(cases))
 
 
+def collate_samples(seed=7, B=5, Dv=34, Dt=24):
+    """Ragged synthetic samples in the layout DatasetVLP/DatasetMR.__getitem__ returns (main/dataset.py:153-240)."""
+    g = torch.Generator().manual_seed(seed)
+    batch = []
+    for i in range(B):
+        lv = int(torch.randint(3, 14, (1,), generator=g)); lt = int(torch.randint(1, 8, (1,), generator=g))
+        ng = int(torch.randint(1, 3, (1,), generator=g))
+        mi = dict(query_feat=torch.randn(lt, Dt, generator=g), video_feat=torch.randn(lv, Dv, generator=g),
+                  timestamp=torch.rand(lv, 2, generator=g), timestamp_window=(torch.rand(lv, generator=g) > 0.5).float(),
+                  span_labels_nn=torch.rand(lv, 2, generator=g), saliency_scores=torch.rand(lv, generator=g).double(),
+                  span_labels=torch.rand(ng, 2, generator=g), saliency_pos_labels=[int(torch.randint(0, lv, (1,), generator=g))],
+                  saliency_neg_labels=[int(torch.randint(0, lv, (1,), generator=g))])
+        batch.append(dict(meta=dict(qid=i, duration=2.0 * lv), model_inputs=mi))
+    return batch
+
+
+def run_collate(ref):
+    """Golden vectors for the wire-format row of SURVEY 8f: start_end_collate_mr + prepare_batch_inputs_mr
+    (main/dataset.py:1037-1052,1071-1100; utils/tensor_utils.py:5-53) on ragged samples."""
+    batch = collate_samples()
+    meta, batched = ref.dataset.start_end_collate_mr(batch)
+    model_inputs, targets = ref.dataset.prepare_batch_inputs_mr(batched, "cpu")
+    store = {}
+    for i, e in enumerate(batch):
+        for k, v in e["model_inputs"].items():
+            store[f"sample/{i}/{k}"] = np.asarray(v if not torch.is_tensor(v) else v.numpy())
+    for k, v in model_inputs.items():
+        store["in/" + k] = v.numpy()
+    for k, v in targets.items():
+        if k == "span_labels":
+            for i, d in enumerate(v):
+                store[f"tg/span_labels/{i}"] = d["spans"].numpy()
+        else:
+            store["tg/" + k] = v.numpy()
+    store["n"] = np.asarray(len(batch))
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **store)
+    print("collate: ok", {k: tuple(v.shape) for k, v in model_inputs.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -335,6 +374,7 @@ def main():
     run_span_utils(ref)
     run_nms(ref)
     run_dense_targets(ref)
+    run_collate(ref)
 
 
 if __name__ == "__main__":

@@ -558,3 +558,33 @@ def test_drop_in_model_packed_option(dev):
     assert float((outs[0] - outs[1]).abs().max()) < 2e-2
     cos = float((grads[0] @ grads[1]) / (grads[0].norm() * grads[1].norm()))
     assert cos > 0.999 and abs(float(grads[1].norm() / grads[0].norm()) - 1) < 1e-2, cos
+
+
+def test_pipeline_collate_upload_matches_reference(dev, golden_dir):
+    """univtg_amd.pipeline.collate_upload_mr (packed valid rows over PCIe + uvtg_ragged_to_padded on device) reproduces the
+    reference's start_end_collate_mr + prepare_batch_inputs_mr bit-exactly (golden collate.npz made by the real reference),
+    and its host-side lengths drive the packed encoder stream."""
+    from univtg_amd.pipeline import collate_upload_mr
+    from tests.test_oracle_golden import _collate_case
+    z, batch = _collate_case(golden_dir)
+    for e in batch:
+        e["model_inputs"] = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in e["model_inputs"].items()}
+    meta, model_inputs, targets = collate_upload_mr(batch, dev)
+    torch.cuda.synchronize()
+    assert [m["qid"] for m in meta] == list(range(len(batch)))
+    for k in ("src_txt", "src_txt_mask", "src_vid", "src_vid_mask"):
+        assert np.array_equal(model_inputs[k].cpu().numpy(), z["in/" + k]), k
+    for k, v in targets.items():
+        if k == "span_labels":
+            for i, d in enumerate(v):
+                assert np.array_equal(d["spans"].cpu().numpy(), z[f"tg/span_labels/{i}"])
+        else:
+            ref = z["tg/" + k]
+            assert np.array_equal(v.cpu().numpy(), ref) and v.cpu().numpy().dtype == ref.dtype, k
+    lv, lt = model_inputs["_lens_host"]
+    assert lv == [int(x) for x in z["in/src_vid_mask"].sum(1)] and lt == [int(x) for x in z["in/src_txt_mask"].sum(1)]
+    # bf16 wire format: features rounded to bf16, everything else unchanged
+    _, mi16, _ = collate_upload_mr(batch, dev, feature_dtype=torch.bfloat16)
+    ref16 = torch.from_numpy(z["in/src_vid"]).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(mi16["src_vid"].cpu().numpy(), ref16)
+    assert np.array_equal(mi16["src_vid_mask"].cpu().numpy(), z["in/src_vid_mask"])

@@ -157,3 +157,30 @@ def test_oracle_vs_live_reference_full_width():
     la, lb = crit(a, tg), O.criterion(b, tg, cfg)
     for k in la:
         assert abs(float(la[k]) - float(lb[k])) < 1e-4 * max(1, abs(float(la[k])))
+
+
+def _collate_case(golden_dir):
+    z = np.load(os.path.join(golden_dir, "collate.npz"))
+    n = int(z["n"])
+    batch = []
+    for i in range(n):
+        mi = {k.split("/", 2)[2]: z[k] for k in z.files if k.startswith(f"sample/{i}/")}
+        for k in ("saliency_pos_labels", "saliency_neg_labels"):
+            mi[k] = [int(x) for x in mi[k]]
+        batch.append(dict(meta=dict(qid=i), model_inputs=mi))
+    return z, batch
+
+
+def test_pipeline_oracle_matches_reference_collate(golden_dir):
+    """oracle/pipeline_oracle.py vs the real start_end_collate_mr + prepare_batch_inputs_mr (golden collate.npz): bit-exact."""
+    from oracle import pipeline_oracle as PO
+    z, batch = _collate_case(golden_dir)
+    model_inputs, targets = PO.collate_mr(batch)
+    for k, v in model_inputs.items():
+        assert np.array_equal(v, z["in/" + k]), k
+    for k, v in targets.items():
+        if k == "span_labels":
+            for i, sp in enumerate(v):
+                assert np.array_equal(sp, z[f"tg/span_labels/{i}"])
+        else:
+            assert np.array_equal(v, z["tg/" + k]) and v.dtype == z["tg/" + k].dtype, k

@@ -46,6 +46,7 @@ SIGNATURES = {
     "uvtg_layernorm_bwd": (_I, [_P] * 8 + [_I, _I, _P]),
     "uvtg_attention_fwd": (_I, [_P] * 4 + [_I] * 5 + [_P]),
     "uvtg_attention_bwd": (_I, [_P] * 7 + [_F] + [_I] * 4 + [_P]),
+    "uvtg_ragged_to_padded": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "uvtg_sine_position": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "uvtg_adamw_clip_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
     "uvtg_debug_force_nt_tile": (_I, [_I]),

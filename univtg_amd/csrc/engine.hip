@@ -939,6 +939,11 @@ extern "C" int uvtg_attention_bwd(const void* qkv, const unsigned char* kvalid, 
   a.hd = hd; a.dO = (const bf16_t*)dO; a.lddo = H * hd; a.delta = delta; a.dqkv = (bf16_t*)dqkv; a.lddqkv = 3 * H * hd; a.qscale = qscale;
   return launch_attn_bwd(a, (hipStream_t)st);
 }
+extern "C" int uvtg_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask,
+                                     uvtg_stream_t st) {
+  if (!packed || !offsets || !out) return -20;
+  return launch_ragged_to_padded(packed, src_bf16, offsets, B, Lmax, D, out, mask, (hipStream_t)st);
+}
 extern "C" int uvtg_sine_position(const float* vid_mask, const float* txt_mask, const float* dim_t, float* pos, unsigned char* kvalid,
                                   int B, int Lv, int Lt, int d, uvtg_stream_t st) {
   if (!vid_mask || !txt_mask || !dim_t || !pos || !kvalid) return -20;

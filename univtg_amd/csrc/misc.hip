@@ -147,6 +147,26 @@ __global__ __launch_bounds__(256) void conv_w_multi_kernel(const ConvWOps ops) {
   }
 }
 
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+// ---------------- wire format: ragged rows -> zero-padded batch + mask ----------------
+// (pad_sequences_1d, utils/tensor_utils.py:5-53, on device: only the valid rows cross PCIe)
+template <typename T>
+__global__ __launch_bounds__(256) void ragged_to_padded_kernel(const T* packed, const int* offsets, int B, int Lmax, int D, float* out, float* mask) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);     // (b, t) over B * Lmax
+  if (row >= (long long)B * Lmax) return;
+  const int b = (int)(row / Lmax), t = (int)(row % Lmax);
+  const int len = offsets[b + 1] - offsets[b];
+  float* o = out + (size_t)row * D;
+  if (mask && lane == 0) mask[row] = t < len ? 1.f : 0.f;
+  if (t < len) {
+    const T* src = packed + (size_t)(offsets[b] + t) * D;
+    for (int c = lane; c < D; c += 64) o[c] = ldf<T>(src + c);
+  } else {
+    for (int c = lane; c < D; c += 64) o[c] = 0.f;
+  }
+}
+
 // ---------------- packed (ragged) encoder stream ----------------
 // Every padded clip of a sample enters the encoder with the same value (LN(0) projected + type embedding, and the sine PE
 // is constant beyond the last valid clip), is masked as a key, and only ever acts as a query.  Its encoder output is
@@ -229,7 +249,6 @@ __global__ __launch_bounds__(256) void pack_reduce_dvm_kernel(const bf16_t* dvm,
 }
 
 // ---------------- heads: last conv layer + activations ----------------
-template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
@@ -661,6 +680,14 @@ __global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const Salien
 
 }  // namespace
 
+int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask, hipStream_t s) {
+  if (B <= 0 || Lmax <= 0 || D <= 0) return -11;
+  const unsigned blocks = (unsigned)(((long long)B * Lmax + 3) / 4);
+  if (src_bf16) hipLaunchKernelGGL(ragged_to_padded_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)packed, offsets, B, Lmax, D, out, mask);
+  else hipLaunchKernelGGL(ragged_to_padded_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)packed, offsets, B, Lmax, D, out, mask);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
 int launch_pack_tables(const int* lens_dev, int B, int Lv, int Lt, const PackTables& t, hipStream_t s) {
   hipLaunchKernelGGL(pack_tables_kernel, dim3(B), dim3(128), 0, s, lens_dev, B, Lv, Lt, t);
   UVTG_CHECK_LAUNCH();
