@@ -78,7 +78,8 @@ int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* params, void* 
  *          pad_sequences_1d computes them, utils/tensor_utils.py:34-53); masks must be the matching prefix masks.  When given (bf16
  *          mode, memory == NULL) the encoder runs on the packed rows -- valid clips, ONE representative padded clip per sample,
  *          valid text tokens -- which reproduces the padded computation exactly (see misc.hip) at ~25 % fewer rows on ragged
- *          batches.  uvtg_backward must get the same array. */
+ *          batches.  (With training-time input dropout the padded clips of a sample share the dropout realisation of its first padded
+ *          clip instead of independent ones.)  uvtg_backward must get the same array. */
 int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                  const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                  const float* dim_t,
