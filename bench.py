@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=WORKLOAD["B"], help="per-GPU batch (config 2: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra instrumented steps for the roofline line")
+    ap.add_argument("--no-padded-compare", action="store_true", help="skip the extra timing of the padded (non-packed) execution")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,6 +161,20 @@ def main():
         elapsed = float(t)
     losses = step.losses[:5].tolist()
 
+    # ---- the same batches through the padded execution (every padded position computed, as the reference does) ----
+    padded_ms = None
+    if rank == 0 and world == 1 and not args.no_padded_compare:
+        step_p = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=False)
+        for i in range(3):
+            step_p.step(*batches[i % 2])
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for i in range(10):
+            step_p.step(*batches[i % 2])
+        torch.cuda.synchronize()
+        padded_ms = (time.perf_counter() - tp) / 10 * 1e3
+        del step_p
+
     # ---- roofline of the dominant kernel: HIP events around every gemm_nt<bf16> launch, on the launch stream ----
     lib = _lib.load()
     roof = None
@@ -199,11 +214,13 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
                    config=dict(workload="QVHighlights training shape (BASELINE config 2): L_v=75 L_t=32 D_v=2818 D_t=512 d=1024 F=1024 "
-                                        "H=8 E=4, full train step (fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1",
+                                        "H=8 E=4, full train step (fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, ragged valid lengths (SURVEY 8d variant B), "
+                                        "packed encoder stream (valid rows + one representative padded clip per sample)",
                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
                    samples_per_sec=round(B * world * args.steps / elapsed, 1),
                    encoder_mfma_frac_of_step=round(enc_flops / (elapsed / args.steps) / 2.5e15, 4),      # reference-algorithmic (padded) encoder FLOPs / step time / peak
                    packed_rows_fraction=round(sum(sum(a) + sum(b) + sum(1 for x in a if x < Lv) for a, b in (bt[0]["_lens_host"] for bt in batches)) / (len(batches) * B * (Lv + Lt)), 4),
+                   padded_execution_ms_per_step=None if padded_ms is None else round(padded_ms, 3),
                    losses=[round(x, 5) for x in losses], roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:
