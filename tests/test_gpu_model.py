@@ -588,3 +588,57 @@ def test_pipeline_collate_upload_matches_reference(dev, golden_dir):
     ref16 = torch.from_numpy(z["in/src_vid"]).to(torch.bfloat16).float().numpy()
     assert np.array_equal(mi16["src_vid"].cpu().numpy(), ref16)
     assert np.array_equal(mi16["src_vid_mask"].cpu().numpy(), z["in/src_vid_mask"])
+
+
+def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir):
+    """Train-mode parity: input dropout (p=0.5), attention dropout and DropPath all on.  The kernels' counter-based masks are
+    regenerated on the host (tests/philox_ref.py), handed to the CPU oracle as explicit Bernoulli masks, and outputs, losses and
+    parameter gradients must agree -- this pins nn.Dropout's 1/(1-p) scaling, drop_path's x/keep*floor(keep+U)
+    (model/transformer_encoder_droppath.py:154-183) and that backward re-creates exactly the forward masks."""
+    import philox_ref as R
+    from oracle import univtg_oracle as O
+    meta, _, params, inputs, tg, *_ = load_case(golden_dir, "tiny_eval_ragged")
+    cfg = O.make_cfg(**{**meta["cfg"], "input_dropout": 0.5, "dropout": 0.1, "droppath": 0.25})
+    model, crit = build(cfg, params, dev, "bf16")
+    model.train()
+    model.set_seed(20240917)
+    out = model(**to_dev(inputs, dev))
+    losses = crit(out, to_dev(tg, dev))
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    total.backward()
+
+    seed = (20240917 * 1000003 + 1) & 0xFFFFFFFFFFFFFFFF              # first training call after set_seed (model.py: _dims)
+    B, Lv, Dv = inputs["src_vid"].shape
+    Lt, Dt = inputs["src_txt"].shape[1:]
+    d, H, E, S = cfg.hidden_dim, cfg.nheads, cfg.enc_layers, Lv + Lt
+    t = lambda a: torch.from_numpy(a)
+    rng = {"vid_keep": [t(R.row_keep(seed, R.RNG_IN_VID, B * Lv, Dv, 0.5)).view(B, Lv, Dv),
+                        t(R.row_keep(seed, R.RNG_IN_VID + 1, B * Lv, d, 0.5)).view(B, Lv, d)],
+           "txt_keep": [t(R.row_keep(seed, R.RNG_IN_TXT, B * Lt, Dt, 0.5)).view(B, Lt, Dt),
+                        t(R.row_keep(seed, R.RNG_IN_TXT + 1, B * Lt, d, 0.5)).view(B, Lt, d)],
+           "dp_scale": t(R.droppath_scales(seed, E, B, 0.25)),
+           "attn_keep": torch.stack([t(R.attn_keep(seed, l, B, H, S, 0.1)) for l in range(E)])}
+    assert 0 < float((rng["dp_scale"] == 0).float().mean()) < 1           # the case exercises dropped AND kept branches
+    ref_params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref_out = O.forward(ref_params, cfg, inputs["src_txt"], inputs["src_txt_mask"], inputs["src_vid"], inputs["src_vid_mask"], rng=rng)
+    ref_losses = O.criterion(ref_out, tg, cfg)
+    O.total_loss(ref_losses, cfg).backward()
+
+    valid = inputs["src_vid_mask"].bool()
+    assert float((out["saliency_scores"].detach().cpu() - ref_out["saliency_scores"].detach())[valid].abs().max()) < 2e-2
+    for k, tol in (("pred_logits", 4e-2), ("pred_spans", 4e-2), ("vid_mem_proj", 4e-2), ("txt_mem_proj", 4e-2)):
+        err = float((out[k].detach().cpu() - ref_out[k].detach()).abs().max())
+        assert err < tol, (k, err)
+    for k in ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra"):
+        got, ref = float(losses[k].detach()), float(ref_losses[k].detach())
+        assert abs(got - ref) < 3e-2 * max(1.0, abs(ref)), (k, got, ref)
+    named, bad = dict(model.named_parameters()), {}
+    for k, p in ref_params.items():
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            continue
+        a, r = named[k].grad.cpu().double().flatten(), p.grad.double().flatten()
+        cos = float((a @ r) / (a.norm() * r.norm() + 1e-30))
+        ratio = float(a.norm() / (r.norm() + 1e-30))
+        if cos < 0.98 or abs(ratio - 1) > 0.06:
+            bad[k] = (cos, ratio)
+    assert not bad, bad

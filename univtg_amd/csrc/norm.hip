@@ -66,6 +66,24 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned st
   return k[c & 3];
 }
 
+// VEC == 2: the two lanes of an even/odd pair cover ONE Philox counter (4 columns) per iteration.  The even lane draws the counter
+// of iteration 2*ip, the odd lane the one of 2*ip+1, and the halves are swapped with one cross-lane exchange: one Philox call per
+// lane per TWO iterations instead of one per iteration (the 2818-wide input LayerNorm was ALU-bound on Philox, not HBM-bound).
+__device__ __forceinline__ void drop_pair2(unsigned long long seed, unsigned stream, long long row, int ip, int lane, int D4,
+                                           float p, float (&ks)[2][2]) {
+  const int odd = lane & 1;
+  const int c4 = ((2 * ip + odd) * 64 + (lane & ~1)) >> 1;
+  unsigned r[4];
+  philox4(seed, (unsigned long long)row * (unsigned long long)D4 + (unsigned long long)c4, stream, r);
+  const unsigned s0 = odd ? r[0] : r[2], s1 = odd ? r[1] : r[3];
+  const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+  const float inv = 1.0f / (1.0f - p);
+  ks[0][0] = (u01(odd ? g0 : r[0]) >= p) ? inv : 0.0f;      // iteration 2*ip   : the even lane's draw (words 0,1 | 2,3)
+  ks[0][1] = (u01(odd ? g1 : r[1]) >= p) ? inv : 0.0f;
+  ks[1][0] = (u01(odd ? r[2] : g0) >= p) ? inv : 0.0f;      // iteration 2*ip+1 : the odd lane's draw
+  ks[1][1] = (u01(odd ? r[3] : g1) >= p) ? inv : 0.0f;
+}
+
 template <int VEC, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
   const int lane = threadIdx.x & 63;
@@ -109,9 +127,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     const float* posr = (a.pos && is_vid) ? a.pos + (size_t)(b * a.Lv + s) * D : nullptr;
     if (a.pos_row) { const int pr = a.pos_row[row]; posr = (a.pos && pr >= 0) ? a.pos + (size_t)pr * D : nullptr; }
     const size_t prow = is_vid ? (size_t)(b * (a.Lv + 2) + s + 1) : 0;
+    float ks2[2][2] = {{1.f, 1.f}, {1.f, 1.f}};
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * VEC;
+      if constexpr (VEC == 2 && NV % 2 == 0) {            // all lanes take part in the exchange (outside the c < D guard)
+        if ((i & 1) == 0 && a.p_drop > 0.f) drop_pair2(a.seed, a.stream_id, row, i >> 1, lane, D4, a.p_drop, ks2);
+      }
       if (c < D) {
         float y[VEC], gm[VEC], bt[VEC];
         loadv<VEC>(a.gamma + c, gm);
@@ -119,8 +141,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) y[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
         if (a.p_drop > 0.f) {
+          if constexpr (VEC == 2 && NV % 2 == 0) {
 #pragma unroll
-          for (int e = 0; e < VEC; e++) y[e] *= drop_scale(a.seed, a.stream_id, row, c + e, D4, a.p_drop);
+            for (int e = 0; e < VEC; e++) y[e] *= ks2[i & 1][e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; e++) y[e] *= drop_scale(a.seed, a.stream_id, row, c + e, D4, a.p_drop);
+          }
         }
         if (a.yF) storev<VEC>(a.yF + (size_t)row * a.ldyF + c, y);
         if (a.yF2) storev<VEC>(a.yF2 + (size_t)row * a.ldyF2 + c, y);
@@ -254,6 +281,7 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512) void ln_bwd_kernel(const
       const bool live = row < a.rows;
       unsigned pm[NV];                  // bit e set: x > 0 (ReLU mask of the producing layer)
       float s1 = 0.f, s2 = 0.f;
+      float ks2[2][2] = {{1.f, 1.f}, {1.f, 1.f}};
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         const int c = (i * 64 + lane) * VEC;
@@ -262,7 +290,11 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512) void ln_bwd_kernel(const
 #pragma unroll
           for (int e = 0; e < VEC; e++) pm[i] |= (xv[rr][i][e] > 0.f ? 1u : 0u) << e;
         }
-        if (a.p_drop > 0.f && c < D) {
+        if constexpr (VEC == 2 && NV % 2 == 0) {
+          if ((i & 1) == 0 && a.p_drop > 0.f) drop_pair2(a.seed, a.stream_id, rowi[rr], i >> 1, lane, D4, a.p_drop, ks2);
+#pragma unroll
+          for (int e = 0; e < VEC; e++) gv[rr][i][e] *= ks2[i & 1][e];
+        } else if (a.p_drop > 0.f && c < D) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) gv[rr][i][e] *= drop_scale(a.seed, a.stream_id, rowi[rr], c + e, D4, a.p_drop);
         }
