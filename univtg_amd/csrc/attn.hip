@@ -44,8 +44,10 @@ __device__ __forceinline__ s16x8 cat4(s16x4 a, s16x4 b) { return (s16x8){a[0], a
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// min 2 workgroups per CU: without the bound hipcc spreads over 276 VGPR+AGPR (HD=128) and ONE workgroup per CU stays resident --
+// the kernel then runs at a single wave per SIMD with every global-load latency exposed (measured: SQ_WAVE_CYCLES == SQ_BUSY_CU_CYCLES)
 template <int HD, bool PRECISE>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int VSTR = HD + (HD >= 64 ? 32 : 0);
   constexpr int NP = PRECISE ? 2 : 1;
   __shared__ __attribute__((aligned(16))) bf16_t sK[NP][64 * HD];
@@ -82,24 +84,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
 
   const int ntiles = (S + 63) / 64;
+  // bf16 mode: the next K / V tile (and its key-validity bytes) is fetched into registers while the current one is consumed
+  constexpr int CH = HD / 8, NPF = PRECISE ? 1 : (64 * CH) / 256;     // 16-byte chunks per row; pieces per thread
+  u32x4 pk[NPF], pvv[NPF];
+  unsigned char pval = 0;
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NPF; i++) {
+      const int q = tid + 256 * i, r = q / CH, c = q % CH;
+      const int key = kt * 64 + r;
+      pk[i] = (u32x4){0, 0, 0, 0}; pvv[i] = (u32x4){0, 0, 0, 0};
+      if (key < S) {
+        const bf16_t* base = (const bf16_t*)a.qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
+        pk[i] = *(const u32x4*)(base + a.H * HD);
+        pvv[i] = *(const u32x4*)(base + 2 * a.H * HD);
+      }
+    }
+    if (tid < 64) { const int key = kt * 64 + tid; pval = (key < S) ? a.kvalid[rowbase + key] : 0; }
+  };
+  if constexpr (!PRECISE) fetch(0);
   for (int kt = 0; kt < ntiles; kt++) {
     __syncthreads();
     // ---- stage K / V tile (keys kt*64 .. +63), zero-filled beyond S ----
     if constexpr (!PRECISE) {
-      constexpr int CH = HD / 8;                       // 16-byte chunks per row
 #pragma unroll
-      for (int i = 0; i < (64 * CH) / 256; i++) {
+      for (int i = 0; i < NPF; i++) {
         const int q = tid + 256 * i, r = q / CH, c = q % CH;
-        const int key = kt * 64 + r;
-        u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-        if (key < S) {
-          const bf16_t* base = (const bf16_t*)a.qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
-          kv = *(const u32x4*)(base + a.H * HD);
-          vv = *(const u32x4*)(base + 2 * a.H * HD);
-        }
-        *(u32x4*)(&sK[0][KS::off(r, c)]) = kv;
-        *(u32x4*)(&sV[0][r * VSTR + c * 8]) = vv;
+        *(u32x4*)(&sK[0][KS::off(r, c)]) = pk[i];
+        *(u32x4*)(&sV[0][r * VSTR + c * 8]) = pvv[i];
       }
+      if (tid < 64) sValid[tid] = pval;
+      if (kt + 1 < ntiles) fetch(kt + 1);
     } else {
       constexpr int PC = HD / 4;                       // float4 pieces per row
 #pragma unroll
@@ -121,7 +136,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         }
       }
     }
-    if (tid < 64) { const int key = kt * 64 + tid; sValid[tid] = (key < S) ? a.kvalid[rowbase + key] : 0; }
+    if constexpr (PRECISE) {
+      if (tid < 64) { const int key = kt * 64 + tid; sValid[tid] = (key < S) ? a.kvalid[rowbase + key] : 0; }
+    }
     __syncthreads();
 
     // ---- S^T = K Q^T : sc[kb][r] <-> key kb*32 + (r&3)+8(r>>2)+4g, query l31 ----
@@ -203,7 +220,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         }
       }
   }
-  if (q_raw < S) {
+  if constexpr (!PRECISE && HD >= 64) {
+    // O^T fragments hold (channel, query): a direct store is 8 B per lane at a 2 KB stride (16-byte pieces of 32 different
+    // cache lines per instruction).  Transpose through a wave-private slab in the dead V stage instead, half the channels per
+    // pass, and store 16 B per lane with HD/16 lanes covering one contiguous half row.
+    constexpr int OSTR = HD / 2 + 8, CPR = HD / 16;
+    static_assert(4 * 32 * OSTR <= 64 * VSTR, "output slab must fit the V stage");
+    __syncthreads();                                   // every wave is done reading sV
+    bf16_t* slab = &sV[0][0] + wave * 32 * OSTR;
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+      for (int dvh = 0; dvh < HD / 64; dvh++)
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+          const int dvb = pass * (HD / 64) + dvh;
+          u32x2 t;
+          t[0] = pack_bf2(oacc[dvb][4 * rq] * inv, oacc[dvb][4 * rq + 1] * inv);
+          t[1] = pack_bf2(oacc[dvb][4 * rq + 2] * inv, oacc[dvb][4 * rq + 3] * inv);
+          *(u32x2*)(slab + l31 * OSTR + dvh * 32 + 8 * rq + 4 * g) = t;
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < (32 * CPR) / 64; i++) {
+        const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR;
+        const int q = blockIdx.x * 128 + wave * 32 + row;
+        const u32x4 v = *(const u32x4*)(slab + row * OSTR + ch * 8);
+        if (q < S) *(u32x4*)((bf16_t*)a.o + (rowbase + q) * a.ldo + h * HD + pass * (HD / 2) + ch * 8) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (q_raw < S && a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run + __logf(l_run);
+  } else if (q_raw < S) {
     const float inv = 1.0f / l_run;
 #pragma unroll
     for (int dvb = 0; dvb < HD / 32; dvb++)
@@ -375,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
 // backward: dQ   (one wave = 32 queries, loops over 64-key tiles)
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   constexpr int KSTR = HD + 8;
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * KSTR];
   __shared__ __attribute__((aligned(16))) bf16_t sV[64 * KSTR];
@@ -510,7 +559,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
     for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
   constexpr int NP = (32 * CH + 255) / 256;          // staging pieces per thread per operand
   u32x4 pq[NP], po[NP];
+  float pl = 0.f, pdl = 0.f;                         // lse / delta of query qb*32 + tid (tid < 32), fetched with the block's rows
   auto prefetch = [&](int qb) {
+    if (tid < 32) {
+      const int qi = min(qb * 32 + tid, S - 1);
+      pl = a.lse[((size_t)b * a.H + h) * a.S + qi];
+      pdl = a.delta[((size_t)b * a.H + h) * a.S + qi];
+    }
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int q = tid + 256 * i, r = q / CH, c = q % CH, qi = qb * 32 + r;
@@ -530,14 +585,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
       const int q = tid + 256 * i, r = q / CH, c = q % CH;
       if (q < 32 * CH) { *(u32x4*)(&sQ[r * QSTR + c * 8]) = pq[i]; *(u32x4*)(&sO[r * QSTR + c * 8]) = po[i]; }
     }
-    if (tid < 32) {
-      const int qi = qb * 32 + tid;
-      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * a.S + qi] : 0.f;
-      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * a.S + qi] : 0.f;
-    }
+    if (tid < 32) { sL[tid] = pl; sD[tid] = pdl; }   // rows beyond S: clamped duplicates, masked by qi < S below
     if (qb + 1 < nqb) prefetch(qb + 1);
     // V fragments are re-fetched (L2 hits) per query block instead of living in 32 registers across the whole loop:
     // with the 128 dK / dV accumulators that keeps the kernel at two workgroups per CU without spilling
+    // (hoisting these loads above the first barrier measured 11 % slower)
     s16x8 vf[HD / 16];
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) vf[ks] = *(const s16x8*)(vrow + 16 * ks);
