@@ -20,6 +20,9 @@ LIB = os.path.join(HERE, "libuvtg.so")
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "misc.hip", "losses.hip", "postproc.hip", "optim.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-value",
          "-Wno-pass-failed"]
+# per-source extras.  norm.hip: the row-batched LayerNorm kernels are fully unrolled register tiles; past LLVM's default
+# pragma-unroll budget the unroll is silently refused and the tiles become scratch arrays (seen as ScratchSize > 0).
+EXTRA_FLAGS = {"norm.hip": ["-mllvm", "-pragma-unroll-threshold=131072"]}
 
 
 def _hipcc():
@@ -34,7 +37,7 @@ def _stamp(paths):
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(paths[0]), [])).encode())
     return h.hexdigest()
 
 
@@ -54,7 +57,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         sp, op, st, stp = job
-        r = subprocess.run([hipcc] + FLAGS + ["-c", sp, "-o", op], capture_output=True, text=True)
+        r = subprocess.run([hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", op],
+                           capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {sp}:\n{r.stderr[-4000:]}")
         with open(stp, "w") as f:

@@ -185,9 +185,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
 // dx = rstd * (gh - mean(gh) - xhat * mean(gh * xhat)),  gh = g * gamma;  dgamma += g * xhat; dbeta += g
 // RPW rows per wave are in flight together (the row loop is a chain load -> two wave reductions -> store: one row at a time
 // leaves the kernel latency-bound at half the HBM rate).
+#ifndef UVTG_LN_RPW
+#define UVTG_LN_RPW 2   // 4 rows in flight measured 10 % slower (256 VGPRs, sweeps quantise worse)
+#endif
 template <int VEC, int NV, bool BF>     // BF: x, g, g2 are bf16 (the fast mode's streams); else fp32
 __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512) void ln_bwd_kernel(const LnBwdArgs a) {
-  constexpr int RPW = (NV * VEC > 32) ? 1 : 2;
+  constexpr int RPW = (NV * VEC > 32) ? 1 : (NV * VEC > 16 ? 2 : UVTG_LN_RPW);
   extern __shared__ float red[];       // [waves][2][D] per-wave dgamma / dbeta partials
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int D = a.D, D4 = (D + 3) >> 2;
@@ -311,12 +314,11 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512) void ln_bwd_kernel(const
         }
       }
       const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
-      if (!live) continue;
-      const float rs = a.rowscale ? a.rowscale[a.row_sample ? a.row_sample[row] : row / a.rs_seg] : 1.0f;
+      const float rs = (live && a.rowscale) ? a.rowscale[a.row_sample ? a.row_sample[row] : row / a.rs_seg] : 1.0f;
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         const int c = (i * 64 + lane) * VEC;
-        if (c < D) {
+        if (live && c < D) {
           float dx[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; e++) dx[e] = rstd[rr] * (gv[rr][i][e] - c1 - xv[rr][i][e] * c2);
