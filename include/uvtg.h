@@ -210,6 +210,8 @@ double uvtg_profile_event_floor_ms(void);
 int uvtg_debug_force_nt_tile(int tile);
 /* ... and the tile HEIGHT of the persistent 256-wide kernel (0 = automatic per launch, 128, 192, 256) */
 int uvtg_debug_force_nt_bm(int bm);
+/* Parity-test aid: 0 = automatic, 4 = 256-column tiles (one workgroup per CU), 2 = 128-column tiles (two per CU). */
+int uvtg_debug_force_nt_wn(int wn);
 
 const char* uvtg_strerror(int code);
 int uvtg_version(void);

@@ -375,6 +375,20 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     return 0;
   }
+  if (argc >= 6 && !strcmp(argv[1], "time")) {      // time M N K mode [mode ...] : persistent 2x4 kernel only
+    const int M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]);
+    bf16_t *A, *B, *Cb; float* C;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&Cb, (size_t)M * N * 2));
+    fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1);
+    fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2);
+    const double fl = 2.0 * M * N * K;
+    for (int i = 5; i < argc; i++) {
+      LabArgs a{A, B, M, N, K, K, K, nullptr, C, Cb, N, atoi(argv[i]), nullptr};
+      const float t = time_us([&] { launch256p<2, 4>(a); });
+      printf("%dx%dx%d mode %3d: %8.1f us %7.1f TF\n", M, N, K, a.mode, t, fl / t / 1e6);
+    }
+    return 0;
+  }
   // ---- correctness at an awkward shape ----
   {
     const int M = 700, N = 520, K = 192;

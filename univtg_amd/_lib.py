@@ -51,6 +51,7 @@ SIGNATURES = {
     "uvtg_adamw_clip_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
     "uvtg_debug_force_nt_tile": (_I, [_I]),
     "uvtg_debug_force_nt_bm": (_I, [_I]),
+    "uvtg_debug_force_nt_wn": (_I, [_I]),
     "uvtg_profile_start": (_I, []),
     "uvtg_profile_stop": (_I, [_P, _P, _P]),
     "uvtg_profile_event_floor_ms": (C.c_double, []),

@@ -237,12 +237,18 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // GATHER: row gather / scatter / conv taps / groups present (integer divisions per row); the plain variant has none.
 // TM: 32-row fragments per wave along M -> tile height BM = 64 TM (256 / 192 / 128): the launcher picks the height that
 // wastes the fewest CU-rounds for the launch's tile count (ragged batches give awkward row counts).
-template <bool GATHER, int TM>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
-  constexpr int TB = 256, KB = 64, TN = 2, BM = 64 * TM;
+// WN = 4: 256-wide tile, 8 waves, one workgroup per CU (128 KB of stages).  WN = 2: 128-wide tile, 4 waves, 80 KB (TM = 3) or
+// 64 KB (TM = 2) of stages so that TWO workgroups share a CU: they drift apart, and one's epilogue / barrier stalls overlap the
+// other's MFMA stream (in lockstep the epilogue of a 256-wide tile costs ~25 % of a K = 1024 GEMM with the matrix cores idle).
+template <bool GATHER, int TM, int WN>
+__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(const GemmArgs p) {
+  constexpr int TB = 64 * WN, KB = 64, TN = 2, BM = 64 * TM, NW = 2 * WN, PA = 8 * TM / NW;
+  constexpr int BOFF = (WN == 4) ? 32768 : BM * 128;            // byte offset of the B rows inside a stage
+  constexpr int SSTR = (WN == 4) ? 65536 : (BM + TB) * 128;     // stage stride
+  static_assert(NW * 8192 <= SSTR, "epilogue slabs must fit the consumed stage");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN, g = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + BM - 1) / BM;
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
@@ -255,11 +261,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
     gz = l / per_group; l -= gz * per_group;
     m0 = (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
   };
-  unsigned aofs[TM], bofs[4];    // byte offsets of this lane's TM + 4 staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
+  unsigned aofs[PA], bofs[4];    // byte offsets of this lane's TM + 4 staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
   auto set_offsets = [&](int gz, int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
-      const int r = (wave * TM + i) * 8 + sr;
+    for (int i = 0; i < PA; i++) {
+      const int r = (wave * PA + i) * 8 + sr;
       const int c = (sc ^ ((r >> 1) & 7)) * 8;
       const int am = GATHER ? map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off) : min(m0 + r, p.M - 1);
       aofs[i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
   };
   int s_tap = 0, s_kk = 0;        // conv tap / column within the tap of the K tile staged next (GATHER only)
   auto stage = [&](int s, int kt) {
-    unsigned char* base = smem256 + s * 65536;
+    unsigned char* base = smem256 + s * SSTR;
     const int k0 = kt * KB;
     unsigned ka = (unsigned)k0 * 2u;
     const unsigned kb = (unsigned)k0 * 2u;
@@ -284,18 +290,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
       if (s_kk >= p.ktap) { s_kk = 0; s_tap++; }
     }
 #pragma unroll
-    for (int i = 0; i < TM; i++)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.A + (aofs[i] + ka)), (lds_void_t*)(base + (wave * TM + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < PA; i++)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.A + (aofs[i] + ka)), (lds_void_t*)(base + (wave * PA + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i] + kb)), (lds_void_t*)(base + 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i] + kb)), (lds_void_t*)(base + BOFF + (wave * 4 + i) * 1024), 16, 0, 0);
   };
   int aoff[TM], boff[TN];
   const int swz = (l31 >> 1) & 7;           // identical for every 32-row fragment of the wave
 #pragma unroll
   for (int i = 0; i < TM; i++) aoff[i] = (wm * (32 * TM) + i * 32 + l31) * 128;
 #pragma unroll
-  for (int j = 0; j < TN; j++) boff[j] = 32768 + (wn * 64 + j * 32 + l31) * 128;
+  for (int j = 0; j < TN; j++) boff[j] = BOFF + (wn * 64 + j * 32 + l31) * 128;
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
       __syncthreads();                       // vmcnt(0) + barrier: K tile `it` landed, the other stage is free
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
       else if (next < ntiles) { tile_origin(next, ngz, nm0, nn0); set_offsets(ngz, nm0, nn0); stage(cur ^ 1, 0); }
-      const unsigned char* base = smem256 + cur * 65536;
+      const unsigned char* base = smem256 + cur * SSTR;
       s16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
       for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmArgs p) {
       if (t == 123.456f) p.outF[0] = t;
     } else {
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
-      float* wbuf = (float*)(smem256 + ((it - 1) & 1) * 65536) + wave * 2048;    // [32][64] fp32, wave-private
+      float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
       const int c8 = (lane & 7) * 8;
       const int n = n0 + wn * 64 + c8;
       const bool ncol = n < p.N;
@@ -817,17 +823,28 @@ static bool nt256_ok(const GemmArgs& a) {
   return amax * 2 < (1LL << 32) && bmax * 2 < (1LL << 32);
 }
 static int g_num_cu = 0;
-template <int TM> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, hipStream_t s) {
+// relative time per output element of the persistent NT structures (TM, WN); two-per-CU tiles share the CU, hence the x2 in the cost
+#ifndef UVTG_NT_F44
+#define UVTG_NT_F44 1.00
+#define UVTG_NT_F34 1.09
+#define UVTG_NT_F24 1.22
+#define UVTG_NT_F32 1.04
+#define UVTG_NT_F22 1.13
+#endif
+template <int TM, int WN> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, hipStream_t s) {
+  constexpr int smem = (WN == 4) ? 131072 : 2 * (64 * TM + 64 * WN) * 128;
   static bool attr = false;
   if (!attr) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
     attr = true;
   }
-  if (gather) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM>), dim3(grid), dim3(512), 131072, s, b);
-  else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM>), dim3(grid), dim3(512), 131072, s, b);
+  if (gather) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, WN>), dim3(grid), dim3(128 * WN), smem, s, b);
+  else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, WN>), dim3(grid), dim3(128 * WN), smem, s, b);
   return 0;
 }
+static int g_force_wn = 0;     // 0: automatic, 2 / 4: force the 128-wide two-per-CU or the 256-wide one-per-CU persistent kernel
+extern "C" int uvtg_debug_force_nt_wn(int wn) { if (wn != 0 && wn != 2 && wn != 4) return -21; g_force_wn = wn; return 0; }
 static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   if (!g_num_cu) {
     int dev = 0; hipDeviceProp_t pr;
@@ -837,20 +854,33 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
-  // tile height: whole rounds of one tile per CU cost rounds x BM; the 192- and 128-row tiles run the same loop a little less
-  // efficiently per row (more B traffic per MFMA), hence the small penalties
-  int best_tm = 4; double best = 1e30;
-  for (int tm = 4; tm >= 2; tm--) {
-    const long long tiles = (long long)cdiv(b.M, 64 * tm) * cdiv(b.N, 256) * b.groups;
-    const double cost = (double)((tiles + g_num_cu - 1) / g_num_cu) * (64.0 * tm) * (tm == 4 ? 1.0 : (tm == 3 ? 1.04 : 1.10));
-    if (cost < best) { best = cost; best_tm = tm; }
+  // Candidates: 256-wide tiles of 256 / 192 / 128 rows, one workgroup per CU, and 128-wide tiles of 192 / 128 rows, two per CU.
+  // Cost = tiles per CU x rows x columns of a tile x a per-structure factor (measured relative time per output element).
+  struct Cand { int tm, wn; double f; };
+  static const Cand cands[] = {{4, 4, UVTG_NT_F44}, {3, 4, UVTG_NT_F34}, {2, 4, UVTG_NT_F24}, {3, 2, UVTG_NT_F32}, {2, 2, UVTG_NT_F22}};
+  int best_tm = 4, best_wn = 4; double best = 1e30;
+  for (const Cand& c : cands) {
+    // the two-per-CU structure wins 4-10 % at the kernel-level entry point (tools/nt_variants.py) but nothing on the whole step
+    // with the real epilogues (tools/step_variants.py: 10.18 vs 10.19 ms), so the automatic choice stays with the 256-wide tiles
+    if (c.wn != (g_force_wn ? g_force_wn : 4)) continue;
+    if (g_force_bm && c.tm * 64 != g_force_bm) continue;
+    const long long tiles = (long long)cdiv(b.M, 64 * c.tm) * cdiv(b.N, 64 * c.wn) * b.groups;
+    // a CU works through ceil(tiles / #CU) tiles; with two resident workgroups an odd one out has the CU to itself, i.e. the
+    // CU's time is (tiles on it) / 2 rounds of two concurrent tiles -- half-round granularity (fits the measured table in
+    // tools/nt_variants.py within ~4 %)
+    const double rounds = (double)((tiles + g_num_cu - 1) / g_num_cu);
+    const double cost = rounds * (64.0 * c.tm) * (64.0 * c.wn) * c.f;
+    if (cost < best) { best = cost; best_tm = c.tm; best_wn = c.wn; }
   }
-  if (g_force_bm) best_tm = g_force_bm / 64;
-  const int tiles = cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
-  const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+  if (best >= 1e30) return -21;          // forced combination that does not exist (256 rows x 128 columns)
+  const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 64 * best_wn) * b.groups;
+  const long long slots = (long long)g_num_cu * (best_wn == 2 ? 2 : 1);
+  const int grid = (int)(tiles < slots ? tiles : slots);
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1;
   uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
-  int rc = best_tm == 4 ? launch_nt256_tm<4>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3>(b, grid, gather, s) : launch_nt256_tm<2>(b, grid, gather, s));
+  int rc;
+  if (best_wn == 4) rc = best_tm == 4 ? launch_nt256_tm<4, 4>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3, 4>(b, grid, gather, s) : launch_nt256_tm<2, 4>(b, grid, gather, s));
+  else rc = best_tm == 3 ? launch_nt256_tm<3, 2>(b, grid, gather, s) : launch_nt256_tm<2, 2>(b, grid, gather, s);
   uvtg_prof_end_launch(3, s);
   if (rc) return rc;
   UVTG_CHECK_LAUNCH();
