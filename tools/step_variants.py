@@ -27,6 +27,8 @@ def run(n=20):
 
 settings = [("auto", 0, 0), ("wn4 auto-bm", 4, 0), ("wn4 bm256", 4, 256), ("wn4 bm192", 4, 192), ("wn4 bm128", 4, 128),
             ("wn2 auto-bm", 2, 0), ("wn2 bm192", 2, 192), ("wn2 bm128", 2, 128), ("auto", 0, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "quick":
+    settings = [("auto", 0, 0)] * 3
 for name, wn, bm in settings:
     _lib.check(lib.uvtg_debug_force_nt_wn(wn)); _lib.check(lib.uvtg_debug_force_nt_bm(bm))
     print(f"{name:14s}: {run():7.3f} ms/step", flush=True)

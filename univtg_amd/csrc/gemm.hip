@@ -320,6 +320,27 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int next = tile + gridDim.x;
     int ngz = 0, nm0 = 0, nn0 = 0;
+    // this lane's 8 output columns and their bias: fetched at the head of the tile, not in the epilogue (there the load sits
+    // right behind the barrier with every wave of the block waiting on it and the matrix cores idle)
+    const int c8 = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + c8;
+    const bool ncol = n < p.N;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) bv[e] = 0.f;
+    if (ncol && p.act != 100) {
+      if (p.bias) {
+        const float* bias = p.bias + (size_t)gz * p.gBias + n;
+        const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+      }
+      if (p.bias2) {
+        const f32x4 b0 = *(const f32x4*)(p.bias2 + n), b1 = *(const f32x4*)(p.bias2 + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+      }
+    }
     for (int kt = 0; kt < nk; kt++, it++) {
       const int cur = it & 1;
       __syncthreads();                       // vmcnt(0) + barrier: K tile `it` landed, the other stage is free
@@ -369,26 +390,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
     } else {
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
-      const int c8 = (lane & 7) * 8;
-      const int n = n0 + wn * 64 + c8;
-      const bool ncol = n < p.N;
       const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
-      float bv[8];
-#pragma unroll
-      for (int e = 0; e < 8; e++) bv[e] = 0.f;
-      if (ncol) {
-        if (p.bias) {
-          const float* bias = p.bias + (size_t)gz * p.gBias + n;
-          const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
-#pragma unroll
-          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
-        }
-        if (p.bias2) {
-          const f32x4 b0 = *(const f32x4*)(p.bias2 + n), b1 = *(const f32x4*)(p.bias2 + n + 4);
-#pragma unroll
-          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
-        }
-      }
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
 #pragma unroll
       for (int i = 0; i < TM; i++) {

@@ -186,10 +186,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
 // RPW rows per wave are in flight together (the row loop is a chain load -> two wave reductions -> store: one row at a time
 // leaves the kernel latency-bound at half the HBM rate).
 #ifndef UVTG_LN_RPW
-#define UVTG_LN_RPW 2   // 4 rows in flight measured 10 % slower (256 VGPRs, sweeps quantise worse)
+#define UVTG_LN_RPW 1
+#define UVTG_LN_WPE 4   // second __launch_bounds__ argument = waves per SIMD (not workgroups per CU)
 #endif
 template <int VEC, int NV, bool BF>     // BF: x, g, g2 are bf16 (the fast mode's streams); else fp32
-__global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512) void ln_bwd_kernel(const LnBwdArgs a) {
+__global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512, (NV * VEC <= 16) ? UVTG_LN_WPE : 1) void ln_bwd_kernel(const LnBwdArgs a) {
   constexpr int RPW = (NV * VEC > 32) ? 1 : (NV * VEC > 16 ? 2 : UVTG_LN_RPW);
   extern __shared__ float red[];       // [waves][2][D] per-wave dgamma / dbeta partials
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
