@@ -132,18 +132,46 @@ __global__ void transpose_bf16_multi_kernel(const TransposeOps ops) {
     if (c < cols && r < rows) dst[(size_t)c * ld + r] = f2bf(t[threadIdx.x][i]);
   }
 }
-__global__ __launch_bounds__(256) void conv_w_multi_kernel(const ConvWOps ops) {
+__global__ __launch_bounds__(256) void conv_w_multi_kernel(const ConvWOps ops, int tiled_bwd) {
   const int op = blockIdx.y, N = ops.N, C = ops.C;
+  if (tiled_bwd && ops.kind[op] != 0) return;          // dgrad operands are written by conv_w_bwd_tiled_kernel
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)N * 3 * C) return;
   const float* w = ops.w[op];
   bf16_t* dst = ops.dst[op];
   if (ops.kind[op] == 0) {
-    const int n = (int)(i / (3 * C)), rem = (int)(i % (3 * C)), tap = rem / C, c = rem % C;
-    dst[(size_t)n * ops.ld[op] + rem] = f2bf(w[((size_t)n * C + c) * 3 + tap]);
-  } else {
+    // one thread per (n, c): its three taps are 12 contiguous bytes; the three stores are each contiguous across the wave
+    if (i >= (long long)N * C) return;
+    const int n = (int)(i / C), c = (int)(i % C);
+    const float* src = w + (size_t)i * 3;
+    bf16_t* d = dst + (size_t)n * ops.ld[op] + c;
+    const float t0 = src[0], t1 = src[1], t2 = src[2];
+    d[0] = f2bf(t0); d[C] = f2bf(t1); d[2 * C] = f2bf(t2);
+  } else if ((N % 64) || (C % 32)) {
     const int c = (int)(i / (3 * N)), rem = (int)(i % (3 * N)), tp = rem / N, n = rem % N;
     dst[(size_t)c * ops.ld[op] + tp * ops.ntot[op] + ops.n_off[op] + n] = f2bf(w[((size_t)n * C + c) * 3 + (2 - tp)]);
+  }
+}
+// dgrad operand (kind 1) as a tiled transpose: a block moves a 64 (n) x 32 (c) x 3 (tap) tile -- 384-byte contiguous reads per
+// output channel, 128-byte contiguous bf16 writes per (c, tap) row (the element-wise mapping above reads at a 12 KB stride)
+__global__ __launch_bounds__(256) void conv_w_bwd_tiled_kernel(const ConvWOps ops) {
+  __shared__ float tile[3][32][65];
+  const int op = blockIdx.y, N = ops.N, C = ops.C;
+  if (ops.kind[op] != 1) return;
+  const int tiles_c = C / 32;
+  const int n0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 32;
+  const float* w = ops.w[op];
+  bf16_t* dst = ops.dst[op];
+#pragma unroll
+  for (int k = 0; k < 24; k++) {
+    const int j = threadIdx.x + 256 * k, nl = j / 96, q = j % 96;
+    tile[q % 3][q / 3][nl] = w[((size_t)(n0 + nl) * C + c0) * 3 + q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 24; k++) {
+    const int j = threadIdx.x + 256 * k, nl = j % 64, cl = (j / 64) % 32, tp = j / 2048;
+    dst[(size_t)(c0 + cl) * ops.ld[op] + tp * ops.ntot[op] + ops.n_off[op] + n0 + nl] = f2bf(tile[2 - tp][cl][nl]);
   }
 }
 
@@ -765,8 +793,14 @@ int launch_transpose_bf16_multi(const TransposeOps& ops, hipStream_t s) {
 int launch_conv_w_multi(const ConvWOps& ops, hipStream_t s) {
   if (ops.count <= 0) return 0;
   const long long n = (long long)ops.N * 3 * ops.C;
-  hipLaunchKernelGGL(conv_w_multi_kernel, dim3((unsigned)((n + 255) / 256), ops.count), dim3(256), 0, s, ops);
+  const int tiled = (ops.N % 64 == 0 && ops.C % 32 == 0) ? 1 : 0;
+  const long long nblk = tiled ? ((long long)ops.N * ops.C + 255) / 256 : (n + 255) / 256;    // forward operands: one thread per (n, c)
+  hipLaunchKernelGGL(conv_w_multi_kernel, dim3((unsigned)nblk, ops.count), dim3(256), 0, s, ops, tiled);
   UVTG_CHECK_LAUNCH();
+  if (tiled) {
+    hipLaunchKernelGGL(conv_w_bwd_tiled_kernel, dim3((ops.N / 64) * (ops.C / 32), ops.count), dim3(256), 0, s, ops);
+    UVTG_CHECK_LAUNCH();
+  }
   return 0;
 }
 int launch_conv_w_fwd(const float* w, int N, int C, bf16_t* dstB, float* dstF, int ld, hipStream_t s) {
