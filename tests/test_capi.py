@@ -82,3 +82,17 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_hot_kernels_resources():
+    """Resource guard read from the built gfx950 code objects (no GPU needed): the GEMM and attention kernels must not spill
+    (a spilling 256-row GEMM build once returned garbage) and must keep at least two waves per SIMD -- rocprofv3's ``vgpr``
+    column hides both, and `attn_fwd_kernel<128>` silently ran at one wave per SIMD for most of round 1."""
+    from univtg_amd import build
+    res = {k["name"]: k for k in build.kernel_resources(build.build(verbose=False))}
+    assert len(res) > 50
+    hot = [k for n, k in res.items() if "gemm_nt256" in n or "gemm_tn256" in n or "attn_fwd_kernelILi128ELb0" in n or "attn_bwd_fused" in n]
+    assert len(hot) >= 12
+    for k in hot:
+        assert k["scratch"] == 0, (k["name"], k["scratch"])
+        assert k["waves_per_simd"] >= 2, (k["name"], k["vgpr"])

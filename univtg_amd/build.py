@@ -81,3 +81,40 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+
+
+def kernel_resources(lib: str = LIB):
+    """Per-kernel register / scratch / LDS use read from the gfx950 code objects embedded in ``libuvtg.so`` (AMDGPU metadata
+    notes).  rocprofv3's ``vgpr`` column does not show the accumulator half or what hipcc really allocated; this does:
+    ``waves_per_simd = 512 // (vgpr_count rounded to 8)`` is the occupancy the kernel can reach (before LDS limits).
+    Returns a list of dicts: name, vgpr (unified total), agpr (the accumulation part of it), sgpr, scratch, lds, max_flat_workgroup_size, waves_per_simd."""
+    import re
+    import shutil
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tmp = tempfile.mkdtemp(prefix="uvtg_co_")
+    try:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, so)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], cwd=tmp, capture_output=True, text=True, check=True)
+        out = []
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(tmp, f)],
+                                   capture_output=True, text=True, check=True).stdout
+            for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+                g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk)
+                name = g("name")
+                if not name:
+                    continue
+                agpr = int(re.match(r"\s*(\d+)", blk).group(1))
+                vgpr = int(g("vgpr_count").group(1))
+                tot = (vgpr + 7) // 8 * 8            # .vgpr_count is the unified total (architectural + accumulation registers)
+                out.append(dict(name=name.group(1), vgpr=vgpr, agpr=agpr, sgpr=int(g("sgpr_count").group(1)),
+                                scratch=int(g("private_segment_fixed_size").group(1)), lds=int(g("group_segment_fixed_size").group(1)),
+                                max_flat_workgroup_size=int(g("max_flat_workgroup_size").group(1)),
+                                waves_per_simd=min(8, 512 // max(tot, 8))))
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
