@@ -244,7 +244,7 @@ def test_production_width_vs_oracle(dev):
     sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
     named = dict(model.named_parameters())
     for k in ("transformer.encoder.layers.0.self_attn.in_proj_weight", "transformer.encoder.layers.1.linear2.weight",
-              "input_vid_proj.0.net.1.weight", "input_vid_proj.0.LayerNorm.weight", "span_embed.layers.0.weight",
+              "input_vid_proj.0.net.1.weight", "input_vid_proj.0.LayerNorm.weight", "input_vid_proj.0.LayerNorm.bias", "span_embed.layers.0.weight",
               "class_embed.layers.2.weight", "weightedpool.weight", "token_type_embeddings.weight",
               "transformer.encoder.layers.0.norm1.bias", "input_txt_proj.1.net.1.bias"):
         a, r = named[k].grad.cpu().double().flatten(), p2[k].grad.double().flatten()
@@ -590,15 +590,21 @@ def test_pipeline_collate_upload_matches_reference(dev, golden_dir):
     assert np.array_equal(mi16["src_vid_mask"].cpu().numpy(), z["in/src_vid_mask"])
 
 
-def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir):
+@pytest.mark.parametrize("case", ["tiny_golden", "production_width"])
+def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
     """Train-mode parity: input dropout (p=0.5), attention dropout and DropPath all on.  The kernels' counter-based masks are
     regenerated on the host (tests/philox_ref.py), handed to the CPU oracle as explicit Bernoulli masks, and outputs, losses and
     parameter gradients must agree -- this pins nn.Dropout's 1/(1-p) scaling, drop_path's x/keep*floor(keep+U)
     (model/transformer_encoder_droppath.py:154-183) and that backward re-creates exactly the forward masks."""
     import philox_ref as R
     from oracle import univtg_oracle as O
-    meta, _, params, inputs, tg, *_ = load_case(golden_dir, "tiny_eval_ragged")
-    cfg = O.make_cfg(**{**meta["cfg"], "input_dropout": 0.5, "dropout": 0.1, "droppath": 0.25})
+    if case == "tiny_golden":
+        meta, _, params, inputs, tg, *_ = load_case(golden_dir, "tiny_eval_ragged")
+        cfg = O.make_cfg(**{**meta["cfg"], "input_dropout": 0.5, "dropout": 0.1, "droppath": 0.25})
+    else:       # d=1024, D_v=2818: the wide-row LayerNorm kernels and their lane-pair Philox sharing
+        cfg = O.make_cfg(input_dropout=0.5, dropout=0.1, droppath=0.25, enc_layers=1)
+        params = O.init_params(cfg, seed=11)
+        inputs, tg = O.make_batch(cfg, 4, 12, 5, seed=12, ragged=True)
     model, crit = build(cfg, params, dev, "bf16")
     model.train()
     model.set_seed(20240917)

@@ -377,6 +377,128 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const LnBwdArgs a, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide rows (the 2818-wide feature LayerNorm of the video projection, model/univtg.py:91-100).  One wave per row keeps
+// 48 values + gamma/beta in registers per lane (218-450 VGPRs: one or two waves per SIMD); here a whole 256-thread block
+// takes a row, 2 columns x NVW per thread, and the two row statistics go through LDS -- 8 waves per SIMD instead.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* sh) {     // all 256 threads get the sum; sh: 4 floats, reused safely
+  v = wave_sum(v);
+  __syncthreads();                         // previous use of sh is over
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+// keep-scales of the 2 columns this thread owns at column-iteration k (columns (k*256 + tid)*2 ..+1) of `row`: the even/odd
+// thread pair shares one Philox counter (4 columns); even threads draw for even k, odd threads for odd k, halves are exchanged
+__device__ __forceinline__ void drop_pair_wide(unsigned long long seed, unsigned stream, long long row, int kp, int tid, int D4,
+                                               float p, float (&ks)[2][2]) {
+  const int odd = tid & 1;
+  const int c4 = ((2 * kp + odd) * 256 + (tid & ~1)) >> 1;
+  unsigned r[4];
+  philox4(seed, (unsigned long long)row * (unsigned long long)D4 + (unsigned long long)c4, stream, r);
+  const unsigned s0 = odd ? r[0] : r[2], s1 = odd ? r[1] : r[3];
+  const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+  const float inv = 1.0f / (1.0f - p);
+  ks[0][0] = (u01(odd ? g0 : r[0]) >= p) ? inv : 0.0f;
+  ks[0][1] = (u01(odd ? g1 : r[1]) >= p) ? inv : 0.0f;
+  ks[1][0] = (u01(odd ? r[2] : g0) >= p) ? inv : 0.0f;
+  ks[1][1] = (u01(odd ? r[3] : g1) >= p) ? inv : 0.0f;
+}
+template <int NVW>      // NVW even: column iterations of 512 columns each
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwdArgs a) {
+  __shared__ float sh[4];
+  const int tid = threadIdx.x, D = a.D, D4 = (D + 3) >> 2;
+  for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    const float* xr = a.x + (size_t)row * a.ldx;
+    float v[NVW][2];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NVW; k++) {
+      const int c = (k * 256 + tid) * 2;
+      v[k][0] = 0.f; v[k][1] = 0.f;
+      if (c < D) loadv<2>(xr + c, v[k]);
+      sum += v[k][0] + v[k][1];
+    }
+    const float mean = block_sum256(sum, sh) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NVW; k++) {
+      const int c = (k * 256 + tid) * 2;
+      if (c < D) { const float t0 = v[k][0] - mean, t1 = v[k][1] - mean; sq += t0 * t0 + t1 * t1; }
+    }
+    const float rstd = rsqrtf(block_sum256(sq, sh) / (float)D + a.eps);
+    if (tid == 0) {
+      if (a.mean) a.mean[row] = mean;
+      if (a.rstd) a.rstd[row] = rstd;
+    }
+    float ks[2][2] = {{1.f, 1.f}, {1.f, 1.f}};
+#pragma unroll
+    for (int k = 0; k < NVW; k++) {
+      const int c = (k * 256 + tid) * 2;
+      if ((k & 1) == 0 && a.p_drop > 0.f) drop_pair_wide(a.seed, a.stream_id, row, k >> 1, tid, D4, a.p_drop, ks);
+      if (c < D) {
+        float gm[2], bt[2], y[2];
+        loadv<2>(a.gamma + c, gm);
+        loadv<2>(a.beta + c, bt);
+#pragma unroll
+        for (int e = 0; e < 2; e++) y[e] = ((v[k][e] - mean) * rstd * gm[e] + bt[e]) * ks[k & 1][e];
+        if (a.yF2) storev<2>(a.yF2 + (size_t)row * a.ldyF2 + c, y);
+        if (a.yB) storeb<2>(a.yB + (size_t)row * a.ldyB + c, y);
+      }
+    }
+    if (a.Dpad > D) {
+      for (int c = D + tid; c < a.Dpad; c += 256) {
+        if (a.yB) a.yB[(size_t)row * a.ldyB + c] = 0;
+        if (a.yF2) a.yF2[(size_t)row * a.ldyF2 + c] = 0.f;
+      }
+    }
+  }
+}
+// dgamma / dbeta only (the feature LayerNorm has no upstream: dx is never needed), i.e. a pure column reduction over the rows:
+// thread = 2 columns, block = 512 columns x a slice of rows, per-block partials folded by ln_bwd_reduce_kernel.
+__global__ __launch_bounds__(256) void ln_dgb_wide_kernel(const LnBwdArgs a, int rows_per_block) {
+  const int tid = threadIdx.x, D = a.D, D4 = (D + 3) >> 2;
+  const int c = (blockIdx.x * 256 + tid) * 2;
+  const bool on = c < D;
+  const int cc = on ? c : 0;                       // inactive threads still take part in the pair exchange
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(a.rows, r0 + rows_per_block);
+  float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+  for (int r = r0; r < r1; r += 2) {
+    const int rb = min(r + 1, r1 - 1);             // second row of the pair (duplicate of the first on an odd tail: weight 0)
+    const float wb = (r + 1 < r1) ? 1.f : 0.f;
+    float ga[2], xa[2], gb[2], xb[2];
+    loadv<2>(a.g + (size_t)r * a.ldg + cc, ga);
+    loadv<2>(a.x + (size_t)r * a.ldx + cc, xa);
+    loadv<2>(a.g + (size_t)rb * a.ldg + cc, gb);
+    loadv<2>(a.x + (size_t)rb * a.ldx + cc, xb);
+    const float ma = a.mean[r], sa = a.rstd[r], mb = a.mean[rb], sb = a.rstd[rb];
+    float ka[2] = {1.f, 1.f}, kb[2] = {1.f, 1.f};
+    if (a.p_drop > 0.f) {
+      // even threads draw the pair's counter for row r, odd threads for row rb; halves exchanged (one Philox call per thread per 2 rows)
+      const int odd = tid & 1;
+      const int c4 = c >> 2;                       // the even/odd pair covers columns 4*c4 .. 4*c4+3 (also when one of them is past D)
+      unsigned q[4];
+      philox4(a.seed, (unsigned long long)(odd ? rb : r) * (unsigned long long)D4 + (unsigned long long)c4, a.stream_id, q);
+      const unsigned s0 = odd ? q[0] : q[2], s1 = odd ? q[1] : q[3];
+      const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+      const float inv = 1.0f / (1.0f - a.p_drop);
+      ka[0] = (u01(odd ? g0 : q[0]) >= a.p_drop) ? inv : 0.f; ka[1] = (u01(odd ? g1 : q[1]) >= a.p_drop) ? inv : 0.f;
+      kb[0] = (u01(odd ? q[2] : g0) >= a.p_drop) ? inv : 0.f; kb[1] = (u01(odd ? q[3] : g1) >= a.p_drop) ? inv : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const float g0 = ga[e] * ka[e], g1 = gb[e] * kb[e] * wb;
+      dg[e] += g0 * ((xa[e] - ma) * sa) + g1 * ((xb[e] - mb) * sb);
+      db[e] += g0 + g1;
+    }
+  }
+  if (on) {
+    float* out = a.partial + (size_t)blockIdx.y * 2 * D;
+    out[c] = dg[0]; out[c + 1] = dg[1]; out[D + c] = db[0]; out[D + c + 1] = db[1];
+  }
+}
+
 template <int VEC, int NV> int run_fwd(const LnFwdArgs& a, hipStream_t s) {
   const int blocks = min(cdiv(a.rows, 4), 8192);
   hipLaunchKernelGGL((ln_fwd_kernel<VEC, NV>), dim3(blocks), dim3(256), 0, s, a);
@@ -442,6 +564,11 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
                       al(a.yP, a.ldyP, 2, 4) && al(a.yPF, a.ldyP, 4, 8) && al(a.gamma, 0, 4, 8) && al(a.beta, 0, 4, 8) &&
                       al(a.pos, a.D, 4, 8);
   const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.yB, a.ldyB, 2, 16) && al(a.yU, a.ldyU, 2, 16) && al(a.yP, a.ldyP, 2, 16);
+  if (a.D > 2048 && a.D <= 3072 && a.D % 2 == 0 && align8 && a.x && !a.yF && !a.pos && !a.pos_row && !a.yU && !a.yUF && !a.yP && !a.yPF) {
+    hipLaunchKernelGGL((ln_fwd_wide_kernel<6>), dim3(min(a.rows, 4096)), dim3(256), 0, s, a);     // block per row (see the kernel)
+    UVTG_CHECK_LAUNCH();
+    return 0;
+  }
   LN_DISPATCH(run_fwd, a)
 }
 
@@ -455,5 +582,18 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
                       al(a.dxF, a.lddxF, 4, 8) && al(a.dxB, a.lddxB, 2, 4) && al(a.gamma, 0, 4, 8);
   const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.gB, a.ldgB, 2, 16) && al(a.g2B, a.ldg2B, 2, 16) &&
                        al(a.dxB, a.lddxB, 2, 16) && al(a.dxB2, a.lddxB2, 2, 16);
+  if (a.D > 2048 && a.D % 2 == 0 && align8 && a.x && a.g && !a.g2 && !a.gB && !a.g2B && a.dgamma && a.dbeta && !a.dxF && !a.dxB && !a.dxB2 &&
+      a.partial) {
+    // parameter gradients only: column reduction (ln_dgb_wide_kernel)
+    int rpb = cdiv(a.rows, 384);
+    rpb = (rpb < 32 ? 32 : rpb + (rpb & 1));
+    const int rb = cdiv(a.rows, rpb);
+    if ((long long)rb * 2 * a.D <= a.partial_floats) {
+      hipLaunchKernelGGL(ln_dgb_wide_kernel, dim3(cdiv(a.D, 512), rb), dim3(256), 0, s, a, rpb);
+      hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a.D, 16)), dim3(256), 0, s, a, rb);
+      UVTG_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   LN_DISPATCH(run_bwd, a)
 }
