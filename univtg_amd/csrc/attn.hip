@@ -534,20 +534,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
   __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * QSTR];
   __shared__ __attribute__((aligned(16))) bf16_t sO[32 * QSTR];
   __shared__ __attribute__((aligned(16))) bf16_t sDS[32 * DSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sDQ[32 * QSTR];   // dQ rows of the previous query block, stored out coalesced
   __shared__ float sL[32], sD[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
   const bf16_t* qkv = (const bf16_t*)a.qkv;
-  // K (all keys) -> LDS, zero rows beyond S
-#pragma unroll
-  for (int i = 0; i < (128 * CH) / 256; i++) {
-    const int q = tid + 256 * i, r = q / CH, c = q % CH;
-    u32x4 kv = {0, 0, 0, 0};
-    if (r < S) kv = *(const u32x4*)(qkv + (rowbase + r) * a.ldqkv + d + h * HD + c * 8);
-    *(u32x4*)(&sK[r * KSTR + c * 8]) = kv;
-  }
   const int key = wave * 32 + l31;
   const int krow = min(key, S - 1);
   const bool kok = key < S && a.kvalid[rowbase + krow];
@@ -577,9 +570,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
     }
   };
   const int nqb = (S + 31) / 32;
-  prefetch(0);
+  prefetch(0);                                       // first query block's rows are in flight while K is staged
+  // K (all keys) -> LDS, zero rows beyond S
+#pragma unroll
+  for (int i = 0; i < (128 * CH) / 256; i++) {
+    const int q = tid + 256 * i, r = q / CH, c = q % CH;
+    u32x4 kv = {0, 0, 0, 0};
+    if (r < S) kv = *(const u32x4*)(qkv + (rowbase + r) * a.ldqkv + d + h * HD + c * 8);
+    *(u32x4*)(&sK[r * KSTR + c * 8]) = kv;
+  }
+  // the dQ^T fragments hold (head dim, query): 8 bytes per lane at a 6 KB stride.  Each wave drops its tile into sDQ instead and
+  // the whole block writes the 32 rows out 16 bytes per lane, 16 lanes per contiguous 256-byte row, one query block later.
+  auto flush_dq = [&](int qbp) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const int q = tid + 256 * i, r = q / CH, c = q % CH, qi = qbp * 32 + r;
+      if (q < 32 * CH && qi < S) *(u32x4*)(a.dqkv + (rowbase + qi) * a.lddqkv + h * HD + c * 8) = *(const u32x4*)(&sDQ[r * QSTR + c * 8]);
+    }
+  };
   for (int qb = 0; qb < nqb; qb++) {
-    __syncthreads();                                 // previous block's readers of sQ / sO / sDS are done
+    __syncthreads();                                 // previous block's readers of sQ / sO / sDS are done, its dQ tiles are in sDQ
+    if (qb > 0) flush_dq(qb - 1);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int q = tid + 256 * i, r = q / CH, c = q % CH;
@@ -643,32 +654,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
         const s16x8 db = *(const s16x8*)(&sDS[l31 * DSTR + 16 * kk + 8 * g]);
         dq = mfma32(kt_, db, dq);
       }
-      const int qi = qb * 32 + l31;
-      if (qi < S) {
 #pragma unroll
-        for (int rq = 0; rq < 4; rq++) {
-          const int c = wave * 32 + 8 * rq + 4 * g;
-          u32x2 t;
-          t[0] = pack_bf2(dq[4 * rq] * a.qscale, dq[4 * rq + 1] * a.qscale);
-          t[1] = pack_bf2(dq[4 * rq + 2] * a.qscale, dq[4 * rq + 3] * a.qscale);
-          *(u32x2*)(a.dqkv + (rowbase + qi) * a.lddqkv + h * HD + c) = t;
-        }
+      for (int rq = 0; rq < 4; rq++) {
+        const int c = wave * 32 + 8 * rq + 4 * g;
+        u32x2 t;
+        t[0] = pack_bf2(dq[4 * rq] * a.qscale, dq[4 * rq + 1] * a.qscale);
+        t[1] = pack_bf2(dq[4 * rq + 2] * a.qscale, dq[4 * rq + 3] * a.qscale);
+        *(u32x2*)(&sDQ[l31 * QSTR + c]) = t;
       }
     }
   }
-  if (key < S) {
+  __syncthreads();                                   // last dQ tiles are in sDQ; nobody reads sK any more
+  flush_dq(nqb - 1);
+  // dK, dV: same transposition through a wave-private slab in the dead K tile (32 keys x HD, padded rows)
+  bf16_t* slab = sK + wave * 32 * KSTR;
+#pragma unroll
+  for (int which = 0; which < 2; which++) {
 #pragma unroll
     for (int blk = 0; blk < HD / 32; blk++)
 #pragma unroll
       for (int rq = 0; rq < 4; rq++) {
         const int c = blk * 32 + 8 * rq + 4 * g;
-        bf16_t* base = a.dqkv + (rowbase + key) * a.lddqkv + h * HD + c;
         u32x2 t;
-        t[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); t[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]);
-        *(u32x2*)(base + d) = t;
-        t[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); t[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]);
-        *(u32x2*)(base + 2 * d) = t;
+        if (which == 0) { t[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); t[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]); }
+        else { t[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); t[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]); }
+        *(u32x2*)(slab + l31 * KSTR + c) = t;
       }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < (32 * CH) / 64; i++) {
+      const int idx = lane + 64 * i, r = idx / CH, c = idx % CH, kk = wave * 32 + r;
+      const u32x4 v = *(const u32x4*)(slab + r * KSTR + c * 8);
+      if (kk < S) *(u32x4*)(a.dqkv + (rowbase + kk) * a.lddqkv + (which + 1) * d + h * HD + c * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
