@@ -3,6 +3,7 @@
 // caller's HIP stream (graph-capturable: no allocation, no host sync, all state in caller-owned buffers).
 // Token-major layout: row (b*S + s) of every [M, *] activation, s < Lv video clips then Lt text tokens.
 #include "uvtg_kernels.h"
+#include <cstdlib>
 #include "../../include/uvtg.h"
 #include <cmath>
 #include <cstring>
@@ -476,14 +477,18 @@ struct Fwd {
     const void* Wqkv = fast ? (const void*)w.wqkv[l] : (const void*)P[m.lay(l, IPW)];
     const size_t es = fast ? 2 : 4;
     // q,k from (x + pos); v from x  (transformer_encoder_droppath.py:116-117)
-    GemmArgs g = gemm_base(ub_in, d, Wqkv, d, M, 2 * d, d);
+    const bool one_launch = (2 * d) % 256 == 0;      // A-operand switch at a tile boundary: q,k columns read x + pos, v columns read x
+    GemmArgs g = gemm_base(ub_in, d, Wqkv, d, M, one_launch ? 3 * d : 2 * d, d);
+    if (one_launch) { g.A2 = xb_in; g.a2_n0 = 2 * d; }
     g.bias = P[m.lay(l, IPB)]; g.colscale = 1.0f / sqrtf((float)m.hd); g.colscale_n = d;
     set_out(g, ws.qkv[l], 3 * d);
     TRY(run_gemm(g, !fast));
-    g = gemm_base(xb_in, d, (const char*)Wqkv + (size_t)2 * d * d * es, d, M, d, d);
-    g.bias = P[m.lay(l, IPB)] + 2 * d;
-    set_out(g, (char*)ws.qkv[l] + (size_t)2 * d * es, 3 * d);
-    TRY(run_gemm(g, !fast));
+    if (!one_launch) {
+      g = gemm_base(xb_in, d, (const char*)Wqkv + (size_t)2 * d * d * es, d, M, d, d);
+      g.bias = P[m.lay(l, IPB)] + 2 * d;
+      set_out(g, (char*)ws.qkv[l] + (size_t)2 * d * es, 3 * d);
+      TRY(run_gemm(g, !fast));
+    }
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
     if (packed) { at.seq_start = ws.pk.seq_start; at.seq_count = ws.pk.seq_count; at.row_sample = ws.pk.row_sample; at.total_rows = M; }

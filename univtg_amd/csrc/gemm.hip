@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int gz = blockIdx.z;
 
-  const char* Ab = (const char*)p.A + (size_t)gz * p.gA * (X3 ? 4 : 2);
+  const char* Ab = (const char*)((p.A2 && n0 >= p.a2_n0) ? p.A2 : p.A) + (size_t)gz * p.gA * (X3 ? 4 : 2);
   const char* Bb = (const char*)p.B + (size_t)gz * p.gB * (X3 ? 4 : 2);
 
   // per-thread staging coordinates: 4 x 16-byte pieces of A and of B per K tile
@@ -263,7 +263,9 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
     m0 = (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
   };
   unsigned aofs[PA], bofs[4];    // byte offsets of this lane's TM + 4 staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
+  const char* Abase = (const char*)p.A;      // A operand of the tile being loaded (A2 for the column tiles from a2_n0 on)
   auto set_offsets = [&](int gz, int m0, int n0) {
+    Abase = (const char*)((p.A2 && n0 >= p.a2_n0) ? p.A2 : p.A);
 #pragma unroll
     for (int i = 0; i < PA; i++) {
       const int r = (wave * PA + i) * 8 + sr;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
     }
 #pragma unroll
     for (int i = 0; i < PA; i++)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.A + (aofs[i] + ka)), (lds_void_t*)(base + (wave * PA + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Abase + (aofs[i] + ka)), (lds_void_t*)(base + (wave * PA + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; i++)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i] + kb)), (lds_void_t*)(base + BOFF + (wave * 4 + i) * 1024), 16, 0, 0);
@@ -819,6 +821,7 @@ void uvtg_prof_end_launch(int family, hipStream_t s);
 
 static int check_nt(const GemmArgs& a, int elem) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
+  if (a.A2 && ((a.a2_n0 % 256) || ((uintptr_t)a.A2 & 15))) return -3;
   const int al = 16 / elem;   // elements per 16 bytes
   if (a.lda % al || a.ldb % al || a.ktap <= 0) return -2;
   if (a.ktap < a.K && (a.ktap % (elem == 2 ? 64 : 32))) return -2;

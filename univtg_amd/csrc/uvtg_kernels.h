@@ -8,6 +8,9 @@
 // ---------------------------------------------------------------------------------------------
 struct GemmArgs {
   const void* A;      // bf16 (fast) or fp32 (x3) [rows, lda]
+  // optional second A operand (same layout) for the output columns n >= a2_n0 (a multiple of 256): one launch computes
+  // [A | A2-columns] -- the q,k projections read x + pos and the v projection reads x (transformer_encoder_droppath.py:116-117)
+  const void* A2; int a2_n0;
   const void* B;      // bf16 / fp32 [N, ldb]
   int M, N, K, lda, ldb;
   // A-row gather: arow(m) = (m / a_seg) * a_seg_stride + (m % a_seg) + a_off   (a_seg == 0: identity)
