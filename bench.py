@@ -180,8 +180,9 @@ def main():
     roof = None
     if rank == 0:
         lib.uvtg_profile_start()
-        for i in range(args.profile_steps):
-            step.step(*batches[i % 2])
+    for i in range(args.profile_steps):          # EVERY rank runs these steps (they contain the gradient all-reduce); only rank 0 instruments them
+        step.step(*batches[i % 2])
+    if rank == 0:
         ms, fl, n = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
         _lib.check(lib.uvtg_profile_stop(ms, fl, n), "uvtg_profile_stop")
         fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel", "gemm_nt256_kernel"]
