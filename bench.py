@@ -120,11 +120,18 @@ def main():
         print("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)", file=sys.stderr)
         sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # plumbing test on a 1-GPU box: UVTG_BENCH_BACKEND=gloo UVTG_BENCH_SAME_DEVICE=1 runs the N>1 control flow with every rank on cuda:0
+    backend = os.environ.get("UVTG_BENCH_BACKEND", "nccl")
+    if os.environ.get("UVTG_BENCH_SAME_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)     # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group(backend="nccl", device_id=dev)     # "nccl" == RCCL on ROCm
+        else:
+            torch.distributed.init_process_group(backend=backend)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -648,3 +648,21 @@ def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
         if cos < 0.98 or abs(ratio - 1) > 0.06:
             bad[k] = (cos, ratio)
     assert not bad, bad
+
+
+def test_bench_two_rank_control_flow(dev):
+    """bench.py launched the way the driver launches N>1 (torch.distributed.run, one process per rank), with gloo and both ranks
+    on cuda:0 so that it runs on a 1-GPU box: every rank must take part in every collective (an instrumented step that only
+    rank 0 ran once deadlocked this path) and rank 0 prints the one JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UVTG_BENCH_BACKEND="gloo", UVTG_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--profile-steps", "1", "--batch", "32"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0 and out["roofline"]["achieved"] > 0
