@@ -666,3 +666,31 @@ def test_bench_two_rank_control_flow(dev):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0 and out["roofline"]["achieved"] > 0
+
+
+def test_dynamic_tile_handout_identical(dev):
+    """uvtg_set_dynamic_tiles(1): per-XCD atomic tile counters instead of the static stride in the persistent GEMMs (what TrainStep
+    switches on for N>1, where RCCL kernels share the CUs).  Same tiles, same arithmetic: losses and gradients must agree to rounding."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import _lib
+    from univtg_amd.trainer import TrainStep
+    lib = _lib.load()
+    cfg = O.make_cfg(input_dropout=0.5, droppath=0.1, dropout=0.0)
+    params = O.init_params(cfg, seed=21)
+    inputs, tg = O.make_batch(cfg, 256, 75, 32, seed=22, ragged=True)       # config-2 size: > 256 tiles per GEMM, i.e. several rounds
+    res = []
+    try:
+        for dyn in (0, 1):
+            _lib.check(lib.uvtg_set_dynamic_tiles(dyn))
+            model, crit = build(cfg, params, dev, "bf16", proj_precise="auto")
+            model.train(); model.set_seed(3)
+            step = TrainStep(model, crit, packed=False)
+            losses = step.step(to_dev(inputs, dev), to_dev(tg, dev), optimize=False).clone()
+            res.append((losses.cpu(), step.grads.clone().cpu()))
+            del step, model, crit
+    finally:
+        lib.uvtg_set_dynamic_tiles(0)
+    # (a few small kernels accumulate with fp32 atomics, so run-to-run equality is to rounding, not bitwise)
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-6, atol=1e-7)
+    g0, g1 = res[0][1].double(), res[1][1].double()
+    assert float((g0 - g1).norm() / (g0.norm() + 1e-30)) < 1e-6

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuvtg.so")
+LIB_PATH = os.environ.get("UVTG_LIB_PATH") or os.path.join(_HERE, "libuvtg.so")      # override: A/B of two builds (dev)
 
 
 class Dims(C.Structure):
@@ -52,6 +52,7 @@ SIGNATURES = {
     "uvtg_debug_force_nt_tile": (_I, [_I]),
     "uvtg_debug_force_nt_bm": (_I, [_I]),
     "uvtg_debug_force_nt_wn": (_I, [_I]),
+    "uvtg_set_dynamic_tiles": (_I, [_I]),
     "uvtg_profile_start": (_I, []),
     "uvtg_profile_stop": (_I, [_P, _P, _P]),
     "uvtg_profile_event_floor_ms": (C.c_double, []),

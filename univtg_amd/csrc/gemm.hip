@@ -241,7 +241,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // WN = 4: 256-wide tile, 8 waves, one workgroup per CU (128 KB of stages).  WN = 2: 128-wide tile, 4 waves, 80 KB (TM = 3) or
 // 64 KB (TM = 2) of stages so that TWO workgroups share a CU: they drift apart, and one's epilogue / barrier stalls overlap the
 // other's MFMA stream (in lockstep the epilogue of a 256-wide tile costs ~25 % of a K = 1024 GEMM with the matrix cores idle).
-template <bool GATHER, int TM, int WN>
+template <bool GATHER, int TM, int WN, bool DYN>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(const GemmArgs p) {
   constexpr int TB = 64 * WN, KB = 64, TN = 2, BM = 64 * TM, NW = 2 * WN, PA = 8 * TM / NW;
   constexpr int BOFF = (WN == 4) ? 32768 : BM * 128;            // byte offset of the B rows inside a stage
@@ -306,6 +306,8 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
 #pragma unroll
   for (int j = 0; j < TN; j++) boff[j] = BOFF + (wn * 64 + j * 32 + l31) * 128;
 
+  int* const s_next_p = (int*)(smem256 + 2 * SSTR);      // WN == 4 only (16 extra bytes of dynamic LDS): next tile of this workgroup
+  constexpr bool dyn = DYN;            // (host: only with WN == 4 and a registered counter slot)
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
   int gz, m0, n0;
@@ -321,32 +323,39 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int next = tile + gridDim.x;
+    int next = tile + gridDim.x;
     int ngz = 0, nm0 = 0, nn0 = 0;
-    // this lane's 8 output columns and their bias: fetched at the head of the tile, not in the epilogue (there the load sits
-    // right behind the barrier with every wave of the block waiting on it and the matrix cores idle)
+    // this lane's 8 output columns and their bias: the static kernels fetch it at the head of the tile (in the epilogue the load sits
+    // right behind the barrier with every wave of the block waiting on it); the dynamic ones have no registers left for that
     const int c8 = (lane & 7) * 8;
     const int n = n0 + wn * 64 + c8;
     const bool ncol = n < p.N;
     float bv[8];
+    auto fetch_bias = [&]() {
 #pragma unroll
-    for (int e = 0; e < 8; e++) bv[e] = 0.f;
-    if (ncol && p.act != 100) {
-      if (p.bias) {
-        const float* bias = p.bias + (size_t)gz * p.gBias + n;
-        const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
+      for (int e = 0; e < 8; e++) bv[e] = 0.f;
+      if (ncol && p.act != 100) {
+        if (p.bias) {
+          const float* bias = p.bias + (size_t)gz * p.gBias + n;
+          const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
 #pragma unroll
-        for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+        }
+        if (p.bias2) {
+          const f32x4 b0 = *(const f32x4*)(p.bias2 + n), b1 = *(const f32x4*)(p.bias2 + n + 4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+        }
       }
-      if (p.bias2) {
-        const f32x4 b0 = *(const f32x4*)(p.bias2 + n), b1 = *(const f32x4*)(p.bias2 + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
-      }
-    }
+    };
+    if constexpr (!DYN) fetch_bias();
     for (int kt = 0; kt < nk; kt++, it++) {
       const int cur = it & 1;
       __syncthreads();                       // vmcnt(0) + barrier: K tile `it` landed, the other stage is free
+      if constexpr (dyn) {                   // tiles t with t % 8 == XCD belong to this workgroup's XCD (see tile_origin)
+        if (kt == nk - 2 && tid == 0) *s_next_p = ((int)(gridDim.x >> 3) + atomicAdd(p.tile_counter + (blockIdx.x & 7), 1)) * 8 + (int)(blockIdx.x & 7);
+        if (kt == nk - 1) next = *s_next_p;
+      }
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
       else if (next < ntiles) { tile_origin(next, ngz, nm0, nn0); set_offsets(ngz, nm0, nn0); stage(cur ^ 1, 0); }
       const unsigned char* base = smem256 + cur * SSTR;
@@ -394,13 +403,14 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
       const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
+      if constexpr (DYN) fetch_bias();
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
       // The bf16 operand stream of the epilogue (residual, else the pre-activation of the activation gradient) is fetched one
       // 32-row group AHEAD into registers the main loop no longer needs: in lockstep behind the barrier every wave of the block
       // would otherwise expose a global-load latency per 8-row step (measured 0.5 ms of a 9.9 ms step).
       // (256-row tiles have no registers left for it -- an attempt spilled, and the spilled build returned garbage -- so TM = 4
       // keeps the direct loads)
-      constexpr bool EPF = TM < 4 && WN == 4;
+      constexpr bool EPF = TM < 4 && WN == 4 && !(GATHER && DYN);   // (the dynamic gather variant is at the register cap)
       const bf16_t* esrc = !EPF ? nullptr : (p.residB ? p.residB : (p.actgrad ? p.gradPre + gp : nullptr));
       const int eld = p.residB ? p.ldrB : p.ldgp;
       u32x4 epf[2][4];
@@ -862,18 +872,23 @@ static int g_num_cu = 0;
 #define UVTG_NT_F32 1.04
 #define UVTG_NT_F22 1.13
 #endif
-template <int TM, int WN> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, hipStream_t s) {
-  constexpr int smem = (WN == 4) ? 131072 : 2 * (64 * TM + 64 * WN) * 128;
+template <int TM, int WN, bool DYN> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, hipStream_t s) {
+  constexpr int smem = (WN == 4) ? 131072 + 16 : 2 * (64 * TM + 64 * WN) * 128;      // + the dynamic tile hand-out word
   static bool attr = false;
   if (!attr) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, WN, DYN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, WN, DYN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
     attr = true;
   }
-  if (gather) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, WN>), dim3(grid), dim3(128 * WN), smem, s, b);
-  else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, WN>), dim3(grid), dim3(128 * WN), smem, s, b);
+  if (gather) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, WN, DYN>), dim3(grid), dim3(128 * WN), smem, s, b);
+  else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, WN, DYN>), dim3(grid), dim3(128 * WN), smem, s, b);
   return 0;
 }
+static int* g_ctr_base = nullptr; static int g_ctr_slots = 0, g_ctr_next = 0;
+static int g_dynamic_tiles = 0;      // 0: static tile stride (default), 1: dynamic hand-out where the engine registers counters
+extern "C" int uvtg_set_dynamic_tiles(int on) { g_dynamic_tiles = on ? 1 : 0; return 0; }
+int uvtg_dynamic_tiles_enabled() { return g_dynamic_tiles; }
+void uvtg_nt_counter_pool(int* base, int slots) { g_ctr_base = g_dynamic_tiles ? base : nullptr; g_ctr_slots = slots; g_ctr_next = 0; }
 static int g_force_wn = 0;     // 0: automatic, 2 / 4: force the 128-wide two-per-CU or the 256-wide one-per-CU persistent kernel
 extern "C" int uvtg_debug_force_nt_wn(int wn) { if (wn != 0 && wn != 2 && wn != 4) return -21; g_force_wn = wn; return 0; }
 static int launch_nt256(const GemmArgs& a, hipStream_t s) {
@@ -908,10 +923,16 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   const long long slots = (long long)g_num_cu * (best_wn == 2 ? 2 : 1);
   const int grid = (int)(tiles < slots ? tiles : slots);
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1;
+  b.tile_counter = nullptr;
+  if (g_ctr_base && g_ctr_next < g_ctr_slots && best_wn == 4 && tiles > slots && grid % 8 == 0 && b.K >= 128)
+    b.tile_counter = g_ctr_base + 8 * (g_ctr_next++);
   uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
   int rc;
-  if (best_wn == 4) rc = best_tm == 4 ? launch_nt256_tm<4, 4>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3, 4>(b, grid, gather, s) : launch_nt256_tm<2, 4>(b, grid, gather, s));
-  else rc = best_tm == 3 ? launch_nt256_tm<3, 2>(b, grid, gather, s) : launch_nt256_tm<2, 2>(b, grid, gather, s);
+  if (best_wn == 4 && b.tile_counter)
+    rc = best_tm == 4 ? launch_nt256_tm<4, 4, true>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3, 4, true>(b, grid, gather, s) : launch_nt256_tm<2, 4, true>(b, grid, gather, s));
+  else if (best_wn == 4)
+    rc = best_tm == 4 ? launch_nt256_tm<4, 4, false>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3, 4, false>(b, grid, gather, s) : launch_nt256_tm<2, 4, false>(b, grid, gather, s));
+  else rc = best_tm == 3 ? launch_nt256_tm<3, 2, false>(b, grid, gather, s) : launch_nt256_tm<2, 2, false>(b, grid, gather, s);
   uvtg_prof_end_launch(3, s);
   if (rc) return rc;
   UVTG_CHECK_LAUNCH();
