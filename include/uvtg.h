@@ -213,10 +213,9 @@ int uvtg_debug_force_nt_bm(int bm);
 /* Parity-test aid: 0 = automatic, 4 = 256-column tiles (one workgroup per CU), 2 = 128-column tiles (two per CU). */
 int uvtg_debug_force_nt_wn(int wn);
 
-/* Process-wide: 1 = the persistent GEMM launches of uvtg_forward / uvtg_backward hand their tiles out dynamically (per-XCD
- * atomic counters in the workspace) instead of by a static stride.  Meant for data-parallel runs whose RCCL kernels overlap the
- * backward pass: a launch that does not get every CU then still finishes together instead of waiting for late workgroups.
- * Identical results either way; default 0 (≈1 % faster when the GPU is not shared). */
+/* Process-wide experiment knob: 1 = the persistent GEMM launches of uvtg_forward / uvtg_backward hand their tiles out dynamically
+ * (per-XCD atomic counters in the workspace) instead of by a static stride.  Identical results; default 0 -- with part of the CUs
+ * held by another stream (RCCL) the static stride measured faster (tools/hog_experiment.py). */
 int uvtg_set_dynamic_tiles(int on);
 
 const char* uvtg_strerror(int code);
