@@ -1,6 +1,6 @@
-"""Dev tool: per-parameter gradient agreement (HIP bf16 path vs CPU oracle autograd): max-rel error, cosine, norm ratio."""
+"""Diagnostic (test infrastructure, uses the oracle; not collected by pytest): per-parameter gradient agreement (HIP bf16 path vs CPU oracle autograd): max-rel error, cosine, norm ratio."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import univtg_oracle as O
 from tests.test_gpu_model import args_from_cfg, to_dev
