@@ -1,14 +1,19 @@
 #!/usr/bin/env python
 """Benchmark of the UniVTG hot path on MI355X (BASELINE.json: clips/sec fwd+bwd, L=75, d=1024).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10 [--config 2|3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one full training step of BASELINE config 2 on synthetic features resident in HBM: input projections
--> 4-layer encoder -> conv heads + saliency -> dense criterion -> backward -> (RCCL gradient all-reduce) ->
-global-norm clip + AdamW.  bf16 MFMA operands / fp32 accumulation, reference dropouts (0.5 / 0 / 0.1).
+A step = one full training step on synthetic features resident in HBM: input projections -> 4-layer encoder -> conv heads +
+saliency -> dense criterion -> backward -> (RCCL gradient all-reduce) -> global-norm clip + AdamW.  bf16 MFMA operands / fp32
+accumulation, the reference's training dropouts (input 0.5 / attention 0 / DropPath 0.1, scripts/pretrain.sh:33-35).
 Per-GPU batch is fixed (weak scaling).  Rank 0 prints ONE JSON line.
+
+`value` is the reference-equivalent execution: every clip row of the padded batch is computed (under input dropout each padded
+clip has its own mask); only padded TEXT tokens -- masked keys whose outputs nobody reads -- are left out of the encoder stream
+(exact, tests/test_gpu_parity_full.py::test_bench_path_trainstep_dropout_replayed_through_oracle).  The fully padded execution is
+timed next to it (`padded_execution_ms_per_step`).
 """
 from __future__ import annotations
 
@@ -25,14 +30,25 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-WORKLOAD = dict(B=256, L_v=75, L_t=32, D_v=2818, D_t=512, d=1024, F=1024, H=8, E=4)
+MODEL = dict(D_v=2818, D_t=512, d=1024, F=1024, H=8, E=4)
+# BASELINE.json configs that run on one GPU (config 3 = its per-GPU shard; config 1 is the CPU plumbing case)
+CONFIGS = {
+    2: dict(B=256, L_v=75, L_t=32, what="QVHighlights training shape (BASELINE config 2)", lens="len_v~U{38..75}, len_t~U{8..32} (SURVEY 8d variant B)"),
+    3: dict(B=256, L_v=128, L_t=32, what="4M VLP pretraining shape, per-GPU shard of the global batch 2048 (BASELINE config 3)",
+            lens="len_v~U{64..128}, len_t~U{8..32}"),
+    4: dict(B=32, L_v=1200, L_t=32, what="Ego4D-NLQ long-video shape (BASELINE config 4), tiled attention S=1232", lens="len_v~U{600..1200}, len_t~U{8..32}"),
+    5: dict(B=64, L_v=600, L_t=32, what="multi-dataset co-training batch (BASELINE config 5), mixed L_v in {75,200,600}",
+            lens="len_v drawn from {75: 0.45, 200: 0.40, 600: 0.15} (QVHighlights / Charades-STA+ANet / TACoS-length videos; assumed mix, "
+                 "the co-training lists are not shipped), len_t~U{8..32}"),
+}
+WORKLOAD = dict(MODEL, **{k: CONFIGS[2][k] for k in ("B", "L_v", "L_t")})       # (kept for the tools that import it)
 
 
 def model_args(**over):
     from types import SimpleNamespace
-    a = dict(device="cuda", hidden_dim=WORKLOAD["d"], dropout=0.0, droppath=0.1, nheads=WORKLOAD["H"],
-             dim_feedforward=WORKLOAD["F"], enc_layers=WORKLOAD["E"], dec_layers=2, pre_norm=False, position_embedding="sine",
-             max_q_l=75, input_dropout=0.5, t_feat_dim=WORKLOAD["D_t"], v_feat_dim=WORKLOAD["D_v"], span_loss_type="l1",
+    a = dict(device="cuda", hidden_dim=MODEL["d"], dropout=0.0, droppath=0.1, nheads=MODEL["H"],
+             dim_feedforward=MODEL["F"], enc_layers=MODEL["E"], dec_layers=2, pre_norm=False, position_embedding="sine",
+             max_q_l=75, input_dropout=0.5, t_feat_dim=MODEL["D_t"], v_feat_dim=MODEL["D_v"], span_loss_type="l1",
              use_txt_pos=False, n_input_proj=2, set_cost_span=10, set_cost_giou=1, set_cost_class=4, max_v_l=75,
              b_loss_coef=10, g_loss_coef=1, f_loss_coef=10, s_loss_intra_coef=0.1, s_loss_inter_coef=0.1,
              dset_type="vlp", train_path=["synthetic"], eos_coef=0.1, temperature=0.07, saliency_margin=0.2)
@@ -40,13 +56,27 @@ def model_args(**over):
     return SimpleNamespace(**a)
 
 
-def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev):
-    """Synthetic config-2 batch generated ON DEVICE (shape/statistics of SURVEY 8d: L2-normalised feature blocks,
-    TEF columns, ragged valid lengths, one GT window per sample with dense targets as main/dataset.py:173-230)."""
+def mixed_length_lens(B, seed=0, lengths=(75, 200, 600), probs=(0.45, 0.40, 0.15)):
+    """Config 5: per-sample clip counts of a co-training batch (one dataset length per sample); the longest length is always present
+    (the collate pads to the batch maximum, utils/tensor_utils.py:34-53)."""
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.multinomial(torch.tensor(probs), B, replacement=True, generator=g).tolist()
+    lens = [lengths[i] for i in idx]
+    lens[0] = max(lengths)
+    return lens
+
+
+def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev, lens_v=None):
+    """Synthetic batch generated ON DEVICE (shape/statistics of SURVEY 8d: L2-normalised feature blocks, TEF columns, ragged valid
+    lengths, one GT window per sample with dense targets as main/dataset.py:173-230)."""
     g = torch.Generator(device=dev).manual_seed(seed)
-    lens_v = torch.randint(38, Lv + 1, (B,), generator=g, device=dev)
+    if lens_v is None:
+        lens_v = torch.randint((Lv + 1) // 2, Lv + 1, (B,), generator=g, device=dev)
+        lens_v[0] = Lv
+    else:
+        lens_v = torch.tensor(lens_v, device=dev)
     lens_t = torch.randint(8, Lt + 1, (B,), generator=g, device=dev)
-    lens_v[0], lens_t[0] = Lv, Lt
+    lens_t[0] = Lt
     tv = torch.arange(Lv, device=dev)[None]
     vm = (tv < lens_v[:, None]).float()
     tm = (torch.arange(Lt, device=dev)[None] < lens_t[:, None]).float()
@@ -67,9 +97,10 @@ def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev):
     empty = inside.sum(1) == 0
     if bool(empty.any()):                                                       # dataset.py:202-205
         idx = torch.clamp((win[:, 0] * lens_v).long(), max=Lv - 1).clamp(min=0)
+        idx = torch.minimum(idx, lens_v - 1)
         inside[empty, idx[empty]] = 1.0
     span_nn = win[:, None, :] * inside[..., None]
-    pos = torch.multinomial(inside + 1e-9, 1, generator=g)                      # dataset.py:230 (random fg clip)
+    pos = torch.multinomial(inside + 1e-9 * vm, 1, generator=g)                 # dataset.py:230 (random fg clip)
     targets = dict(timestamp=torch.stack([ts, ts], -1).contiguous(), timestamp_mask=vm.contiguous(),
                    timestamp_window=inside.contiguous(), span_labels_nn=span_nn.contiguous(),
                    saliency_scores=inside.clone(), saliency_pos_labels=pos, _pos_idx=pos[:, 0].contiguous())
@@ -80,37 +111,56 @@ def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev):
     return inputs, targets
 
 
-def cpu_baseline(sample_B=32, steps=3):
-    """The oracle (CPU restatement of the reference, same torch CPU ops) timed on the host cores: fwd + criterion +
-    bwd at the config-2 shape, bounded sample of `sample_B` samples per step."""
+def cpu_baseline(batch, micro=32, max_micro=8):
+    """The oracle (CPU restatement of the reference, same torch CPU ops) timed on the host cores in TRAIN mode on the same synthetic
+    batch the GPU ran: fwd + criterion + bwd in micro-batches of `micro` samples (the reference's bernoulli_ draws for input dropout
+    and DropPath inside the timed region), bounded to `max_micro` micro-steps."""
     from oracle import univtg_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, 32))          # more threads than this only adds contention on the 2-socket host
-    cfg = O.make_cfg(input_dropout=0.0, dropout=0.0, droppath=0.0)              # stochastic masks are not part of the oracle timing
+    inputs, tg = batch
+    cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
     params = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}
-    inputs, tg = O.make_batch(cfg, sample_B, WORKLOAD["L_v"], WORKLOAD["L_t"], seed=0, ragged=True)
-    times = []
-    for i in range(steps + 1):
+    cpu_in = {k: v.cpu() for k, v in inputs.items() if torch.is_tensor(v)}
+    cpu_tg = {k: v.cpu() for k, v in tg.items() if torch.is_tensor(v) and not k.startswith("_")}
+    B, Lv = cpu_in["src_vid"].shape[:2]
+    Lt = cpu_in["src_txt"].shape[1]
+    n_micro = min(max_micro, B // micro)
+    keep_p = 1.0 - cfg.droppath
+
+    def one(i):
+        sl = slice(i * micro, (i + 1) * micro)
+        mi = {k: v[sl] for k, v in cpu_in.items()}
+        mt = {k: v[sl] for k, v in cpu_tg.items()}
         for p in params.values():
             p.grad = None
         t0 = time.perf_counter()
-        out = O.forward(params, cfg, **inputs)
-        O.total_loss(O.criterion(out, tg, cfg), cfg).backward()
-        times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return dict(value=sample_B * WORKLOAD["L_v"] / t, unit="clips/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle fwd+criterion+bwd, fp32, B={sample_B} L_v=75 L_t=32 d=1024 E=4, median of {steps} steps after 1 warm-up "
-                       f"({t:.2f} s/step)")
+        bern = lambda *shape: torch.bernoulli(torch.full(shape, 0.5))
+        rng = {"vid_keep": [bern(micro, Lv, cfg.v_feat_dim), bern(micro, Lv, cfg.hidden_dim)],
+               "txt_keep": [bern(micro, Lt, cfg.t_feat_dim), bern(micro, Lt, cfg.hidden_dim)],
+               "dp_scale": torch.floor(keep_p + torch.rand(cfg.enc_layers, 2, micro)) / keep_p}
+        out = O.forward(params, cfg, mi["src_txt"], mi["src_txt_mask"], mi["src_vid"], mi["src_vid_mask"], rng=rng)
+        O.total_loss(O.criterion(out, mt, cfg), cfg).backward()
+        return time.perf_counter() - t0
+    one(0)                                                       # warm-up
+    times = [one(i) for i in range(n_micro)]
+    t = sum(times)
+    return dict(value=n_micro * micro * Lv / t, unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle fwd+criterion+bwd, fp32, TRAIN mode (input dropout 0.5 + DropPath 0.1 drawn with bernoulli_/rand inside the "
+                       f"timed region), the first {n_micro * micro} samples of the GPU run's synthetic batch as {n_micro} micro-steps of "
+                       f"{micro} after 1 warm-up ({t:.2f} s total, {t / n_micro:.2f} s per micro-step)")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=WORKLOAD["B"], help="per-GPU batch (config 2: 256)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline metric)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra instrumented steps for the roofline line")
     ap.add_argument("--no-padded-compare", action="store_true", help="skip the extra timing of the padded (non-packed) execution")
+    ap.add_argument("--packed", default="auto", choices=["auto", "off"], help="encoder row stream (auto = exact packed stream)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,28 +176,29 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_size = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.distributed.init_process_group(backend="nccl", device_id=dev)     # "nccl" == RCCL on ROCm
         else:
             torch.distributed.init_process_group(backend=backend)
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        comm_size = torch.distributed.get_world_size()
 
     from univtg_amd import _lib
     from univtg_amd.model import build_model
     from univtg_amd.trainer import TrainStep
+    wl = CONFIGS[args.config]
+    B, Lv, Lt = args.batch or wl["B"], wl["L_v"], wl["L_t"]
     torch.manual_seed(2018)
-    model, crit = build_model(model_args())
+    model, crit = build_model(model_args(max_v_l=Lv))
     model.to(dev).train()
     crit.to(dev).train()
     model.set_seed(2018 + rank)
-    step = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1)
-    B, Lv, Lt = args.batch, WORKLOAD["L_v"], WORKLOAD["L_t"]
-    batches = [synth_batch(B, Lv, Lt, WORKLOAD["D_v"], WORKLOAD["D_t"], 1000 * rank + i, dev) for i in range(2)]
+    packed = False if args.packed == "off" else "auto"
+    step = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=packed)
+    lens_fn = (lambda s: mixed_length_lens(B, seed=s)) if args.config == 5 else (lambda s: None)
+    batches = [synth_batch(B, Lv, Lt, MODEL["D_v"], MODEL["D_t"], 1000 * rank + i, dev, lens_fn(1000 * rank + i)) for i in range(2)]
 
     def barrier():
         if world > 1:
@@ -157,20 +208,24 @@ def main():
     for i in range(args.warmup):
         step.step(*batches[i % 2])
     barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    evs[0].record()
     for i in range(args.steps):
         step.step(*batches[i % 2])
+        evs[i + 1].record()                                   # on the launch stream (torch's current stream)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     losses = step.losses[:5].tolist()
 
     # ---- the same batches through the padded execution (every padded position computed, as the reference does) ----
     padded_ms = None
-    if rank == 0 and world == 1 and not args.no_padded_compare:
+    if rank == 0 and world == 1 and not args.no_padded_compare and packed:
         step_p = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=False)
         for i in range(3):
             step_p.step(*batches[i % 2])
@@ -182,9 +237,9 @@ def main():
         padded_ms = (time.perf_counter() - tp) / 10 * 1e3
         del step_p
 
-    # ---- roofline of the dominant kernel: HIP events around every gemm_nt<bf16> launch, on the launch stream ----
+    # ---- roofline of the dominant kernel: HIP events around every GEMM launch, on the launch stream ----
     lib = _lib.load()
-    roof = None
+    roof, sect = None, None
     if rank == 0:
         lib.uvtg_profile_start()
     for i in range(args.profile_steps):          # EVERY rank runs these steps (they contain the gradient all-reduce); only rank 0 instruments them
@@ -192,43 +247,80 @@ def main():
     if rank == 0:
         ms, fl, n = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
         _lib.check(lib.uvtg_profile_stop(ms, fl, n), "uvtg_profile_stop")
+        floor = lib.uvtg_profile_event_floor_ms()
         fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel", "gemm_nt256_kernel"]
         dom = max(range(4), key=lambda i: ms[i])
-        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        raw_ms = ms[dom] + floor * n[dom]                     # durations as the event pairs saw them (no floor correction)
+        ach = fl[dom] / (raw_ms * 1e-3) / 1e12 if raw_ms > 0 else 0.0
+        ach_corr = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         traffic, traffic_note = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_nt256.json")       # separate rocprofv3 --pmc passes of this same command
-        if fam[dom] == "gemm_nt256_kernel" and os.path.exists(pmc):
-            with open(pmc) as f:
-                pj = json.load(f)
-            traffic = pj["traffic_bytes_per_launch"]
-            traffic_note = ("HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed in "
-                            "profiles/r01_pmc_nt256.json; measured MFMA-busy fraction %.3f" % pj["mfma_busy_frac"])
+        for tag in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_nt256.json")       # separate rocprofv3 --pmc passes of this same command
+            if fam[dom] == "gemm_nt256_kernel" and os.path.exists(pmc):
+                with open(pmc) as f:
+                    pj = json.load(f)
+                traffic = pj["traffic_bytes_per_launch"]
+                traffic_note = (f"NOT measured in this run: replayed from profiles/{tag}_pmc_nt256.json (rocprofv3 --pmc passes of this command: "
+                                "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE per launch; MFMA-busy fraction %.3f)" % pj["mfma_busy_frac"])
+                break
         roof = dict(bound="mfma", kernel=fam[dom], achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                     traffic=traffic, traffic_note=traffic_note, launches_per_step=int(n[dom] // max(1, args.profile_steps)),
-                    avg_launch_us=round(ms[dom] * 1e3 / max(1, n[dom]), 2),
-                    event_pair_floor_us=round(lib.uvtg_profile_event_floor_ms() * 1e3, 2),
+                    avg_launch_us=round(raw_ms * 1e3 / max(1, n[dom]), 2),
+                    event_pair_floor_us=round(floor * 1e3, 2), achieved_floor_corrected=round(ach_corr, 2),
+                    note="achieved = sum(2MNK) / sum(event-pair duration) over the launches, durations NOT floor-corrected",
                     algorithmic_gflop_per_launch=round(fl[dom] / max(1, n[dom]) / 1e9, 2),
                     all_gemm_kernels={fam[i]: dict(ms_per_step=round(ms[i] / max(1, args.profile_steps), 3),
                                                    tflops=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else 0.0,
                                                    launches_per_step=int(n[i] // max(1, args.profile_steps))) for i in range(4)})
+    # ---- section timing: encoder forward / backward (roofline.achieved = encoder fwd+bwd FLOPs / t_encoder / peak) ----
+    if rank == 0:
+        lib.uvtg_profile_sections_start()
+    for i in range(args.profile_steps):
+        step.step(*batches[i % 2])
+    if rank == 0:
+        sm, sn = (C.c_double * 4)(), (C.c_longlong * 4)()
+        _lib.check(lib.uvtg_profile_sections_stop(sm, sn), "uvtg_profile_sections_stop")
+        k = max(1, args.profile_steps)
+        sect = dict(encoder_fwd_ms=round(sm[0] / k, 3), encoder_bwd_ms=round(sm[1] / k, 3), forward_ms=round(sm[2] / k, 3),
+                    backward_ms=round(sm[3] / k, 3))
     if world > 1:
         torch.distributed.barrier()
 
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
+        cpu = cpu_baseline(batches[0])
+
     if rank == 0:
         clips = B * Lv * world * args.steps
-        S, d, F_, E = Lv + Lt, WORKLOAD["d"], WORKLOAD["F"], WORKLOAD["E"]
-        enc_flops = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)
-        out = dict(metric="clips/sec (L=75,d=1024) fwd+bwd", value=round(clips / elapsed, 1), unit="clips/s", n_gpus=world,
+        S, d, F_, E = Lv + Lt, MODEL["d"], MODEL["F"], MODEL["E"]
+        enc_flops = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)      # padded positions count
+        t_enc = (sect["encoder_fwd_ms"] + sect["encoder_bwd_ms"]) * 1e-3
+        lens = [bt[0]["_lens_host"] for bt in batches]
+        valid_clips = sum(sum(a) for a, _ in lens) / len(lens)
+        rows_full = sum(sum(a) + sum(b) + sum(1 for x in a if x < Lv) for a, b in lens) / (len(lens) * B * S)
+        rows_text = sum(B * Lv + sum(b) for a, b in lens) / (len(lens) * B * S)
+        out = dict(metric="clips/sec (L=75,d=1024) fwd+bwd" if args.config == 2 else f"clips/sec fwd+bwd (BASELINE config {args.config})",
+                   value=round(clips / elapsed, 1), unit="clips/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
-                   config=dict(workload="QVHighlights training shape (BASELINE config 2): L_v=75 L_t=32 D_v=2818 D_t=512 d=1024 F=1024 "
-                                        "H=8 E=4, full train step (fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, ragged valid lengths (SURVEY 8d variant B), "
-                                        "packed encoder stream (valid rows + one representative padded clip per sample)",
-                               per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
+                   config=dict(workload=f"{wl['what']}: L_v={Lv} L_t={Lt} D_v=2818 D_t=512 d=1024 F=1024 H=8 E=4, full train step "
+                                        f"(fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, ragged valid lengths: {wl['lens']}; every clip row "
+                                        "computed (padded clips included), padded text tokens left out of the encoder stream (exact)"
+                                        if packed else f"{wl['what']}: padded execution",
+                               baseline_config=args.config, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
+                   world_size=world, comm_backend=(backend if world > 1 else None), comm_world_size=comm_size,
                    samples_per_sec=round(B * world * args.steps / elapsed, 1),
-                   encoder_mfma_frac_of_step=round(enc_flops / (elapsed / args.steps) / 2.5e15, 4),      # reference-algorithmic (padded) encoder FLOPs / step time / peak
-                   packed_rows_fraction=round(sum(sum(a) + sum(b) + sum(1 for x in a if x < Lv) for a, b in (bt[0]["_lens_host"] for bt in batches)) / (len(batches) * B * (Lv + Lt)), 4),
+                   valid_clips_per_sec=round(valid_clips * world * args.steps / elapsed, 1),
+                   ms_per_step_event_median=round(per_step[len(per_step) // 2], 3), ms_per_step_event_min=round(per_step[0], 3),
+                   t_encoder_ms=round(t_enc * 1e3, 3), sections=sect,
+                   roofline_encoder=dict(achieved=round(enc_flops / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s",
+                                         frac=round(enc_flops / t_enc / 2.5e15, 4),
+                                         note="SURVEY 8d: 3*E*B*(8Sd^2+4SdF+4S^2d) (padded positions count, as the reference computes them) / "
+                                              "(encoder fwd + bwd section time, HIP events on the launch stream) / 2.5 PFLOP/s"),
+                   encoder_rows_fraction=round(rows_text if packed else 1.0, 4), full_packed_rows_fraction=round(rows_full, 4),
                    padded_execution_ms_per_step=None if padded_ms is None else round(padded_ms, 3),
+                   numerics="train-mode calls run the input projections on plain bf16 operands (saliency_scores within 3e-2 of fp32); the "
+                            "1e-4 saliency clause holds for inference calls (split-bf16 projections)",
                    losses=[round(x, 5) for x in losses], roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:

@@ -75,11 +75,15 @@ int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* params, void* 
  *          pred_logits [B,Lv,1], pred_spans [B,Lv,2], txt_mem_proj [B,1,d], saliency [B,Lv]
  *          memory [B,S,d] encoder output (optional, may be NULL)
  * lens_host (optional): the per-sample valid lengths the caller's collate already knows on the host (the reference's
- *          pad_sequences_1d computes them, utils/tensor_utils.py:34-53); masks must be the matching prefix masks.  When given (bf16
- *          mode, memory == NULL) the encoder runs on the packed rows -- valid clips, ONE representative padded clip per sample,
- *          valid text tokens -- which reproduces the padded computation exactly (see misc.hip) at ~25 % fewer rows on ragged
- *          batches.  (With training-time input dropout the padded clips of a sample share the dropout realisation of its first padded
- *          clip instead of independent ones.)  uvtg_backward must get the same array. */
+ *          pad_sequences_1d computes them, utils/tensor_utils.py:34-53); masks must be the matching prefix masks (the device-side
+ *          tables are rebuilt from the masks; lens_host is read synchronously, for the row count only, and may be freed on return).
+ *          When given (bf16 mode) the encoder runs on a packed row stream that reproduces the padded computation exactly:
+ *            - eval, or training with p_in == 0 and p_attn == 0: valid clips + ONE representative padded clip per sample + valid text
+ *              tokens (all padded clips of a sample are then identical rows; ~25 % fewer rows on ragged batches);
+ *            - training with input or attention dropout: EVERY clip row (each padded clip draws its own mask in the reference,
+ *              model/univtg.py:392-404) + the valid text tokens (padded text tokens are masked keys whose outputs nobody reads).
+ *          The choice is a function of (dims, lens_host != NULL) only, so uvtg_backward -- which must get the same array -- makes the
+ *          same one.  With memory != NULL: ignored in eval calls, error -24 in training calls. */
 int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                  const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                  const float* dim_t,
@@ -188,6 +192,17 @@ int uvtg_decode_rank_nms(const float* pred_logits, const float* pred_spans, cons
                          const float* timestamp_mask, const float* durations, int B, int Lv,
                          float nms_thd, int max_before, int max_after,
                          double* windows_out, int* order, int* keep, int* n_keep, uvtg_stream_t stream);
+/* The full per-batch tail of compute_mr_results + eval_epoch_post_processing (main/inference_mr.py:109-192,31-40): as above, plus
+ *   clip_length > 0 : PostProcessorDETR's round_multiple (eval/postprocessing.py:46-51) on the 4-decimal rows BEFORE the NMS, as the
+ *                     reference orders them -- fp32 torch.round(w / clip_length) * clip_length (half-to-even), so the windows come
+ *                     out as exact integer multiples of clip_length; score re-rounded to 4 decimals (:35).  <= 0: off (--round_multiple -1)
+ *   saliency_out    : (optional, [B,Lv] fp32) pred_saliency_scores = fp16(saliency) (+ pred_logits when eval_mode_add, the
+ *                     reference's --eval_mode add), main/inference_mr.py:124-128; the caller truncates row b to its len_v (:133-136). */
+int uvtg_postprocess_mr(const float* pred_logits, const float* pred_spans, const float* saliency /* [B,Lv] or NULL */,
+                        const float* timestamp, const float* timestamp_mask, const float* durations, int B, int Lv,
+                        float clip_length, int eval_mode_add, float nms_thd, int max_before, int max_after,
+                        double* windows_out, int* order, int* keep, int* n_keep, float* saliency_out /* or NULL */,
+                        uvtg_stream_t stream);
 
 /* ---- training-step shell: replaces clip_grad_norm_ + AdamW.step (main/train_vlp_ddp.py:66-68,
  * main/config.py:349-350) over ONE flat fp32 buffer laid out by uvtg_param_offsets.
@@ -204,6 +219,12 @@ int uvtg_profile_start(void);
 int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
 /* the empty-event-pair floor (ms) that uvtg_profile_stop measured on the launch stream and subtracted from every launch */
 double uvtg_profile_event_floor_ms(void);
+
+/* Section timing (its own pass, so that the per-launch events above do not sit inside the sections): one event pair on the launch
+ * stream around 0: the E encoder layers of uvtg_forward, 1: their backward in uvtg_backward (LayerNorm / dgrad / attention /
+ * weight-gradient kernels of the E layers), 2: the whole uvtg_forward, 3: the whole uvtg_backward.  host arrays [4]. */
+int uvtg_profile_sections_start(void);
+int uvtg_profile_sections_stop(double* total_ms, long long* counts);
 
 /* Test knob: force the NT GEMM tile size (0 = automatic choice, 128, 256) so that both kernels can be compared on
  * identical inputs.  Process-wide. */

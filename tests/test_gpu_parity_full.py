@@ -1,0 +1,572 @@
+"""Parity at the BENCHMARKED configurations (BASELINE config 2 at full size, the exact bench path, configs 4 and 5), HIP path vs
+the CPU oracle on the same seeded inputs, through the drop-in boundary.  The oracle runs take seconds (B = 256 fwd+bwd ~10 s)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_model import args_from_cfg, build, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _threads():
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+
+def _grad_report(named_or_flat, ref_params, get):
+    """per-parameter (cosine, norm ratio) of HIP gradients vs oracle autograd."""
+    rep = {}
+    for k, p in ref_params.items():
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            continue
+        a, r = get(k).detach().cpu().double().flatten(), p.grad.double().flatten()
+        rep[k] = (float((a @ r) / (a.norm() * r.norm() + 1e-30)), float(a.norm() / (r.norm() + 1e-30)))
+    return rep
+
+
+def _ref_keep(ref_pre, ref_nms):
+    """reference post-NMS rows -> their rank positions in the ranked (pre-NMS) list"""
+    rows = [tuple(r) for r in ref_pre]
+    used, out = set(), []
+    for r in ref_nms:
+        idx = next(i for i, rr in enumerate(rows) if rr == tuple(r) and i not in used)
+        used.add(idx)
+        out.append(idx)
+    return out
+
+
+@pytest.fixture(scope="module")
+def config2(dev):
+    """Config 2 at FULL size (B=256, L_v=75, L_t=32, d=1024, E=4, ragged): oracle forward, losses and gradients (eval mode)."""
+    from oracle import univtg_oracle as O
+    _threads()
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0)
+    params = O.init_params(cfg, seed=101)
+    inputs, tg = O.make_batch(cfg, 256, 75, 32, seed=102, ragged=True)
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(p2, cfg, **inputs)
+    losses = O.criterion(ref, tg, cfg)
+    O.total_loss(losses, cfg).backward()
+    return cfg, params, inputs, tg, p2, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ref.items()}, \
+        {k: float(v) for k, v in losses.items()}
+
+
+def test_config2_full_size_fp32x3_forward_and_post_nms_indices(dev, config2):
+    """north_star at production size: saliency within 1e-4, and the post-NMS span indices (ranking + keep-set, raw and with
+    round_multiple) identical to the reference algorithm run on the ORACLE's outputs, for all 256 samples."""
+    from oracle import postproc_oracle as P
+    from univtg_amd import ops
+    cfg, params, inputs, tg, _, ref, _ = config2
+    model, _ = build(cfg, params, dev, "fp32x3")
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(inputs, dev))
+    valid = inputs["src_vid_mask"].bool()
+    e_sal = float((out["saliency_scores"].cpu() - ref["saliency_scores"])[valid].abs().max())
+    e_log = float((out["pred_logits"].cpu() - ref["pred_logits"]).abs().max())
+    e_spn = float((out["pred_spans"].cpu() - ref["pred_spans"]).abs().max())
+    print(f"\n[config2 fp32x3] saliency err {e_sal:.2e}  pred_logits err {e_log:.2e}  pred_spans err {e_spn:.2e}")
+    assert e_sal < 1e-4 and e_log < 3e-4 and e_spn < 3e-4
+    B, Lv = inputs["src_vid"].shape[:2]
+    durations = torch.tensor([float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(B)])
+    pl_ref, ps_ref = ref["pred_logits"].numpy(), ref["pred_spans"].numpy()
+    ts, tm = tg["timestamp"].numpy(), tg["timestamp_mask"].numpy()
+    ref_order = P.ranked_clip_indices(pl_ref, tm)
+    ref_pre = P.decode_windows(pl_ref, ps_ref, ts, tm, durations.tolist())
+    for clip_length in (0.0, 2.0):
+        pre = ref_pre if clip_length == 0 else [P.round_multiple(p, clip_length) for p in ref_pre]
+        ref_nms = [P.temporal_nms(p[:1000], 0.7, 10) for p in pre]
+        win, order, keep, nk, _ = ops.postprocess_mr(out["pred_logits"], out["pred_spans"], None, tg["timestamp"].to(dev),
+                                                     tg["timestamp_mask"].to(dev), durations.to(dev), clip_length=clip_length)
+        order, keep, nk, win = order.cpu().tolist(), keep.cpu().tolist(), nk.cpu().tolist(), win.cpu().numpy()
+        bad_rank, bad_keep, near_tie = [], [], 0
+        sc = pl_ref[..., 0].copy()
+        sc[~tm.astype(bool)] = 0
+        for b in range(B):
+            rk = _ref_keep(pre[b], ref_nms[b])
+            ok_rank, ok_keep = order[b] == ref_order[b], keep[b][: nk[b]] == rk
+            if not ok_rank:
+                # a ranking difference is only admissible between clips whose ORACLE scores are closer than the fp32x3 error
+                diff = [i for i in range(Lv) if order[b][i] != ref_order[b][i]]
+                gaps = [abs(float(sc[b, order[b][i]]) - float(sc[b, ref_order[b][i]])) for i in diff]
+                if max(gaps) <= 4 * e_log:
+                    near_tie += 1
+                else:
+                    bad_rank.append((b, max(gaps)))
+            if not ok_keep and ok_rank:
+                bad_keep.append(b)
+            if ok_rank and ok_keep and clip_length > 0:
+                # integer clip multiples, bit-exact (eval/postprocessing.py:46-51)
+                got = np.array([win[b, i] for i in keep[b][: nk[b]]])
+                want = np.array(ref_nms[b])
+                assert np.array_equal(got[:, :2], want[:, :2]), b
+                assert np.all(np.mod(got[:, :2], clip_length) == 0)
+        print(f"[config2 fp32x3, clip_length={clip_length}] samples with identical ranking+keep-set: "
+              f"{B - near_tie - len(bad_rank) - len(bad_keep)}/{B}; ranking differences confined to oracle near-ties (< 4x the measured "
+              f"logit error): {near_tie}")
+        assert not bad_rank and not bad_keep, (bad_rank, bad_keep)
+        assert near_tie <= B // 16
+
+
+def test_config2_full_size_bf16_losses_gradients_and_index_agreement(dev, config2):
+    """The benchmarked arithmetic (bf16 operands) at config 2 full size, eval mode: five losses, EVERY parameter gradient, and the
+    measured top-10 post-NMS index agreement with the fp32 reference algorithm."""
+    from oracle import postproc_oracle as P
+    from univtg_amd import ops
+    cfg, params, inputs, tg, p2, ref, ref_losses = config2
+    model, crit = build(cfg, params, dev, "bf16")
+    model.eval()
+    ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    out = model(**ind)
+    ld = crit(out, tgd)
+    sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
+    for k in ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra"):
+        got, want = float(ld[k]), ref_losses[k]
+        assert abs(got - want) < 2e-2 * max(1.0, abs(want)), (k, got, want)
+    named = dict(model.named_parameters())
+    rep = _grad_report(named, p2, lambda k: named[k].grad)
+    worst_cos = min(rep.items(), key=lambda kv: kv[1][0])
+    worst_ratio = max(rep.items(), key=lambda kv: abs(kv[1][1] - 1))
+    print(f"\n[config2 bf16] {len(rep)} parameter gradients; worst cosine {worst_cos[1][0]:.5f} ({worst_cos[0]}), "
+          f"worst norm ratio {worst_ratio[1][1]:.4f} ({worst_ratio[0]})")
+    bad = {k: v for k, v in rep.items() if v[0] < 0.998 or abs(v[1] - 1) > 0.01}
+    assert not bad, bad
+    # index agreement of the bf16 inference path with the fp32 algorithm (reported, with a floor)
+    B = inputs["src_vid"].shape[0]
+    durations = torch.tensor([float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(B)])
+    ref_pre = P.decode_windows(ref["pred_logits"].numpy(), ref["pred_spans"].numpy(), tg["timestamp"].numpy(),
+                               tg["timestamp_mask"].numpy(), durations.tolist())
+    ref_order = P.ranked_clip_indices(ref["pred_logits"].numpy(), tg["timestamp_mask"].numpy())
+    ref_nms = [P.temporal_nms(p[:1000], 0.7, 10) for p in ref_pre]
+    with torch.no_grad():
+        o = model(**ind)
+    win, order, keep, nk = ops.decode_rank_nms(o["pred_logits"], o["pred_spans"], tgd["timestamp"], tgd["timestamp_mask"], durations.to(dev))
+    order, keep, nk = order.cpu().tolist(), keep.cpu().tolist(), nk.cpu().tolist()
+    top1 = same_set = same_list = 0
+    for b in range(B):
+        got = [order[b][i] for i in keep[b][: nk[b]]]
+        want = [ref_order[b][i] for i in _ref_keep(ref_pre[b], ref_nms[b])]
+        top1 += got[:1] == want[:1]
+        same_list += got == want
+        same_set += set(got) == set(want)
+    print(f"[config2 bf16] post-NMS top-10 clip indices vs fp32 reference algorithm: identical ordered list {same_list}/{B}, "
+          f"identical set {same_set}/{B}, identical top-1 {top1}/{B}")
+    assert top1 >= 0.9 * B
+
+
+def test_bench_path_trainstep_dropout_replayed_through_oracle(dev):
+    """The EXACT bench.py path: native TrainStep, train mode, config 2 full size (B=256, E=4), input dropout 0.5 + DropPath 0.1,
+    packed="auto" with the collate's host-side lengths.  The device Philox masks are regenerated on the host and handed to the
+    oracle; losses and every parameter gradient must agree.  (Under input dropout the engine's packed stream keeps every clip row and
+    drops only padded text tokens -- exact, unlike round 1's shared-mask representative.)"""
+    import philox_ref as R
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    _threads()
+    cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
+    params = O.init_params(cfg, seed=201)
+    B, Lv, Lt = 256, 75, 32
+    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=202, ragged=True)
+    res = {}
+    for packed in (False, "auto"):
+        model, crit = build(cfg, params, dev, "bf16", proj_precise="auto")
+        model.train()
+        model.set_seed(777)
+        step = TrainStep(model, crit, grad_clip=0.1, packed=packed)
+        batch = to_dev(inputs, dev)
+        batch["_lens_host"] = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+        losses = step.step(batch, to_dev(tg, dev), optimize=False)
+        torch.cuda.synchronize()
+        res[packed] = (losses.cpu(), step.grads.clone(), model, step.pred_logits.clone())
+    # the two executions draw the same masks and compute the same rows: equal to re-association noise
+    l0, g0, _, pl0 = res[False]
+    l1, g1, model, pl1 = res["auto"]
+    assert float((l0 - l1).abs().max()) < 2e-3 * max(1.0, float(l0.abs().max()))
+    gg0, gg1 = g0.double(), g1.double()
+    assert float((gg0 @ gg1) / (gg0.norm() * gg1.norm())) > 0.9995
+    # ---- replay through the oracle ----
+    seed = (777 * 1000003 + 1) & 0xFFFFFFFFFFFFFFFF
+    Dv, Dt, d, E = cfg.v_feat_dim, cfg.t_feat_dim, cfg.hidden_dim, cfg.enc_layers
+    t = lambda a: torch.from_numpy(a)
+    rng = {"vid_keep": [t(R.row_keep(seed, R.RNG_IN_VID, B * Lv, Dv, 0.5)).view(B, Lv, Dv),
+                        t(R.row_keep(seed, R.RNG_IN_VID + 1, B * Lv, d, 0.5)).view(B, Lv, d)],
+           "txt_keep": [t(R.row_keep(seed, R.RNG_IN_TXT, B * Lt, Dt, 0.5)).view(B, Lt, Dt),
+                        t(R.row_keep(seed, R.RNG_IN_TXT + 1, B * Lt, d, 0.5)).view(B, Lt, d)],
+           "dp_scale": t(R.droppath_scales(seed, E, B, 0.1))}
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(p2, cfg, inputs["src_txt"], inputs["src_txt_mask"], inputs["src_vid"], inputs["src_vid_mask"], rng=rng)
+    ref_losses = O.criterion(ref, tg, cfg)
+    O.total_loss(ref_losses, cfg).backward()
+    e = float((pl1.cpu() - ref["pred_logits"].detach()).abs().max())
+    assert e < 4e-2, e
+    for i, k in enumerate(("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")):
+        got, want = float(l1[i]), float(ref_losses[k])
+        assert abs(got - want) < 3e-2 * max(1.0, abs(want)), (k, got, want)
+    offs = model._offsets(model._dims(B, Lv, Lt, Dv, Dt, False))
+    names = {id(p): k for k, p in model.named_parameters()}
+    flat = {names[id(p)]: g1[offs[i]: offs[i] + p.numel()] for i, p in enumerate(model._ordered_params())}
+    rep = _grad_report(None, p2, lambda k: flat[k])
+    worst_cos = min(rep.items(), key=lambda kv: kv[1][0])
+    worst_ratio = max(rep.items(), key=lambda kv: abs(kv[1][1] - 1))
+    print(f"\n[bench path, train mode, B=256] {len(rep)} gradients; worst cosine {worst_cos[1][0]:.5f} ({worst_cos[0]}), "
+          f"worst norm ratio {worst_ratio[1][1]:.4f} ({worst_ratio[0]})")
+    bad = {k: v for k, v in rep.items() if v[0] < 0.99 or abs(v[1] - 1) > 0.03}
+    assert not bad, bad
+
+
+def test_eval_after_native_train_step_sees_new_weights(dev):
+    """TrainStep updates the flat parameter buffer with a raw kernel (tensor versions do not move); a later
+    model(...) call must rebuild its bf16 operand cache.  eval -> TrainStep.step -> eval == a fresh model loaded from state_dict()."""
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                     input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=61)
+    inputs, tg = O.make_batch(cfg, 6, 30, 10, seed=62, ragged=True)
+    ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    model, crit = build(cfg, params, dev, "bf16", proj_precise="auto")
+    model.eval()
+    with torch.no_grad():
+        before = model(**ind)["pred_logits"].clone()
+    step = TrainStep(model, crit, lr=1e-2, grad_clip=0.0)
+    with torch.no_grad():
+        assert torch.equal(model(**ind)["pred_logits"], before)          # re-homing the parameters changes nothing
+    for _ in range(3):
+        step.step(ind, tgd, optimize=True)
+    with torch.no_grad():
+        after = model(**ind)["pred_logits"].clone()
+    fresh, _ = build(cfg, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, dev, "bf16", proj_precise="auto")
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(**ind)["pred_logits"]
+    assert float((after - before).abs().max()) > 1e-3                    # the steps did move the predictions
+    assert torch.equal(after, want)
+    # optimizer state round trip in torch.optim.AdamW's layout (reference checkpoints, main/train_vlp_ddp.py:157-195)
+    sd = step.state_dict()
+    ref_opt = torch.optim.AdamW([p for n, p in fresh.named_parameters() if p.requires_grad], lr=1e-2, weight_decay=1e-4)
+    ref_opt.load_state_dict(sd)                                          # loadable by the reference's optimizer
+    fresh2, crit2 = build(cfg, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, dev, "bf16", proj_precise="auto")
+    fresh2.eval()
+    step2 = TrainStep(fresh2, crit2, lr=1e-2, grad_clip=0.0)
+    step2.load_state_dict(sd)
+    assert step2.t == step.t and torch.equal(step2.m, step.m) and torch.equal(step2.v, step.v)
+    a = step.step(ind, tgd, optimize=True)
+    b = step2.step(ind, tgd, optimize=True)
+    torch.cuda.synchronize()
+    assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(a.abs().max()))
+    # (Adam's normalised update turns fp32-atomic-order noise on near-zero gradients into full-size steps for a few elements)
+    assert float(((step.flat - step2.flat).abs() > 1e-4).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["tiny_eval_ragged", "tiny_eval_full", "config1_real_feats"])
+def test_postprocess_round_multiple_and_eval_mode_saliency(dev, golden_dir, name):
+    """round-to-clip on device (integer clip multiples bit-exact) + the --eval_mode add saliency, against what
+    the REAL reference's compute_mr_results / PostProcessorDETR / post_processing_mr_nms produced (tests/golden)."""
+    from test_gpu_model import load_case
+    from univtg_amd import ops
+    meta, cfg, params, inputs, tg, out_ref, eval_ref, *_ = load_case(golden_dir, name)
+    B, Lv = inputs["src_vid"].shape[:2]
+    durations = torch.tensor([float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(B)])
+    args = [eval_ref["pred_logits"].to(dev), eval_ref["pred_spans"].to(dev), eval_ref["saliency_scores"].to(dev), tg["timestamp"].to(dev),
+            tg["timestamp_mask"].to(dev), durations.to(dev)]
+    for tag, clip in (("raw", 0.0), ("rounded", 2.0)):
+        win, order, keep, nk, sal = ops.postprocess_mr(*args, clip_length=clip, eval_mode="add")
+        win, keep, nk, sal = win.cpu().numpy(), keep.cpu().tolist(), nk.cpu().tolist(), sal.cpu().numpy()
+        ref_pre, ref_nms, ref_sal = meta[f"post/{tag}"]["pre"], meta[f"post/{tag}"]["nms"], meta[f"post/{tag}"]["sal"]
+        for b in range(B):
+            assert win[b].tolist() == ref_pre[b], (tag, b)                              # every ranked row, bit-exact
+            assert [win[b, i].tolist() for i in keep[b][: nk[b]]] == ref_nms[b], (tag, b)
+            lv = int(inputs["src_vid_mask"][b].sum())
+            assert sal[b, :lv].astype(np.float64).tolist() == ref_sal[b], (tag, b)
+    _, _, _, _, sal0 = ops.postprocess_mr(*args, clip_length=0.0, eval_mode="none")
+    assert torch.equal(sal0.cpu(), eval_ref["saliency_scores"].half().float())
+
+
+def test_postprocess_round_multiple_known_answers(dev, golden_dir):
+    """PostProcessorDETR(round_multiple) on real QVHighlights prediction rows (tests/golden/nms.json round_in/round_out)."""
+    import json
+    from univtg_amd import ops
+    d = json.load(open(os.path.join(golden_dir, "nms.json")))
+    for rin, rout in list(zip(d["round_in"], d["round_out"]))[:40]:
+        L = len(rin)
+        # rows are already ranked by score; feed them as decoded windows of a duration-150 video (timestamp = 0)
+        st = torch.tensor([[r[0], r[1]] for r in rin], dtype=torch.float64)[None] / 150.0
+        sc = torch.tensor([r[2] for r in rin], dtype=torch.float32)[None, :, None]
+        win, order, *_ = ops.postprocess_mr(sc.to(dev), st.float().to(dev), None, torch.zeros(1, L, 2, device=dev), torch.ones(1, L, device=dev),
+                                            torch.tensor([150.0], device=dev), clip_length=2.0, nms_thd=0.7, max_after=10)
+        got = win[0].cpu().numpy()
+        srt = sorted(range(L), key=lambda i: rin[i][2], reverse=True)
+        want = np.array([rout[i] for i in srt])
+        assert np.array_equal(got[:, :2], want[:, :2])
+        assert np.abs(got[:, 2] - want[:, 2]).max() <= 1.0001e-4
+
+
+def test_pipeline_staging_ring_survives_host_run_ahead(dev, golden_dir):
+    """ADVICE r1 (medium) / SURVEY 8f row 2: two uploads issued back-to-back while a long kernel still occupies the stream -- the
+    host refills the staging buffers before the first batch's H2D copies have run.  Both batches must arrive bit-exact."""
+    from oracle import pipeline_oracle as PO
+    from test_oracle_golden import _collate_case
+    from univtg_amd import pipeline
+    z, batch = _collate_case(golden_dir)
+    for e in batch:
+        e["model_inputs"] = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in e["model_inputs"].items()}
+    batch_a = batch
+    batch_b = [dict(meta=e["meta"], model_inputs={k: (v * 3.0 + 1.0 if (torch.is_tensor(v) and v.is_floating_point() and k in ("video_feat", "query_feat")) else v)
+                                                  for k, v in e["model_inputs"].items()}) for e in reversed(batch)]
+    npb = lambda b: [dict(meta=e["meta"], model_inputs={k: (v.numpy() if torch.is_tensor(v) else v) for k, v in e["model_inputs"].items()}) for e in b]
+    want = [PO.collate_mr(npb(batch_a)), PO.collate_mr(npb(batch_b))]
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(2.0e8))                       # ~0.1 s of device time ahead of the uploads
+    got = [pipeline.collate_upload_mr(batch_a, dev), pipeline.collate_upload_mr(batch_b, dev),
+           pipeline.collate_upload_mr(batch_a, dev), pipeline.collate_upload_mr(batch_b, dev)]
+    torch.cuda.synchronize()
+    for i, (_, mi, tg) in enumerate(got):
+        wmi, wtg = want[i % 2]
+        for k in ("src_txt", "src_txt_mask", "src_vid", "src_vid_mask"):
+            assert np.array_equal(mi[k].cpu().numpy(), wmi[k]), (i, k)
+        for k in ("timestamp", "timestamp_mask", "timestamp_window", "span_labels_nn", "saliency_scores", "saliency_pos_labels"):
+            assert np.array_equal(tg[k].cpu().numpy(), wtg[k]), (i, k)
+
+
+def test_device_prefetcher_overlaps_upload_with_compute(dev):
+    """DevicePrefetcher: batch n + 1 is collated and uploaded on a side stream while batch n trains; results are bit-identical to
+    the synchronous path and the upload time is hidden behind the step (reported)."""
+    import time
+    from oracle import univtg_oracle as O
+    from univtg_amd import pipeline
+    from univtg_amd.trainer import TrainStep
+    cfg = O.make_cfg(input_dropout=0.0, dropout=0.0, droppath=0.0, enc_layers=2)
+    params = O.init_params(cfg, seed=71)
+    g = torch.Generator().manual_seed(5)
+
+    def samples(n, seed):
+        inputs, tg = O.make_batch(cfg, n, 75, 32, seed=seed, ragged=True)
+        out = []
+        for b in range(n):
+            lv, lt = int(inputs["src_vid_mask"][b].sum()), int(inputs["src_txt_mask"][b].sum())
+            out.append(dict(meta=dict(qid=b), model_inputs=dict(
+                query_feat=inputs["src_txt"][b, :lt], video_feat=inputs["src_vid"][b, :lv], timestamp=tg["timestamp"][b, :lv],
+                timestamp_window=tg["timestamp_window"][b, :lv], span_labels_nn=tg["span_labels_nn"][b, :lv],
+                saliency_scores=tg["saliency_scores"][b, :lv], saliency_pos_labels=tg["saliency_pos_labels"][b].tolist())))
+        return out
+    batches = [samples(64, 300 + i) for i in range(6)]
+    runs = {}
+    for mode in ("sync", "prefetch"):
+        model, crit = build(cfg, params, dev, "bf16", proj_precise="auto")
+        model.eval()
+        step = TrainStep(model, crit, lr=1e-4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if mode == "sync":
+            it = (pipeline.collate_upload_mr(b, dev) for b in batches)
+            pf = None
+        else:
+            pf = pipeline.DevicePrefetcher(batches, dev, depth=2, timing=True)
+            it = iter(pf)
+        losses = []
+        for _, mi, tg in it:
+            losses.append(step.step(mi, tg, optimize=True))
+        torch.cuda.synchronize()
+        runs[mode] = (time.perf_counter() - t0, torch.stack(losses).cpu(), step.flat.clone(), pf)
+    # same batches in the same order: equal up to the fp32-atomic ordering of a few small reduction kernels
+    assert torch.allclose(runs["sync"][1], runs["prefetch"][1], rtol=1e-3, atol=1e-5)
+    assert float(((runs["sync"][2] - runs["prefetch"][2]).abs() > 1e-4).float().mean()) < 1e-3
+    st = runs["prefetch"][3].stats
+    print(f"\n[prefetcher] 6 batches of 64: synchronous {runs['sync'][0] * 1e3:.1f} ms, prefetched {runs['prefetch'][0] * 1e3:.1f} ms; "
+          f"upload device time {st['upload_ms']:.1f} ms on the side stream, host collate {st['host_collate_s'] * 1e3:.1f} ms")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# config 4 (Ego4D-NLQ long video: L_v = 1200, S = 1232) -- the tiled attention kernels at their production shape
+# ------------------------------------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, kvalid, B, S, H, hd):
+    d = H * hd
+    q, k, v = [t.view(B, S, H, hd).transpose(1, 2) for t in qkv.double().view(B, S, 3 * d).split(d, dim=-1)]
+    sc = q @ k.transpose(-1, -2)
+    sc = sc.masked_fill(~kvalid.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(sc, -1)
+    return (p @ v).transpose(1, 2).reshape(B * S, d), torch.logsumexp(sc, -1)
+
+
+def test_config4_attention_kernels_at_production_shape(dev):
+    """attn_fwd (multi key-tile), attn_bwd_dkdv, attn_bwd_dq at (B=2, S=1232, H=8, hd=128) vs fp64 torch."""
+    from univtg_amd import ops
+    B, S, H, hd = 2, 1232, 8, 128
+    d = H * hd
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B * S, 3 * d, generator=g)
+    qkv[:, :d] *= hd ** -0.5
+    kv = torch.ones(B, S, dtype=torch.uint8)
+    kv[0, 900:1200] = 0                                   # a short video in a long batch: padded clips, then the text tokens
+    kv[1, 1215:] = 0                                      # padded text
+    kv = kv.to(dev)
+    xb = qkv.to(torch.bfloat16).to(dev)
+    o, lse = ops.attention_fwd(xb, kv, B, S, H, hd, False)
+    xr = xb.double().cpu().requires_grad_(True)
+    ref_o, ref_l = _attn_ref(xr, kv.cpu(), B, S, H, hd)
+    assert float((o.float().cpu() - ref_o.detach()).abs().max()) < 1.5e-2
+    assert float((lse.cpu() - ref_l.detach()).abs().max()) < 2e-3
+    o32, lse32 = ops.attention_fwd(qkv.to(dev), kv, B, S, H, hd, True)
+    r32, l32 = _attn_ref(qkv, kv.cpu(), B, S, H, hd)
+    assert float((o32.cpu() - r32).abs().max()) < 3e-5 and float((lse32.cpu() - l32).abs().max()) < 1e-4
+    do = torch.randn(B * S, d, generator=g).to(torch.bfloat16).to(dev)
+    dqkv = ops.attention_bwd(xb, kv, o, lse, do, 1.0, B, S, H, hd)
+    ref_o.backward(do.double().cpu())
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        a, r = dqkv[:, sl].float().cpu().double(), xr.grad[:, sl]
+        e = float((a - r).abs().max() / (r.abs().max() + 1e-30))
+        assert e < 2.5e-2, (name, e)
+
+
+def test_config4_model_level_vs_oracle(dev):
+    """(B=2, L_v=1200, L_t=32, d=1024, H=8, E=1) against the oracle: fp32x3 forward, bf16 losses + gradients, packed stream."""
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    _threads()
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0, enc_layers=1, max_v_l=1200)
+    params = O.init_params(cfg, seed=401)
+    inputs, tg = O.make_batch(cfg, 2, 1200, 32, seed=402, ragged=True)
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(p2, cfg, **inputs)
+    rl = O.criterion(ref, tg, cfg)
+    O.total_loss(rl, cfg).backward()
+    model, _ = build(cfg, params, dev, "fp32x3")
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(inputs, dev))
+    valid = inputs["src_vid_mask"].bool()
+    assert float((out["saliency_scores"].cpu() - ref["saliency_scores"].detach())[valid].abs().max()) < 1e-4
+    for k in ("pred_logits", "pred_spans"):
+        assert float((out[k].cpu() - ref[k].detach()).abs().max()) < 3e-4, k
+    lens = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+    for packed in (False, True):
+        model, crit = build(cfg, params, dev, "bf16")
+        model.eval()
+        step = TrainStep(model, crit, packed=packed)
+        batch = to_dev(inputs, dev)
+        if packed:
+            batch["_lens_host"] = lens
+        losses = step.step(batch, to_dev(tg, dev), optimize=False).cpu()
+        for i, k in enumerate(("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")):
+            assert abs(float(losses[i]) - float(rl[k])) < 2e-2 * max(1.0, abs(float(rl[k]))), (packed, k)
+        offs = model._offsets(model._dims(2, 1200, 32, cfg.v_feat_dim, cfg.t_feat_dim, False))
+        names = {id(p): k for k, p in model.named_parameters()}
+        flat = {names[id(p)]: step.grads[offs[i]: offs[i] + p.numel()] for i, p in enumerate(model._ordered_params())}
+        rep = _grad_report(None, p2, lambda k: flat[k])
+        bad = {k: v for k, v in rep.items() if v[0] < 0.995 or abs(v[1] - 1) > 0.02}
+        assert not bad, (packed, bad)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# config 5 (multi-dataset co-training, mixed L in {75, 200, 600}): ragged-batch packed attention
+# ------------------------------------------------------------------------------------------------------------------------------
+def test_config5_mixed_length_batch_packed_vs_padded_vs_oracle(dev):
+    from bench import mixed_length_lens
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    _threads()
+    B, Lt = 12, 32
+    lens_v = mixed_length_lens(B, seed=5)
+    assert set(lens_v) <= {75, 200, 600} and max(lens_v) == 600
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0, enc_layers=2, max_v_l=600)
+    params = O.init_params(cfg, seed=501)
+    # build the mixed batch sample by sample (every sample full length for its dataset; the batch pads to the longest)
+    Lv = max(lens_v)
+    parts = [O.make_batch(cfg, 1, lv, Lt, seed=600 + i, ragged=False) for i, lv in enumerate(lens_v)]
+    pad = lambda t, L: torch.cat([t, t.new_zeros((1, L - t.shape[1]) + tuple(t.shape[2:]))], 1)
+    inputs = {k: torch.cat([pad(p[0][k], Lv if "vid" in k else Lt) for p in parts]) for k in parts[0][0]}
+    tg = {k: torch.cat([pad(p[1][k], Lv) for p in parts]) for k in ("timestamp", "timestamp_mask", "timestamp_window", "span_labels_nn", "saliency_scores")}
+    tg["saliency_pos_labels"] = torch.cat([p[1]["saliency_pos_labels"] for p in parts])
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(p2, cfg, **inputs)
+    rl = O.criterion(ref, tg, cfg)
+    O.total_loss(rl, cfg).backward()
+    lens = (lens_v, [Lt] * B)
+    res = {}
+    for packed in (False, True):
+        model, crit = build(cfg, params, dev, "bf16")
+        model.eval()
+        step = TrainStep(model, crit, packed=packed)
+        batch = to_dev(inputs, dev)
+        if packed:
+            batch["_lens_host"] = lens
+        losses = step.step(batch, to_dev(tg, dev), optimize=False).cpu()
+        res[packed] = (losses, step.grads.clone().double(), step.pred_logits.clone())
+        for i, k in enumerate(("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")):
+            assert abs(float(losses[i]) - float(rl[k])) < 2e-2 * max(1.0, abs(float(rl[k]))), (packed, k)
+        e = float((step.pred_logits.cpu() - ref["pred_logits"].detach()).abs().max())
+        assert e < 3e-2, (packed, e)
+        offs = model._offsets(model._dims(B, Lv, Lt, cfg.v_feat_dim, cfg.t_feat_dim, False))
+        names = {id(p): k for k, p in model.named_parameters()}
+        flat = {names[id(p)]: step.grads[offs[i]: offs[i] + p.numel()] for i, p in enumerate(model._ordered_params())}
+        rep = _grad_report(None, p2, lambda k: flat[k])
+        bad = {k: v for k, v in rep.items() if v[0] < 0.995 or abs(v[1] - 1) > 0.02}
+        assert not bad, (packed, bad)
+    g0, g1 = res[False][1], res[True][1]
+    assert float((g0 @ g1) / (g0.norm() * g1.norm())) > 0.9995
+    rows = sum(lv + (lv < Lv) + Lt for lv in lens_v)
+    print(f"\n[config5] mixed lengths {sorted(lens_v)}: packed rows {rows} of {B * (Lv + Lt)} padded ({rows / (B * (Lv + Lt)):.2f})")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference's own DDP wrapper around the drop-in model (main/train_vlp_ddp.py:272-275)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _ddp_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                     input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=81)
+    inputs, tg = O.make_batch(cfg, 8, 30, 10, seed=82, ragged=True)
+    sl = slice(rank * 4, rank * 4 + 4)                                        # DistributedSampler-style shard
+    ind = {k: v[sl].to(dev) for k, v in inputs.items()}
+    tgd = {k: v[sl].to(dev) for k, v in tg.items() if torch.is_tensor(v)}
+    model, crit = build(cfg, params, dev, "bf16")
+    model.eval()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, find_unused_parameters=True)   # :272-275
+    out = ddp(**ind)
+    ld = crit(out, tgd)
+    sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
+    torch.cuda.synchronize()
+    g_ddp = torch.cat([p.grad.flatten() for p in model._ordered_params()]).double().cpu()
+    unused = [k for k, p in model.named_parameters() if p.grad is None]
+    # native exchange on the same shards
+    model2, crit2 = build(cfg, params, dev, "bf16")
+    model2.eval()
+    step = TrainStep(model2, crit2, overlap_comm=False)
+    step.step(ind, tgd, optimize=False)
+    torch.cuda.synchronize()
+    offs = model2._offsets(model2._dims(4, 30, 10, 514, 512, False))
+    g_nat = torch.cat([step.grads[offs[i]: offs[i] + p.numel()] for i, p in enumerate(model2._ordered_params())]).double().cpu() / world
+    if rank == 0:
+        torch.save(dict(ddp=g_ddp, native=g_nat, unused=unused, world=step.world), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_drop_in_model_under_reference_ddp_wrapper(dev, tmp_path):
+    """The autograd Model wrapped in DistributedDataParallel(find_unused_parameters=True) exactly as main/train_vlp_ddp.py:272-275
+    does (2 ranks, gloo, both on cuda:0): DDP's averaged gradients == TrainStep's all-reduced gradients / world."""
+    import torch.multiprocessing as mp
+    out_path = str(tmp_path / "ddp.pt")
+    port = 29700 + os.getpid() % 200
+    mp.spawn(_ddp_worker, args=(2, port, out_path), nprocs=2, join=True)
+    r = torch.load(out_path)
+    assert r["world"] == 2
+    assert all(k.startswith("txt_position_embed") for k in r["unused"]) and len(r["unused"]) == 3
+    a, b = r["ddp"], r["native"]
+    assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())          # same kernels; fp32 atomic order only
+    assert float((a @ b) / (a.norm() * b.norm())) > 0.99999

@@ -21,6 +21,8 @@ template <int HD> struct KSwz {      // swizzle for [rows][HD] bf16 tiles read w
   __device__ static __forceinline__ int off(int r, int chunk) { return r * HD + ((chunk ^ ((r / RPB) % CPR)) * 8); }
 };
 
+// Counter = position in the PADDED [B, H, S, S] probability tensor (S = a.S also on the packed stream, whose in-sample row order under
+// dropout is the padded layout's): padded and packed executions draw identical masks.
 __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned stream, int bh, int q, int k, int S, float p) {
   unsigned r[4];
   philox4(seed, ((unsigned long long)bh * S + q) * (unsigned long long)S + k, stream, r);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          pv[kb][r] *= keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, key, S, a.p_drop);
+          pv[kb][r] *= keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, key, a.S, a.p_drop);
         }
     }
 #pragma unroll
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
       const int ql = (r & 3) + 8 * (r >> 2) + 4 * g, qi = qb * 32 + ql;
       float p = (kok && qi < S) ? __expf(sc[r] - sL[ql]) : 0.f;
       float ksc = 1.f;
-      if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, S, a.p_drop);
+      if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
       pd[r] = p * ksc;
       ds[r] = p * (dp[r] * ksc - sD[ql]);
     }
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         const float p = sValid[kl] ? __expf(sc[r] - lse) : 0.f;
         float ksc = 1.f;
-        if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, kt * 64 + kl, S, a.p_drop);
+        if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, kt * 64 + kl, a.S, a.p_drop);
         ds[r] = p * (dp[r] * ksc - dl);
       }
 #pragma unroll

@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstring>
 
+void uvtg_prof_section(int section, int end, hipStream_t s);   // optim.hip: section timing hooks (bench.py)
+
 namespace {
 
 // ---- parameter table -------------------------------------------------------------------------
@@ -257,13 +259,25 @@ __global__ void add_vec_kernel(float* dst, const float* src, int n) {
 
 #define TRY(x) do { int e__ = (x); if (e__) return e__; } while (0)
 
+// Packed (ragged) encoder stream, decided identically by uvtg_forward and uvtg_backward from (dims, lens_host):
+//   PACK_FULL : valid clips + ONE representative padded clip + valid text tokens per sample.  Exact whenever no per-row randomness
+//               touches the padded clips (eval, or training with input_dropout == 0 and attention dropout == 0; DropPath is per sample).
+//   PACK_TEXT : every clip row (padded ones included: under input / attention dropout each of them carries its own mask in the
+//               reference, model/univtg.py:392-404) + valid text tokens.  Padded text tokens are masked keys whose outputs nobody
+//               reads, so dropping them is exact under every dropout.
+enum { PACK_NONE = 0, PACK_FULL = 1, PACK_TEXT = 2 };
+int pack_mode(const uvtg_dims& c, const int* lens_host) {
+  if (!lens_host || c.precise) return PACK_NONE;
+  if (c.training && (c.p_in > 0.f || c.p_attn > 0.f)) return PACK_TEXT;
+  return PACK_FULL;
+}
 // rows of the packed encoder stream for these host-side lengths (lens[0..B) clips, lens[B..2B) text tokens per sample)
-int packed_rows(const Dm& m, const int* lens, int* out) {
+int packed_rows(const Dm& m, const int* lens, int mode, int* out) {
   long long n = 0;
   for (int b = 0; b < m.c.B; b++) {
     const int lv = lens[b], lt = lens[m.c.B + b];
     if (lv < 1 || lv > m.c.Lv || lt < 1 || lt > m.c.Lt) return -23;
-    n += lv + (lv < m.c.Lv ? 1 : 0) + lt;
+    n += (mode == PACK_TEXT ? m.c.Lv : lv + (lv < m.c.Lv ? 1 : 0)) + lt;
   }
   *out = (int)n;
   return 0;
@@ -310,6 +324,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -21: return "force_nt_tile: tile must be 0, 128 or 256";
     case -22: return "backward: ready_events must hold enc_layers + 1 events (or n_events = 0)";
     case -23: return "lens_host: every sample needs 1 <= len_v <= Lv clips and 1 <= len_t <= Lt text tokens";
+    case -24: return "forward: lens_host (packed encoder stream) cannot be combined with the memory output in training mode";
     default: return "invalid argument";
   }
 }
@@ -603,22 +618,32 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   Fwd f{m, P, w, ws, s, !m.c.precise, m.c.training != 0, m.c.precise || m.c.proj_precise};
   if (uvtg_dynamic_tiles_enabled()) { if (hipError_t e = hipMemsetAsync(ws.tile_ctr, 0, 64 * 8 * sizeof(int), s)) return (int)e; }
   CtrScope ctr_scope(ws.tile_ctr, 64);
-  if (lens_host && f.fast && !memory) {         // packed (ragged) encoder stream
-    int mp = 0;
-    TRY(packed_rows(m, lens_host, &mp));
-    f.packed = true; f.Mrows = mp;
-    if (hipError_t e = hipMemcpyAsync(ws.lens_dev, lens_host, 2 * (size_t)m.c.B * sizeof(int), hipMemcpyHostToDevice, s)) return (int)e;
-    TRY(launch_pack_tables(ws.lens_dev, m.c.B, m.c.Lv, m.c.Lt, ws.pk, s));
+  int pmode = pack_mode(m.c, lens_host);
+  if (pmode != PACK_NONE && memory) {           // the packed stream has no [B, S, d] encoder output to hand out
+    if (m.c.training) return -24;               // (uvtg_backward could not know: refuse instead of silently diverging from it)
+    pmode = PACK_NONE;
   }
+  if (pmode != PACK_NONE) {                     // packed (ragged) encoder stream
+    int mp = 0;
+    TRY(packed_rows(m, lens_host, pmode, &mp));
+    f.packed = true; f.Mrows = mp;
+    // the device-side tables are built from the MASKS (no copy out of the caller's pageable lens_host, which is only read here,
+    // synchronously, for the row count): lens_host must be the masks' prefix lengths
+    TRY(launch_pack_tables(src_vid_mask, src_txt_mask, ws.lens_dev, m.c.B, m.c.Lv, m.c.Lt, pmode == PACK_TEXT, ws.pk, s));
+  }
+  uvtg_prof_section(2, 0, s);
   TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, s));
   if (f.tr && m.c.p_path > 0.f) TRY(launch_droppath_scales(ws.dps, 2 * m.c.E, m.c.B, m.c.p_path, m.c.seed, s));
   TRY(f.project(0, src_vid, x0));
   TRY(f.project(1, src_txt, x0));
   if (f.packed) TRY(launch_pack_rows((const bf16_t*)ws.xb[0], (const bf16_t*)ws.ub[0], ws.pk.row_src, f.Mrows, m.c.d, ws.xb0p, ws.ub0p, s));
+  uvtg_prof_section(0, 0, s);
   for (int l = 0; l < m.c.E; l++) TRY(f.layer(l, memory));
+  uvtg_prof_section(0, 1, s);
   TRY(f.heads(pred_logits, pred_spans));
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, txt_mem_proj, saliency);
   TRY(launch_saliency_fwd(sa, s));
+  uvtg_prof_section(2, 1, s);
   return 0;
 }
 
@@ -647,12 +672,14 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   CtrScope ctr_scope(ws.tile_ctr, 64);
   const int d = m.c.d, F = m.c.F, S = m.S, Lv = m.c.Lv, B = m.c.B, E = m.c.E;
   // packed (ragged) encoder stream: must match the forward call (same lens_host); the tables are still in the workspace
-  const bool packed = lens_host != nullptr;
+  const int pmode = pack_mode(m.c, lens_host);
+  const bool packed = pmode != PACK_NONE;
   int M = m.M;
-  if (packed) TRY(packed_rows(m, lens_host, &M));
+  if (packed) TRY(packed_rows(m, lens_host, pmode, &M));
   long long off[PER_LAYER * MAXE + N_TAIL + 1];
   { long long o = 0; for (int i = 0; i < m.np; i++) { off[i] = o; o += (pnumel(m, i) + 3) / 4 * 4; } off[m.np] = o; }
   auto G = [&](int idx) { return grads + off[idx]; };
+  uvtg_prof_section(3, 0, s);
   hipMemsetAsync(grads, 0, (size_t)off[m.np] * sizeof(float), s);
   const int splits_M = 8, splits_v = 8;
   auto wgrad = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, int cs,
@@ -730,7 +757,8 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // The gradient stream is bf16 (like the activation stream): gin = gradient wrt the layer output; dyB = LayerNorm input
   // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
   const bf16_t* gin = nullptr;                  // null = zero
-  if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, ws.g2p, s));   // conv-head gradient onto the packed rows
+  uvtg_prof_section(1, 0, s);
+  if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT, ws.g2p, s));   // conv-head gradient onto the packed rows
   const int* row_sample = packed ? ws.pk.row_sample : nullptr;
   for (int l = E - 1; l >= 0; l--) {
     const bf16_t* xb_in = (packed && l == 0) ? ws.xb0p : (const bf16_t*)ws.xb[l];
@@ -790,6 +818,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
     if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
   }
+  uvtg_prof_section(1, 1, s);
   const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]
   // ---------------- saliency branch ----------------
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
@@ -831,6 +860,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
   }
+  uvtg_prof_section(3, 1, s);
   return 0;
 }
 

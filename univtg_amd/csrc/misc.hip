@@ -203,16 +203,29 @@ __global__ __launch_bounds__(256) void ragged_to_padded_kernel(const T* packed, 
 // nothing (masked keys, outputs never read).  So the encoder runs on: the valid clips, one representative padded clip (when
 // the sample is shorter than the batch), the valid text tokens -- exactly the reference's results with ~25 % fewer rows on
 // ragged batches.  Row order inside a sample: valid clips, representative, valid text.
-__global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B, int Lv, int Lt, PackTables t) {
+// per-sample valid lengths out of the 0/1 prefix masks (utils/tensor_utils.py:49-52): lens[b] clips, lens[B + b] text tokens
+__global__ __launch_bounds__(64) void lens_from_masks_kernel(const float* vmask, const float* tmask, int B, int Lv, int Lt, int* lens) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float a = 0.f, c = 0.f;
+  for (int i = lane; i < Lv; i += 64) a += vmask[(size_t)b * Lv + i];
+  for (int i = lane; i < Lt; i += 64) c += tmask[(size_t)b * Lt + i];
+  a = wave_sum(a); c = wave_sum(c);
+  if (lane == 0) { lens[b] = (int)(a + 0.5f); lens[B + b] = (int)(c + 0.5f); }
+}
+// keep_pad: all Lv clip rows of the sample stay rows of the stream (padded ones too, each with its own dropout realisation);
+// only the padded text tokens are dropped.  Row order inside a sample is then exactly the padded layout's.
+__global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B, int Lv, int Lt, int keep_pad, PackTables t) {
   const int b = blockIdx.x, S = Lv + Lt;
   __shared__ int s_start;
   if (threadIdx.x == 0) {
     int st = 0;
-    for (int i = 0; i < b; i++) { const int lv = lens[i], lt = lens[B + i]; st += lv + (lv < Lv ? 1 : 0) + lt; }
+    for (int i = 0; i < b; i++) { const int lv = lens[i], lt = lens[B + i]; st += (keep_pad ? Lv : lv + (lv < Lv ? 1 : 0)) + lt; }
     s_start = st;
   }
   __syncthreads();
-  const int lv = lens[b], lt = lens[B + b], rep = lv < Lv ? 1 : 0, n = lv + rep + lt, st = s_start;
+  const int lvr = lens[b], lt = lens[B + b];           // lvr: real number of valid clips
+  const int lv = keep_pad ? Lv : lvr;                  // clip rows kept one-to-one
+  const int rep = lv < Lv ? 1 : 0, n = lv + rep + lt, st = s_start;
   if (threadIdx.x == 0) { t.seq_start[b] = st; t.seq_count[b] = n; }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int r = st + i;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
     t.row_sample[r] = b;
     t.row_src[r] = b * S + ps;
     t.row_pos[r] = ps < Lv ? b * Lv + ps : -1;
-    t.kvalid[r] = (i >= lv && i < lv + rep) ? 0 : 1;   // the representative is a padded position: never a key
+    t.kvalid[r] = (ps < Lv && ps >= lvr) ? 0 : 1;      // padded clip positions (the representative included) are never keys
   }
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     int pk, gm;
@@ -254,13 +267,13 @@ __global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, co
 }
 // conv-head gradient wrt the clip rows (padded layout) -> packed rows: valid clips copy, the representative gets the SUM over the
 // sample's padded clips, text rows zero
-__global__ __launch_bounds__(256) void pack_reduce_dvm_kernel(const bf16_t* dvm, PackTables t, int B, int S, int Lv, int Mp, int d, bf16_t* out) {
+__global__ __launch_bounds__(256) void pack_reduce_dvm_kernel(const bf16_t* dvm, PackTables t, int B, int S, int Lv, int Mp, int d, int keep_pad, bf16_t* out) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= Mp) return;
   const int b = t.row_sample[r], src = t.row_src[r], ps = src - b * S;
   bf16_t* o = out + (size_t)r * d;
-  const bool rep = t.kvalid[r] == 0;
+  const bool rep = !keep_pad && t.kvalid[r] == 0;
   for (int c = lane * 8; c < d; c += 512) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ps < Lv) {
@@ -716,8 +729,10 @@ int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_pack_tables(const int* lens_dev, int B, int Lv, int Lt, const PackTables& t, hipStream_t s) {
-  hipLaunchKernelGGL(pack_tables_kernel, dim3(B), dim3(128), 0, s, lens_dev, B, Lv, Lt, t);
+int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev, int B, int Lv, int Lt, bool keep_pad, const PackTables& t,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(lens_from_masks_kernel, dim3(B), dim3(64), 0, s, vid_mask, txt_mask, B, Lv, Lt, lens_dev);
+  hipLaunchKernelGGL(pack_tables_kernel, dim3(B), dim3(128), 0, s, lens_dev, B, Lv, Lt, keep_pad ? 1 : 0, t);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -733,9 +748,9 @@ int launch_unpack_vm(const bf16_t* packed, const int* pad2pack, int B, int S, in
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bf16_t* out, hipStream_t s) {
+int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bool keep_pad, bf16_t* out, hipStream_t s) {
   if (d % 8) return -2;
-  hipLaunchKernelGGL(pack_reduce_dvm_kernel, dim3(cdiv(Mp, 4)), dim3(256), 0, s, dvm, t, B, S, Lv, Mp, d, out);
+  hipLaunchKernelGGL(pack_reduce_dvm_kernel, dim3(cdiv(Mp, 4)), dim3(256), 0, s, dvm, t, B, S, Lv, Mp, d, keep_pad ? 1 : 0, out);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -51,6 +51,10 @@ struct Prof {
   std::vector<hipEvent_t> ev[4];
   size_t used[4] = {0, 0, 0, 0};
   double flops[4] = {0, 0, 0, 0};
+  // section timing (its own pass: the per-launch events above would sit inside the sections)
+  bool sec_on = false;
+  std::vector<hipEvent_t> sev[4];
+  size_t sused[4] = {0, 0, 0, 0};
 } g_prof;
 
 }  // namespace
@@ -121,3 +125,39 @@ extern "C" int uvtg_profile_stop(double* ms, double* flops, long long* launches)
   return 0;
 }
 extern "C" double uvtg_profile_event_floor_ms(void) { return g_prof.floor_ms; }
+
+// ---- section timing: one event pair around a whole section of uvtg_forward / uvtg_backward, on the launch stream ----
+// sections: 0 encoder forward (the E layers), 1 encoder backward (LayerNorm / dgrad / attention / weight gradients of the E layers),
+// 2 whole uvtg_forward, 3 whole uvtg_backward
+void uvtg_prof_section(int section, int end, hipStream_t s) {
+  if (!g_prof.sec_on) return;
+  auto& ev = g_prof.sev[section];
+  size_t& u = g_prof.sused[section];
+  if (!end) {
+    while (ev.size() < u + 2) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }
+    hipEventRecord(ev[u], s);
+  } else {
+    hipEventRecord(ev[u + 1], s);
+    u += 2;
+  }
+}
+extern "C" int uvtg_profile_sections_start(void) {
+  for (int f = 0; f < 4; f++) g_prof.sused[f] = 0;
+  g_prof.sec_on = true;
+  return 0;
+}
+extern "C" int uvtg_profile_sections_stop(double* ms, long long* counts) {
+  g_prof.sec_on = false;
+  if (!ms || !counts) return -20;
+  if (hipError_t e = hipDeviceSynchronize()) return (int)e;
+  for (int f = 0; f < 4; f++) {
+    double tot = 0;
+    for (size_t i = 0; i + 1 < g_prof.sused[f]; i += 2) {
+      float t = 0;
+      hipEventElapsedTime(&t, g_prof.sev[f][i], g_prof.sev[f][i + 1]);
+      tot += t;
+    }
+    ms[f] = tot; counts[f] = (long long)(g_prof.sused[f] / 2);
+  }
+  return 0;
+}

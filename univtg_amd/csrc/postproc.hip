@@ -10,9 +10,14 @@ namespace {
 
 __device__ __forceinline__ double round4(float x) { return rint((double)x * 1e4) / 1e4; }   // float(f"{x:.4f}")
 
+// clip_length > 0: the rows additionally go through PostProcessorDETR's round_multiple (eval/postprocessing.py:26-37,46-51), which
+// the reference applies to the 4-decimal rows BEFORE the NMS (main/inference_mr.py:183-192 inside compute_mr_results, the NMS in
+// eval_epoch_post_processing): torch.tensor(rows) -> fp32, torch.round(w / clip) * clip (half-to-even), score re-rounded to 4 decimals.
+// saliency (optional): pred_saliency_scores of main/inference_mr.py:124-136 = fp16(saliency) [+ prob when eval_mode == 'add'], fp32 out.
 __global__ __launch_bounds__(64) void decode_rank_nms_kernel(const float* pred_logits, const float* pred_spans,
     const float* timestamp, const float* ts_mask, const float* durations, int B, int Lv, float nms_thd,
-    int max_before, int max_after, double* windows_out, int* order, int* keep, int* n_keep) {
+    int max_before, int max_after, float clip_length, const float* saliency, int sal_add, float* saliency_out,
+    double* windows_out, int* order, int* keep, int* n_keep) {
   extern __shared__ unsigned char smem[];
   const int b = blockIdx.x, lane = threadIdx.x;
   float* sc = (float*)smem;                         // [Lv] masked scores
@@ -33,7 +38,16 @@ __global__ __launch_bounds__(64) void decode_rank_nms_kernel(const float* pred_l
     const int i = b * Lv + t;
     float w0 = (timestamp[2 * i] + pred_spans[2 * i]) * dur, w1 = (timestamp[2 * i + 1] + pred_spans[2 * i + 1]) * dur;
     w0 = fminf(fmaxf(w0, 0.f), dur); w1 = fminf(fmaxf(w1, 0.f), dur);     // clamp  (:152-153)
-    const double r0 = round4(w0), r1 = round4(w1), rs = round4(s);         // 4-decimal rounding  (:159)
+    double r0 = round4(w0), r1 = round4(w1), rs = round4(s);               // 4-decimal rounding  (:159)
+    if (clip_length > 0.f) {                                                // round_multiple on the fp32 image of the rounded rows
+      r0 = (double)(rintf(__fdiv_rn((float)r0, clip_length)) * clip_length);
+      r1 = (double)(rintf(__fdiv_rn((float)r1, clip_length)) * clip_length);
+      rs = round4((float)rs);
+    }
+    if (saliency_out) {
+      const float h = (float)(_Float16)saliency[i];                        // .half(): round-to-nearest-even
+      saliency_out[i] = sal_add ? h + pred_logits[i] : h;                  // half + float promotes to float  (:124-128)
+    }
     order[b * Lv + rank] = t;
     st[rank] = r0; ed[rank] = r1;
     double* wo = windows_out + ((size_t)b * Lv + rank) * 3;
@@ -166,17 +180,27 @@ __global__ void lsap_kernel(const float* cost, int B, int Q, const int* tgt_off,
 
 }  // namespace
 
+extern "C" int uvtg_postprocess_mr(const float* pred_logits, const float* pred_spans, const float* saliency, const float* timestamp,
+                                   const float* timestamp_mask, const float* durations, int B, int Lv,
+                                   float clip_length, int eval_mode_add, float nms_thd, int max_before, int max_after,
+                                   double* windows_out, int* order, int* keep, int* n_keep, float* saliency_out,
+                                   uvtg_stream_t stream) {
+  if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !durations || !windows_out || !order || !keep || !n_keep) return -20;
+  if (saliency_out && !saliency) return -20;
+  if (B <= 0 || Lv <= 0 || max_after <= 0 || max_before <= 0) return -11;
+  const size_t sh = (size_t)((Lv + 1) & ~1) * 4 + (size_t)Lv * 16 + Lv + 16;
+  hipLaunchKernelGGL(decode_rank_nms_kernel, dim3(B), dim3(64), sh, (hipStream_t)stream, pred_logits, pred_spans, timestamp,
+                     timestamp_mask, durations, B, Lv, nms_thd, max_before, max_after, clip_length, saliency, eval_mode_add ? 1 : 0,
+                     saliency_out, windows_out, order, keep, n_keep);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int uvtg_decode_rank_nms(const float* pred_logits, const float* pred_spans, const float* timestamp,
                                     const float* timestamp_mask, const float* durations, int B, int Lv,
                                     float nms_thd, int max_before, int max_after,
                                     double* windows_out, int* order, int* keep, int* n_keep, uvtg_stream_t stream) {
-  if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !durations || !windows_out || !order || !keep || !n_keep) return -20;
-  if (B <= 0 || Lv <= 0 || max_after <= 0 || max_before <= 0) return -11;
-  const size_t sh = (size_t)((Lv + 1) & ~1) * 4 + (size_t)Lv * 16 + Lv + 16;
-  hipLaunchKernelGGL(decode_rank_nms_kernel, dim3(B), dim3(64), sh, (hipStream_t)stream, pred_logits, pred_spans, timestamp,
-                     timestamp_mask, durations, B, Lv, nms_thd, max_before, max_after, windows_out, order, keep, n_keep);
-  UVTG_CHECK_LAUNCH();
-  return 0;
+  return uvtg_postprocess_mr(pred_logits, pred_spans, nullptr, timestamp, timestamp_mask, durations, B, Lv, 0.f, 0, nms_thd, max_before,
+                             max_after, windows_out, order, keep, n_keep, nullptr, stream);
 }
 
 extern "C" int uvtg_hungarian(const float* pred_logits, int n_cls, const float* pred_spans_cxw, int B, int Q,

@@ -154,10 +154,12 @@ struct PackTables {
   int* grad_map;                      // [B*S]: token row -> packed row carrying its gradient (valid rows, first padded clip), else -1
   unsigned char* kvalid;              // [Mp]
 };
-int launch_pack_tables(const int* lens_dev /* [2B] */, int B, int Lv, int Lt, const PackTables& t, hipStream_t s);
+// keep_pad: every clip row of the padded layout stays a row of the stream (only padded text tokens are dropped)
+int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev /* scratch [2B] */, int B, int Lv, int Lt, bool keep_pad,
+                       const PackTables& t, hipStream_t s);
 int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp, hipStream_t s);
 int launch_unpack_vm(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s);
-int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bf16_t* out, hipStream_t s);
+int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bool keep_pad, bf16_t* out, hipStream_t s);
 
 int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask, hipStream_t s);
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,

@@ -190,8 +190,10 @@ class Model(nn.Module):
         if proj_precise not in (True, False, "auto"):
             raise ValueError("proj_precise must be True, False or 'auto'")
         self.precision, self.proj_precise, self.return_memory = precision, proj_precise, False
-        # packed=True: run the encoder on the valid rows only (+ one representative padded clip per sample) -- identical results,
-        # fewer rows on ragged batches; costs one device->host read of the mask sums per call (see include/uvtg.h, lens_host)
+        # packed=True: run the encoder on the packed (ragged) row stream -- identical results, fewer rows on ragged batches; costs one
+        # device->host read of the mask sums per call.  The engine picks the exact variant itself (include/uvtg.h, lens_host): valid
+        # rows + one representative padded clip per sample, or -- under training-time input / attention dropout, where every padded
+        # clip carries its own mask -- all clip rows and the valid text tokens
         self.packed = bool(packed)
         # ---- parameters, registered in the reference's order / names ----
         self.transformer = _encoder_bag(d, dim_feedforward, enc_layers)
@@ -212,6 +214,7 @@ class Model(nn.Module):
         self._step = 0
         self._seed = 0x5EED
         self._wcache = {}
+        self._param_epoch = 0
         self._dimt = None
         self._off_cache = {}
 
@@ -267,7 +270,9 @@ class Model(nn.Module):
         """(Re)build the MFMA operand cache when any parameter changed (tracked by tensor versions)."""
         lib = _lib.load()
         key = (dims.precise, dims.training, dims.proj_precise, dims.Dv, dims.Dt)
-        sig = tuple((p.data_ptr(), p._version) for p in params)
+        # _param_epoch: bumped by whoever rewrites the parameter storage behind autograd's back (TrainStep's raw AdamW kernel
+        # updates the flat buffer the parameters are views of: tensor versions do not move)
+        sig = (self._param_epoch,) + tuple((p.data_ptr(), p._version) for p in params)
         ent = self._wcache.get(key)
         if ent is None or ent[0] != sig:
             nbytes = lib.uvtg_wcache_bytes(C.byref(dims))
@@ -286,6 +291,10 @@ class Model(nn.Module):
 
     def set_seed(self, seed: int):
         self._seed, self._step = int(seed), 0
+
+    def invalidate_operand_cache(self):
+        """Call after rewriting parameter storage without going through torch in-place ops (raw kernels on a flat buffer)."""
+        self._param_epoch += 1
 
     def forward(self, src_txt, src_txt_mask, src_vid, src_vid_mask, src_cls=None, src_cls_mask=None):
         if src_cls is not None:

@@ -142,3 +142,23 @@ def decode_rank_nms(pred_logits, pred_spans, timestamp, timestamp_mask, duration
                                                 int(max_before), int(max_after), _ptr(win), _ptr(order), _ptr(keep), _ptr(nk),
                                                 _stream()), "uvtg_decode_rank_nms")
     return win, order, keep, nk
+
+
+def postprocess_mr(pred_logits, pred_spans, saliency, timestamp, timestamp_mask, durations, clip_length=0.0, eval_mode="add",
+                   nms_thd=0.7, max_before=1000, max_after=10):
+    """decode_rank_nms + PostProcessorDETR round_multiple (clip_length > 0) before the NMS + pred_saliency_scores
+    (fp16(saliency) [+ prob]); main/inference_mr.py:109-192, eval/postprocessing.py:46-51.  Returns
+    (windows, order, keep, n_keep, saliency_out[B,Lv] fp32 or None)."""
+    _need_cuda(pred_logits)
+    B, Lv = pred_logits.shape[:2]
+    dev = pred_logits.device
+    win = torch.empty(B, Lv, 3, dtype=torch.float64, device=dev)
+    order = torch.empty(B, Lv, dtype=torch.int32, device=dev)
+    keep = torch.empty(B, max_after, dtype=torch.int32, device=dev)
+    nk = torch.empty(B, dtype=torch.int32, device=dev)
+    sal_out = torch.empty(B, Lv, device=dev) if saliency is not None else None
+    _lib.check(_lib.load().uvtg_postprocess_mr(_ptr(_f32c(pred_logits)), _ptr(_f32c(pred_spans)), _ptr(None if saliency is None else _f32c(saliency)),
+                                               _ptr(_f32c(timestamp)), _ptr(_f32c(timestamp_mask)), _ptr(_f32c(durations)), B, Lv,
+                                               float(clip_length), int(eval_mode == "add"), float(nms_thd), int(max_before), int(max_after),
+                                               _ptr(win), _ptr(order), _ptr(keep), _ptr(nk), _ptr(sal_out), _stream()), "uvtg_postprocess_mr")
+    return win, order, keep, nk, sal_out

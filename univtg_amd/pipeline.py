@@ -11,10 +11,19 @@ the padded ``model_inputs`` / ``targets`` tensors on the device -- but
 * the per-sample lengths the collate knows anyway are handed on as ``model_inputs["_lens_host"]`` so that the engine can run
   its packed (ragged) encoder stream without a device->host sync;
 * ``feature_dtype=torch.bfloat16`` optionally halves the feature bytes on the wire (not bit-exact: the features are rounded).
+
+Staging: every key owns a RING of pinned host buffers; a buffer is reused only after the event recorded behind its last H2D
+copy has fired (the host runs ahead of a training loop that never synchronises -- a single buffer per key would be refilled
+while its previous copy is still queued behind the running step).
+
+``DevicePrefetcher(batches, device)`` wraps any iterable of sample lists (a ``DataLoader`` with ``collate_fn=lambda b: b``) and
+uploads batch n + 1 on a side stream while the caller computes on batch n: the H2D copies and the padding kernels overlap the
+step instead of preceding it (the reference's loop does the copy synchronously inside the step, main/train_vlp_ddp.py:52).
 """
 from __future__ import annotations
 
-import ctypes as C
+import collections
+import time
 
 import torch
 
@@ -25,20 +34,45 @@ _PADDED_KEYS = ("query_feat", "video_feat", "timestamp", "timestamp_window", "sp
 
 
 class _Staging:
-    """Grow-only pinned host buffers, one per key (reused across batches)."""
+    """Per key: a ring of grow-only pinned host buffers, each guarded by the event recorded after its last H2D copy."""
 
-    def __init__(self):
-        self.buf = {}
+    def __init__(self, depth=3):
+        self.depth = depth
+        self.ring = {}           # key -> list of [buffer, event-or-None]
+        self.next = {}
+        self.waits = 0           # how often the host had to wait for a slot (ran more than `depth` uploads ahead)
 
-    def get(self, key, numel, dtype):
-        b = self.buf.get(key)
-        if b is None or b.numel() < numel or b.dtype != dtype:
-            b = torch.empty(max(numel, 1), dtype=dtype).pin_memory()
-            self.buf[key] = b
-        return b[:numel]
+    def acquire(self, key, numel, dtype):
+        ring = self.ring.setdefault(key, [[None, None] for _ in range(self.depth)])
+        i = self.next.get(key, 0)
+        self.next[key] = (i + 1) % self.depth
+        slot = ring[i]
+        if slot[1] is not None and not slot[1].query():
+            self.waits += 1
+            slot[1].synchronize()                     # the copy out of this buffer is still in flight
+        if slot[0] is None or slot[0].numel() < numel or slot[0].dtype != dtype:
+            slot[0] = torch.empty(max(numel, 1), dtype=dtype).pin_memory()
+        return slot
+
+    @staticmethod
+    def release(slot):
+        """Call right after enqueueing the H2D copy that reads the slot's buffer (on the current stream)."""
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record()
 
 
 _staging = _Staging()
+
+
+def _upload(key, host_tensor_fn, numel, dtype, device):
+    """pinned slot <- host_tensor_fn(out=view), async H2D on the current stream, slot guarded by an event."""
+    slot = _staging.acquire(key, numel, dtype)
+    view = slot[0][:numel]
+    host_tensor_fn(view)
+    dev = view.to(device, non_blocking=True)
+    _staging.release(slot)
+    return dev
 
 
 def _pad_on_device(key, seqs, device, wire_dtype):
@@ -51,13 +85,12 @@ def _pad_on_device(key, seqs, device, wire_dtype):
     for e in extra:
         D *= int(e)
     total, B, Lmax = sum(lengths), len(seqs), max(lengths)
-    stage = _staging.get(key, total * D, wire_dtype)
-    torch.cat([s.reshape(s.shape[0], -1).to(wire_dtype) for s in seqs], 0, out=stage.view(total, D))
-    packed = stage.to(device, non_blocking=True)
+    packed = _upload(key, lambda out: torch.cat([s.reshape(s.shape[0], -1).to(wire_dtype) for s in seqs], 0, out=out.view(total, D)),
+                     total * D, wire_dtype, device)
     offs = [0]
     for n in lengths:
         offs.append(offs[-1] + n)
-    offsets = torch.tensor(offs, dtype=torch.int32).to(device, non_blocking=True)
+    offsets = _upload(key + "/offsets", lambda out: out.copy_(torch.tensor(offs, dtype=torch.int32)), B + 1, torch.int32, device)
     out = torch.empty((B, Lmax) + extra, dtype=torch.float32, device=device)
     mask = torch.empty(B, Lmax, dtype=torch.float32, device=device)
     _lib.check(lib.uvtg_ragged_to_padded(_ptr(packed), int(wire_dtype == torch.bfloat16), _ptr(offsets), B, Lmax, D, _ptr(out), _ptr(mask),
@@ -66,7 +99,8 @@ def _pad_on_device(key, seqs, device, wire_dtype):
 
 
 def collate_upload_mr(batch, device, feature_dtype=torch.float32):
-    """(batch_meta, model_inputs, targets): the reference's collate + device upload for a list of dataset samples."""
+    """(batch_meta, model_inputs, targets): the reference's collate + device upload for a list of dataset samples.
+    All device work is enqueued on the CURRENT stream; nothing waits for it."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("univtg_amd.pipeline uploads to an MI355X: device must be a ROCm device (no CPU fallback)")
@@ -78,7 +112,8 @@ def collate_upload_mr(batch, device, feature_dtype=torch.float32):
         if k == "span_labels":
             data[k] = [dict(spans=torch.as_tensor(v, dtype=torch.float32).to(device, non_blocking=True)) for v in vals]
         elif k in ("saliency_pos_labels", "saliency_neg_labels"):
-            data[k] = torch.LongTensor(vals).to(device, non_blocking=True)
+            t = torch.LongTensor(vals)
+            data[k] = _upload(k, lambda out, t=t: out.view(t.shape).copy_(t), t.numel(), torch.int64, device).view(t.shape)
         else:
             wire = feature_dtype if k in ("query_feat", "video_feat") else torch.float32
             data[k] = _pad_on_device(k, vals, device, wire)
@@ -98,3 +133,69 @@ def collate_upload_mr(batch, device, feature_dtype=torch.float32):
     if "weight_ablation" in data:
         targets["weight_ablation"] = data["weight_ablation"][0]
     return meta, model_inputs, targets
+
+
+def _device_tensors(obj):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _device_tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _device_tensors(v)
+
+
+class DevicePrefetcher:
+    """Iterate ``(meta, model_inputs, targets)`` over an iterable of sample lists, keeping ``depth`` uploads in flight on a side
+    stream.  The consumer's stream waits for the upload's event only (no host synchronisation); uploaded tensors are tied to the
+    consumer's stream with ``record_stream`` so that the caching allocator does not recycle them under a running step.
+
+    ``stats`` after (or during) iteration: ``host_collate_s`` (host time spent packing + enqueueing), ``batches`` and
+    ``upload_ms`` -- device time of the uploads measured by events on the side stream -- all of which is hidden behind the
+    consumer's compute as long as the consumer's step is longer than the upload."""
+
+    def __init__(self, batches, device, feature_dtype=torch.float32, depth=2, timing=False):
+        self.batches, self.device, self.feature_dtype, self.depth, self.timing = batches, torch.device(device), feature_dtype, depth, timing
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.stats = dict(host_collate_s=0.0, batches=0, upload_ms=0.0)
+        self._timers = []
+
+    def _enqueue(self, samples):
+        t0 = time.perf_counter()
+        with torch.cuda.stream(self.stream):
+            if self.timing:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            item = collate_upload_mr(samples, self.device, self.feature_dtype)
+            ev = torch.cuda.Event(enable_timing=self.timing)
+            ev.record()
+            if self.timing:
+                self._timers.append((e0, ev))
+        self.stats["host_collate_s"] += time.perf_counter() - t0
+        self.stats["batches"] += 1
+        return item, ev
+
+    def __iter__(self):
+        q = collections.deque()
+        it = iter(self.batches)
+        done = False
+        while True:
+            while not done and len(q) < self.depth:
+                try:
+                    q.append(self._enqueue(next(it)))
+                except StopIteration:
+                    done = True
+            if not q:
+                break
+            item, ev = q.popleft()
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in _device_tensors(item):
+                t.record_stream(cur)
+            yield item
+        if self.timing:
+            torch.cuda.synchronize(self.device)
+            self.stats["upload_ms"] = sum(a.elapsed_time(b) for a, b in self._timers)
+            self._timers = []

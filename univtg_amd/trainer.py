@@ -74,9 +74,11 @@ class TrainStep:
                      (4 if "saliency" in criterion.losses else 0)
         # packed (ragged) encoder stream (include/uvtg.h, lens_host): "auto" = when the batch carries the host-side lengths the
         # collate already knows (inputs["_lens_host"] = (lens_v, lens_t)); True = always (lengths read back from the masks: one
-        # device->host sync per step); False = padded execution
+        # device->host sync per step); False = padded execution.  Both packed variants are exact: the engine keeps every clip row
+        # whenever input / attention dropout is active (each padded clip then has its own mask) and drops only padded text tokens
         self.packed = packed
         self._lens_arr = None
+        self._names = None
         self._shape = None
         self.params = model._ordered_params()
         self.ptrs = model._param_ptrs(self.params)
@@ -143,7 +145,51 @@ class TrainStep:
             chk(lib.uvtg_adamw_clip_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.flat.numel(),
                                          self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, float(self.clip),
                                          1.0 / self.world, _ptr(self.scratch), st), "uvtg_adamw_clip_step")
-        return self.losses[:5]
+            model.invalidate_operand_cache()      # the raw kernel rewrote the parameters: model(...) must rebuild its bf16 operands
+        return self.losses[:5].clone()            # (the internal buffer is overwritten by the next step)
+
+    # ---- optimizer checkpointing: torch.optim.AdamW state_dict layout, indexed like the reference's optimizer --------------
+    def _param_index(self):
+        """table parameter -> index in the reference optimizer's single param group
+        ([p for n, p in model.named_parameters() if p.requires_grad], main/config.py:349)."""
+        idx = {id(p): i for i, (n, p) in enumerate((n, p) for n, p in self.model.named_parameters() if p.requires_grad)}
+        return [idx[id(p)] for p in self.params], len(idx)
+
+    def state_dict(self):
+        """What ``optimizer.state_dict()`` holds in the reference's checkpoints (main/train_vlp_ddp.py:157-195): loadable by
+        ``torch.optim.AdamW.load_state_dict`` and by ``TrainStep.load_state_dict``."""
+        index, n = self._param_index()
+        offs = self.model._offsets(self.model._dims(1, 4, 4, self.model.vid_dim, self.model.txt_dim, False))
+        state = {}
+        if self.t > 0:
+            for i, p in enumerate(self.params):
+                sl = slice(offs[i], offs[i] + p.numel())
+                state[index[i]] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[sl].view_as(p).clone(),
+                                   "exp_avg_sq": self.v[sl].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "params": list(range(n))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        index, _ = self._param_index()
+        offs = self.model._offsets(self.model._dims(1, 4, 4, self.model.vid_dim, self.model.txt_dim, False))
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.wd = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        for i, p in enumerate(self.params):
+            ent = sd["state"].get(index[i])
+            if ent is None:
+                continue
+            sl = slice(offs[i], offs[i] + p.numel())
+            self.m[sl].copy_(ent["exp_avg"].reshape(-1))
+            self.v[sl].copy_(ent["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(ent["step"])))
+        if len(steps) > 1:
+            raise ValueError("TrainStep keeps ONE step count for all parameters (the reference's optimizer steps them together)")
+        self.t = steps.pop() if steps else 0
 
 
     def _host_lens(self, inputs, B):
@@ -159,7 +205,7 @@ class TrainStep:
         vals = [int(x) for x in lv] + [int(x) for x in lt]
         if len(vals) != 2 * B:
             raise ValueError("_lens_host must hold B clip counts and B token counts")
-        self._lens_arr = (C.c_int * (2 * B))(*vals)     # kept alive: the engine copies it to the device asynchronously
+        self._lens_arr = (C.c_int * (2 * B))(*vals)     # read synchronously by the engine (row count only; tables come from the masks)
         return self._lens_arr
 
     # ---- data-parallel gradient exchange -------------------------------------------------------------------------
