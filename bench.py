@@ -294,7 +294,7 @@ def main():
         clips = B * Lv * world * args.steps
         S, d, F_, E = Lv + Lt, MODEL["d"], MODEL["F"], MODEL["E"]
         enc_flops = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)      # padded positions count
-        t_enc = (sect["encoder_fwd_ms"] + sect["encoder_bwd_ms"]) * 1e-3
+        t_enc = max((sect["encoder_fwd_ms"] + sect["encoder_bwd_ms"]) * 1e-3, 1e-9)
         lens = [bt[0]["_lens_host"] for bt in batches]
         valid_clips = sum(sum(a) for a, _ in lens) / len(lens)
         rows_full = sum(sum(a) + sum(b) + sum(1 for x in a if x < Lv) for a, b in lens) / (len(lens) * B * S)

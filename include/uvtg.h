@@ -190,7 +190,8 @@ int uvtg_hungarian(const float* pred_logits, int n_cls, const float* pred_spans_
  * float(f"{x:.4f}") (main/inference_mr.py:159), so they compare equal to the reference's Python floats. */
 int uvtg_decode_rank_nms(const float* pred_logits, const float* pred_spans, const float* timestamp,
                          const float* timestamp_mask, const float* durations, int B, int Lv,
-                         float nms_thd, int max_before, int max_after,
+                         double nms_thd /* the reference's Python float: compared in double, so that a hull-IoU of exactly 7/10 is NOT > 0.7 */,
+                         int max_before, int max_after,
                          double* windows_out, int* order, int* keep, int* n_keep, uvtg_stream_t stream);
 /* The full per-batch tail of compute_mr_results + eval_epoch_post_processing (main/inference_mr.py:109-192,31-40): as above, plus
  *   clip_length > 0 : PostProcessorDETR's round_multiple (eval/postprocessing.py:46-51) on the 4-decimal rows BEFORE the NMS, as the
@@ -200,7 +201,7 @@ int uvtg_decode_rank_nms(const float* pred_logits, const float* pred_spans, cons
  *                     reference's --eval_mode add), main/inference_mr.py:124-128; the caller truncates row b to its len_v (:133-136). */
 int uvtg_postprocess_mr(const float* pred_logits, const float* pred_spans, const float* saliency /* [B,Lv] or NULL */,
                         const float* timestamp, const float* timestamp_mask, const float* durations, int B, int Lv,
-                        float clip_length, int eval_mode_add, float nms_thd, int max_before, int max_after,
+                        float clip_length, int eval_mode_add, double nms_thd, int max_before, int max_after,
                         double* windows_out, int* order, int* keep, int* n_keep, float* saliency_out /* or NULL */,
                         uvtg_stream_t stream);
 
@@ -231,14 +232,9 @@ int uvtg_profile_sections_stop(double* total_ms, long long* counts);
 int uvtg_debug_force_nt_tile(int tile);
 /* ... and the tile HEIGHT of the persistent 256-wide kernel (0 = automatic per launch, 128, 192, 256) */
 int uvtg_debug_force_nt_bm(int bm);
-/* Parity-test aid: 0 = automatic, 4 = 256-column tiles (one workgroup per CU), 2 = 128-column tiles (two per CU). */
-int uvtg_debug_force_nt_wn(int wn);
-
-/* Process-wide experiment knob: 1 = the persistent GEMM launches of uvtg_forward / uvtg_backward hand their tiles out dynamically
- * (per-XCD atomic counters in the workspace) instead of by a static stride.  Identical results; default 0 -- with part of the CUs
- * held by another stream (RCCL) the static stride measured faster (tools/hog_experiment.py). */
-int uvtg_set_dynamic_tiles(int on);
-
+/* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
+ * launches on different streams can run side by side. */
+int uvtg_debug_gemm_cus(int n);
 const char* uvtg_strerror(int code);
 int uvtg_version(void);
 

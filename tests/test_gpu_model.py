@@ -352,15 +352,22 @@ def test_nt256_engine_path_matches_nt128(dev):
     step = TrainStep(model, crit, grad_clip=0.1)
     res = {}
     try:
-        for tile in (128, 256):
-            _lib.check(lib.uvtg_debug_force_nt_tile(tile))
+        for tile, bm in ((128, 0), (256, 0), (256, 256), (256, 192), (256, 128)):     # every tile height of the persistent kernel,
+            _lib.check(lib.uvtg_debug_force_nt_tile(tile))                             # with its fused epilogues (residual, act-grad, ...)
+            _lib.check(lib.uvtg_debug_force_nt_bm(bm))
             losses = step.step(ind, tgd, optimize=False).clone()
             torch.cuda.synchronize()
-            res[tile] = (losses, step.grads.clone(), step.pred_logits.clone(), step.pred_spans.clone())
+            res[(tile, bm)] = (losses, step.grads.clone(), step.pred_logits.clone(), step.pred_spans.clone())
     finally:
         lib.uvtg_debug_force_nt_tile(0)
-    l1, g1, pl1, ps1 = res[128]
-    l2, g2, pl2, ps2 = res[256]
+        lib.uvtg_debug_force_nt_bm(0)
+    l1, g1, pl1, ps1 = res[(128, 0)]
+    for key in ((256, 256), (256, 192), (256, 128)):
+        lk, gk, plk, psk = res[key]
+        assert float((pl1 - plk).abs().max()) < 1e-6 and float((ps1 - psk).abs().max()) < 1e-6, key
+        assert float((l1 - lk).abs().max()) < 1e-5 * max(1.0, float(l1.abs().max())), key
+        assert float((g1 - gk).norm() / g1.norm()) < 1e-4, key
+    l2, g2, pl2, ps2 = res[(256, 0)]
     assert torch.isfinite(g2).all()
     assert float((pl1 - pl2).abs().max()) < 1e-6 and float((ps1 - ps2).abs().max()) < 1e-6
     assert float((l1 - l2).abs().max()) < 1e-5 * max(1.0, float(l1.abs().max()))
@@ -666,31 +673,3 @@ def test_bench_two_rank_control_flow(dev):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0 and out["roofline"]["achieved"] > 0
-
-
-def test_dynamic_tile_handout_identical(dev):
-    """uvtg_set_dynamic_tiles(1): per-XCD atomic tile counters instead of the static stride in the persistent GEMMs (what TrainStep
-    switches on for N>1, where RCCL kernels share the CUs).  Same tiles, same arithmetic: losses and gradients must agree to rounding."""
-    from oracle import univtg_oracle as O
-    from univtg_amd import _lib
-    from univtg_amd.trainer import TrainStep
-    lib = _lib.load()
-    cfg = O.make_cfg(input_dropout=0.5, droppath=0.1, dropout=0.0)
-    params = O.init_params(cfg, seed=21)
-    inputs, tg = O.make_batch(cfg, 256, 75, 32, seed=22, ragged=True)       # config-2 size: > 256 tiles per GEMM, i.e. several rounds
-    res = []
-    try:
-        for dyn in (0, 1):
-            _lib.check(lib.uvtg_set_dynamic_tiles(dyn))
-            model, crit = build(cfg, params, dev, "bf16", proj_precise="auto")
-            model.train(); model.set_seed(3)
-            step = TrainStep(model, crit, packed=False)
-            losses = step.step(to_dev(inputs, dev), to_dev(tg, dev), optimize=False).clone()
-            res.append((losses.cpu(), step.grads.clone().cpu()))
-            del step, model, crit
-    finally:
-        lib.uvtg_set_dynamic_tiles(0)
-    # (a few small kernels accumulate with fp32 atomics, so run-to-run equality is to rounding, not bitwise)
-    assert torch.allclose(res[0][0], res[1][0], rtol=1e-6, atol=1e-7)
-    g0, g1 = res[0][1].double(), res[1][1].double()
-    assert float((g0 - g1).norm() / (g0.norm() + 1e-30)) < 1e-6

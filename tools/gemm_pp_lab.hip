@@ -1,0 +1,546 @@
+// Dev lab (not shipped): the ping-pong persistent NT GEMM structure, A/B against the round-1 one-barrier structure.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/gemm_pp_lab tools/gemm_pp_lab.hip && tools/gemm_pp_lab
+//
+// C[M,N] = A[M,K] * B[N,K]^T, bf16 operands, 256 x 256 x 64 tiles, 8 waves (2 x 4, 128 x 64 each), persistent grid.
+// The two wave groups (wm = 0 / 1: one wave of each on every SIMD) run ONE BARRIER OUT OF PHASE: while a group issues its
+// fragment reads + global_load_lds pieces (a "load slot"), the other group's 8 MFMAs own the matrix pipe (a "compute slot").
+// A K tile is 4 phases per wave, one per quadrant of its 128 x 64 output block, whole K = 64 each:
+//   P0: A frags 0,1 (8 reads) + B frag 0 (4 reads)          -> acc[0..1][0]
+//   P1: B frag 1 (4 reads)          + 3 glds (A_own(it+1))  -> acc[0..1][1]
+//   P2: A frags 2,3 (8 reads)       + 2 glds (B(it+2))      -> acc[2..3][1]
+//   P3:                               3 glds (B(it+2) x2, A_own(it+2)) + counted vmcnt -> acc[2..3][0]
+// Region lifetimes inside a stage (2 stages x [A 256 rows | B 256 rows] x 128 B): B is read in P0/P1 only, the own A half in
+// P0/P2 only, so the pieces of K tile it+2 re-use the CURRENT stage from P2 on: ~1.5 K tiles of prefetch distance in 128 KB.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <cstring>
+#include "../univtg_amd/csrc/uvtg_common.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+#define BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+struct LabArgs {
+  const bf16_t* A; const bf16_t* B; int M, N, K, lda, ldb;
+  const float* bias; const bf16_t* resid;
+  float* outF; bf16_t* outB; int ldo;
+  int mode;   // 0: no epilogue (sink), 1: bf16 out (+bias, +resid when set)
+};
+
+template <bool STAGGER, bool PRIO>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const LabArgs p) {
+  constexpr int SSTR = 65536, BOFF = 32768, EOFF = 131072;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = p.K / 64;
+  const int G = gridDim.x;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int ntw = (ntiles - (int)blockIdx.x + G - 1) / G;       // tiles of this workgroup
+  const int total = ntw * nk;                                   // its K-tile stream
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    m0 = (l / tiles_n) * 256; n0 = (l % tiles_n) * 256;
+  };
+  // ---- staging: this wave's pieces (1 KB = 8 rows x 128 B each) ----
+  const int sr = lane >> 3, sc = lane & 7;
+  const int arow = wm * 128 + wn * 32 + sr;        // + i * 8 : rows of the OWN A half
+  const int brow = wave * 32 + sr;                 // + i * 8
+  auto glds_a = [&](int stage, int m0, int k, int i) {
+    const int r = arow + i * 8;
+    const int c = (sc ^ ((r >> 1) & 7)) * 8;
+    const char* src = (const char*)p.A + ((size_t)min(m0 + r, p.M - 1) * p.lda + c + k * 64) * 2;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + stage * SSTR + (wm * 128 + wn * 32 + i * 8) * 128), 16, 0, 0);
+  };
+  auto glds_b = [&](int stage, int n0, int k, int i) {
+    const int r = brow + i * 8;
+    const int c = (sc ^ ((r >> 1) & 7)) * 8;
+    const char* src = (const char*)p.B + ((size_t)min(n0 + r, p.N - 1) * p.ldb + c + k * 64) * 2;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + stage * SSTR + BOFF + (wave * 32 + i * 8) * 128), 16, 0, 0);
+  };
+  // ---- fragment addressing ----
+  const int swz = (l31 >> 1) & 7;
+  const int aoff = (wm * 128 + l31) * 128;         // + i * 4096
+  const int boff = BOFF + (wn * 64 + l31) * 128;   // + j * 4096
+  auto frag = [&](const unsigned char* base, int off, int ks) -> s16x8 {
+    return *(const s16x8*)(base + off + (((2 * ks + g) ^ swz) << 4));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // stream cursors: K tile `it` (c0), it + 1 (c1), it + 2 (c2): tile origin + k index
+  int t0 = blockIdx.x, m0_0, n0_0, k0 = 0;
+  tile_origin(t0, m0_0, n0_0);
+  int t1 = t0, m0_1 = m0_0, n0_1 = n0_0, k1 = 1;
+  if (k1 == nk) { k1 = 0; t1 += G; if (t1 < ntiles) tile_origin(t1, m0_1, n0_1); }
+  int t2 = t1, m0_2 = m0_1, n0_2 = n0_1, k2 = k1 + 1;
+  if (k2 == nk) { k2 = 0; t2 += G; if (t2 < ntiles) tile_origin(t2, m0_2, n0_2); }
+
+  // ---- prologue: K tile 0 completely, K tile 1 except the three A pieces phase 1 of K tile 0 issues ----
+#pragma unroll
+  for (int i = 0; i < 4; i++) glds_b(0, n0_0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) glds_a(0, m0_0, 0, i);
+  if (total > 1) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) glds_b(1, n0_1, k1, i);
+    glds_a(1, m0_1, k1, 0);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  BAR();
+  if (STAGGER && wm == 1) BAR();
+
+  s16x8 fa[2][4], fb0[4], fb1[4];
+  for (int it = 0; it < total; it++) {
+    const int cur = it & 1;
+    const unsigned char* base = smem + cur * SSTR;
+    const bool has1 = it + 1 < total, has2 = it + 2 < total;
+    // ================= phase 0 =================
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { fa[0][ks] = frag(base, aoff, ks); fa[1][ks] = frag(base, aoff + 4096, ks); fb0[ks] = frag(base, boff, ks); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    BAR();
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { acc[0][0] = mfma32(fa[0][ks], fb0[ks], acc[0][0]); acc[1][0] = mfma32(fa[1][ks], fb0[ks], acc[1][0]); }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    BAR();
+    // ================= phase 1 =================
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) fb1[ks] = frag(base, boff + 4096, ks);
+    if (has1) { glds_a(cur ^ 1, m0_1, k1, 1); glds_a(cur ^ 1, m0_1, k1, 2); glds_a(cur ^ 1, m0_1, k1, 3); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    BAR();
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { acc[0][1] = mfma32(fa[0][ks], fb1[ks], acc[0][1]); acc[1][1] = mfma32(fa[1][ks], fb1[ks], acc[1][1]); }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    BAR();
+    // ================= phase 2 =================
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { fa[0][ks] = frag(base, aoff + 2 * 4096, ks); fa[1][ks] = frag(base, aoff + 3 * 4096, ks); }
+    if (has2) { glds_b(cur, n0_2, k2, 0); glds_b(cur, n0_2, k2, 1); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    BAR();
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { acc[2][1] = mfma32(fa[0][ks], fb1[ks], acc[2][1]); acc[3][1] = mfma32(fa[1][ks], fb1[ks], acc[3][1]); }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    BAR();
+    // ================= phase 3 =================
+    if (has2) {
+      glds_b(cur, n0_2, k2, 2); glds_b(cur, n0_2, k2, 3); glds_a(cur, m0_2, k2, 0);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");       // everything issued up to phase 1 of this K tile (= K tile it + 1) has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    BAR();
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { acc[2][0] = mfma32(fa[0][ks], fb0[ks], acc[2][0]); acc[3][0] = mfma32(fa[1][ks], fb0[ks], acc[3][0]); }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool tile_end = k0 == nk - 1;
+    // ---- epilogue: the late group runs it BEFORE the closing barrier of this slot, the early group after it, so that both
+    // epilogues share one slot (otherwise they would serialise with the matrix pipe idle twice) ----
+    auto epilogue = [&]() {
+      if (p.mode == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) t += acc[i][j][r];
+        if (t == 123.456f) p.outF[0] = t;
+      } else {
+        float* slab = (float*)(smem + EOFF + wave * 4096);        // [16][64] fp32, wave-private
+        const int c8 = (lane & 7) * 8;
+        const int n = n0_0 + wn * 64 + c8;
+        const bool ncol = n < p.N;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) bv[e] = 0.f;
+        if (p.bias && ncol) {
+          const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+          // consume the loads HERE on every path: a load that some path never waits for reaches the loop header as "maybe pending",
+          // and hipcc then drains vmcnt(0) -- the whole prefetch ring -- before the first fragment read that re-uses its register
+          asm volatile("" :: "v"(b0), "v"(b1));
+#pragma unroll
+          for (int e = 0; e < 4; e++) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+              for (int rr = 0; rr < 8; rr++) {
+                const int r = h * 8 + rr;
+                slab[((rr & 3) + 8 * (rr >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
+              }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              const int lr = q * 8 + (lane >> 3);
+              const int m = m0_0 + wm * 128 + i * 32 + h * 16 + lr;
+              const f32x4 v0 = *(const f32x4*)(slab + lr * 64 + c8), v1 = *(const f32x4*)(slab + lr * 64 + c8 + 4);
+              if (m < p.M && ncol) {
+                float v[8] = {v0[0] + bv[0], v0[1] + bv[1], v0[2] + bv[2], v0[3] + bv[3], v1[0] + bv[4], v1[1] + bv[5], v1[2] + bv[6], v1[3] + bv[7]};
+                if (p.resid) {
+                  const u32x4 t = *(const u32x4*)(p.resid + (size_t)m * p.ldo + n);
+#pragma unroll
+                  for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
+                }
+                u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
+                *(u32x4*)(p.outB + (size_t)m * p.ldo + n) = t;
+              }
+            }
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    };
+    if (tile_end && (!STAGGER || wm == 1)) epilogue();
+    BAR();
+    if (tile_end && STAGGER && wm == 0) epilogue();
+    // ---- advance the cursors ----
+    t0 = t1; m0_0 = m0_1; n0_0 = n0_1; k0 = k1;
+    t1 = t2; m0_1 = m0_2; n0_1 = n0_2; k1 = k2;
+    k2++;
+    if (k2 == nk) { k2 = 0; t2 += G; if (t2 < ntiles) tile_origin(t2, m0_2, n0_2); }
+  }
+  if (STAGGER && wm == 0) BAR();     // balance the late group's extra barrier
+}
+
+template <bool STAGGER, bool PRIO> void launch_pp(const LabArgs& a, int grid_cap = 256) {
+  static bool once = false;
+  if (!once) { CK(hipFuncSetAttribute((const void*)gemm_pp_kernel<STAGGER, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); once = true; }
+  int grid = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (grid > grid_cap) grid = grid_cap;
+  hipLaunchKernelGGL((gemm_pp_kernel<STAGGER, PRIO>), dim3(grid), dim3(512), 163840, 0, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// round-1 structure (one __syncthreads per K tile, fragment prefetch one k-step ahead), for the A/B
+// ------------------------------------------------------------------------------------------------
+// V: 0 = round-1 order (all 8 global_load_lds at the head of the K tile), 1 = the 8 pieces interleaved with the MFMAs of k-steps 0/1
+//    (4 each; the fragment reads of k-step 0 go first), 2 = as 1 but spread over k-steps 0..3 (2 each)
+// ABL (timing-only ablations, results garbage): 1 no global_load_lds in the loop, 2 no fragment reads after the first K tile,
+//    4 no barrier / vmcnt wait, 8 no MFMA
+template <int V, int ABL>
+__global__ __launch_bounds__(512) void gemm_r1_kernel(const LabArgs p) {
+  constexpr int TM = 4, TN = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / 4, wn = wave % 4, g = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = p.K / 64;
+  const int sr = lane >> 3, sc = lane & 7;
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    m0 = (l / tiles_n) * 256; n0 = (l % tiles_n) * 256;
+  };
+  unsigned aofs[4], bofs[4];
+  auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = (wave * 4 + i) * 8 + sr;
+      const int c = (sc ^ ((r >> 1) & 7)) * 8;
+      aofs[i] = ((unsigned)min(m0 + r, p.M - 1) * p.lda + c) * 2;
+      bofs[i] = ((unsigned)min(n0 + r, p.N - 1) * p.ldb + c) * 2;
+    }
+  };
+  auto stage = [&](int s, int kt) {
+    unsigned char* base = smem + s * 65536 + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)p.A + aofs[i] + kt * 128), (lds_void*)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)p.B + bofs[i] + kt * 128), (lds_void*)(base + 32768 + i * 1024), 16, 0, 0);
+    }
+  };
+  int aoff[TM], boff[TN];
+  const int swz = (l31 >> 1) & 7;
+#pragma unroll
+  for (int i = 0; i < TM; i++) aoff[i] = (wm * 128 + i * 32 + l31) * 128;
+#pragma unroll
+  for (int j = 0; j < TN; j++) boff[j] = 32768 + (wn * 64 + j * 32 + l31) * 128;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int m0, n0;
+  tile_origin(tile, m0, n0);
+  set_offsets(m0, n0);
+  stage(0, 0);
+  int it = 0;
+  while (true) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    int next = tile + gridDim.x, nm0 = 0, nn0 = 0;
+    s16x8 fa[2][TM], fb[2][TN];
+    for (int kt = 0; kt < nk; kt++, it++) {
+      const int cur = it & 1;
+      if (!(ABL & 4)) __syncthreads();
+      const bool more = kt + 1 < nk;
+      const bool nxt = !more && next < ntiles;
+      if (V == 0) { if (nxt) { tile_origin(next, nm0, nn0); set_offsets(nm0, nn0); } }
+      else if (!more) {          // V > 0: the pieces are issued unconditionally (straight-line K-tile body: the scheduling pins need ONE basic
+        if (nxt) tile_origin(next, nm0, nn0); else { nm0 = m0; nn0 = n0; }     // block); without a next tile they re-load this tile into the idle stage
+        set_offsets(nm0, nn0);
+      }
+      const int skt = more ? kt + 1 : 0;
+      const bool do_stage = V == 0 ? ((more || nxt) && !(ABL & 1)) : !(ABL & 1);
+      auto piece = [&](int i) {      // one A + one B piece of the next K tile
+        unsigned char* sb = smem + (cur ^ 1) * 65536 + wave * 4096;
+        __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)p.A + aofs[i] + skt * 128), (lds_void*)(sb + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)p.B + bofs[i] + skt * 128), (lds_void*)(sb + 32768 + i * 1024), 16, 0, 0);
+      };
+      if (V == 0 && do_stage) { piece(0); piece(1); piece(2); piece(3); }
+      const unsigned char* base = smem + cur * 65536;
+      const bool rd = !(ABL & 2) || it == 0;
+      if (rd) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb[0][j] = *(const s16x8*)(base + boff[j] + ((g ^ swz) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        if (ks < 3 && rd) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) fa[(ks + 1) & 1][i] = *(const s16x8*)(base + aoff[i] + (((2 * ks + 2 + g) ^ swz) << 4));
+#pragma unroll
+          for (int j = 0; j < TN; j++) fb[(ks + 1) & 1][j] = *(const s16x8*)(base + boff[j] + (((2 * ks + 2 + g) ^ swz) << 4));
+        }
+        if (V == 1 && do_stage && ks < 2) { piece(2 * ks); piece(2 * ks + 1); }
+        if (V == 2 && do_stage) piece(ks);
+        if (!(ABL & 8)) {
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; i++) acc[i][0][0] += __builtin_bit_cast(float, (int)fa[ks & 1][i][0] | ((int)fb[ks & 1][i & 1][1] << 16));
+        }
+      }
+      if (ABL == 0) {
+        // pin the software pipeline: 6 reads up front, then per k-step the 8 MFMAs cover the 6 reads of the next k-step (+ the pieces)
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+          const int nv = V == 1 ? (ks < 2 ? 4 : 0) : (V == 2 ? 2 : 0);
+#pragma unroll
+          for (int n = 0; n < TM + TN; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+          if (nv == 4) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          } else if (nv == 2) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+          }
+        }
+        if (V == 2) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+      }
+    }
+    if (p.mode == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) t += acc[i][j][r];
+      if (t == 123.456f) p.outF[0] = t;
+    } else {
+      __builtin_amdgcn_s_barrier();
+      float* wbuf = (float*)(smem + ((it - 1) & 1) * 65536) + wave * 2048;
+      const int c8 = (lane & 7) * 8;
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            wbuf[((r & 3) + 8 * (r >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
+        const int mb = m0 + wm * 128 + i * 32, n = n0 + wn * 64 + c8;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int row = q * 8 + (lane >> 3), m = mb + row;
+          f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
+          if (m < p.M && n < p.N) {
+            if (p.bias) { v0 += *(const f32x4*)(p.bias + n); v1 += *(const f32x4*)(p.bias + n + 4); }
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (p.resid) {
+              const u32x4 t = *(const u32x4*)(p.resid + (size_t)m * p.ldo + n);
+#pragma unroll
+              for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
+            }
+            u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
+            *(u32x4*)(p.outB + (size_t)m * p.ldo + n) = t;
+          }
+        }
+      }
+    }
+    if (next >= ntiles) break;
+    tile = next; m0 = nm0; n0 = nn0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+template <int V = 0, int ABL = 0> void launch_r1(const LabArgs& a, int grid_cap = 256) {
+  static bool once = false;
+  if (!once) { CK(hipFuncSetAttribute((const void*)gemm_r1_kernel<V, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); once = true; }
+  int grid = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (grid > grid_cap) grid = grid_cap;
+  hipLaunchKernelGGL((gemm_r1_kernel<V, ABL>), dim3(grid), dim3(512), 131072, 0, a);
+}
+
+// naive reference (bf16 output path: fp32 accumulate + bias + resid)
+__global__ void ref_kernel(const bf16_t* A, const bf16_t* B, const float* bias, const bf16_t* resid, float* C, int M, int N, int K) {
+  const int n = blockIdx.x * 16 + threadIdx.x, m = blockIdx.y * 16 + threadIdx.y;
+  if (m >= M || n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < K; k++) s += bf2f(A[(size_t)m * K + k]) * bf2f(B[(size_t)n * K + k]);
+  C[(size_t)m * N + n] = s + (bias ? bias[n] : 0.f) + (resid ? bf2f(resid[(size_t)m * N + n]) : 0.f);
+}
+__global__ void fill_kernel(bf16_t* p, size_t n, unsigned seed, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  p[i] = f2bf((((x >> 8) * (1.0f / 8388608.0f)) - 1.0f) * scale);
+}
+
+template <typename F> float time_us(F f, int n = 20) {
+  for (int i = 0; i < 3; i++) f();
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < n; i++) f();
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / n;
+}
+
+static double check(const LabArgs& a, const float* R, int runs, const char* name, void (*launch)(const LabArgs&, int), int cap) {
+  const size_t n = (size_t)a.M * a.N;
+  std::vector<bf16_t> hb(n); std::vector<float> hr(n);
+  CK(hipMemcpy(hr.data(), R, n * 4, hipMemcpyDeviceToHost));
+  double worst = 0; size_t bad = 0;
+  for (int run = 0; run < runs; run++) {
+    CK(hipMemset(a.outB, 0xff, n * 2));
+    launch(a, cap);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hb.data(), a.outB, n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+      unsigned u = (unsigned)hb[i] << 16; float f; memcpy(&f, &u, 4);
+      const double e = fabs((double)f - hr[i]) / (fabs((double)hr[i]) + 1.0);
+      if (!(e < 1e-2)) bad++;
+      if (e > worst || e != e) worst = e != e ? 1e30 : e;
+    }
+  }
+  printf("check %-22s M=%5d N=%4d K=%4d cap %3d x%d runs: worst rel err %.3e, bad elements %zu\n", name, a.M, a.N, a.K, cap, runs, worst, bad);
+  return worst;
+}
+
+int main(int argc, char** argv) {
+  // ---- correctness + race screen (several runs, awkward and production shapes, small and full grids) ----
+  const int cshapes[][3] = {{700, 520, 192}, {1000, 256, 1024}, {5000, 1032, 256}, {27392, 1024, 1024}};
+  for (auto& s : cshapes) {
+    const int M = s[0], N = s[1], K = s[2];
+    bf16_t *A, *B, *Cb, *Rs; float *R, *bias;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&Cb, (size_t)M * N * 2)); CK(hipMalloc(&Rs, (size_t)M * N * 2));
+    CK(hipMalloc(&R, (size_t)M * N * 4)); CK(hipMalloc(&bias, N * 4));
+    fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1, 1.0f);
+    fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2, 0.05f);
+    fill_kernel<<<(unsigned)(((size_t)M * N + 255) / 256), 256>>>(Rs, (size_t)M * N, 3, 1.0f);
+    std::vector<float> hb(N); for (int i = 0; i < N; i++) hb[i] = 0.01f * (i % 97);
+    CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
+    ref_kernel<<<dim3((N + 15) / 16, (M + 15) / 16), dim3(16, 16)>>>(A, B, bias, Rs, R, M, N, K);
+    CK(hipDeviceSynchronize());
+    LabArgs a{A, B, M, N, K, K, K, bias, Rs, nullptr, Cb, N, 1};
+    const int runs = M > 20000 ? 3 : 5;
+    for (int cap : {256, 3}) {
+      if (cap < 256 && M > 20000) continue;
+      check(a, R, 2, "r1 V0", [](const LabArgs& x, int c) { launch_r1<0, 0>(x, c); }, cap);
+      check(a, R, runs, "r1 V1 (interleaved 4+4)", [](const LabArgs& x, int c) { launch_r1<1, 0>(x, c); }, cap);
+      check(a, R, runs, "r1 V2 (interleaved 2x4)", [](const LabArgs& x, int c) { launch_r1<2, 0>(x, c); }, cap);
+      check(a, R, 2, "pp<stagger,prio>", [](const LabArgs& x, int c) { launch_pp<true, true>(x, c); }, cap);
+    }
+    hipFree(A); hipFree(B); hipFree(Cb); hipFree(Rs); hipFree(R); hipFree(bias);
+  }
+  // ---- timing (random data) ----
+  const int shapes[][3] = {{27392, 1024, 1024}, {24300, 1024, 1024}, {27392, 3072, 1024}, {27392, 1024, 3072}, {4096, 4096, 4096}, {8192, 8192, 8192}};
+  for (auto& s : shapes) {
+    const int M = s[0], N = s[1], K = s[2];
+    bf16_t *A, *B, *Cb, *Rs; float* C;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, 1024)); CK(hipMalloc(&Cb, (size_t)M * N * 2)); CK(hipMalloc(&Rs, (size_t)M * N * 2));
+    fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1, 1.0f);
+    fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2, 1.0f);
+    fill_kernel<<<(unsigned)(((size_t)M * N + 255) / 256), 256>>>(Rs, (size_t)M * N, 3, 1.0f);
+    const double fl = 2.0 * M * N * K;
+    for (int mode : {0, 2}) {     // 0: main loop only, 2: bf16 out + bf16 residual
+      LabArgs a{A, B, M, N, K, K, K, nullptr, mode == 2 ? Rs : nullptr, C, Cb, N, mode ? 1 : 0};
+      float t[4] = {0, 0, 0, 0};
+      for (int round = 0; round < 3; round++) {
+        t[0] += time_us([&] { launch_r1<0, 0>(a); }, 10);
+        t[1] += time_us([&] { launch_r1<1, 0>(a); }, 10);
+        t[2] += time_us([&] { launch_r1<2, 0>(a); }, 10);
+        t[3] += time_us([&] { launch_pp<true, true>(a); }, 10);
+      }
+      for (int i = 0; i < 4; i++) t[i] /= 3;
+      printf("%5dx%4dx%4d mode %d: r1 V0 %7.1f us %6.0f TF | V1 %7.1f us %6.0f TF | V2 %7.1f us %6.0f TF | pp %7.1f us %6.0f TF\n", M, N, K, mode,
+             t[0], fl / t[0] / 1e6, t[1], fl / t[1] / 1e6, t[2], fl / t[2] / 1e6, t[3], fl / t[3] / 1e6);
+    }
+    if (K == 1024 && N == 1024 && M == 27392) {     // ablations of the round-1 structure (timing only)
+      LabArgs a{A, B, M, N, K, K, K, nullptr, nullptr, C, Cb, N, 0};
+      const float t0 = time_us([&] { launch_r1<0, 0>(a); }, 20), t1 = time_us([&] { launch_r1<0, 1>(a); }, 20), t2 = time_us([&] { launch_r1<0, 2>(a); }, 20),
+                  t3 = time_us([&] { launch_r1<0, 3>(a); }, 20), t4 = time_us([&] { launch_r1<0, 4>(a); }, 20), t7 = time_us([&] { launch_r1<0, 7>(a); }, 20),
+                  t8 = time_us([&] { launch_r1<0, 8>(a); }, 20), t9 = time_us([&] { launch_r1<0, 9>(a); }, 20);
+      printf("ablation 27392x1024x1024 (us): full %.1f | no glds %.1f | no frag reads %.1f | neither %.1f | no barrier %.1f | MFMA only %.1f | no MFMA %.1f | glds-less no MFMA %.1f\n",
+             t0, t1, t2, t3, t4, t7, t8, t9);
+    }
+    hipFree(A); hipFree(B); hipFree(C); hipFree(Cb); hipFree(Rs);
+  }
+  return 0;
+}

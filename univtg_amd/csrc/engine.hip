@@ -117,7 +117,6 @@ struct WCache {
 // ---- workspace -------------------------------------------------------------------------------
 struct WSpace {
   float* pos; unsigned char* kvalid; float* dps;
-  int* tile_ctr;             // 64 slots x 8 ints: per-launch tile counters of the persistent GEMM (zeroed at the start of forward / backward)
   // packed (ragged) execution: tables, packed layer-0 operands, packed conv-head gradient
   PackTables pk; int* lens_dev; bf16_t *xb0p, *ub0p, *g2p;
   // projections (index 0 = video, 1 = text)
@@ -143,7 +142,6 @@ struct WSpace {
     const bool pp = m.c.precise || m.c.proj_precise;
     pos = a.take<float>((size_t)m.Mv * d); kvalid = a.take<unsigned char>(M); dps = a.take<float>(2 * E * B);
     lens_dev = a.take<int>(2 * B);
-    tile_ctr = a.take<int>(64 * 8);
     pk.seq_start = a.take<int>(B); pk.seq_count = a.take<int>(B);
     pk.row_sample = a.take<int>(M); pk.row_src = a.take<int>(M); pk.row_pos = a.take<int>(M);
     pk.pad2pack = a.take<int>(M); pk.grad_map = a.take<int>(M); pk.kvalid = a.take<unsigned char>(M);
@@ -283,10 +281,6 @@ int packed_rows(const Dm& m, const int* lens, int mode, int* out) {
   return 0;
 }
 
-struct CtrScope {            // registers the workspace's tile-counter pool for the GEMM launches of one forward / backward call
-  CtrScope(int* base, int slots) { uvtg_nt_counter_pool(base, slots); }
-  ~CtrScope() { uvtg_nt_counter_pool(nullptr, 0); }
-};
 GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N, int K) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -616,8 +610,6 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   WCache w(m, (void*)wcache);
   WSpace ws(m, workspace, x0);
   Fwd f{m, P, w, ws, s, !m.c.precise, m.c.training != 0, m.c.precise || m.c.proj_precise};
-  if (uvtg_dynamic_tiles_enabled()) { if (hipError_t e = hipMemsetAsync(ws.tile_ctr, 0, 64 * 8 * sizeof(int), s)) return (int)e; }
-  CtrScope ctr_scope(ws.tile_ctr, 64);
   int pmode = pack_mode(m.c, lens_host);
   if (pmode != PACK_NONE && memory) {           // the packed stream has no [B, S, d] encoder output to hand out
     if (m.c.training) return -24;               // (uvtg_backward could not know: refuse instead of silently diverging from it)
@@ -668,8 +660,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   Dm m(*dm);
   WCache w(m, (void*)wcache);
   WSpace ws(m, workspace, (float*)x0);
-  if (uvtg_dynamic_tiles_enabled()) { if (hipError_t e = hipMemsetAsync(ws.tile_ctr, 0, 64 * 8 * sizeof(int), s)) return (int)e; }
-  CtrScope ctr_scope(ws.tile_ctr, 64);
   const int d = m.c.d, F = m.c.F, S = m.S, Lv = m.c.Lv, B = m.c.B, E = m.c.E;
   // packed (ragged) encoder stream: must match the forward call (same lens_host); the tables are still in the workspace
   const int pmode = pack_mode(m.c, lens_host);

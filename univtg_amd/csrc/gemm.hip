@@ -10,6 +10,7 @@
 //            reduction dimension, fragments come from ds_read_b64_tr_b16 transposing LDS reads.
 #include "uvtg_kernels.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -220,36 +221,68 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_nt256: the large-shape bf16 path.  256 x 256 x 64 tiles, 8 waves (2 x 4, 128 x 64 each, 128 accumulator
-// registers), operands staged with global_load_lds (16 B per lane, no VGPR round trip) into two 64 KB stages,
-// ONE barrier per K tile.  Persistent: grid = min(tiles, #CU); every workgroup walks tiles bid, bid + G, ... and the
-// K-tile stream never drains at a tile boundary -- the last K step of a tile prefetches K tile 0 of the next tile into
-// the other stage while the epilogue of the finished tile runs out of the stage just consumed (an 8 KB fp32 slab per
-// wave, row-contiguous 16/32-byte global accesses) and its stores stay in flight behind the next tile's main loop.
-// LDS image of a stage: A [256][64] bf16, then B [256][64] bf16; rows are 128 B; the 16-byte chunk c of row r sits at
-// chunk position c ^ ((r >> 1) & 7): global_load_lds writes lane-linearly, so the permutation is applied to the per-lane
+// gemm_nt256: the large-shape bf16 path.  (64 TM) x 256 x 64 tiles, 8 waves (2 x 4, (32 TM) x 64 each), operands staged with
+// global_load_lds (16 B per lane, no VGPR round trip) into two 64 KB stages, ONE barrier per K tile.  Persistent: grid =
+// min(tiles, #CU); every workgroup walks tiles bid, bid + G, ... and the K-tile stream never drains at a tile boundary -- the last
+// K tile of an output tile prefetches K tile 0 of the next one into the other stage while the epilogue of the finished tile runs
+// out of the stage just consumed (an 8 KB fp32 slab per wave, row-contiguous 16-byte global accesses).
+// LDS image of a stage: A [64 TM][64] bf16, then (at 32 KB) B [256][64] bf16; rows are 128 B; the 16-byte chunk c of row r sits
+// at chunk position c ^ ((r >> 1) & 7): global_load_lds writes lane-linearly, so the permutation is applied to the per-lane
 // SOURCE address and again on the ds_read_b128 fragment reads (conflict-free for the 32-row fragments).
-// Tiles are enumerated XCD-aware: the 8 workgroups that run concurrently on one XCD take neighbouring tiles, which
-// share the A row panel through that XCD's L2.
+// K-tile body (round 2, measured in tools/gemm_pp_lab.hip): the staging pieces of the NEXT K tile are not issued in one burst at
+// the head of the K tile (8 waves x 8 pieces hit the CU's one address path together: ~1000 cycles with the matrix cores idle,
+// 941 TF/s at 27392 x 1024 x 1024) but AFTER the fragment reads of k-step 0 and interleaved with the MFMAs of k-steps 0 and 1
+// (1075 TF/s; a ping-pong structure with the two wave halves one barrier out of phase measured slower than both: 8 barriers per
+// K tile).  The body is straight-line code (pieces are issued unconditionally: without a next tile they re-load the current one
+// into the idle stage), because sched_group_barrier pins only work inside one basic block.
+// Epilogue operand (EOP: the bf16 residual, or the pre-activation of an activation gradient): for tiles of <= 192 rows the
+// wave's whole (32 TM) x 64 operand block is fetched into registers during k-steps 2 and 3 of the LAST K tile, under the MFMAs --
+// in the epilogue every wave of every workgroup would wait for these loads at the same time (bf16 out + residual: 853 vs
+// 1075 TF/s main loop only at N = K = 1024).
+// Tiles are enumerated XCD-aware: the 8 workgroups that run concurrently on one XCD take neighbouring tiles, which share the A
+// row panel through that XCD's L2.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
+// sched_group_barrier sequences (the builtin wants literal arguments): NV VMEM issues two at a time with one MFMA between the
+// groups while MFMAs are left (M), then the remaining MFMAs
+template <int NV, int M> __device__ __forceinline__ void sgb_vmem_mfma() {
+  if constexpr (NV >= 1) {
+    __builtin_amdgcn_sched_group_barrier(0x020, NV >= 2 ? 2 : 1, 0);
+    if constexpr (M > 0) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); sgb_vmem_mfma<(NV >= 2 ? NV - 2 : 0), M - 1>(); }
+    else sgb_vmem_mfma<(NV >= 2 ? NV - 2 : 0), 0>();
+  } else if constexpr (M > 0) {
+    __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+  }
+}
+template <int N> __device__ __forceinline__ void sgb_pairs() {      // N x (one MFMA, one fragment read)
+  if constexpr (N > 0) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); sgb_pairs<N - 1>(); }
+}
+// one k-step: Mf MFMAs, (READS) the R fragment reads of the next k-step, NV VMEM issues
+template <int Mf, int R, bool READS, int NV> __device__ __forceinline__ void sgb_kstep() {
+  constexpr int PAIRS = READS ? (Mf < R ? Mf : R) : 0;
+  sgb_pairs<PAIRS>();
+  if constexpr (READS && R > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, R - PAIRS, 0);
+  sgb_vmem_mfma<NV, Mf - PAIRS>();
+}
+
 // GATHER: row gather / scatter / conv taps / groups present (integer divisions per row); the plain variant has none.
 // TM: 32-row fragments per wave along M -> tile height BM = 64 TM (256 / 192 / 128): the launcher picks the height that
 // wastes the fewest CU-rounds for the launch's tile count (ragged batches give awkward row counts).
-// WN = 4: 256-wide tile, 8 waves, one workgroup per CU (128 KB of stages).  WN = 2: 128-wide tile, 4 waves, 80 KB (TM = 3) or
-// 64 KB (TM = 2) of stages so that TWO workgroups share a CU: they drift apart, and one's epilogue / barrier stalls overlap the
-// other's MFMA stream (in lockstep the epilogue of a 256-wide tile costs ~25 % of a K = 1024 GEMM with the matrix cores idle).
-template <bool GATHER, int TM, int WN, bool DYN>
-__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(const GemmArgs p) {
-  constexpr int TB = 64 * WN, KB = 64, TN = 2, BM = 64 * TM, NW = 2 * WN, PA = 8 * TM / NW;
-  constexpr int BOFF = (WN == 4) ? 32768 : BM * 128;            // byte offset of the B rows inside a stage
-  constexpr int SSTR = (WN == 4) ? 65536 : (BM + TB) * 128;     // stage stride
-  static_assert(NW * 8192 <= SSTR, "epilogue slabs must fit the consumed stage");
+// EOP: the launch has a bf16 epilogue operand (residB / gradPre).
+// ORD: 0 = all staging pieces of the next K tile right behind the barrier (round-1 order), 1 = behind the fragment reads of k-step 0,
+// interleaved with the MFMAs of k-steps 0 and 1
+template <bool GATHER, int TM, bool EOP, int ORD>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
+  constexpr int TB = 256, KB = 64, TN = 2, BM = 64 * TM, PA = TM, PB = 4, NP = PA + PB;
+  constexpr int BOFF = 32768, SSTR = 65536;
+  // epilogue-operand groups (32 rows x 64 columns = 4 x 16 B per lane each) fetched during the last K tile; the remaining ones are
+  // fetched inside the epilogue one group ahead, into the registers the fragments no longer need
+  constexpr int NPF = !EOP ? 0 : (TM == 4 ? 0 : (TM == 3 ? 1 : 2));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN, g = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + BM - 1) / BM;
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
     gz = l / per_group; l -= gz * per_group;
     m0 = (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
   };
-  unsigned aofs[PA], bofs[4];    // byte offsets of this lane's TM + 4 staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
+  unsigned aofs[PA], bofs[PB];   // byte offsets of this lane's staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
   const char* Abase = (const char*)p.A;      // A operand of the tile being loaded (A2 for the column tiles from a2_n0 on)
   auto set_offsets = [&](int gz, int m0, int n0) {
     Abase = (const char*)((p.A2 && n0 >= p.a2_n0) ? p.A2 : p.A);
@@ -274,30 +307,24 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
       aofs[i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int r = (wave * 4 + i) * 8 + sr;
+    for (int i = 0; i < PB; i++) {
+      const int r = (wave * PB + i) * 8 + sr;
       const int c = (sc ^ ((r >> 1) & 7)) * 8;
       bofs[i] = (unsigned)(((size_t)min(n0 + r, p.N - 1) * p.ldb + c + (size_t)gz * p.gB) * 2);
     }
   };
-  int s_tap = 0, s_kk = 0;        // conv tap / column within the tap of the K tile staged next (GATHER only)
-  auto stage = [&](int s, int kt) {
-    unsigned char* base = smem256 + s * SSTR;
-    const int k0 = kt * KB;
-    unsigned ka = (unsigned)k0 * 2u;
-    const unsigned kb = (unsigned)k0 * 2u;
+  // byte offsets (A, B) of K tile kt inside the operand rows; the conv taps switch the A row every ktap columns
+  auto k_offsets = [&](int kt, unsigned& ka, unsigned& kb) {
+    kb = (unsigned)kt * (KB * 2u);
+    ka = kb;
     if constexpr (GATHER) {
-      if (kt == 0) { s_tap = 0; s_kk = 0; }
-      ka = (unsigned)(s_tap * p.lda + s_kk) * 2u;
-      s_kk += KB;
-      if (s_kk >= p.ktap) { s_kk = 0; s_tap++; }
+      const int k0 = kt * KB, tap = k0 / p.ktap;
+      ka = (unsigned)(tap * p.lda + (k0 - tap * p.ktap)) * 2u;
     }
-#pragma unroll
-    for (int i = 0; i < PA; i++)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Abase + (aofs[i] + ka)), (lds_void_t*)(base + (wave * PA + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i] + kb)), (lds_void_t*)(base + BOFF + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+  auto piece = [&](unsigned char* sbase, unsigned ka, unsigned kb, int i) {      // staging piece i of NP: A pieces first
+    if (i < PA) __builtin_amdgcn_global_load_lds((gbl_void_t*)(Abase + (aofs[i < PA ? i : 0] + ka)), (lds_void_t*)(sbase + (wave * PA + i) * 1024), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i >= PA ? i - PA : 0] + kb)), (lds_void_t*)(sbase + BOFF + (wave * PB + (i - PA)) * 1024), 16, 0, 0);
   };
   int aoff[TM], boff[TN];
   const int swz = (l31 >> 1) & 7;           // identical for every 32-row fragment of the wave
@@ -306,14 +333,19 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
 #pragma unroll
   for (int j = 0; j < TN; j++) boff[j] = BOFF + (wn * 64 + j * 32 + l31) * 128;
 
-  int* const s_next_p = (int*)(smem256 + 2 * SSTR);      // WN == 4 only (16 extra bytes of dynamic LDS): next tile of this workgroup
-  constexpr bool dyn = DYN;            // (host: only with WN == 4 and a registered counter slot)
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
   int gz, m0, n0;
   tile_origin(tile, gz, m0, n0);
   set_offsets(gz, m0, n0);
-  stage(0, 0);
+  {
+    unsigned ka, kb;
+    k_offsets(0, ka, kb);
+#pragma unroll
+    for (int i = 0; i < NP; i++) piece(smem256, ka, kb, i);
+  }
+  // this lane's 8 output columns
+  const int c8 = (lane & 7) * 8;
   int it = 0;
   while (true) {
     f32x16 acc[TM][TN];
@@ -323,47 +355,63 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    int next = tile + gridDim.x;
-    int ngz = 0, nm0 = 0, nn0 = 0;
-    // this lane's 8 output columns and their bias: the static kernels fetch it at the head of the tile (in the epilogue the load sits
-    // right behind the barrier with every wave of the block waiting on it); the dynamic ones have no registers left for that
-    const int c8 = (lane & 7) * 8;
+    const int next = tile + gridDim.x;
+    int ngz = gz, nm0 = m0, nn0 = n0;
     const int n = n0 + wn * 64 + c8;
     const bool ncol = n < p.N;
+    // bias of the lane's columns, fetched at the head of the tile (in the epilogue the load would sit behind the barrier with
+    // every wave of the block waiting on it); consumed here on every path (see the note on pending loads in the epilogue)
     float bv[8];
-    auto fetch_bias = [&]() {
 #pragma unroll
-      for (int e = 0; e < 8; e++) bv[e] = 0.f;
-      if (ncol && p.act != 100) {
-        if (p.bias) {
-          const float* bias = p.bias + (size_t)gz * p.gBias + n;
-          const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
+    for (int e = 0; e < 8; e++) bv[e] = 0.f;
+    if (ncol && p.act != 100) {
+      if (p.bias) {
+        const float* bias = p.bias + (size_t)gz * p.gBias + n;
+        const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
 #pragma unroll
-          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
-        }
-        if (p.bias2) {
-          const f32x4 b0 = *(const f32x4*)(p.bias2 + n), b1 = *(const f32x4*)(p.bias2 + n + 4);
-#pragma unroll
-          for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
-        }
+        for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
       }
+      if (p.bias2) {
+        const f32x4 b0 = *(const f32x4*)(p.bias2 + n), b1 = *(const f32x4*)(p.bias2 + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bv[e] += b0[e]; bv[4 + e] += b1[e]; }
+      }
+    }
+    // a load some path never waits for reaches the K loop as "maybe pending", and hipcc then drains vmcnt(0) before the first
+    // fragment read that re-uses its register: make every path wait here
+    asm volatile("" :: "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]));
+    // epilogue operand: residual, else the pre-activation of the activation gradient
+    const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
+    const bf16_t* esrc = !EOP ? nullptr : (p.residB ? p.residB : p.gradPre + gp);
+    const int eld = !EOP ? 0 : (p.residB ? p.ldrB : p.ldgp);
+    u32x4 eg[EOP ? TM : 1][4];
+    auto fetch_group = [&](int i, int q) {     // one 16-byte piece: rows q * 8 + lane / 8 of 32-row group i
+      const int m = min(m0 + wm * (32 * TM) + i * 32 + q * 8 + (lane >> 3), p.M - 1);     // clamped: loaded, not used
+      const size_t orow = GATHER ? (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off) : (size_t)m;
+      eg[EOP ? i : 0][q] = *(const u32x4*)(esrc + orow * eld + (ncol ? n : 0));
     };
-    if constexpr (!DYN) fetch_bias();
-    for (int kt = 0; kt < nk; kt++, it++) {
+
+    // ---- one K tile: barrier, fragment reads of k-step 0, then the MFMAs of every k-step cover the reads of the next one, the
+    // staging pieces of the next K tile (k-steps 0, 1) and -- LAST only -- the epilogue-operand block (k-steps 2, 3) ----
+    auto ktile = [&](int kt, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
       const int cur = it & 1;
       __syncthreads();                       // vmcnt(0) + barrier: K tile `it` landed, the other stage is free
-      if constexpr (dyn) {                   // tiles t with t % 8 == XCD belong to this workgroup's XCD (see tile_origin)
-        if (kt == nk - 2 && tid == 0) *s_next_p = ((int)(gridDim.x >> 3) + atomicAdd(p.tile_counter + (blockIdx.x & 7), 1)) * 8 + (int)(blockIdx.x & 7);
-        if (kt == nk - 1) next = *s_next_p;
-      }
-      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-      else if (next < ntiles) { tile_origin(next, ngz, nm0, nn0); set_offsets(ngz, nm0, nn0); stage(cur ^ 1, 0); }
+      unsigned ka, kb;
+      k_offsets(LAST ? 0 : kt + 1, ka, kb);
+      unsigned char* sbase = smem256 + (cur ^ 1) * SSTR;
       const unsigned char* base = smem256 + cur * SSTR;
       s16x8 fa[2][TM], fb[2][TN];
+      if (ORD == 0) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
+      }
 #pragma unroll
       for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
 #pragma unroll
       for (int j = 0; j < TN; j++) fb[0][j] = *(const s16x8*)(base + boff[j] + ((g ^ swz) << 4));
+      constexpr int G0 = ORD == 0 ? 0 : (NP + 1) / 2, G1 = ORD == 0 ? 0 : NP - (NP + 1) / 2;          // pieces issued under k-step 0 / 1
+      constexpr int E2 = (NPF * 4 + 1) / 2, E3 = NPF * 4 - E2;  // epilogue-operand loads under k-step 2 / 3
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         if (ks < 3) {
@@ -372,23 +420,41 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
 #pragma unroll
           for (int j = 0; j < TN; j++) fb[(ks + 1) & 1][j] = *(const s16x8*)(base + boff[j] + (((2 * ks + 2 + g) ^ swz) << 4));
         }
+        if (ORD == 1 && ks == 0) {
+#pragma unroll
+          for (int i = 0; i < G0; i++) piece(sbase, ka, kb, i);
+        }
+        if (ORD == 1 && ks == 1) {
+#pragma unroll
+          for (int i = G0; i < NP; i++) piece(sbase, ka, kb, i);
+        }
+        if constexpr (LAST && NPF > 0) {
+          if (ks >= 2) {
+#pragma unroll
+            for (int e = (ks == 2 ? 0 : E2); e < (ks == 2 ? E2 : NPF * 4); e++) fetch_group(e >> 2, e & 3);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
       }
-      // pin the software pipeline the source expresses (hipcc otherwise sinks every fragment read next to its MFMAs):
-      // 6 reads up front, then each k-step's 8 MFMAs cover the 6 reads of the next k-step
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-      for (int ks = 0; ks < 3; ks++) {
-#pragma unroll
-        for (int n = 0; n < (TM + TN < TM * TN ? TM + TN : TM * TN); n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        if (TM * TN > TM + TN) __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
-        if (TM * TN < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN - TM * TN, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-    }
+      // pin the software pipeline the source expresses (hipcc otherwise sinks every fragment read next to its MFMAs and moves the
+      // pieces to the head): R reads up front; per k-step (MFMA, read) pairs, then the VMEM issues two at a time between MFMAs
+      constexpr int Mf = TM * TN, R = TM + TN;
+      if (ORD == 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+      sgb_kstep<Mf, R, true, G0>();
+      sgb_kstep<Mf, R, true, G1>();
+      sgb_kstep<Mf, R, true, LAST ? E2 : 0>();
+      sgb_kstep<Mf, R, false, LAST ? E3 : 0>();
+      it++;
+    };
+    for (int kt = 0; kt + 1 < nk; kt++) ktile(kt, std::false_type{});
+    // last K tile of this output tile: the pieces now belong to K tile 0 of the next tile (or, without one, re-load this tile's)
+    if (next < ntiles) tile_origin(next, ngz, nm0, nn0);
+    set_offsets(ngz, nm0, nn0);
+    ktile(nk - 1, std::true_type{});
     // ---------------- epilogue of `tile`, out of the stage consumed last ----------------
     if (p.act == 100) {   // measurement aid: main loop only
       float t = 0.f;
@@ -402,43 +468,31 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
     } else {
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
-      const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
-      if constexpr (DYN) fetch_bias();
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
-      // The bf16 operand stream of the epilogue (residual, else the pre-activation of the activation gradient) is fetched one
-      // 32-row group AHEAD into registers the main loop no longer needs: in lockstep behind the barrier every wave of the block
-      // would otherwise expose a global-load latency per 8-row step (measured 0.5 ms of a 9.9 ms step).
-      // (256-row tiles have no registers left for it -- an attempt spilled, and the spilled build returned garbage -- so TM = 4
-      // keeps the direct loads)
-      constexpr bool EPF = TM < 4 && WN == 4 && !(GATHER && DYN);   // (the dynamic gather variant is at the register cap)
-      const bf16_t* esrc = !EPF ? nullptr : (p.residB ? p.residB : (p.actgrad ? p.gradPre + gp : nullptr));
-      const int eld = p.residB ? p.ldrB : p.ldgp;
-      u32x4 epf[2][4];
+      constexpr bool GROUPS = EOP && TM < 4;      // (256-row tiles have no registers for a group in flight: direct loads at use)
+      if (GROUPS && NPF < TM) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) { epf[0][q] = (u32x4){0, 0, 0, 0}; epf[1][q] = (u32x4){0, 0, 0, 0}; }
-      auto fetch_ops = [&](int i, u32x4 (&dst)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int m = min(m0 + wm * (32 * TM) + i * 32 + q * 8 + (lane >> 3), p.M - 1);     // clamped: loaded, not used
-          const size_t orow = GATHER ? (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off) : (size_t)m;
-          dst[q] = *(const u32x4*)(esrc + orow * eld + (ncol ? n : 0));
-        }
-      };
-      if (EPF && esrc) fetch_ops(0, epf[0]);
+        for (int q = 0; q < 4; q++) fetch_group(NPF, q);
+      }
 #pragma unroll
       for (int i = 0; i < TM; i++) {
-        if (EPF && esrc && i + 1 < TM) fetch_ops(i + 1, epf[(i + 1) & 1]);
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
           for (int r = 0; r < 16; r++)
             wbuf[((r & 3) + 8 * (r >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
-        // the q loop stays rolled (12 unrolled copies of this body cost > 256 VGPRs); the prefetched operands rotate through e0
-        u32x4 e0 = epf[i & 1][0], e1 = epf[i & 1][1], e2 = epf[i & 1][2], e3 = epf[i & 1][3];
+        if (GROUPS && i + 1 < TM && i + 1 > NPF) {      // one group ahead
+#pragma unroll
+          for (int q = 0; q < 4; q++) fetch_group(i + 1, q);
+        }
+        // the q loop stays ROLLED: TM x 4 unrolled copies of this body are ~100 KB of code per kernel -- more than the instruction
+        // cache, and the epilogue then runs at the cache-miss rate (measured: the whole gain of the new main loop was lost again);
+        // the prefetched operand pieces rotate through e0
+        u32x4 e0 = eg[EOP ? i : 0][0], e1 = eg[EOP ? i : 0][1], e2 = eg[EOP ? i : 0][2], e3 = eg[EOP ? i : 0][3];
 #pragma unroll 1
         for (int q = 0; q < 4; q++) {
-          u32x4 ecur = e0;
-          if constexpr (EPF) { e0 = e1; e1 = e2; e2 = e3; }
+          const u32x4 ecur = e0;
+          e0 = e1; e1 = e2; e2 = e3;
           const int row = q * 8 + (lane >> 3);
           const int m = m0 + wm * (32 * TM) + i * 32 + row;
           const f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
@@ -458,11 +512,13 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = gelu_erf(v[e]);
           }
-          if (p.actgrad) {
-            const u32x4 t = (!EPF || p.residB) ? *(const u32x4*)(p.gradPre + gp + orow * p.ldgp + n) : ecur;
+          u32x4 eop = {0, 0, 0, 0};
+          if constexpr (GROUPS) eop = ecur;
+          else if constexpr (EOP) eop = *(const u32x4*)(esrc + orow * eld + n);
+          if (EOP && p.actgrad && !p.residB) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-              const float q0 = __uint_as_float(t[e] << 16), q1 = __uint_as_float(t[e] & 0xffff0000u);
+              const float q0 = __uint_as_float(eop[e] << 16), q1 = __uint_as_float(eop[e] & 0xffff0000u);
               if (p.actgrad == 1) { v[2 * e] = q0 > 0.f ? v[2 * e] : 0.f; v[2 * e + 1] = q1 > 0.f ? v[2 * e + 1] : 0.f; }
               else { v[2 * e] *= gelu_erf_grad(q0); v[2 * e + 1] *= gelu_erf_grad(q1); }
             }
@@ -478,10 +534,9 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
 #pragma unroll
             for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
           }
-          if (p.residB) {
-            const u32x4 t = EPF ? ecur : *(const u32x4*)(p.residB + orow * p.ldrB + n);
+          if (EOP && p.residB) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
+            for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(eop[e] << 16); v[2 * e + 1] += __uint_as_float(eop[e] & 0xffff0000u); }
           }
           if (p.outF) {
             float* op = p.outF + go + orow * p.ldoF + n;
@@ -515,6 +570,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt256_kernel(c
     if (next >= ntiles) break;
     tile = next; gz = ngz; m0 = nm0; n0 = nn0;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -636,6 +692,24 @@ struct TNPlan {              // per-launch plan of the grouped 256-tile weight-g
   int count, splits, steps_per, total_tiles;
   float* scratch;
 };
+typedef int __attribute__((ext_vector_type(4))) i32x4;
+// raw buffer descriptor (base, stride 0, num_records bytes, the flags __builtin_amdgcn_make_buffer_rsrc callers here use), wave-uniform
+__device__ __forceinline__ i32x4 tn_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+// 64 lanes x 16 B from buffer offset voff (out-of-range lanes read zeros) to LDS bytes [lds_dst, lds_dst + 1024), lane-linear.
+// M0 is the compiler's: saved and restored inside the statement that uses it.
+__device__ __forceinline__ void tn_dma16(i32x4 rsrc, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -658,8 +732,12 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
   const int st0 = split * steps_per, st1 = min(steps_total, st0 + steps_per);
 
   const int q_tap = p.ktap > 0 ? k0 / p.ktap : 0, kq0 = k0 - q_tap * (p.ktap > 0 ? p.ktap : 0);   // conv tap of this k tile
-  __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, bytes_p, 0x00020000);
-  __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, bytes_q, 0x00020000);
+  // The LDS-DMA is issued from inline asm: hipcc answers every ds_read_b64_tr_b16 INTRINSIC that follows an LDS-DMA it knows of with
+  // s_waitcnt vmcnt(0) (it cannot prove the transposing read does not alias the DMA's LDS target; plain ds_read_b128 loads do not get
+  // this), which serialised round 1's kernel completely -- stage, wait for it, compute.  A DMA the compiler does not see costs no wait;
+  // its completion is awaited by the explicit vmcnt(0) in front of every barrier below.
+  const i32x4 rp = tn_rsrc(p.P, bytes_p), rq = tn_rsrc(p.Q, bytes_q);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem256;      // LDS byte address of the dynamic segment (the only LDS object of the kernel)
   unsigned vp[4], vq[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -673,8 +751,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
     unsigned char* base = smem256 + s * 65536 + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void_t*)(base + i * 1024), 16, vp[i], 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)(base + 32768 + i * 1024), 16, vq[i], 0, 0, 0);
+      tn_dma16(rp, vp[i], lds0 + (unsigned)(s * 65536 + wave * 4096 + i * 1024));
+      tn_dma16(rq, vq[i], lds0 + (unsigned)(s * 65536 + wave * 4096 + 32768 + i * 1024));
       vp[i] += dp; vq[i] += dq;
     }
   };
@@ -702,13 +780,18 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
   const bool do_bias = p.dbias && tile_k == 0 && wn == 0;
 
   if (st0 < st1) stage(0);
+  // K-step body: straight-line (the staging pieces of the next step are issued unconditionally -- past the last step they fetch rows
+  // beyond this split into the idle stage, or zeros through the buffer bounds check -- so that the scheduling pins below see ONE basic
+  // block): the 12 transposing reads of k-step 0 go first, the 8 buffer_load ... lds pieces follow between the MFMAs of k-steps 0 and 1
+  // instead of bursting at the head of the step (same measurement as for the NT kernel, tools/gemm_pp_lab.hip)
   auto main_loop = [&](auto with_bias) {
   constexpr bool BIAS = decltype(with_bias)::value;
   for (int st = st0; st < st1; st++) {
     const int cur = (st - st0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the stage about to be read have landed
     __syncthreads();
-    if (st + 1 < st1) stage(cur ^ 1);
     const unsigned char* base = smem256 + cur * 65536;
+    const unsigned sb = lds0 + (unsigned)((cur ^ 1) * 65536 + wave * 4096);
     s16x4 ta[2][4][2], tb[2][2][2];       // [buffer][tile][row half]: 4 m-rows each, two halves make one MFMA operand
 #pragma unroll
     for (int i = 0; i < 4; i++) { ta[0][i][0] = lds_tr16((const bf16_t*)(base + aoff[i])); ta[0][i][1] = lds_tr16((const bf16_t*)(base + aoff[i] + 2048)); }
@@ -726,6 +809,14 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
         for (int j = 0; j < 2; j++) {
           tb[(ks + 1) & 1][j][0] = lds_tr16((const bf16_t*)(base + boff[j] + (ks + 1) * 8192));
           tb[(ks + 1) & 1][j][1] = lds_tr16((const bf16_t*)(base + boff[j] + (ks + 1) * 8192 + 2048));
+        }
+      }
+      if (ks < 2) {
+#pragma unroll
+        for (int i = 2 * ks; i < 2 * ks + 2; i++) {
+          tn_dma16(rp, vp[i], sb + i * 1024);
+          tn_dma16(rq, vq[i], sb + 32768 + i * 1024);
+          vp[i] += dp; vq[i] += dq;
         }
       }
       s16x8 a[4], b[2];
@@ -750,7 +841,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
           for (int e = 0; e < 8; e++) bsum[i] += bf2f((bf16_t)a[i][e]);
       }
     }
-    {   // pin the fragment prefetch pipeline (12 transposing reads per k-step under the previous k-step's 8 MFMAs)
+    {   // pin the fragment pipeline: 12 transposing reads up front; per k-step 6 x (MFMA, 2 reads) + 2 MFMAs (the asm DMA statements keep
+        // their program order among the reads: 4 after the reads issued under k-step 0, 4 after those under k-step 1)
       __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
       for (int ks = 0; ks < 3; ks++) {
@@ -764,6 +856,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
   };
   if (do_bias) main_loop(std::true_type{}); else main_loop(std::false_type{});
   // ---- partial tile -> fp32 slab [256 n][256 k] of this (split, tile) unit, row-contiguous 16-byte stores ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces issued past the last step must not land in the slabs below
   __syncthreads();
   float* slab = plan.scratch + ((size_t)split * tiles + tile_g) * 65536;
   float* wbuf = (float*)smem256 + wave * 2048;        // [32][64] fp32, wave-private
@@ -864,33 +957,47 @@ static bool nt256_ok(const GemmArgs& a) {
   return amax * 2 < (1LL << 32) && bmax * 2 < (1LL << 32);
 }
 static int g_num_cu = 0;
-// relative time per output element of the persistent NT structures (TM, WN); two-per-CU tiles share the CU, hence the x2 in the cost
-#ifndef UVTG_NT_F44
-#define UVTG_NT_F44 1.00
-#define UVTG_NT_F34 1.09
-#define UVTG_NT_F24 1.22
-#define UVTG_NT_F32 1.04
-#define UVTG_NT_F22 1.13
+static int g_cu_cap = 0;       // experiment knob: the persistent GEMM grids use at most this many CUs (0 = all)
+extern "C" int uvtg_debug_gemm_cus(int n) { g_cu_cap = n > 0 ? n : 0; return 0; }
+static int eff_cus() { return (g_cu_cap > 0 && g_cu_cap < g_num_cu) ? g_cu_cap : g_num_cu; }
+// relative time per output element of the persistent NT structure at the three tile heights
+#ifndef UVTG_NT_F4
+#define UVTG_NT_F4 1.00
+#define UVTG_NT_F3 1.07
+#define UVTG_NT_F2 1.20
 #endif
-template <int TM, int WN, bool DYN> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, hipStream_t s) {
-  constexpr int smem = (WN == 4) ? 131072 + 16 : 2 * (64 * TM + 64 * WN) * 128;      // + the dynamic tile hand-out word
+template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, bool eop, hipStream_t s) {
+  constexpr int smem = 131072;
   static bool attr = false;
   if (!attr) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, WN, DYN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, WN, DYN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, false, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, true, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, false, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, true, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
     attr = true;
   }
-  if (gather) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, WN, DYN>), dim3(grid), dim3(128 * WN), smem, s, b);
-  else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, WN, DYN>), dim3(grid), dim3(128 * WN), smem, s, b);
+  if (gather) {
+    if (eop) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, true, ORD>), dim3(grid), dim3(512), smem, s, b);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, false, ORD>), dim3(grid), dim3(512), smem, s, b);
+  } else {
+    if (eop) hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, true, ORD>), dim3(grid), dim3(512), smem, s, b);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, false, ORD>), dim3(grid), dim3(512), smem, s, b);
+  }
   return 0;
 }
-static int* g_ctr_base = nullptr; static int g_ctr_slots = 0, g_ctr_next = 0;
-static int g_dynamic_tiles = 0;      // 0: static tile stride (default), 1: dynamic hand-out where the engine registers counters
-extern "C" int uvtg_set_dynamic_tiles(int on) { g_dynamic_tiles = on ? 1 : 0; return 0; }
-int uvtg_dynamic_tiles_enabled() { return g_dynamic_tiles; }
-void uvtg_nt_counter_pool(int* base, int slots) { g_ctr_base = g_dynamic_tiles ? base : nullptr; g_ctr_slots = slots; g_ctr_next = 0; }
-static int g_force_wn = 0;     // 0: automatic, 2 / 4: force the 128-wide two-per-CU or the 256-wide one-per-CU persistent kernel
-extern "C" int uvtg_debug_force_nt_wn(int wn) { if (wn != 0 && wn != 2 && wn != 4) return -21; g_force_wn = wn; return 0; }
+// Staging order per tile height (TM = 2, 3, 4).  Measured on the whole training step (tools/ord_ab.sh, same box, two rounds): the
+// interleaved order wins 5-10 % on the bare main loop at every height (tools/nt_ab.py) but only the 256-row tiles keep a gain once the
+// real epilogues run (conv / K = 3072 launches -7 %); 192-row tiles LOSE 3 % (their K tile has 24 MFMAs to cover the same pieces), so
+// they stay on the round-1 order.  Experiment override: UVTG_NT_ORD="<o2><o3><o4>".
+static int nt_order(int tm) {
+  static int ord[3] = {-1, -1, -1};
+  if (ord[0] < 0) {
+    static const int dflt[3] = {0, 0, 1};
+    const char* e = getenv("UVTG_NT_ORD");
+    for (int i = 0; i < 3; i++) ord[i] = (e && strlen(e) == 3 && (e[i] == '0' || e[i] == '1')) ? e[i] - '0' : dflt[i];
+  }
+  return ord[tm - 2];
+}
 static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   if (!g_num_cu) {
     int dev = 0; hipDeviceProp_t pr;
@@ -900,39 +1007,29 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
-  // Candidates: 256-wide tiles of 256 / 192 / 128 rows, one workgroup per CU, and 128-wide tiles of 192 / 128 rows, two per CU.
-  // Cost = tiles per CU x rows x columns of a tile x a per-structure factor (measured relative time per output element).
-  struct Cand { int tm, wn; double f; };
-  static const Cand cands[] = {{4, 4, UVTG_NT_F44}, {3, 4, UVTG_NT_F34}, {2, 4, UVTG_NT_F24}, {3, 2, UVTG_NT_F32}, {2, 2, UVTG_NT_F22}};
-  int best_tm = 4, best_wn = 4; double best = 1e30;
+  // Candidates: 256-wide tiles of 256 / 192 / 128 rows, one workgroup per CU.
+  // Cost = tiles per CU x rows of a tile x a per-height factor (measured relative time per output element).
+  struct Cand { int tm; double f; };
+  static const Cand cands[] = {{4, UVTG_NT_F4}, {3, UVTG_NT_F3}, {2, UVTG_NT_F2}};
+  int best_tm = 0; double best = 1e30;
   for (const Cand& c : cands) {
-    // the two-per-CU structure wins 4-10 % at the kernel-level entry point (tools/nt_variants.py) but nothing on the whole step
-    // with the real epilogues (tools/step_variants.py: 10.18 vs 10.19 ms), so the automatic choice stays with the 256-wide tiles
-    if (c.wn != (g_force_wn ? g_force_wn : 4)) continue;
     if (g_force_bm && c.tm * 64 != g_force_bm) continue;
-    const long long tiles = (long long)cdiv(b.M, 64 * c.tm) * cdiv(b.N, 64 * c.wn) * b.groups;
-    // a CU works through ceil(tiles / #CU) tiles; with two resident workgroups an odd one out has the CU to itself, i.e. the
-    // CU's time is (tiles on it) / 2 rounds of two concurrent tiles -- half-round granularity (fits the measured table in
-    // tools/nt_variants.py within ~4 %)
-    const double rounds = (double)((tiles + g_num_cu - 1) / g_num_cu);
-    const double cost = rounds * (64.0 * c.tm) * (64.0 * c.wn) * c.f;
-    if (cost < best) { best = cost; best_tm = c.tm; best_wn = c.wn; }
+    const long long tiles = (long long)cdiv(b.M, 64 * c.tm) * cdiv(b.N, 256) * b.groups;
+    const double rounds = (double)((tiles + eff_cus() - 1) / eff_cus());
+    const double cost = rounds * (64.0 * c.tm) * c.f;
+    if (cost < best) { best = cost; best_tm = c.tm; }
   }
-  if (best >= 1e30) return -21;          // forced combination that does not exist (256 rows x 128 columns)
-  const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 64 * best_wn) * b.groups;
-  const long long slots = (long long)g_num_cu * (best_wn == 2 ? 2 : 1);
-  const int grid = (int)(tiles < slots ? tiles : slots);
+  if (!best_tm) return -21;
+  const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
+  const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1;
-  b.tile_counter = nullptr;
-  if (g_ctr_base && g_ctr_next < g_ctr_slots && best_wn == 4 && tiles > slots && grid % 8 == 0 && b.K >= 128)
-    b.tile_counter = g_ctr_base + 8 * (g_ctr_next++);
+  const bool eop = b.residB || (b.actgrad && b.gradPre);
   uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
   int rc;
-  if (best_wn == 4 && b.tile_counter)
-    rc = best_tm == 4 ? launch_nt256_tm<4, 4, true>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3, 4, true>(b, grid, gather, s) : launch_nt256_tm<2, 4, true>(b, grid, gather, s));
-  else if (best_wn == 4)
-    rc = best_tm == 4 ? launch_nt256_tm<4, 4, false>(b, grid, gather, s) : (best_tm == 3 ? launch_nt256_tm<3, 4, false>(b, grid, gather, s) : launch_nt256_tm<2, 4, false>(b, grid, gather, s));
-  else rc = best_tm == 3 ? launch_nt256_tm<3, 2, false>(b, grid, gather, s) : launch_nt256_tm<2, 2, false>(b, grid, gather, s);
+  if (nt_order(best_tm) == 0)
+    rc = best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, s));
+  else
+    rc = best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, s));
   uvtg_prof_end_launch(3, s);
   if (rc) return rc;
   UVTG_CHECK_LAUNCH();
@@ -962,7 +1059,8 @@ int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s) {
 static int g_tn_cus = 256;
 static void tn256_splits(int M, int total_tiles, int& splits, int& steps_per) {
   const int steps_total = cdiv(M, 64);
-  int want = g_tn_cus / total_tiles;                   // tiles x splits ~ one unit per CU
+  const int cus = (g_cu_cap > 0 && g_cu_cap < g_tn_cus) ? g_cu_cap : g_tn_cus;
+  int want = cus / total_tiles;                        // tiles x splits ~ one unit per CU
   if (want < 1) want = 1;
   if (want > steps_total) want = steps_total;
   steps_per = cdiv(steps_total, want);

@@ -15,7 +15,7 @@ __device__ __forceinline__ double round4(float x) { return rint((double)x * 1e4)
 // eval_epoch_post_processing): torch.tensor(rows) -> fp32, torch.round(w / clip) * clip (half-to-even), score re-rounded to 4 decimals.
 // saliency (optional): pred_saliency_scores of main/inference_mr.py:124-136 = fp16(saliency) [+ prob when eval_mode == 'add'], fp32 out.
 __global__ __launch_bounds__(64) void decode_rank_nms_kernel(const float* pred_logits, const float* pred_spans,
-    const float* timestamp, const float* ts_mask, const float* durations, int B, int Lv, float nms_thd,
+    const float* timestamp, const float* ts_mask, const float* durations, int B, int Lv, double nms_thd,
     int max_before, int max_after, float clip_length, const float* saliency, int sal_add, float* saliency_out,
     double* windows_out, int* order, int* keep, int* n_keep) {
   extern __shared__ unsigned char smem[];
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void decode_rank_nms_kernel(const float* pred_l
         const double inter = fmax(0.0, fmin(he, ed[j]) - fmax(hs, st[j]));
         const double hull = fmax(he, ed[j]) - fmin(hs, st[j]);
         const double iou = hull == 0.0 ? 0.0 : inter / hull;
-        if (iou > (double)nms_thd) { alive[j] = 0; removed++; }
+        if (iou > nms_thd) { alive[j] = 0; removed++; }      // nms_thd is the reference's Python float (a double): 7/10 > 0.7 is False
       }
     }
     removed = (int)wave_sum((float)removed);
@@ -182,7 +182,7 @@ __global__ void lsap_kernel(const float* cost, int B, int Q, const int* tgt_off,
 
 extern "C" int uvtg_postprocess_mr(const float* pred_logits, const float* pred_spans, const float* saliency, const float* timestamp,
                                    const float* timestamp_mask, const float* durations, int B, int Lv,
-                                   float clip_length, int eval_mode_add, float nms_thd, int max_before, int max_after,
+                                   float clip_length, int eval_mode_add, double nms_thd, int max_before, int max_after,
                                    double* windows_out, int* order, int* keep, int* n_keep, float* saliency_out,
                                    uvtg_stream_t stream) {
   if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !durations || !windows_out || !order || !keep || !n_keep) return -20;
@@ -197,7 +197,7 @@ extern "C" int uvtg_postprocess_mr(const float* pred_logits, const float* pred_s
 }
 extern "C" int uvtg_decode_rank_nms(const float* pred_logits, const float* pred_spans, const float* timestamp,
                                     const float* timestamp_mask, const float* durations, int B, int Lv,
-                                    float nms_thd, int max_before, int max_after,
+                                    double nms_thd, int max_before, int max_after,
                                     double* windows_out, int* order, int* keep, int* n_keep, uvtg_stream_t stream) {
   return uvtg_postprocess_mr(pred_logits, pred_spans, nullptr, timestamp, timestamp_mask, durations, B, Lv, 0.f, 0, nms_thd, max_before,
                              max_after, windows_out, order, keep, n_keep, nullptr, stream);

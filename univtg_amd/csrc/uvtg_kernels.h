@@ -11,10 +11,6 @@ struct GemmArgs {
   // optional second A operand (same layout) for the output columns n >= a2_n0 (a multiple of 256): one launch computes
   // [A | A2-columns] -- the q,k projections read x + pos and the v projection reads x (transformer_encoder_droppath.py:116-117)
   const void* A2; int a2_n0;
-  // persistent 256-wide kernel only: 8 zeroed ints (one per XCD).  Set: after its first tile a workgroup takes its next tiles from
-  // its XCD's counter instead of the static stride, so a launch that gets fewer than all CUs (RCCL kernels resident) still ends
-  // together.  Filled in by launch_gemm_nt_bf16 from the pool the engine registers (uvtg_nt_counter_pool); null = static.
-  int* tile_counter;
   const void* B;      // bf16 / fp32 [N, ldb]
   int M, N, K, lda, ldb;
   // A-row gather: arow(m) = (m / a_seg) * a_seg_stride + (m % a_seg) + a_off   (a_seg == 0: identity)
@@ -42,9 +38,6 @@ struct GemmArgs {
   bf16_t* outU; float* outUF; int ldoU;        // (value + pos) in bf16 / fp32
 };
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s);
-// pool of zeroed per-launch tile counters (8 ints per slot) for the launches that follow; (nullptr, 0) ends the scope
-void uvtg_nt_counter_pool(int* base, int slots);
-int uvtg_dynamic_tiles_enabled();
 int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s);
 
 // C[N,K] (+)= P[M,N]^T * Q[M,K]  (reduction over rows; fp32 atomic accumulation, split over M)

@@ -64,9 +64,6 @@ class TrainStep:
         # backward kernels keep running (the reference gets the same effect from DDP's bucketed autograd hooks).
         # overlap_comm="force" runs the bucketed side-stream exchange even at world size 1 (single-GPU test of the plumbing)
         self.overlap = bool(overlap_comm) and (self.world > 1 or overlap_comm == "force") and dev.type == "cuda"
-        # (uvtg_set_dynamic_tiles(1) -- dynamic tile hand-out in the persistent GEMMs -- is NOT switched on here: with 16-32 CUs held
-        # by another stream for most of the step, tools/hog_experiment.py measures the static stride 3-5 % FASTER; the partially
-        # filled last round already gives late workgroups room)
         self._events = self._ev_arr = self._comm_stream = None
         wd = criterion.weight_dict
         self.go = torch.tensor([wd.get(k, 0.0) for k in LOSS_KEYS], dtype=torch.float32, device=dev)
