@@ -10,10 +10,12 @@ saliency -> dense criterion -> backward -> (RCCL gradient all-reduce) -> global-
 accumulation, the reference's training dropouts (input 0.5 / attention 0 / DropPath 0.1, scripts/pretrain.sh:33-35).
 Per-GPU batch is fixed (weak scaling).  Rank 0 prints ONE JSON line.
 
-`value` is the reference-equivalent execution: every clip row of the padded batch is computed (under input dropout each padded
-clip has its own mask); only padded TEXT tokens -- masked keys whose outputs nobody reads -- are left out of the encoder stream
-(exact, tests/test_gpu_parity_full.py::test_bench_path_trainstep_dropout_replayed_through_oracle).  The fully padded execution is
-timed next to it (`padded_execution_ms_per_step`).
+`value` is the native training step, whose losses and parameter gradients are exactly the reference's for the same dropout masks
+(tests/test_gpu_parity_full.py::test_bench_path_trainstep_dropout_replayed_through_oracle): the encoder runs on the valid clips, the
+three padded clips per sample that the conv heads can see from a valid position (each with its own dropout mask) and the valid text
+tokens -- a padded clip is never an attention key and every loss masks padded positions, so nothing else can reach a loss.  Timed next
+to it: the stream that keeps EVERY clip row (`all_clip_rows_ms_per_step`: outputs at padded positions equal the reference's too) and
+the fully padded execution (`padded_execution_ms_per_step`).
 """
 from __future__ import annotations
 
@@ -224,18 +226,22 @@ def main():
     losses = step.losses[:5].tolist()
 
     # ---- the same batches through the padded execution (every padded position computed, as the reference does) ----
-    padded_ms = None
+    padded_ms = allrows_ms = None
     if rank == 0 and world == 1 and not args.no_padded_compare and packed:
-        step_p = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=False)
-        for i in range(3):
-            step_p.step(*batches[i % 2])
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for i in range(10):
-            step_p.step(*batches[i % 2])
-        torch.cuda.synchronize()
-        padded_ms = (time.perf_counter() - tp) / 10 * 1e3
-        del step_p
+        for kind in ("padded", "allrows"):
+            step_p = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=False if kind == "padded" else "auto", loss_only=False)
+            for i in range(3):
+                step_p.step(*batches[i % 2])
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for i in range(10):
+                step_p.step(*batches[i % 2])
+            torch.cuda.synchronize()
+            if kind == "padded":
+                padded_ms = (time.perf_counter() - tp) / 10 * 1e3
+            else:
+                allrows_ms = (time.perf_counter() - tp) / 10 * 1e3
+            del step_p
 
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch, on the launch stream ----
     lib = _lib.load()
@@ -299,13 +305,21 @@ def main():
         valid_clips = sum(sum(a) for a, _ in lens) / len(lens)
         rows_full = sum(sum(a) + sum(b) + sum(1 for x in a if x < Lv) for a, b in lens) / (len(lens) * B * S)
         rows_text = sum(B * Lv + sum(b) for a, b in lens) / (len(lens) * B * S)
+        rows_halo = sum(sum(min(Lv, x + 3) for x in a) + sum(b) for a, b in lens) / (len(lens) * B * S)
+        # FLOPs the encoder actually executes on the packed stream (rows of every sample: kept clips + valid text)
+        if packed:
+            per = [[min(Lv, x + 3) + y for x, y in zip(a, b)] for a, b in lens]
+            exe_flops = sum(3 * E * sum(r * (8 * d * d + 4 * d * F_) + 4 * r * r * d for r in rows) for rows in per) / len(per)
+        else:
+            exe_flops = enc_flops
         out = dict(metric="clips/sec (L=75,d=1024) fwd+bwd" if args.config == 2 else f"clips/sec fwd+bwd (BASELINE config {args.config})",
                    value=round(clips / elapsed, 1), unit="clips/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
                    config=dict(workload=f"{wl['what']}: L_v={Lv} L_t={Lt} D_v=2818 D_t=512 d=1024 F=1024 H=8 E=4, full train step "
-                                        f"(fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, ragged valid lengths: {wl['lens']}; every clip row "
-                                        "computed (padded clips included), padded text tokens left out of the encoder stream (exact)"
+                                        f"(fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, ragged valid lengths: {wl['lens']}; encoder rows = valid "
+                                        "clips + the 3 padded clips per sample inside the conv heads' receptive field + valid text tokens (losses and "
+                                        "all gradients exactly the padded execution's)"
                                         if packed else f"{wl['what']}: padded execution",
                                baseline_config=args.config, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
                    world_size=world, comm_backend=(backend if world > 1 else None), comm_world_size=comm_size,
@@ -315,9 +329,13 @@ def main():
                    t_encoder_ms=round(t_enc * 1e3, 3), sections=sect,
                    roofline_encoder=dict(achieved=round(enc_flops / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s",
                                          frac=round(enc_flops / t_enc / 2.5e15, 4),
-                                         note="SURVEY 8d: 3*E*B*(8Sd^2+4SdF+4S^2d) (padded positions count, as the reference computes them) / "
-                                              "(encoder fwd + bwd section time, HIP events on the launch stream) / 2.5 PFLOP/s"),
-                   encoder_rows_fraction=round(rows_text if packed else 1.0, 4), full_packed_rows_fraction=round(rows_full, 4),
+                                         executed_tflops=round(exe_flops / t_enc / 1e12, 1), executed_frac=round(exe_flops / t_enc / 2.5e15, 4),
+                                         note="achieved / frac: SURVEY 8d's algorithmic FLOPs 3*E*B*(8Sd^2+4SdF+4S^2d) (padded positions count, as the "
+                                              "reference computes them) / (encoder fwd + bwd section time, HIP events on the launch stream) / 2.5 PFLOP/s; "
+                                              "executed_*: the FLOPs of the rows the packed stream really runs, same time"),
+                   encoder_rows_fraction=round(rows_halo if packed else 1.0, 4), all_clip_rows_fraction=round(rows_text, 4),
+                   eval_packed_rows_fraction=round(rows_full, 4),
+                   all_clip_rows_ms_per_step=None if allrows_ms is None else round(allrows_ms, 3),
                    padded_execution_ms_per_step=None if padded_ms is None else round(padded_ms, 3),
                    numerics="train-mode calls run the input projections on plain bf16 operands (saliency_scores within 3e-2 of fp32); the "
                             "1e-4 saliency clause holds for inference calls (split-bf16 projections)",

@@ -39,6 +39,8 @@ typedef struct uvtg_dims {
                                 saliency logits within 1e-4 of the fp32 reference)                 */
   float p_in, p_attn, p_path;/* input_dropout, dropout (attention), droppath                       */
   unsigned long long seed;   /* Philox seed of this step (stochastic ops are counter-based)        */
+  int loss_only;             /* 1: the caller consumes only what the dense criterion consumes (a native training step): outputs
+                                at PADDED clip positions may differ from the reference's -- see lens_host below               */
 } uvtg_dims;
 
 /* ---- parameter table -------------------------------------------------------------------------
@@ -81,7 +83,12 @@ int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* params, void* 
  *            - eval, or training with p_in == 0 and p_attn == 0: valid clips + ONE representative padded clip per sample + valid text
  *              tokens (all padded clips of a sample are then identical rows; ~25 % fewer rows on ragged batches);
  *            - training with input or attention dropout: EVERY clip row (each padded clip draws its own mask in the reference,
- *              model/univtg.py:392-404) + the valid text tokens (padded text tokens are masked keys whose outputs nobody reads).
+ *              model/univtg.py:392-404) + the valid text tokens (padded text tokens are masked keys whose outputs nobody reads);
+ *            - the same with dims.loss_only (and p_attn == 0): valid clips + the FIRST THREE padded clips of every sample + valid
+ *              text.  A padded clip is never a key, so it reaches a valid position only through the 3-layer k = 3 conv heads
+ *              (receptive field +-3); every loss masks the padded positions (model/univtg.py:195-282).  Losses and ALL parameter
+ *              gradients are therefore exactly the reference's; pred_* at padded positions beyond the halo come out as the heads'
+ *              response to zero rows (finite, meaningless -- nothing reads them in training).
  *          The choice is a function of (dims, lens_host != NULL) only, so uvtg_backward -- which must get the same array -- makes the
  *          same one.  With memory != NULL: ignored in eval calls, error -24 in training calls. */
 int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wcache,

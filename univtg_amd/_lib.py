@@ -16,7 +16,7 @@ class Dims(C.Structure):
                 ("Dv", C.c_int), ("Dt", C.c_int), ("n_proj", C.c_int),
                 ("precise", C.c_int), ("training", C.c_int), ("proj_precise", C.c_int),
                 ("p_in", C.c_float), ("p_attn", C.c_float), ("p_path", C.c_float),
-                ("seed", C.c_ulonglong)]
+                ("seed", C.c_ulonglong), ("loss_only", C.c_int)]
 
 
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong

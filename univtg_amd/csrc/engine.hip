@@ -263,10 +263,15 @@ __global__ void add_vec_kernel(float* dst, const float* src, int n) {
 //   PACK_TEXT : every clip row (padded ones included: under input / attention dropout each of them carries its own mask in the
 //               reference, model/univtg.py:392-404) + valid text tokens.  Padded text tokens are masked keys whose outputs nobody
 //               reads, so dropping them is exact under every dropout.
-enum { PACK_NONE = 0, PACK_FULL = 1, PACK_TEXT = 2 };
+//   PACK_HALO : (dims.loss_only, training, p_attn == 0) valid clips + the first three padded clips + valid text.  Padded clips are
+//               never keys; they reach valid positions only through the k = 3 x 3-layer conv heads (receptive field +-3), and every
+//               loss masks padded positions: losses and all parameter gradients stay exact, only pred_* at padded positions beyond
+//               the halo differ (the heads see zero rows there).
+enum { PACK_NONE = 0, PACK_FULL = 1, PACK_TEXT = 2, PACK_HALO = 3 };
+constexpr int HALO = 3;
 int pack_mode(const uvtg_dims& c, const int* lens_host) {
   if (!lens_host || c.precise) return PACK_NONE;
-  if (c.training && (c.p_in > 0.f || c.p_attn > 0.f)) return PACK_TEXT;
+  if (c.training && (c.p_in > 0.f || c.p_attn > 0.f)) return (c.loss_only && c.p_attn <= 0.f) ? PACK_HALO : PACK_TEXT;
   return PACK_FULL;
 }
 // rows of the packed encoder stream for these host-side lengths (lens[0..B) clips, lens[B..2B) text tokens per sample)
@@ -275,7 +280,7 @@ int packed_rows(const Dm& m, const int* lens, int mode, int* out) {
   for (int b = 0; b < m.c.B; b++) {
     const int lv = lens[b], lt = lens[m.c.B + b];
     if (lv < 1 || lv > m.c.Lv || lt < 1 || lt > m.c.Lt) return -23;
-    n += (mode == PACK_TEXT ? m.c.Lv : lv + (lv < m.c.Lv ? 1 : 0)) + lt;
+    n += (mode == PACK_TEXT ? m.c.Lv : (mode == PACK_HALO ? (lv + HALO < m.c.Lv ? lv + HALO : m.c.Lv) : lv + (lv < m.c.Lv ? 1 : 0))) + lt;
   }
   *out = (int)n;
   return 0;
@@ -621,7 +626,8 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
     f.packed = true; f.Mrows = mp;
     // the device-side tables are built from the MASKS (no copy out of the caller's pageable lens_host, which is only read here,
     // synchronously, for the row count): lens_host must be the masks' prefix lengths
-    TRY(launch_pack_tables(src_vid_mask, src_txt_mask, ws.lens_dev, m.c.B, m.c.Lv, m.c.Lt, pmode == PACK_TEXT, ws.pk, s));
+    TRY(launch_pack_tables(src_vid_mask, src_txt_mask, ws.lens_dev, m.c.B, m.c.Lv, m.c.Lt, pmode == PACK_TEXT ? m.c.Lv : (pmode == PACK_HALO ? HALO : -1),
+                           ws.pk, s));
   }
   uvtg_prof_section(2, 0, s);
   TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, s));
@@ -748,7 +754,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
   const bf16_t* gin = nullptr;                  // null = zero
   uvtg_prof_section(1, 0, s);
-  if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT, ws.g2p, s));   // conv-head gradient onto the packed rows
+  if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT || pmode == PACK_HALO, ws.g2p, s));   // conv-head gradient onto the packed rows
   const int* row_sample = packed ? ws.pk.row_sample : nullptr;
   for (int l = E - 1; l >= 0; l--) {
     const bf16_t* xb_in = (packed && l == 0) ? ws.xb0p : (const bf16_t*)ws.xb[l];

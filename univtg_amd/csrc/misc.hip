@@ -212,20 +212,22 @@ __global__ __launch_bounds__(64) void lens_from_masks_kernel(const float* vmask,
   a = wave_sum(a); c = wave_sum(c);
   if (lane == 0) { lens[b] = (int)(a + 0.5f); lens[B + b] = (int)(c + 0.5f); }
 }
-// keep_pad: all Lv clip rows of the sample stay rows of the stream (padded ones too, each with its own dropout realisation);
-// only the padded text tokens are dropped.  Row order inside a sample is then exactly the padded layout's.
+// keep_pad >= 0: the valid clips and the first keep_pad padded clips of the sample stay rows of the stream, each with its own dropout
+// realisation (keep_pad >= Lv: all of them); further padded clips are dropped altogether (training-only: see engine.hip PACK_HALO);
+// padded text tokens are always dropped.  keep_pad < 0: one representative row stands for all padded clips.
 __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B, int Lv, int Lt, int keep_pad, PackTables t) {
   const int b = blockIdx.x, S = Lv + Lt;
   __shared__ int s_start;
+  auto kept = [&](int lvr) { return keep_pad < 0 ? lvr : min(Lv, lvr + keep_pad); };
   if (threadIdx.x == 0) {
     int st = 0;
-    for (int i = 0; i < b; i++) { const int lv = lens[i], lt = lens[B + i]; st += (keep_pad ? Lv : lv + (lv < Lv ? 1 : 0)) + lt; }
+    for (int i = 0; i < b; i++) { const int lvi = lens[i], lt = lens[B + i]; st += kept(lvi) + ((keep_pad < 0 && lvi < Lv) ? 1 : 0) + lt; }
     s_start = st;
   }
   __syncthreads();
   const int lvr = lens[b], lt = lens[B + b];           // lvr: real number of valid clips
-  const int lv = keep_pad ? Lv : lvr;                  // clip rows kept one-to-one
-  const int rep = lv < Lv ? 1 : 0, n = lv + rep + lt, st = s_start;
+  const int lv = kept(lvr);                            // clip rows kept one-to-one
+  const int rep = (keep_pad < 0 && lv < Lv) ? 1 : 0, n = lv + rep + lt, st = s_start;
   if (threadIdx.x == 0) { t.seq_start[b] = st; t.seq_count[b] = n; }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int r = st + i;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     int pk, gm;
     if (s < lv) { pk = st + s; gm = pk; }
-    else if (s < Lv) { pk = st + lv; gm = (s == lv) ? pk : -1; }      // padded clip -> representative; its gradient on the first one
+    else if (s < Lv) { pk = rep ? st + lv : -1; gm = (rep && s == lv) ? pk : -1; }   // padded clip -> representative (its gradient on the first one), or dropped
     else if (s - Lv < lt) { pk = st + lv + rep + (s - Lv); gm = pk; }
     else { pk = -1; gm = -1; }
     t.pad2pack[b * S + s] = pk; t.grad_map[b * S + s] = gm;
@@ -262,8 +264,10 @@ __global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, co
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, s) over B * Lv
   if (row >= B * Lv) return;
   const int b = row / Lv, s = row % Lv;
-  const size_t src = (size_t)pad2pack[b * S + s] * d, dst = (size_t)(b * (Lv + 2) + s + 1) * d;
-  for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + dst + c) = *(const u32x4*)(packed + src + c);
+  const int pk = pad2pack[b * S + s];
+  const size_t src = (size_t)(pk < 0 ? 0 : pk) * d, dst = (size_t)(b * (Lv + 2) + s + 1) * d;
+  const u32x4 z = {0, 0, 0, 0};                 // dropped padded clips (beyond the conv halo): zero rows
+  for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + dst + c) = pk < 0 ? z : *(const u32x4*)(packed + src + c);
 }
 // conv-head gradient wrt the clip rows (padded layout) -> packed rows: valid clips copy, the representative gets the SUM over the
 // sample's padded clips, text rows zero
@@ -729,10 +733,10 @@ int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev, int B, int Lv, int Lt, bool keep_pad, const PackTables& t,
+int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev, int B, int Lv, int Lt, int keep_pad, const PackTables& t,
                        hipStream_t s) {
   hipLaunchKernelGGL(lens_from_masks_kernel, dim3(B), dim3(64), 0, s, vid_mask, txt_mask, B, Lv, Lt, lens_dev);
-  hipLaunchKernelGGL(pack_tables_kernel, dim3(B), dim3(128), 0, s, lens_dev, B, Lv, Lt, keep_pad ? 1 : 0, t);
+  hipLaunchKernelGGL(pack_tables_kernel, dim3(B), dim3(128), 0, s, lens_dev, B, Lv, Lt, keep_pad, t);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -147,8 +147,9 @@ struct PackTables {
   int* grad_map;                      // [B*S]: token row -> packed row carrying its gradient (valid rows, first padded clip), else -1
   unsigned char* kvalid;              // [Mp]
 };
-// keep_pad: every clip row of the padded layout stays a row of the stream (only padded text tokens are dropped)
-int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev /* scratch [2B] */, int B, int Lv, int Lt, bool keep_pad,
+// keep_pad < 0: valid clips + ONE representative padded clip per sample; keep_pad >= 0: valid clips + the first keep_pad padded clips,
+// each its own row (keep_pad >= Lv: every clip row), no representative; padded clips beyond that are dropped (pad2pack = -1)
+int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev /* scratch [2B] */, int B, int Lv, int Lt, int keep_pad,
                        const PackTables& t, hipStream_t s);
 int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp, hipStream_t s);
 int launch_unpack_vm(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s);

@@ -38,7 +38,7 @@ def flatten_parameters(model: Model) -> torch.Tensor:
 
 class TrainStep:
     def __init__(self, model: Model, criterion: SetCriterion, lr=1e-4, weight_decay=1e-4, grad_clip=0.1,
-                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64, overlap_comm=True, packed="auto"):
+                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64, overlap_comm=True, packed="auto", loss_only=True):
         if model.precision != "bf16":
             raise RuntimeError("training uses precision='bf16'")
         self.lib = _lib.load()
@@ -71,9 +71,13 @@ class TrainStep:
                      (4 if "saliency" in criterion.losses else 0)
         # packed (ragged) encoder stream (include/uvtg.h, lens_host): "auto" = when the batch carries the host-side lengths the
         # collate already knows (inputs["_lens_host"] = (lens_v, lens_t)); True = always (lengths read back from the masks: one
-        # device->host sync per step); False = padded execution.  Both packed variants are exact: the engine keeps every clip row
-        # whenever input / attention dropout is active (each padded clip then has its own mask) and drops only padded text tokens
+        # device->host sync per step); False = padded execution.  Every packed variant gives exactly the padded execution's losses and
+        # parameter gradients: under input dropout each padded clip has its own mask, so the engine keeps the valid clips plus the three
+        # padded clips the conv heads can see from a valid position (no loss reads anything further out) and the valid text tokens
         self.packed = packed
+        # loss_only: this step hands out nothing but losses / gradients, so the packed stream may drop the padded clips no loss can see
+        # (include/uvtg.h, dims.loss_only); False keeps every clip row (outputs at padded positions equal the reference's too)
+        self.loss_only = bool(loss_only)
         self._lens_arr = None
         self._names = None
         self._shape = None
@@ -107,6 +111,7 @@ class TrainStep:
         B, Lv, Dv = src_vid.shape
         Lt, Dt = src_txt.shape[1], src_txt.shape[2]
         dims = model._dims(B, Lv, Lt, Dv, Dt, True)
+        dims.loss_only = int(self.loss_only)
         if self._shape != (B, Lv, Lt):
             self._alloc(B, Lv, Lt, dims)
         st = _stream()
