@@ -79,6 +79,8 @@ def load():
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if name.startswith("uvtg_debug_") and not hasattr(lib, name) and os.environ.get("UVTG_LIB_PATH"):
+            continue                     # an older build loaded for an A/B (dev): experiment knobs may be missing
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -301,16 +301,21 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: dK, dV   (one wave = 32 keys, loops over 32-query blocks)
+// backward: dK, dV   (one wave = 32 keys, loops over 32-query blocks) -- the long-sequence path (S > 128: BASELINE config 4)
+// Round 2: (1) the wave's K and V fragments are loop invariants: they live in registers (fetched once, straight from HBM) instead of
+// being re-read from a 64 KB LDS copy every query block; (2) the next query block's Q / dO rows, lse and delta are fetched into
+// registers while the current one is multiplied (round 1 loaded, stored to LDS and synchronised with the load latency exposed), and
+// the Q / dO tiles are double-buffered, so one barrier per query block; (3) 34 KB of LDS and <= 256 registers: two workgroups per CU.
+// (head_dim 128: one workgroup per CU -- the fragments and the 128 accumulator registers do not fit 256 -- but no LDS re-reads.)
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   constexpr int QSTR = HD + 8;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[128 * HD];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[128 * HD];
-  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * QSTR];
-  __shared__ __attribute__((aligned(16))) bf16_t sO[32 * QSTR];
-  __shared__ float sL[32], sD[32];
+  constexpr bool VREG = true;          // (head_dim 128 needs ~280 registers with K and V resident: one workgroup per CU there, no spill)
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[2][32 * QSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[2][32 * QSTR];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[VREG ? 8 : 128 * HD];
+  __shared__ float sL[2][32], sD[2][32];
   using KS = KSwz<HD>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
@@ -320,22 +325,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   const int key0 = blockIdx.x * 128;
   const bf16_t* qkv = (const bf16_t*)a.qkv;
   constexpr int CH = HD / 8;
-  // stage this block's 128 keys of K and V
-#pragma unroll
-  for (int i = 0; i < (128 * CH) / 256; i++) {
-    const int q = tid + 256 * i, r = q / CH, c = q % CH;
-    const int key = key0 + r;
-    u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-    if (key < S) {
-      const bf16_t* base = qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
-      kv = *(const u32x4*)(base + d);
-      vv = *(const u32x4*)(base + 2 * d);
-    }
-    *(u32x4*)(&sK[KS::off(r, c)]) = kv;
-    *(u32x4*)(&sV[KS::off(r, c)]) = vv;
-  }
   const int key = key0 + wave * 32 + l31;            // this lane's key (lane <-> key in S, dP tiles)
-  const bool kok = key < S && a.kvalid[rowbase + min(key, S - 1)];
+  const bool kin = key < S;
+  const bool kok = kin && a.kvalid[rowbase + min(key, S - 1)];
+  // this lane's K / V row as MFMA B fragments: k-step ks covers head-dim columns 16 ks + 8 g .. + 7
+  s16x8 kf[HD / 16], vf[VREG ? HD / 16 : 1];
+  {
+    const bf16_t* base = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ks++) {
+      const u32x4 z = {0, 0, 0, 0};
+      const u32x4 kv = kin ? *(const u32x4*)(base + d + 16 * ks) : z;
+      kf[ks] = __builtin_bit_cast(s16x8, kv);
+      if constexpr (VREG) { const u32x4 vv = kin ? *(const u32x4*)(base + 2 * d + 16 * ks) : z; vf[ks] = __builtin_bit_cast(s16x8, vv); }
+      else *(u32x4*)(&sV[KS::off(wave * 32 + l31, 2 * ks + g)]) = kin ? *(const u32x4*)(base + 2 * d + 16 * ks) : z;   // wave-private rows
+    }
+  }
   f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
   for (int i = 0; i < HD / 32; i++)
@@ -343,53 +348,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
     for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
   const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
 
-  const int nqb = (S + 31) / 32;
-  for (int qb = 0; qb < nqb; qb++) {
-    __syncthreads();
+  constexpr int NPT = (32 * CH + 255) / 256;         // staging pieces per thread per operand
+  u32x4 pq[NPT], po[NPT];
+  float pl = 0.f, pdl = 0.f;
+  auto prefetch = [&](int qb) {
 #pragma unroll
-    for (int i = 0; i < (32 * CH + 255) / 256; i++) {
+    for (int i = 0; i < NPT; i++) {
+      const int q = tid + 256 * i, r = q / CH, c = q % CH;
+      const int qi = min(qb * 32 + r, S - 1);          // clamped rows are loaded, masked in the math (qi < S)
+      const bool on = q < 32 * CH;
+      const u32x4 z = {0, 0, 0, 0};
+      pq[i] = on ? *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8) : z;
+      po[i] = on ? *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8) : z;
+    }
+    if (tid < 32) {
+      const int qi = min(qb * 32 + tid, S - 1);
+      pl = a.lse[((size_t)b * a.H + h) * a.S + qi];
+      pdl = a.delta[((size_t)b * a.H + h) * a.S + qi];
+    }
+  };
+  const int nqb = (S + 31) / 32;
+  prefetch(0);
+  for (int qb = 0; qb < nqb; qb++) {
+    const int buf = qb & 1;
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
       const int q = tid + 256 * i;
       if (q < 32 * CH) {
         const int r = q / CH, c = q % CH;
-        const int qi = qb * 32 + r;
-        u32x4 qv = {0, 0, 0, 0}, ov = {0, 0, 0, 0};
-        if (qi < S) {
-          qv = *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8);
-          ov = *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8);
-        }
-        *(u32x4*)(&sQ[r * QSTR + c * 8]) = qv;
-        *(u32x4*)(&sO[r * QSTR + c * 8]) = ov;
+        *(u32x4*)(&sQ[buf][r * QSTR + c * 8]) = pq[i];
+        *(u32x4*)(&sO[buf][r * QSTR + c * 8]) = po[i];
       }
     }
-    if (tid < 32) {
-      const int qi = qb * 32 + tid;
-      sL[tid] = qi < S ? a.lse[((size_t)b * a.H + h) * a.S + qi] : 0.f;
-      sD[tid] = qi < S ? a.delta[((size_t)b * a.H + h) * a.S + qi] : 0.f;
-    }
-    __syncthreads();
+    if (tid < 32) { sL[buf][tid] = pl; sD[buf][tid] = pdl; }
+    __syncthreads();          // (the other buffer's last readers passed the previous iteration's barrier)
+    if (qb + 1 < nqb) prefetch(qb + 1);
+    const bf16_t* bq = sQ[buf];
+    const bf16_t* bo = sO[buf];
     // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
     f32x16 sc, dp;
 #pragma unroll
     for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) {
-      const s16x8 qf = *(const s16x8*)(&sQ[l31 * QSTR + 16 * ks + 8 * g]);
-      const s16x8 of = *(const s16x8*)(&sO[l31 * QSTR + 16 * ks + 8 * g]);
-      const int ko = KS::off(wave * 32 + l31, 2 * ks + g);
-      const s16x8 kf = *(const s16x8*)(&sK[ko]);
-      const s16x8 vf = *(const s16x8*)(&sV[ko]);
-      sc = mfma32(qf, kf, sc);
-      dp = mfma32(of, vf, dp);
+      const s16x8 qf = *(const s16x8*)(&bq[l31 * QSTR + 16 * ks + 8 * g]);
+      const s16x8 of = *(const s16x8*)(&bo[l31 * QSTR + 16 * ks + 8 * g]);
+      sc = mfma32(qf, kf[ks], sc);
+      if constexpr (VREG) dp = mfma32(of, vf[ks], dp);
+      else dp = mfma32(of, *(const s16x8*)(&sV[KS::off(wave * 32 + l31, 2 * ks + g)]), dp);
     }
     float pd[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int ql = (r & 3) + 8 * (r >> 2) + 4 * g, qi = qb * 32 + ql;
-      float p = (kok && qi < S) ? __expf(sc[r] - sL[ql]) : 0.f;
+      float p = (kok && qi < S) ? __expf(sc[r] - sL[buf][ql]) : 0.f;
       float ksc = 1.f;
       if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
       pd[r] = p * ksc;
-      ds[r] = p * (dp[r] * ksc - sD[ql]);
+      ds[r] = p * (dp[r] * ksc - sD[buf][ql]);
     }
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
@@ -399,14 +415,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnArgs a) {
 #pragma unroll
       for (int blk = 0; blk < HD / 32; blk++) {
         const int col = blk * 32 + 16 * qd + 4 * (i16 & 3);
-        const s16x8 ot = cat4(lds_tr16(&sO[qr * QSTR + col]), lds_tr16(&sO[(qr + 8) * QSTR + col]));
-        const s16x8 qt = cat4(lds_tr16(&sQ[qr * QSTR + col]), lds_tr16(&sQ[(qr + 8) * QSTR + col]));
+        const s16x8 ot = cat4(lds_tr16(&bo[qr * QSTR + col]), lds_tr16(&bo[(qr + 8) * QSTR + col]));
+        const s16x8 qt = cat4(lds_tr16(&bq[qr * QSTR + col]), lds_tr16(&bq[(qr + 8) * QSTR + col]));
         dv[blk] = mfma32(ot, pb, dv[blk]);
         dk[blk] = mfma32(qt, db, dk[blk]);
       }
     }
   }
-  if (key < S) {
+  if (kin) {
 #pragma unroll
     for (int blk = 0; blk < HD / 32; blk++)
 #pragma unroll

@@ -572,13 +572,17 @@ __global__ __launch_bounds__(256) void saliency_cos_kernel(const SaliencyArgs a)
 //   video row t: g = dx0 + g_sal (qhat - cos vhat) / |v| + g_vid (+ g_vrow on the positive row)
 //   dq           = g_pooled + sum_t g_sal (vhat - cos qhat) / |q|
 //   text row s : g = dx0 + alpha dq + dlog w_pool,  dlog = alpha (dq.x_s - sum alpha dq.x);  dw_pool += sum dlog x_s
+// block = 64 columns x 4 row phases (one block per (sample, 256 columns) with a serial walk over the clips was latency-bound:
+// 535 us at L_v = 1200): thread (cc, ph) walks clips ph, ph + 4, ...; the four phases meet in LDS
 __global__ __launch_bounds__(256) void saliency_dq_kernel(const SaliencyArgs a) {
-  extern __shared__ float sm[];                 // [Lv] gs / |v| | [Lv] gs cos / |v|... kept as three arrays
+  extern __shared__ float sm[];                 // [Lv] gs | [Lv] |v| | [Lv] cos | [256] partial sums
   float* s_gs = sm;
   float* s_vn = s_gs + a.Lv;
   float* s_cs = s_vn + a.Lv;
+  float* red = s_cs + a.Lv;
   const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
-  const int c = blockIdx.y * 256 + tid;
+  const int cc = tid & 63, ph = tid >> 6;
+  const int c = blockIdx.y * 64 + cc;
   const float qn = fmaxf(a.qnorm[b], 1e-8f);
   for (int t = tid; t < a.Lv; t += 256) {
     s_gs[t] = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
@@ -586,15 +590,20 @@ __global__ __launch_bounds__(256) void saliency_dq_kernel(const SaliencyArgs a) 
     s_cs[t] = a.cosv[b * a.Lv + t];
   }
   __syncthreads();
-  if (c >= d) return;
   const float* xv = a.x0 + (size_t)b * a.S * d;
-  const float qh = a.pooled[(size_t)b * d + c] / qn;
-  float dq = a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f;
-  for (int t = 0; t < a.Lv; t++) {
-    const float gs = s_gs[t];
-    if (gs != 0.f) dq += gs * (xv[(size_t)t * d + c] / s_vn[t] - s_cs[t] * qh) / qn;
+  const float qh = c < d ? a.pooled[(size_t)b * d + c] / qn : 0.f;
+  float acc = 0.f;
+  if (c < d) {
+#pragma unroll 4
+    for (int t = ph; t < a.Lv; t += 4) {
+      const float gs = s_gs[t];
+      acc += gs * (xv[(size_t)t * d + c] / s_vn[t] - s_cs[t] * qh);
+    }
   }
-  a.dq[(size_t)b * d + c] = dq;
+  red[tid] = acc;
+  __syncthreads();
+  if (ph == 0 && c < d)
+    a.dq[(size_t)b * d + c] = (a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f) + (red[cc] + red[64 + cc] + red[128 + cc] + red[192 + cc]) / qn;
 }
 __global__ __launch_bounds__(1024) void saliency_dlog_kernel(const SaliencyArgs a) {
   extern __shared__ float sm[];                 // [Lt] da
@@ -866,7 +875,7 @@ int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
   return 0;
 }
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 256)), dim3(256), 3 * a.Lv * sizeof(float), s, a);
+  hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 64)), dim3(256), (3 * a.Lv + 256) * sizeof(float), s, a);
   hipLaunchKernelGGL(saliency_dlog_kernel, dim3(a.B), dim3(1024), a.Lt * sizeof(float), s, a);
   const dim3 grid(a.B, cdiv(a.S, 32));
   if (a.d == 1024) hipLaunchKernelGGL(saliency_rows_kernel<4>, grid, dim3(256), 0, s, a);
