@@ -145,6 +145,7 @@ struct WSpace {
     pk.seq_start = a.take<int>(B); pk.seq_count = a.take<int>(B);
     pk.row_sample = a.take<int>(M); pk.row_src = a.take<int>(M); pk.row_pos = a.take<int>(M);
     pk.pad2pack = a.take<int>(M); pk.grad_map = a.take<int>(M); pk.kvalid = a.take<unsigned char>(M);
+    pk.fstart = a.take<int>(B); pk.kept = a.take<int>(B); pk.frame_valid = a.take<float>((size_t)m.Rp + 1);
     xb0p = fast ? a.take<bf16_t>(M * d) : nullptr; ub0p = fast ? a.take<bf16_t>(M * d) : nullptr;
     g2p = (fast && tr) ? a.take<bf16_t>(M * d) : nullptr;
     for (int i = 0; i < 2; i++) {
@@ -195,7 +196,7 @@ struct WSpace {
     alpha = a.take<float>((size_t)B * m.c.Lt); cosv = a.take<float>(m.Mv); vnorm = a.take<float>(m.Mv); qnorm = a.take<float>(B);
     if (tr) {
       dvm = nullptr; gx[0] = gx[1] = nullptr; dyF = nullptr;       // (fp32 gradient stream: not used by the bf16 training path)
-      dvmB = a.take<bf16_t>((size_t)m.Mv * d); gxb[0] = a.take<bf16_t>(M * d); gxb[1] = a.take<bf16_t>(M * d);
+      dvmB = a.take<bf16_t>((size_t)(m.Rp + 1) * d); gxb[0] = a.take<bf16_t>(M * d); gxb[1] = a.take<bf16_t>(M * d);     // (frame-row space on the loss-only stream)
       dyR = a.take<bf16_t>(M * d); delta = a.take<float>(B * m.c.H * m.S);
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
       {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
@@ -222,16 +223,17 @@ struct WSpace {
 };
 
 // ---- tiny helper kernels ----------------------------------------------------------------------
-__global__ void zero_frame_rows_kernel(char* p, int B, int Lv, int row_bytes) {
-  // rows b*(Lv+2) and b*(Lv+2)+Lv+1 of a zero-framed [B*(Lv+2), *] buffer
+__global__ void zero_frame_rows_kernel(char* p, int B, int Lv, int row_bytes, const int* fstart, const int* kept) {
+  // rows b*(Lv+2) and b*(Lv+2)+Lv+1 of a zero-framed [B*(Lv+2), *] buffer (ragged frames: fstart[b] and fstart[b] + kept[b] + 1)
   const int which = blockIdx.x;                    // 2*B rows
-  const int b = which >> 1, r = b * (Lv + 2) + ((which & 1) ? Lv + 1 : 0);
+  const int b = which >> 1;
+  const int r = fstart ? fstart[b] + ((which & 1) ? kept[b] + 1 : 0) : b * (Lv + 2) + ((which & 1) ? Lv + 1 : 0);
   u32x4* row = (u32x4*)(p + (size_t)r * row_bytes);
   const u32x4 z = {0, 0, 0, 0};
   for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) row[i] = z;
 }
-int zero_frame(void* p, int B, int Lv, int row_bytes, hipStream_t s) {
-  hipLaunchKernelGGL(zero_frame_rows_kernel, dim3(2 * B), dim3(256), 0, s, (char*)p, B, Lv, row_bytes);
+int zero_frame(void* p, int B, int Lv, int row_bytes, hipStream_t s, const int* fstart = nullptr, const int* kept = nullptr) {
+  hipLaunchKernelGGL(zero_frame_rows_kernel, dim3(2 * B), dim3(256), 0, s, (char*)p, B, Lv, row_bytes, fstart, kept);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -273,6 +275,12 @@ int pack_mode(const uvtg_dims& c, const int* lens_host) {
   if (!lens_host || c.precise) return PACK_NONE;
   if (c.training && (c.p_in > 0.f || c.p_attn > 0.f)) return (c.loss_only && c.p_attn <= 0.f) ? PACK_HALO : PACK_TEXT;
   return PACK_FULL;
+}
+// rows of the ragged conv-head frames of the loss-only stream: kept clips + 2 zero rows per sample
+int halo_frame_rows(const Dm& m, const int* lens) {
+  long long n = 0;
+  for (int b = 0; b < m.c.B; b++) n += (lens[b] + HALO < m.c.Lv ? lens[b] + HALO : m.c.Lv) + 2;
+  return (int)n;
 }
 // rows of the packed encoder stream for these host-side lengths (lens[0..B) clips, lens[B..2B) text tokens per sample)
 int packed_rows(const Dm& m, const int* lens, int mode, int* out) {
@@ -450,6 +458,7 @@ struct Fwd {
   const Dm& m; const float* const* P; WCache& w; WSpace& ws; hipStream_t s;
   bool fast, tr, pp;
   bool packed = false; int Mrows = 0;     // packed (ragged) encoder stream: Mrows <= B * S rows (see misc.hip)
+  bool halo = false; int Rf = 0;          // loss-only stream: ragged conv-head frames of Rf rows in all (else B * (Lv + 2))
   int run_gemm(GemmArgs& g, bool x3) { return x3 ? launch_gemm_nt_f32x3(g, s) : launch_gemm_nt_bf16(g, s); }
   void set_out(GemmArgs& g, void* p, int ld) { if (fast) { g.outB = (bf16_t*)p; g.ldoB = ld; } else { g.outF = (float*)p; g.ldoF = ld; } }
 
@@ -558,33 +567,42 @@ struct Fwd {
       if (fast) ln.yP = (bf16_t*)ws.vm_pad; else ln.yPF = (float*)ws.vm_pad;
     }
     TRY(launch_ln_fwd(ln, s));
-    if (last && packed) TRY(launch_unpack_vm((const bf16_t*)ws.xb[l + 1], ws.pk.pad2pack, m.c.B, S, m.c.Lv, d, (bf16_t*)ws.vm_pad, s));
+    if (last && packed) TRY(launch_unpack_vm((const bf16_t*)ws.xb[l + 1], ws.pk, halo, m.c.B, S, m.c.Lv, d, (bf16_t*)ws.vm_pad, s));
     return 0;
   }
 
   int heads(float* pred_logits, float* pred_spans) {
     const int d = m.c.d, Lv = m.c.Lv, B = m.c.B;
     const size_t es = fast ? 2 : 4;
-    TRY(zero_frame(ws.vm_pad, B, Lv, (int)(d * es), s));
-    TRY(zero_frame(ws.h1_pad, B, Lv, (int)(2 * d * es), s));
-    TRY(zero_frame(ws.h2_pad, B, Lv, (int)(2 * d * es), s));
+    const int* fs = halo ? ws.pk.fstart : nullptr;
+    const int* kc = halo ? ws.pk.kept : nullptr;
+    TRY(zero_frame(ws.vm_pad, B, Lv, (int)(d * es), s, fs, kc));
+    if (!halo) {
+      TRY(zero_frame(ws.h1_pad, B, Lv, (int)(2 * d * es), s));
+      TRY(zero_frame(ws.h2_pad, B, Lv, (int)(2 * d * es), s));
+    }
+    // Frame addressing of the 3-tap GEMMs.  Uniform frames: output row m = (b, t) reads frame rows b (Lv + 2) + t + tap and lands on
+    // frame row b (Lv + 2) + t + 1 (the zero rows are never written).  Ragged frames (loss-only stream): the GEMM runs over ALL frame
+    // rows, row f reads f - 1 + tap, and the zero rows are re-established by the 0/1 row factor of the epilogue.
+    auto frame = [&](GemmArgs& g) {
+      if (halo) { g.M = Rf; g.a_off = -1; g.rowscale = ws.pk.frame_valid; g.rs_seg = 1; }
+      else { g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0; g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1; }
+    };
     // conv layer 0 of both heads as one 3-tap GEMM, N = 2d (model/univtg.py:84-85,375-382)
     GemmArgs g = gemm_base(ws.vm_pad, d, fast ? (const void*)w.wc0 : (const void*)w.wc0F, 3 * d, m.Mv, 2 * d, 3 * d);
-    g.ktap = d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
-    g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1;
+    g.ktap = d; frame(g);
     g.bias = w.bc0; g.act = 1;
     set_out(g, ws.h1_pad, 2 * d);
     TRY(run_gemm(g, !fast));
     // conv layer 1: two groups (span | class), each d -> d
     g = gemm_base(ws.h1_pad, 2 * d, fast ? (const void*)w.wc1 : (const void*)w.wc1F, 3 * d, m.Mv, d, 3 * d);
-    g.ktap = d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
-    g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1;
+    g.ktap = d; frame(g);
     g.groups = 2; g.gA = d; g.gB = (long long)d * 3 * d; g.gBias = d; g.gOut = d;
     g.bias = w.bc1; g.act = 1;
     set_out(g, ws.h2_pad, 2 * d);
     TRY(run_gemm(g, !fast));
     HeadsFinalArgs hf; memset(&hf, 0, sizeof(hf));
-    hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.precise = !fast;
+    hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.precise = !fast; hf.fstart = fs; hf.kept = kc;
     hf.w_span = P[m.tail(SP2W)]; hf.b_span = P[m.tail(SP2B)]; hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)];
     hf.B = B; hf.Lv = Lv; hf.d = d; hf.pred_logits = pred_logits; hf.pred_spans = pred_spans;
     TRY(launch_heads_final_fwd(hf, s));
@@ -624,6 +642,7 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
     int mp = 0;
     TRY(packed_rows(m, lens_host, pmode, &mp));
     f.packed = true; f.Mrows = mp;
+    f.halo = pmode == PACK_HALO; f.Rf = f.halo ? halo_frame_rows(m, lens_host) : m.Rp;
     // the device-side tables are built from the MASKS (no copy out of the caller's pageable lens_host, which is only read here,
     // synchronously, for the row count): lens_host must be the masks' prefix lengths
     TRY(launch_pack_tables(src_vid_mask, src_txt_mask, ws.lens_dev, m.c.B, m.c.Lv, m.c.Lt, pmode == PACK_TEXT ? m.c.Lv : (pmode == PACK_HALO ? HALO : -1),
@@ -702,36 +721,46 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   };
   // weight gradient of one Conv1d(k=3): dW[n][c][tap] = sum_rows dY[row][n] * X[row + tap - 1][c] over the zero-framed rows.
   // One launch over K = 3 d (the k tiles pick their tap's row offset) when the 256-tile kernel takes it, else one per tap.
-  auto conv_wgrad = [&](const bf16_t* dY, int ldp, const bf16_t* X, int ldq, float* dW, float* dBi) -> int {
+  auto conv_wgrad = [&](const bf16_t* dY, int ldp, const bf16_t* X, int ldq, float* dW, float* dBi, int rows) -> int {
     GemmTNArgs t; memset(&t, 0, sizeof(t));
-    t.P = dY; t.ldp = ldp; t.Q = X; t.ldq = ldq; t.M = m.Rp; t.N = d; t.K = 3 * d; t.q_row_off = -1; t.Mq = m.Rp;
+    t.P = dY; t.ldp = ldp; t.Q = X; t.ldq = ldq; t.M = rows; t.N = d; t.K = 3 * d; t.q_row_off = -1; t.Mq = rows;
     t.out = dW; t.ldo = 3 * d; t.col_stride = 3; t.dbias = dBi; t.splits = splits_v; t.ktap = d;
     t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
     if (gemm_tn_taps_ok(t)) return launch_gemm_tn_bf16(t, s);
     for (int tap = 0; tap < 3; tap++)
-      TRY(wgrad(dY, ldp, X, ldq, m.Rp, d, d, dW + tap, 3 * d, 3, tap == 1 ? dBi : nullptr, tap - 1, m.Rp, splits_v));
+      TRY(wgrad(dY, ldp, X, ldq, rows, d, d, dW + tap, 3 * d, 3, tap == 1 ? dBi : nullptr, tap - 1, rows, splits_v));
     return 0;
   };
   // ---------------- heads ----------------
-  TRY(zero_frame(ws.dh2_pad, B, Lv, 2 * d * 2, s));
-  TRY(zero_frame(ws.dh1_pad, B, Lv, 2 * d * 2, s));
+  const bool halo = pmode == PACK_HALO;          // ragged conv-head frames (see Fwd::heads)
+  const int Rf = halo ? halo_frame_rows(m, lens_host) : m.Rp;
+  const int* fs = halo ? ws.pk.fstart : nullptr;
+  const int* kc = halo ? ws.pk.kept : nullptr;
+  auto frame = [&](GemmArgs& g, bool scatter_out) {
+    if (halo) { g.M = Rf; g.a_off = -1; g.rowscale = ws.pk.frame_valid; g.rs_seg = 1; }
+    else {
+      g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
+      if (scatter_out) { g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1; }
+    }
+  };
+  TRY(zero_frame(ws.dh2_pad, B, Lv, 2 * d * 2, s, fs, kc));
+  if (!halo) TRY(zero_frame(ws.dh1_pad, B, Lv, 2 * d * 2, s));
   HeadsFinalArgs hf; memset(&hf, 0, sizeof(hf));
   hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.w_span = P[m.tail(SP2W)]; hf.b_span = P[m.tail(SP2B)];
-  hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)]; hf.B = B; hf.Lv = Lv; hf.d = d;
+  hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)]; hf.B = B; hf.Lv = Lv; hf.d = d; hf.fstart = fs; hf.kept = kc;
   hf.pred_logits = (float*)pred_logits; hf.pred_spans = (float*)pred_spans; hf.g_logits = g_logits; hf.g_spans = g_spans;
   hf.dh2 = ws.dh2_pad; hf.lddh = 2 * d;
   hf.dw_span = G(m.tail(SP2W)); hf.db_span = G(m.tail(SP2B)); hf.dw_cls = G(m.tail(CL2W)); hf.db_cls = G(m.tail(CL2B));
   hf.scratch = ws.tn_scratch; hf.scratch_floats = ws.tn_scratch_floats;
   TRY(launch_heads_final_bwd(hf, s));
-  const int Rp = m.Rp;
   for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 1 weight grads: 3 taps x 2 heads
     float* dW = G(m.tail(hd_ == 0 ? SP1W : CL1W));
     float* dBi = G(m.tail(hd_ == 0 ? SP1B : CL1B));
-    TRY(conv_wgrad(ws.dh2_pad + hd_ * d, 2 * d, (const bf16_t*)ws.h1_pad + hd_ * d, 2 * d, dW, dBi));
+    TRY(conv_wgrad(ws.dh2_pad + hd_ * d, 2 * d, (const bf16_t*)ws.h1_pad + hd_ * d, 2 * d, dW, dBi, Rf));
   }
   {                                             // conv layer 1 dgrad (+ relu' of h1) -> dh1_pad
     GemmArgs g = gemm_base(ws.dh2_pad, 2 * d, w.wc1T, 3 * d, m.Mv, d, 3 * d);
-    g.ktap = d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0; g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1;
+    g.ktap = d; frame(g, true);
     g.groups = 2; g.gA = d; g.gB = (long long)d * 3 * d; g.gOut = d; g.gPre = d;
     g.gradPre = (const bf16_t*)ws.h1_pad; g.ldgp = 2 * d; g.actgrad = 1;
     g.outB = ws.dh1_pad; g.ldoB = 2 * d;
@@ -740,11 +769,11 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 0 weight grads
     float* dW = G(m.tail(hd_ == 0 ? SP0W : CL0W));
     float* dBi = G(m.tail(hd_ == 0 ? SP0B : CL0B));
-    TRY(conv_wgrad(ws.dh1_pad + hd_ * d, 2 * d, (const bf16_t*)ws.vm_pad, d, dW, dBi));
+    TRY(conv_wgrad(ws.dh1_pad + hd_ * d, 2 * d, (const bf16_t*)ws.vm_pad, d, dW, dBi, Rf));
   }
-  {                                             // conv layer 0 dgrad -> dvm (fp32, video rows)
+  {                                             // conv layer 0 dgrad -> dvm (bf16; clip rows [B * Lv], or frame rows on the loss-only stream)
     GemmArgs g = gemm_base(ws.dh1_pad, 2 * d, w.wc0T, 6 * d, m.Mv, d, 6 * d);
-    g.ktap = 2 * d; g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0;
+    g.ktap = 2 * d; frame(g, false);
     g.outB = ws.dvmB; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
   }
@@ -754,7 +783,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
   const bf16_t* gin = nullptr;                  // null = zero
   uvtg_prof_section(1, 0, s);
-  if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT || pmode == PACK_HALO, ws.g2p, s));   // conv-head gradient onto the packed rows
+  if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT || pmode == PACK_HALO, pmode == PACK_HALO, ws.g2p, s));   // conv-head gradient onto the packed rows
   const int* row_sample = packed ? ws.pk.row_sample : nullptr;
   for (int l = E - 1; l >= 0; l--) {
     const bf16_t* xb_in = (packed && l == 0) ? ws.xb0p : (const bf16_t*)ws.xb[l];

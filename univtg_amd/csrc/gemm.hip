@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     srow[i] = q >> 3; sch[i] = q & 7;
     int m = min(m0 + srow[i], p.M - 1);
     int n = min(n0 + srow[i], p.N - 1);
-    aoff[i] = (size_t)map_row(m, p.a_seg, p.a_seg_stride, p.a_off) * p.lda;
+    aoff[i] = (size_t)max(map_row(m, p.a_seg, p.a_seg_stride, p.a_off), 0) * p.lda;
     boff[i] = (size_t)n * p.ldb;
   }
   const int nk = (p.K + BK - 1) / BK;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       if (p.actgrad == 1) { v[0] = q0 > 0.f ? v[0] : 0.f; v[1] = q1 > 0.f ? v[1] : 0.f; v[2] = q2 > 0.f ? v[2] : 0.f; v[3] = q3 > 0.f ? v[3] : 0.f; }
       else { v[0] *= gelu_erf_grad(q0); v[1] *= gelu_erf_grad(q1); v[2] *= gelu_erf_grad(q2); v[3] *= gelu_erf_grad(q3); }
     }
-    if (p.rowscale) v *= p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg];
+    if (p.rowscale) { const float rs = p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg]; v = rs == 0.f ? (f32x4){0.f, 0.f, 0.f, 0.f} : v * rs; }
     if (p.resid) { const f32x4 t = *(const f32x4*)(p.resid + orow * p.ldr + n); v += t; }
     if (p.residB) {
       const u32x2 t = *(const u32x2*)(p.residB + orow * p.ldrB + n);
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     for (int i = 0; i < PA; i++) {
       const int r = (wave * PA + i) * 8 + sr;
       const int c = (sc ^ ((r >> 1) & 7)) * 8;
-      const int am = GATHER ? map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off) : min(m0 + r, p.M - 1);
+      const int am = GATHER ? max(map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off), 0) : min(m0 + r, p.M - 1);
       aofs[i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
     }
 #pragma unroll
@@ -523,10 +523,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
               else { v[2 * e] *= gelu_erf_grad(q0); v[2 * e + 1] *= gelu_erf_grad(q1); }
             }
           }
-          if (p.rowscale) {
+          if (p.rowscale) {      // (a zero factor SELECTS zero: the masked frame rows of the conv heads may have accumulated garbage)
             const float rs = p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] *= rs;
+            for (int e = 0; e < 8; e++) v[e] = rs == 0.f ? 0.f : v[e] * rs;
           }
           if (p.resid) {
             const float* rp = p.resid + orow * p.ldr + n;

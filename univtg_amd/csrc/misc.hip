@@ -229,6 +229,16 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
   const int lv = kept(lvr);                            // clip rows kept one-to-one
   const int rep = (keep_pad < 0 && lv < Lv) ? 1 : 0, n = lv + rep + lt, st = s_start;
   if (threadIdx.x == 0) { t.seq_start[b] = st; t.seq_count[b] = n; }
+  if (keep_pad >= 0) {                                 // conv-head frames (ragged on the loss-only stream): kept clips + 2 zero rows per sample
+    __shared__ int s_f;
+    if (threadIdx.x == 0) {
+      int f = 0;
+      for (int i = 0; i < b; i++) f += kept(lens[i]) + 2;
+      s_f = f; t.fstart[b] = f; t.kept[b] = lv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lv + 2; i += blockDim.x) t.frame_valid[s_f + i] = (i >= 1 && i <= lv) ? 1.f : 0.f;
+  }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int r = st + i;
     int ps;                                            // position in the padded layout
@@ -259,19 +269,22 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const bf16_t* xb, const 
   }
 }
 // encoder output (packed) -> zero-framed conv input: every clip position of the padded layout, padded clips from the representative
-__global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad) {
+__global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, const int* pad2pack, const int* fstart, const int* kept, int B, int S, int Lv,
+                                                        int d, bf16_t* vm_pad) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, s) over B * Lv
   if (row >= B * Lv) return;
   const int b = row / Lv, s = row % Lv;
+  if (kept && s >= kept[b]) return;                         // ragged frames: a dropped clip has no frame row
   const int pk = pad2pack[b * S + s];
-  const size_t src = (size_t)(pk < 0 ? 0 : pk) * d, dst = (size_t)(b * (Lv + 2) + s + 1) * d;
+  const size_t src = (size_t)(pk < 0 ? 0 : pk) * d, dst = (size_t)((fstart ? fstart[b] : b * (Lv + 2)) + s + 1) * d;
   const u32x4 z = {0, 0, 0, 0};                 // dropped padded clips (beyond the conv halo): zero rows
   for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + dst + c) = pk < 0 ? z : *(const u32x4*)(packed + src + c);
 }
 // conv-head gradient wrt the clip rows (padded layout) -> packed rows: valid clips copy, the representative gets the SUM over the
 // sample's padded clips, text rows zero
-__global__ __launch_bounds__(256) void pack_reduce_dvm_kernel(const bf16_t* dvm, PackTables t, int B, int S, int Lv, int Mp, int d, int keep_pad, bf16_t* out) {
+__global__ __launch_bounds__(256) void pack_reduce_dvm_kernel(const bf16_t* dvm, PackTables t, int B, int S, int Lv, int Mp, int d, int keep_pad, int ragged,
+                                                              bf16_t* out) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= Mp) return;
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(256) void pack_reduce_dvm_kernel(const bf16_t* dvm,
     if (ps < Lv) {
       const int s1 = rep ? Lv : ps + 1;
       for (int sv = ps; sv < s1; sv++) {
-        const u32x4 v = *(const u32x4*)(dvm + (size_t)(b * Lv + sv) * d + c);
+        const u32x4 v = *(const u32x4*)(dvm + (size_t)(ragged ? t.fstart[b] + sv + 1 : b * Lv + sv) * d + c);
 #pragma unroll
         for (int e = 0; e < 4; e++) { acc[2 * e] += __uint_as_float(v[e] << 16); acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
       }
@@ -321,6 +334,11 @@ __global__ __launch_bounds__(256) void heads_final_fwd_kernel(const HeadsFinalAr
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, t)
   if (row >= a.B * a.Lv) return;
   const int b = row / a.Lv, t = row % a.Lv, d = a.d;
+  const int fs = a.fstart ? a.fstart[b] : b * (a.Lv + 2);
+  if (a.kept && t >= a.kept[b]) {       // no frame row (loss-only stream): constants nobody reads
+    if (lane == 0) { a.pred_spans[(size_t)row * 2] = -0.5f; a.pred_spans[(size_t)row * 2 + 1] = 0.5f; a.pred_logits[row] = 0.5f; }
+    return;
+  }
   const T* h2 = (const T*)a.h2;
   float z0 = 0.f, z1 = 0.f, zc = 0.f;
   for (int c = lane * 8; c < d; c += 512) {
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(256) void heads_final_fwd_kernel(const HeadsFinalAr
     ldw24(a.w_span + (size_t)c * 3, w0); ldw24(a.w_span + ((size_t)d + c) * 3, w1); ldw24(a.w_cls + (size_t)c * 3, wc);
 #pragma unroll
     for (int tap = 0; tap < 3; tap++) {
-      const T* hr = h2 + (size_t)(b * (a.Lv + 2) + t + tap) * a.ldh;
+      const T* hr = h2 + (size_t)(fs + t + tap) * a.ldh;
       float hs[8], hc[8];
       ld8<T>(hr + c, hs); ld8<T>(hr + d + c, hc);
 #pragma unroll
@@ -360,11 +378,13 @@ __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFina
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, u)
   if (row >= a.B * a.Lv) return;
   const int b = row / a.Lv, u = row % a.Lv, d = a.d;
+  if (a.kept && u >= a.kept[b]) return;
+  const int fs = a.fstart ? a.fstart[b] : b * (a.Lv + 2);
   float dz0[3], dz1[3], dzc[3];
 #pragma unroll
   for (int tap = 0; tap < 3; tap++) head_dz(a, b, u - tap + 1, dz0[tap], dz1[tap], dzc[tap]);
-  const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(b * (a.Lv + 2) + u + 1) * a.ldh;
-  bf16_t* out = a.dh2 + (size_t)(b * (a.Lv + 2) + u + 1) * a.lddh;
+  const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(fs + u + 1) * a.ldh;
+  bf16_t* out = a.dh2 + (size_t)(fs + u + 1) * a.lddh;
   for (int c2 = lane * 8; c2 < 2 * d; c2 += 512) {
     const bool cls = c2 >= d;
     const int c = cls ? c2 - d : c2;
@@ -416,7 +436,8 @@ __global__ __launch_bounds__(1024) void heads_final_bwd_dw_kernel(const HeadsFin
   bs0 = wave_sum(bs0); bs1 = wave_sum(bs1); bsc = wave_sum(bsc);
   if ((tid & 63) == 0 && (bs0 != 0.f || bs1 != 0.f || bsc != 0.f)) { atomicAdd(a.db_span, bs0); atomicAdd(a.db_span + 1, bs1); atomicAdd(a.db_cls, bsc); }
   __syncthreads();
-  const int per = (Lv + 3) / 4, u0 = grp * per, u1 = min(Lv, u0 + per);
+  const int kc = a.kept ? a.kept[b] : Lv, fs = a.fstart ? a.fstart[b] : b * (Lv + 2);
+  const int per = (kc + 3) / 4, u0 = grp * per, u1 = min(kc, u0 + per);
   for (int c2 = t8 * 8; c2 < 2 * d + 2047; c2 += 2048) {        // block-uniform trip count; inactive threads only join the barriers
     const bool live = c2 < 2 * d;
     const bool cls = c2 >= d;
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(1024) void heads_final_bwd_dw_kernel(const HeadsFin
 #pragma unroll 4
       for (int u = u0; u < u1; u++) {
         float h[8];
-        ld8<bf16_t>(h2 + (size_t)(b * (Lv + 2) + u + 1) * a.ldh + c2, h);
+        ld8<bf16_t>(h2 + (size_t)(fs + u + 1) * a.ldh + c2, h);
 #pragma unroll
         for (int tap = 0; tap < 3; tap++) {
           const float g0 = z0[u - tap + 2], g1 = z1[u - tap + 2];      // clip t = u - tap + 1 -> index 1 + t
@@ -755,15 +776,17 @@ int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_unpack_vm(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s) {
+int launch_unpack_vm(const bf16_t* packed, const PackTables& t, bool ragged_frames, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s) {
   if (d % 8) return -2;
-  hipLaunchKernelGGL(unpack_vm_kernel, dim3(cdiv(B * Lv, 4)), dim3(256), 0, s, packed, pad2pack, B, S, Lv, d, vm_pad);
+  hipLaunchKernelGGL(unpack_vm_kernel, dim3(cdiv(B * Lv, 4)), dim3(256), 0, s, packed, t.pad2pack, ragged_frames ? t.fstart : nullptr,
+                     ragged_frames ? t.kept : nullptr, B, S, Lv, d, vm_pad);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bool keep_pad, bf16_t* out, hipStream_t s) {
+int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bool keep_pad, bool ragged_frames, bf16_t* out,
+                           hipStream_t s) {
   if (d % 8) return -2;
-  hipLaunchKernelGGL(pack_reduce_dvm_kernel, dim3(cdiv(Mp, 4)), dim3(256), 0, s, dvm, t, B, S, Lv, Mp, d, keep_pad ? 1 : 0, out);
+  hipLaunchKernelGGL(pack_reduce_dvm_kernel, dim3(cdiv(Mp, 4)), dim3(256), 0, s, dvm, t, B, S, Lv, Mp, d, keep_pad ? 1 : 0, ragged_frames ? 1 : 0, out);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

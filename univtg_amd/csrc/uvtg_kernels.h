@@ -146,14 +146,20 @@ struct PackTables {
   int* pad2pack;                      // [B*S]: token row -> packed row (padded clips -> the representative, padded text -> -1)
   int* grad_map;                      // [B*S]: token row -> packed row carrying its gradient (valid rows, first padded clip), else -1
   unsigned char* kvalid;              // [Mp]
+  // conv-head frames (loss-only stream: ragged): sample b owns frame rows fstart[b] .. fstart[b] + kept[b] + 1 (first and last are the
+  // zero rows of the k = 3 convolution); frame_valid [sum(kept + 2)] = 1 on clip rows, 0 on zero rows
+  int* fstart; int* kept; float* frame_valid;
 };
 // keep_pad < 0: valid clips + ONE representative padded clip per sample; keep_pad >= 0: valid clips + the first keep_pad padded clips,
 // each its own row (keep_pad >= Lv: every clip row), no representative; padded clips beyond that are dropped (pad2pack = -1)
 int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev /* scratch [2B] */, int B, int Lv, int Lt, int keep_pad,
                        const PackTables& t, hipStream_t s);
 int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp, hipStream_t s);
-int launch_unpack_vm(const bf16_t* packed, const int* pad2pack, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s);
-int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bool keep_pad, bf16_t* out, hipStream_t s);
+// frames: null = uniform frames of Lv + 2 rows per sample; else t.fstart / t.kept
+int launch_unpack_vm(const bf16_t* packed, const PackTables& t, bool ragged_frames, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s);
+// dvm: gradient wrt the clip rows, [B * Lv, d] (uniform frames) or in frame-row space (ragged_frames)
+int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S, int Lv, int Mp, int d, bool keep_pad, bool ragged_frames, bf16_t* out,
+                           hipStream_t s);
 
 int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask, hipStream_t s);
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
@@ -190,6 +196,9 @@ struct HeadsFinalArgs {           // last conv layer of both heads + sigmoid/sig
   bf16_t* dh2; int lddh;          // zero-framed gradient wrt h2 (pre-activation of layer 3 input), relu' applied
   float* dw_span; float* db_span; float* dw_cls; float* db_cls;
   float* scratch; long long scratch_floats;   // optional [B, 9 d] per-sample weight-gradient partials (else atomics)
+  // ragged frames (null: sample b owns frame rows b * (Lv + 2) .. + Lv + 1): clips t >= kept[b] have no frame row; their predictions
+  // come out as the constants sigmoid(0) = 0.5 / (-0.5, +0.5) (loss-only stream: no loss reads them)
+  const int* fstart; const int* kept;
 };
 int launch_heads_final_fwd(const HeadsFinalArgs& a, hipStream_t s);
 int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s);
