@@ -189,6 +189,23 @@ int uvtg_hungarian(const float* pred_logits, int n_cls, const float* pred_spans_
                    float* cost_out /* [B, Q, max_t] */, long long* out_pred, long long* out_tgt,
                    int* n_match, uvtg_stream_t stream);
 
+/* ---- Moment-DETR set criterion: replaces SetCriterion.get_loss over one decoder layer's outputs
+ * (model/moment_detr.py:166-365, span_loss_type "l1"), given the index pairs uvtg_hungarian produced.
+ * pred_logits [B,Q,2], pred_spans_cxw [B,Q,2]; tgt_cxw, tgt_off, match_pred, match_tgt, n_match, max_t exactly as in uvtg_hungarian.
+ * saliency_scores [B,L] with pos_idx/neg_idx [B,n_pairs] int64 (NULL: loss_s_intra = 0, :257-258);
+ * proj_queries [B,Q,D] / proj_txt_mem [B,T,D] (NULL: no contrastive_align term).
+ * losses [6] (device) = loss_b, loss_g, loss_f, class_error, loss_s_intra, loss_contrastive_align.
+ * go [6] (device) or NULL: upstream gradient of each entry of losses (entry 3 is ignored); when given, the d_* arrays that
+ * are non-NULL receive the gradient with respect to the same-shaped prediction tensor (every element written).
+ * partials [B,8] float scratch.  Sums run in sample order: results are bit-reproducible. */
+int uvtg_detr_criterion(const float* pred_logits, const float* pred_spans_cxw, int B, int Q, const float* tgt_cxw,
+                        const int* tgt_off, const long long* match_pred, const long long* match_tgt, const int* n_match, int max_t,
+                        const float* saliency_scores, const long long* pos_idx, const long long* neg_idx, int n_pairs, int L,
+                        const float* proj_queries, const float* proj_txt_mem, int T, int D,
+                        float eos_coef, float temperature, float saliency_margin, const float* go, float* partials,
+                        float* losses, float* d_logits, float* d_spans, float* d_saliency, float* d_proj_queries,
+                        float* d_proj_txt_mem, uvtg_stream_t stream);
+
 /* ---- inference glue: replaces main/inference_mr.py:109-160 + utils/temporal_nms.py -----------
  * windows[b,t] = clamp((timestamp + pred_spans) * duration[b], 0, duration[b]); scores masked to 0
  * on padded clips; rank by score (stable, descending); greedy hull-IoU NMS.

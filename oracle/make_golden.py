@@ -224,6 +224,50 @@ def run_matcher(ref):
     print("matcher: ok")
 
 
+def run_detr_criterion(ref):
+    """Moment-DETR SetCriterion (model/moment_detr.py:166-365) on the real matcher's pairs: the six loss values, and the
+    autograd gradients of the weighted total with respect to every prediction tensor."""
+    import model.moment_detr as ref_detr
+    g = torch.Generator().manual_seed(23)
+    B, Q, L, T, D, P = 6, 10, 17, 9, 32, 2
+    sizes = [1, 2, 5, 3, 1, 4]
+    leaf = lambda t: t.clone().requires_grad_(True)
+    logits = leaf(torch.randn(B, Q, 2, generator=g))
+    spans = leaf(torch.stack([torch.rand(B, Q, generator=g), 0.05 + 0.4 * torch.rand(B, Q, generator=g)], -1))
+    sal = leaf(torch.randn(B, L, generator=g))
+    pq = leaf(torch.nn.functional.normalize(torch.randn(B, Q, D, generator=g), dim=-1))
+    pt = leaf(torch.nn.functional.normalize(torch.randn(B, T, D, generator=g), dim=-1))
+    tgt = [dict(spans=torch.stack([torch.rand(n, generator=g), 0.05 + 0.5 * torch.rand(n, generator=g)], -1)) for n in sizes]
+    pos = torch.randint(0, L, (B, P), generator=g)
+    neg = torch.randint(0, L, (B, P), generator=g)
+    matcher = ref.matcher.HungarianMatcher(cost_class=4, cost_span=10, cost_giou=1)
+    weight = dict(loss_b=10.0, loss_g=1.0, loss_f=4.0, loss_s_intra=1.0, loss_contrastive_align=0.02)
+    crit = ref_detr.SetCriterion(matcher=matcher, weight_dict=weight, eos_coef=0.1,
+                                 losses=["spans", "labels", "saliency", "contrastive_align"], temperature=0.07,
+                                 span_loss_type="l1", max_v_l=75, saliency_margin=0.2)
+    outputs = dict(pred_logits=logits, pred_spans=spans, saliency_scores=sal, proj_queries=pq, proj_txt_mem=pt)
+    targets = dict(span_labels=tgt, saliency_pos_labels=pos, saliency_neg_labels=neg)
+    losses = crit(outputs, targets)
+    total = sum(losses[k] * weight[k] for k in weight)
+    total.backward()
+    idx = matcher(dict(pred_logits=logits.detach(), pred_spans=spans.detach()), dict(span_labels=tgt))
+    store = dict(logits=logits.detach().numpy(), spans=spans.detach().numpy(), sal=sal.detach().numpy(),
+                 pq=pq.detach().numpy(), pt=pt.detach().numpy(), sizes=np.array(sizes),
+                 tgt=torch.cat([t["spans"] for t in tgt]).numpy(), pos=pos.numpy(), neg=neg.numpy(),
+                 weights=np.array([weight["loss_b"], weight["loss_g"], weight["loss_f"], 0.0, weight["loss_s_intra"],
+                                   weight["loss_contrastive_align"]], np.float32),
+                 hyper=np.array([0.1, 0.07, 0.2], np.float32),
+                 losses=np.array([float(losses[k]) for k in ("loss_b", "loss_g", "loss_f", "class_error", "loss_s_intra",
+                                                              "loss_contrastive_align")], np.float64),
+                 d_logits=logits.grad.numpy(), d_spans=spans.grad.numpy(), d_sal=sal.grad.numpy(), d_pq=pq.grad.numpy(),
+                 d_pt=pt.grad.numpy())
+    for b, (i, j) in enumerate(idx):
+        store[f"i{b}"] = i.numpy()
+        store[f"j{b}"] = j.numpy()
+    np.savez_compressed(os.path.join(OUT, "detr_criterion.npz"), **store)
+    print("detr_criterion: ok", store["losses"])
+
+
 def run_span_utils(ref):
     """Doctest known answers of utils/span_utils.py:13-20,32-39,55-61,106-110 + random matrices."""
     g = torch.Generator().manual_seed(3)
@@ -360,6 +404,9 @@ def run_collate(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    if sys.argv[1:] == ["detr_criterion"]:      # one fixture only (the others are unchanged)
+        run_detr_criterion(ref)
+        return
     tiny = dict(hidden_dim=64, nheads=2, dim_feedforward=96, enc_layers=2, v_feat_dim=34, t_feat_dim=24,
                 max_q_l=16, input_dropout=0.0, dropout=0.0, droppath=0.0)
     run_case(ref, "tiny_eval_ragged", O.make_cfg(**tiny), B=5, L_v=13, L_t=7, seed=11, ragged=True)
@@ -371,6 +418,7 @@ def main():
     run_case(ref, "config1_real_feats", O.make_cfg(**mid), B=1, L_v=15, L_t=12, seed=2018, ragged=False,
              real_feats=True)
     run_matcher(ref)
+    run_detr_criterion(ref)
     run_span_utils(ref)
     run_nms(ref)
     run_dense_targets(ref)

@@ -209,3 +209,86 @@ def hungarian_match(pred_logits, pred_spans_cxw, tgt_list, **w):
         out.append(lsap(C[b, :, off:off + n]))
         off += n
     return out
+
+
+def detr_criterion(pred_logits, pred_spans_cxw, tgt_list, indices, saliency=None, pos=None, neg=None, proj_q=None,
+                   proj_txt=None, eos_coef=0.1, temperature=0.07, margin=1.0, weights=None, dtype=np.float64):
+    """model/moment_detr.py:166-365 (span_loss_type 'l1') for one decoder layer: returns (losses[6], grads) with
+    losses = (loss_b, loss_g, loss_f, class_error, loss_s_intra, loss_contrastive_align) and, when ``weights`` [6] is
+    given, grads = d(sum_k weights[k] * losses[k]) / d(pred_logits, pred_spans, saliency, proj_q, proj_txt).
+    ``indices`` is the matcher's list of (pred_idx, tgt_idx) per sample (model/matcher.py:100)."""
+    f = dtype
+    lg, sp = np.asarray(pred_logits, f), np.asarray(pred_spans_cxw, f)
+    B, Q = sp.shape[:2]
+    w = np.zeros(6, f) if weights is None else np.asarray(weights, f)
+    matched = np.zeros((B, Q), bool)
+    tg = np.zeros((B, Q, 2), f)
+    for b, (i, j) in enumerate(indices):
+        matched[b, np.asarray(i, int)] = True
+        tg[b, np.asarray(i, int)] = np.asarray(tgt_list[b], f)[np.asarray(j, int)]
+    N = f(matched.sum())
+    # spans (:205-230): L1 on (c, w) and 1 - gIoU on (st, ed) over the matched pairs
+    src, tgt = sp[matched], tg[matched]
+    loss_b = np.abs(src - tgt).sum() / (2 * N)
+    x1, x2 = src[:, 0] - f(0.5) * src[:, 1], src[:, 0] + f(0.5) * src[:, 1]
+    y1, y2 = tgt[:, 0] - f(0.5) * tgt[:, 1], tgt[:, 0] + f(0.5) * tgt[:, 1]
+    inter = np.clip(np.minimum(x2, y2) - np.maximum(x1, y1), 0, None)
+    union = (x2 - x1) + (y2 - y1) - inter
+    enc = np.clip(np.maximum(x2, y2) - np.minimum(x1, y1), 0, None)
+    giou = inter / union - (enc - union) / enc
+    loss_g = (1 - giou).sum() / N
+    # labels (:234-253): weighted CE, plain mean over B*Q
+    cls = np.where(matched, 0, 1)
+    mx = lg.max(-1, keepdims=True)
+    lse = mx[..., 0] + np.log(np.exp(lg - mx).sum(-1))
+    cw = np.where(matched, f(1), f(eos_coef))
+    picked = np.take_along_axis(lg, cls[..., None], -1)[..., 0]
+    loss_f = (-cw * (picked - lse)).sum() / f(B * Q)
+    class_error = f(100) - f(100) * f((matched & (lg[..., 0] >= lg[..., 1])).sum()) / N
+    grads = {}
+    soft = np.exp(lg - lse[..., None])
+    onehot = np.stack([cls == 0, cls == 1], -1).astype(f)
+    grads["logits"] = w[2] * cw[..., None] * (soft - onehot) / f(B * Q)
+    # span gradients: every term is piecewise linear in the end points
+    ind = lambda c: c.astype(f)
+    act = ind((np.minimum(x2, y2) - np.maximum(x1, y1)) >= 0)
+    di1, di2 = -act * ind(x1 > y1), act * ind(x2 < y2)
+    du1, du2 = -1 - di1, 1 - di2
+    ea = ind((np.maximum(x2, y2) - np.minimum(x1, y1)) >= 0)
+    de1, de2 = -ea * ind(x1 < y1), ea * ind(x2 > y2)
+    dg1 = (di1 * union - inter * du1) / union ** 2 + (du1 * enc - union * de1) / enc ** 2
+    dg2 = (di2 * union - inter * du2) / union ** 2 + (du2 * enc - union * de2) / enc ** 2
+    dsp = np.zeros_like(sp)
+    d = np.sign(src - tgt) * w[0] / (2 * N)
+    d[:, 0] += -w[1] / N * (dg1 + dg2)
+    d[:, 1] += -w[1] / N * f(0.5) * (dg2 - dg1)
+    dsp[matched] = d
+    grads["spans"] = dsp
+    # saliency hinge (:255-270)
+    loss_s = f(0)
+    if saliency is not None:
+        s = np.asarray(saliency, f)
+        pos, neg = np.asarray(pos, int), np.asarray(neg, int)
+        P = pos.shape[1]
+        rows = np.arange(B)[:, None]
+        h = f(margin) + s[rows, neg] - s[rows, pos]
+        loss_s = np.clip(h, 0, None).sum() / f(B * P) * 2
+        ds = np.zeros_like(s)
+        gsc = ind(h >= 0) * w[4] * 2 / f(B * P)
+        np.add.at(ds, (np.broadcast_to(rows, neg.shape), neg), gsc)
+        np.add.at(ds, (np.broadcast_to(rows, pos.shape), pos), -gsc)
+        grads["sal"] = ds
+    # contrastive alignment (:272-290)
+    loss_c = f(0)
+    if proj_q is not None:
+        q, t = np.asarray(proj_q, f), np.asarray(proj_txt, f)
+        tsum = t.sum(1)                                         # (B, D): einsum('bmd,bnd->bmn').sum(2)
+        l = np.einsum("bqd,bd->bq", q, tsum) / f(temperature)
+        npos = matched.sum(1).astype(f)
+        m = l.max(1, keepdims=True)
+        lse_q = m[:, 0] + np.log(np.exp(l - m).sum(1))
+        loss_c = (-(l * matched).sum(1) / npos + lse_q).mean()
+        dl = w[5] / f(B) * (np.exp(l - lse_q[:, None]) - matched / npos[:, None]) / f(temperature)
+        grads["pq"] = dl[..., None] * tsum[:, None, :]
+        grads["pt"] = np.broadcast_to(np.einsum("bq,bqd->bd", dl, q)[:, None, :], t.shape).copy()
+    return np.array([loss_b, loss_g, loss_f, class_error, loss_s, loss_c], f), grads

@@ -191,6 +191,97 @@ def test_matcher_matches_reference(dev, golden_dir):
             assert i.tolist() == z[f"{pre}i{b}"].tolist() and j.tolist() == z[f"{pre}j{b}"].tolist(), (pre, b)
 
 
+def _detr_targets(z, dev):
+    sizes = z["sizes"].tolist()
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    return dict(span_labels=[dict(spans=torch.from_numpy(z["tgt"][off[b]:off[b + 1]]).to(dev)) for b in range(len(sizes))],
+                saliency_pos_labels=torch.from_numpy(z["pos"]).to(dev), saliency_neg_labels=torch.from_numpy(z["neg"]).to(dev))
+
+
+def test_detr_criterion_matches_reference(dev, golden_dir):
+    """the Moment-DETR SetCriterion (ref model/moment_detr.py:166-365) through the device matcher and
+    uvtg_detr_criterion -- loss values and every gradient against the real reference's autograd (golden), including the
+    aux_outputs repetition against the oracle."""
+    from univtg_amd.model import HungarianMatcher
+    from univtg_amd.moment_detr import SetCriterion
+    from oracle import postproc_oracle as P
+    z = np.load(os.path.join(golden_dir, "detr_criterion.npz"))
+    eos, temp, margin = (float(x) for x in z["hyper"])
+    names = ("loss_b", "loss_g", "loss_f", "class_error", "loss_s_intra", "loss_contrastive_align")
+    weight = {n: float(w) for n, w in zip(names, z["weights"]) if n != "class_error"}
+    crit = SetCriterion(HungarianMatcher(cost_class=4, cost_span=10, cost_giou=1), weight, eos,
+                        ["spans", "labels", "saliency", "contrastive_align"], temp, "l1", 75, saliency_margin=margin).to(dev)
+    leaf = lambda k: torch.from_numpy(z[k]).to(dev).requires_grad_(True)
+    outs = dict(pred_logits=leaf("logits"), pred_spans=leaf("spans"), saliency_scores=leaf("sal"), proj_queries=leaf("pq"),
+                proj_txt_mem=leaf("pt"))
+    targets = _detr_targets(z, dev)
+    losses = crit(outs, targets)
+    assert list(losses) == ["loss_b", "loss_g", "loss_f", "class_error", "loss_s_intra", "loss_contrastive_align"]
+    for n, r in zip(names, z["losses"]):
+        assert abs(float(losses[n]) - r) <= 2e-5 * max(1.0, abs(r)), (n, float(losses[n]), r)
+    sum(losses[k] * weight[k] for k in weight).backward()
+    for k, t in (("logits", "pred_logits"), ("spans", "pred_spans"), ("sal", "saliency_scores"), ("pq", "proj_queries"),
+                 ("pt", "proj_txt_mem")):
+        r = z["d_" + k]
+        err = np.abs(outs[t].grad.cpu().numpy() - r).max()
+        assert err <= 3e-5 * max(1.0, np.abs(r).max()), (k, err)
+    # aux_outputs: same losses again on another layer's predictions, without the saliency term (ref :355-363)
+    g = torch.Generator().manual_seed(5)
+    aux = dict(pred_logits=torch.randn(6, 10, 2, generator=g).to(dev),
+               pred_spans=torch.stack([torch.rand(6, 10, generator=g), 0.05 + 0.4 * torch.rand(6, 10, generator=g)], -1).to(dev),
+               proj_queries=outs["proj_queries"].detach(), proj_txt_mem=outs["proj_txt_mem"].detach())
+    both = crit({**{k: v.detach() for k, v in outs.items()}, "aux_outputs": [aux]}, targets)
+    assert "loss_s_intra_0" not in both and "class_error_0" in both
+    sizes = z["sizes"].tolist()
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    tg = [z["tgt"][off[b]:off[b + 1]] for b in range(len(sizes))]
+    lg, sp = aux["pred_logits"].cpu().numpy(), aux["pred_spans"].cpu().numpy()
+    idx = P.hungarian_match(lg, sp, tg, w_class=4.0, w_span=10.0, w_giou=1.0)
+    want, _ = P.detr_criterion(lg, sp, tg, idx, None, None, None, z["pq"], z["pt"], eos, temp, margin)
+    for n, r in zip(names, want):
+        if n != "loss_s_intra":
+            assert abs(float(both[n + "_0"]) - r) <= 2e-5 * max(1.0, abs(r)), (n, float(both[n + "_0"]), r)
+
+
+def test_detr_criterion_batch256_against_oracle(dev):
+    """Same criterion at a training-size batch (B=256, Q=10, D=64), values and gradients against the fp64 oracle."""
+    from univtg_amd.model import HungarianMatcher
+    from univtg_amd.moment_detr import SetCriterion
+    from oracle import postproc_oracle as P
+    g = torch.Generator().manual_seed(41)
+    B, Q, L, T, D, Pn = 256, 10, 75, 32, 64, 2
+    sizes = torch.randint(1, 6, (B,), generator=g).tolist()
+    tg = [torch.stack([torch.rand(n, generator=g), 0.05 + 0.5 * torch.rand(n, generator=g)], -1) for n in sizes]
+    arr = dict(logits=torch.randn(B, Q, 2, generator=g),
+               spans=torch.stack([torch.rand(B, Q, generator=g), 0.05 + 0.4 * torch.rand(B, Q, generator=g)], -1),
+               sal=torch.randn(B, L, generator=g), pq=torch.nn.functional.normalize(torch.randn(B, Q, D, generator=g), dim=-1),
+               pt=torch.nn.functional.normalize(torch.randn(B, T, D, generator=g), dim=-1))
+    pos, neg = torch.randint(0, L, (B, Pn), generator=g), torch.randint(0, L, (B, Pn), generator=g)
+    w = np.array([10.0, 1.0, 4.0, 0.0, 1.0, 0.02])
+    names = ("loss_b", "loss_g", "loss_f", "class_error", "loss_s_intra", "loss_contrastive_align")
+    crit = SetCriterion(HungarianMatcher(cost_class=4, cost_span=10, cost_giou=1), {}, 0.1,
+                        ["spans", "labels", "saliency", "contrastive_align"], 0.07, "l1", 75, saliency_margin=0.2).to(dev)
+    leaf = {k: v.to(dev).requires_grad_(True) for k, v in arr.items()}
+    outs = dict(pred_logits=leaf["logits"], pred_spans=leaf["spans"], saliency_scores=leaf["sal"], proj_queries=leaf["pq"],
+                proj_txt_mem=leaf["pt"])
+    targets = dict(span_labels=[dict(spans=t.to(dev)) for t in tg], saliency_pos_labels=pos.to(dev), saliency_neg_labels=neg.to(dev))
+    losses = crit(outs, targets)
+    sum(losses[n] * float(w[i]) for i, n in enumerate(names) if w[i]).backward()
+    npa = {k: v.numpy() for k, v in arr.items()}
+    tgn = [t.numpy() for t in tg]
+    idx = P.hungarian_match(npa["logits"], npa["spans"], tgn, w_class=4.0, w_span=10.0, w_giou=1.0)
+    dev_idx = crit.matcher(dict(pred_logits=leaf["logits"], pred_spans=leaf["spans"]), targets)
+    for (a, b), (c, d) in zip(idx, dev_idx):
+        assert a.tolist() == c.tolist() and b.tolist() == d.tolist()
+    want, G = P.detr_criterion(npa["logits"], npa["spans"], tgn, idx, npa["sal"], pos.numpy(), neg.numpy(), npa["pq"], npa["pt"],
+                               0.1, 0.07, 0.2, w)
+    for n, r in zip(names, want):
+        assert abs(float(losses[n]) - r) <= 3e-5 * max(1.0, abs(r)), (n, float(losses[n]), r)
+    for k in ("logits", "spans", "sal", "pq", "pt"):
+        err = np.abs(leaf[k].grad.cpu().numpy() - G[k]).max()
+        assert err <= 3e-5 * max(1e-3, np.abs(G[k]).max()), (k, err, np.abs(G[k]).max())
+
+
 def test_device_nms_known_answers(dev, golden_dir):
     """temporal_nms on real QVHighlights predictions (golden from the reference's own utils/temporal_nms.py)."""
     from univtg_amd import ops

@@ -114,6 +114,31 @@ def test_matcher_matches_reference(golden_dir):
         assert i.tolist() == z[f"u_i{b}"].tolist() and j.tolist() == z[f"u_j{b}"].tolist()
 
 
+def _detr_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "detr_criterion.npz"))
+    sizes = z["sizes"].tolist()
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    tg = [z["tgt"][off[b]:off[b + 1]] for b in range(len(sizes))]
+    idx = [(z[f"i{b}"], z[f"j{b}"]) for b in range(len(sizes))]
+    return z, tg, idx
+
+
+def test_detr_criterion_matches_reference(golden_dir):
+    """Moment-DETR SetCriterion (model/moment_detr.py:166-365): the six losses and the autograd gradients of the real reference."""
+    z, tg, idx = _detr_fixture(golden_dir)
+    got = P.hungarian_match(z["logits"], z["spans"], tg, w_class=4.0, w_span=10.0, w_giou=1.0)
+    for (a, b), (c, d) in zip(got, idx):
+        assert a.tolist() == c.tolist() and b.tolist() == d.tolist()
+    eos, temp, margin = (float(x) for x in z["hyper"])
+    for dt, tol in ((np.float64, 2e-7), (np.float32, 2e-5)):
+        L, G = P.detr_criterion(z["logits"], z["spans"], tg, idx, z["sal"], z["pos"], z["neg"], z["pq"], z["pt"], eos, temp, margin,
+                                z["weights"], dtype=dt)
+        assert np.allclose(L, z["losses"], rtol=tol * 10, atol=tol), (dt, L, z["losses"])
+        for k in ("logits", "spans", "sal", "pq", "pt"):
+            r = z["d_" + k]
+            assert np.abs(G[k] - r).max() <= tol * 10 * max(1.0, np.abs(r).max()), (dt, k)
+
+
 def test_lsap_against_scipy_random():
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(0)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "uvtg_profile_event_floor_ms": (C.c_double, []),
     "uvtg_profile_sections_start": (_I, []),
     "uvtg_profile_sections_stop": (_I, [_P, _P]),
+    "uvtg_detr_criterion": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P,
+                                 _P, _P, _P, _P, _P, _P, _P]),
     "uvtg_hungarian": (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
     "uvtg_decode_rank_nms": (_I, [_P] * 5 + [_I, _I, C.c_double, _I, _I] + [_P] * 4 + [_P]),
     "uvtg_postprocess_mr": (_I, [_P] * 6 + [_I, _I, _F, _I, C.c_double, _I, _I] + [_P] * 5 + [_P]),

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libuvtg.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "misc.hip", "losses.hip", "postproc.hip", "optim.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "misc.hip", "losses.hip", "postproc.hip", "detr.hip", "optim.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-value",
          "-Wno-pass-failed"]
 # per-source extras.  norm.hip: the row-batched LayerNorm kernels are fully unrolled register tiles; past LLVM's default

@@ -400,9 +400,11 @@ class HungarianMatcher(nn.Module):
         self.span_loss_type, self.max_v_l, self.foreground_label = span_loss_type, max_v_l, 0
 
     @torch.no_grad()
-    def forward(self, outputs, targets):
+    def match_device(self, outputs, targets):
+        """The matching as device arrays (no host sync): (pred_idx [B,max_t] int64, tgt_idx, n_match [B] int32, tgt_cxw [T,2],
+        tgt_off [B+1] int32, max_t) -- the layout uvtg_detr_criterion consumes."""
         lib = _lib.load()
-        logits, spans = _f32c(outputs["pred_logits"]), _f32c(outputs["pred_spans"])
+        logits, spans = _f32c(outputs["pred_logits"].detach()), _f32c(outputs["pred_spans"].detach())
         if not logits.is_cuda:
             raise RuntimeError("univtg_amd matcher runs on MI355X only (no CPU fallback)")
         B, Q = spans.shape[:2]
@@ -419,6 +421,12 @@ class HungarianMatcher(nn.Module):
         _lib.check(lib.uvtg_hungarian(_ptr(logits), logits.shape[-1], _ptr(spans), B, Q, _ptr(tgt), _ptr(off), max_t,
                                       float(self.cost_class), float(self.cost_span), float(self.cost_giou),
                                       _ptr(cost), _ptr(op), _ptr(ot), _ptr(nm), _stream()), "uvtg_hungarian")
+        return op, ot, nm, tgt, off, max_t
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        op, ot, nm = self.match_device(outputs, targets)[:3]
+        B = op.shape[0]
         op, ot, nm = op.cpu(), ot.cpu(), nm.cpu().tolist()
         if any(n < 0 for n in nm):
             raise RuntimeError("uvtg_hungarian: problem larger than the device LSAP limits (32 x 256)")
