@@ -273,6 +273,14 @@ template <int Mf, int R, bool READS, int NV> __device__ __forceinline__ void sgb
 // EOP: the launch has a bf16 epilogue operand (residB / gradPre).
 // ORD: 0 = all staging pieces of the next K tile right behind the barrier (round-1 order), 1 = behind the fragment reads of k-step 0,
 // interleaved with the MFMAs of k-steps 0 and 1
+#ifdef UVTG_NT_TRACE
+// measurement build only (tools/nt_trace.py): per-tile phase timestamps (100 MHz wall clock) of every workgroup
+__device__ unsigned long long* g_nt_trace_dev = nullptr;     // [grid][16 tiles][4 stamps] of the launch being traced
+__global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = ptr; }
+#define NT_STAMP(k) do { if (g_nt_trace_dev && tid == 0 && lt < 16) g_nt_trace_dev[((size_t)blockIdx.x * 16 + lt) * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define NT_STAMP(k) do { } while (0)
+#endif
 template <bool GATHER, int TM, bool EOP, int ORD>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   constexpr int TB = 256, KB = 64, TN = 2, BM = 64 * TM, PA = TM, PB = 4, NP = PA + PB;
@@ -347,7 +355,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   // this lane's 8 output columns
   const int c8 = (lane & 7) * 8;
   int it = 0;
+  [[maybe_unused]] int lt = 0;
   while (true) {
+    NT_STAMP(0);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
@@ -450,11 +460,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       sgb_kstep<Mf, R, false, LAST ? E3 : 0>();
       it++;
     };
+#ifdef UVTG_NT_TRACE
+    for (int kt = 0; kt + 1 < nk; kt++) { ktile(kt, std::false_type{}); if (kt == 0) NT_STAMP(1); }
+#else
     for (int kt = 0; kt + 1 < nk; kt++) ktile(kt, std::false_type{});
+#endif
     // last K tile of this output tile: the pieces now belong to K tile 0 of the next tile (or, without one, re-load this tile's)
     if (next < ntiles) tile_origin(next, ngz, nm0, nn0);
     set_offsets(ngz, nm0, nn0);
     ktile(nk - 1, std::true_type{});
+    NT_STAMP(2);
     // ---------------- epilogue of `tile`, out of the stage consumed last ----------------
     if (p.act == 100) {   // measurement aid: main loop only
       float t = 0.f;
@@ -567,6 +582,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         }
       }
     }
+    NT_STAMP(3);
+    lt++;
     if (next >= ntiles) break;
     tile = next; gz = ngz; m0 = nm0; n0 = nn0;
   }
@@ -998,6 +1015,30 @@ static int nt_order(int tm) {
   }
   return ord[tm - 2];
 }
+#ifdef UVTG_NT_TRACE
+static unsigned long long* g_trace_buf = nullptr;
+static int g_trace_next = 0, g_trace_max = 0;
+static int g_trace_info[256][8];
+// buf: device [max_launches][256][16][4] u64 (zeroed by the caller); the next max_launches persistent-NT launches are traced
+extern "C" int uvtg_debug_nt_trace(void* buf, int max_launches) {
+  g_trace_buf = (unsigned long long*)buf; g_trace_next = 0; g_trace_max = max_launches < 256 ? max_launches : 256;
+  return 0;
+}
+extern "C" int uvtg_debug_nt_trace_info(int i, int* out8) {
+  if (i < 0 || i >= g_trace_next) return -1;
+  for (int k = 0; k < 8; k++) out8[k] = g_trace_info[i][k];
+  return 0;
+}
+static void nt_trace_launch(const GemmArgs& b, int tm, int grid, bool gather, bool eop, hipStream_t s) {
+  unsigned long long* ptr = nullptr;
+  if (g_trace_buf && g_trace_next < g_trace_max) {
+    ptr = g_trace_buf + (size_t)g_trace_next * 256 * 16 * 4;
+    int* o = g_trace_info[g_trace_next++];
+    o[0] = b.M; o[1] = b.N; o[2] = b.K; o[3] = tm; o[4] = eop; o[5] = gather; o[6] = grid; o[7] = b.groups;
+  }
+  hipLaunchKernelGGL(nt_trace_set_kernel, dim3(1), dim3(1), 0, s, ptr);
+}
+#endif
 static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   if (!g_num_cu) {
     int dev = 0; hipDeviceProp_t pr;
@@ -1024,6 +1065,9 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1;
   const bool eop = b.residB || (b.actgrad && b.gradPre);
+#ifdef UVTG_NT_TRACE
+  nt_trace_launch(b, best_tm, grid, gather, eop, s);
+#endif
   uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
   int rc;
   if (nt_order(best_tm) == 0)

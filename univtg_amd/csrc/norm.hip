@@ -361,6 +361,139 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512, (NV * VEC <= 16) ? UVTG_
     }
   }
 }
+// wave64 sum without the LDS crossbar: four DPP steps inside each row of 16 lanes, then the four row sums through SGPRs
+// (6 dependent ds_bpermute round trips per __shfl_xor reduction otherwise -- the row loop below is a latency chain)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
+  const int b = __float_as_int(v);      // (the builtin is typed int: a float argument would be converted by VALUE)
+  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+
+// The encoder's LayerNorm backward (bf16 streams, D <= 1024, no dropout / ReLU mask): same math as ln_bwd_kernel, built for the
+// HBM rate -- 164 MB per launch at config 2 (x, g in; dx scaled + unscaled out).
+//  * the next row's x / g (/ g2) are fetched, still PACKED (4 registers per 16 bytes), before the current row's math;
+//  * dgamma / dbeta accumulate in the wave's LDS slab and gamma is read from LDS: 48 fewer live registers than ln_bwd_kernel,
+//    which spilled 20 dwords inside the row loop at its 128-register (4 waves per SIMD) budget.
+template <int NV>
+__global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) {
+  extern __shared__ float red[];       // [waves][2][D] dgamma / dbeta partials, then gamma [D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int D = a.D;
+  float* mine = red + (size_t)wave * 2 * D;
+  float* sgam = red + (size_t)wpb * 2 * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) sgam[c] = a.gamma[c];
+  for (int c = lane; c < 2 * D; c += 64) mine[c] = 0.f;
+  __syncthreads();
+  const int stride = gridDim.x * wpb;
+  const bool have_g2 = a.g2B != nullptr;
+  u32x4 px[NV], pg[NV], pg2[NV];
+  float pmean = 0.f, prstd = 0.f;
+  auto fetch = [&](int r) {            // r is clamped by the caller: always a legal row
+    const size_t row = (size_t)r;
+    pmean = a.mean[row]; prstd = a.rstd[row];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int c = (i * 64 + lane) * 8;
+      px[i] = (u32x4){0, 0, 0, 0}; pg[i] = (u32x4){0, 0, 0, 0}; pg2[i] = (u32x4){0, 0, 0, 0};
+      if (c < D) {
+        px[i] = *(const u32x4*)(a.xB + row * a.ldxB + c);
+        pg[i] = *(const u32x4*)(a.gB + row * a.ldgB + c);
+      }
+    }
+    if (have_g2) {
+      size_t r2 = row;
+      bool on = true;
+      if (a.g2_S > 0) {
+        const int b = r / a.g2_S, sidx = r - b * a.g2_S;
+        on = sidx < a.g2_Lv;
+        r2 = (size_t)(b * a.g2_Lv + sidx);
+      }
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+          const int c = (i * 64 + lane) * 8;
+          if (c < D) pg2[i] = *(const u32x4*)(a.g2B + r2 * a.ldg2B + c);
+        }
+      }
+    }
+  };
+  int row = blockIdx.x * wpb + wave;
+  if (row < a.rows) fetch(row);
+  for (; row < a.rows; row += stride) {
+    u32x4 cx[NV], cg[NV], cg2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) { cx[i] = px[i]; cg[i] = pg[i]; cg2[i] = pg2[i]; }
+    const float mean = pmean, rstd = prstd;
+    fetch(min(row + stride, a.rows - 1));
+    float xh[NV][8], gh[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < D) {
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          xh[i][2 * e] = (__uint_as_float(cx[i][e] << 16) - mean) * rstd;
+          xh[i][2 * e + 1] = (__uint_as_float(cx[i][e] & 0xffff0000u) - mean) * rstd;
+          g[2 * e] = __uint_as_float(cg[i][e] << 16) + __uint_as_float(cg2[i][e] << 16);
+          g[2 * e + 1] = __uint_as_float(cg[i][e] & 0xffff0000u) + __uint_as_float(cg2[i][e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          f32x4 dg = *(f32x4*)(mine + c + 4 * h), db = *(f32x4*)(mine + D + c + 4 * h);
+          const f32x4 gm = *(const f32x4*)(sgam + c + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float gv = g[4 * h + e], x = xh[i][4 * h + e];
+            dg[e] += gv * x; db[e] += gv;
+            const float t = gv * gm[e];
+            gh[i][4 * h + e] = t;
+            s1 += t; s2 += t * x;
+          }
+          *(f32x4*)(mine + c + 4 * h) = dg; *(f32x4*)(mine + D + c + 4 * h) = db;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { xh[i][e] = 0.f; gh[i][e] = 0.f; }
+      }
+    }
+    const float c1 = wave_sum_dpp(s1) / (float)D, c2 = wave_sum_dpp(s2) / (float)D;
+    const float rs = a.rowscale ? a.rowscale[a.row_sample ? a.row_sample[row] : row / a.rs_seg] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < D) {
+        float dx[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) dx[e] = rstd * (gh[i][e] - c1 - xh[i][e] * c2);
+        if (a.dxF) storev<8>(a.dxF + (size_t)row * a.lddxF + c, dx);
+        if (a.dxB2) storeb<8>(a.dxB2 + (size_t)row * a.lddxB2 + c, dx);
+        if (a.dxB) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) dx[e] *= rs;
+          storeb<8>(a.dxB + (size_t)row * a.lddxB + c, dx);
+        }
+      }
+    }
+  }
+  if (a.dgamma) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
+      float t = 0.f;
+      for (int w = 0; w < wpb; w++) t += red[(size_t)w * 2 * D + c];
+      if (a.partial) a.partial[(size_t)blockIdx.x * 2 * D + c] = t;
+      else atomicAdd((c < D ? a.dgamma + c : a.dbeta + (c - D)), t);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const LnBwdArgs a, int nblocks) {
   __shared__ float red2[16][17];
   const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;        // 16 columns x 16 block lanes
@@ -517,6 +650,15 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
   const int blocks = min(cdiv(a.rows, wpb), max(1, (UVTG_LN_BLOCKS) * 8 / wpb));
   LnBwdArgs b = a;
   if (!b.dgamma || b.partial_floats < (long long)blocks * 2 * b.D) b.partial = nullptr;
+  if constexpr (VEC == 8 && NV <= 2) {
+    static const bool lean_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
+    if (bf && a.gB && a.p_drop == 0.f && !a.relu_from_x && wpb == 8 && !lean_off) {
+      hipLaunchKernelGGL((ln_bwd_lean_kernel<NV>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
+      if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 16)), dim3(256), 0, s, b, blocks);
+      UVTG_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (bf) hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, true>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   else hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, false>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 16)), dim3(256), 0, s, b, blocks);
