@@ -912,7 +912,36 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
   const int kq = (p.K + 3) / 4;
   const long long total = (long long)p.N * kq;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < total) {
+  const int taps = p.ktap > 0 ? p.K / p.ktap : 0;
+  if (taps >= 2 && taps <= 4 && p.col_stride == taps && p.ktap % 4 == 0 && taps * p.ktap == p.K && p.ldo % 4 == 0 &&
+      (((uintptr_t)p.out) & 15) == 0) {
+    // conv taps: a thread folds the `taps` tiles that hold columns kk .. kk + 3 of every tap and writes the 4 x taps floats of
+    // out[n][kk .. kk + 3][0 .. taps) as ONE contiguous run (one tap at a time is a stride-`taps` read-modify-write scatter:
+    // 38 us instead of 16 for the 61 MB of slabs of a conv gradient)
+    const int kq2 = p.ktap / 4;
+    if (idx < (long long)p.N * kq2) {
+      const int n = (int)(idx / kq2), kk = (int)(idx % kq2) * 4;
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (t < taps) {
+          const int k = t * p.ktap + kk;
+          const int tile = plan.tile_base[gi] + (n >> 8) * tiles_k + (k >> 8);
+          const float* sp = plan.scratch + (size_t)tile * 65536 + (size_t)(n & 255) * 256 + (k & 255);
+          f32x4 s = {0.f, 0.f, 0.f, 0.f};
+          for (int sidx = 0; sidx < splits; sidx++) s += *(const f32x4*)(sp + (size_t)sidx * tiles * 65536);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e * taps + t] = s[e];      // (taps is uniform: the indices resolve per branch below)
+        }
+      }
+      float* op = p.out + (size_t)n * p.ldo + (size_t)kk * taps;
+      for (int j = 0; j < taps; j++) {
+        f32x4 o = *(f32x4*)(op + 4 * j);
+        o[0] += v[4 * j]; o[1] += v[4 * j + 1]; o[2] += v[4 * j + 2]; o[3] += v[4 * j + 3];
+        *(f32x4*)(op + 4 * j) = o;
+      }
+    }
+  } else if (idx < total) {
     const int n = (int)(idx / kq), k = (int)(idx % kq) * 4;
     const int tile = plan.tile_base[gi] + (n >> 8) * tiles_k + (k >> 8);
     const float* sp = plan.scratch + (size_t)tile * 65536 + (size_t)(n & 255) * 256 + (k & 255);

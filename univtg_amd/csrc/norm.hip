@@ -494,19 +494,30 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
     }
   }
 }
+// Folds the per-block partials [nblocks][2 D] into dgamma / dbeta.  grid = (2 D / 64 column chunks, row splits): a block owns 64
+// consecutive columns (256-byte rows of the partial matrix: full lines) and a slice of the partial rows, 4 row lanes per column,
+// 4 independent loads in flight per thread; the few row splits meet in fp32 atomics (<= 8 per address).
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const LnBwdArgs a, int nblocks) {
-  __shared__ float red2[16][17];
-  const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;        // 16 columns x 16 block lanes
-  const int c = blockIdx.x * 16 + il, n = 2 * a.D;
-  float s = 0.f;
-  if (c < n) for (int b = bl; b < nblocks; b += 16) s += a.partial[(size_t)b * n + c];
-  red2[bl][il] = s;
+  __shared__ float red2[4][64];
+  const int il = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + il, n = 2 * a.D;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(b0 + per, nblocks);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < n) {
+    const float* pp = a.partial + c;
+    int b = b0 + bl;
+    for (; b + 12 < b1; b += 16) {
+      s0 += pp[(size_t)b * n]; s1 += pp[(size_t)(b + 4) * n]; s2 += pp[(size_t)(b + 8) * n]; s3 += pp[(size_t)(b + 12) * n];
+    }
+    for (; b < b1; b += 4) s0 += pp[(size_t)b * n];
+  }
+  red2[bl][il] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (bl == 0 && c < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; k++) t += red2[k][il];
-    if (c < a.D) a.dgamma[c] += t; else a.dbeta[c - a.D] += t;
+    const float t = (red2[0][il] + red2[1][il]) + (red2[2][il] + red2[3][il]);
+    if (gridDim.y == 1) { if (c < a.D) a.dgamma[c] += t; else a.dbeta[c - a.D] += t; }
+    else atomicAdd(c < a.D ? a.dgamma + c : a.dbeta + (c - a.D), t);
   }
 }
 
@@ -654,14 +665,14 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
     static const bool lean_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
     if (bf && a.gB && a.p_drop == 0.f && !a.relu_from_x && wpb == 8 && !lean_off) {
       hipLaunchKernelGGL((ln_bwd_lean_kernel<NV>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
-      if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 16)), dim3(256), 0, s, b, blocks);
+      if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
       UVTG_CHECK_LAUNCH();
       return 0;
     }
   }
   if (bf) hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, true>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   else hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, false>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
-  if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 16)), dim3(256), 0, s, b, blocks);
+  if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -732,7 +743,7 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     const int rb = cdiv(a.rows, rpb);
     if ((long long)rb * 2 * a.D <= a.partial_floats) {
       hipLaunchKernelGGL(ln_dgb_wide_kernel, dim3(cdiv(a.D, 512), rb), dim3(256), 0, s, a, rpb);
-      hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a.D, 16)), dim3(256), 0, s, a, rb);
+      hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a.D, 64), rb >= 128 ? 8 : 1), dim3(256), 0, s, a, rb);
       UVTG_CHECK_LAUNCH();
       return 0;
     }
