@@ -191,13 +191,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       *(u32x2*)(p.outPre + go + orow * p.ldpre_out + n) = t;
     }
     if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    else if (p.act == 2) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+    else if (p.act == 2) {      // (the bf16 mode shares ONE GELU with the persistent kernel: both tile paths must give the same bits)
+      if constexpr (X3) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+      else { v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]); }
+    }
     if (p.actgrad) {
       const u32x2 t = *(const u32x2*)(p.gradPre + gp + orow * p.ldgp + n);
       const float q0 = __uint_as_float(t[0] << 16), q1 = __uint_as_float(t[0] & 0xffff0000u);
       const float q2 = __uint_as_float(t[1] << 16), q3 = __uint_as_float(t[1] & 0xffff0000u);
       if (p.actgrad == 1) { v[0] = q0 > 0.f ? v[0] : 0.f; v[1] = q1 > 0.f ? v[1] : 0.f; v[2] = q2 > 0.f ? v[2] : 0.f; v[3] = q3 > 0.f ? v[3] : 0.f; }
-      else { v[0] *= gelu_erf_grad(q0); v[1] *= gelu_erf_grad(q1); v[2] *= gelu_erf_grad(q2); v[3] *= gelu_erf_grad(q3); }
+      else if constexpr (X3) { v[0] *= gelu_erf_grad(q0); v[1] *= gelu_erf_grad(q1); v[2] *= gelu_erf_grad(q2); v[3] *= gelu_erf_grad(q3); }
+      else { v[0] *= gelu_fast_grad(q0); v[1] *= gelu_fast_grad(q1); v[2] *= gelu_fast_grad(q2); v[3] *= gelu_fast_grad(q3); }
     }
     if (p.rowscale) { const float rs = p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg]; v = rs == 0.f ? (f32x4){0.f, 0.f, 0.f, 0.f} : v * rs; }
     if (p.resid) { const f32x4 t = *(const f32x4*)(p.resid + orow * p.ldr + n); v += t; }
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
           } else if (p.act == 2) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 8; e++) v[e] = gelu_fast(v[e]);
           }
           u32x4 eop = {0, 0, 0, 0};
           if constexpr (GROUPS) eop = ecur;
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             for (int e = 0; e < 4; e++) {
               const float q0 = __uint_as_float(eop[e] << 16), q1 = __uint_as_float(eop[e] & 0xffff0000u);
               if (p.actgrad == 1) { v[2 * e] = q0 > 0.f ? v[2 * e] : 0.f; v[2 * e + 1] = q1 > 0.f ? v[2 * e + 1] : 0.f; }
-              else { v[2 * e] *= gelu_erf_grad(q0); v[2 * e + 1] *= gelu_erf_grad(q1); }
+              else { v[2 * e] *= gelu_fast_grad(q0); v[2 * e + 1] *= gelu_fast_grad(q1); }
             }
           }
           if (p.rowscale) {      // (a zero factor SELECTS zero: the masked frame rows of the conv heads may have accumulated garbage)
