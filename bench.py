@@ -318,8 +318,8 @@ def main():
                    scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
                    config=dict(workload=f"{wl['what']}: L_v={Lv} L_t={Lt} D_v=2818 D_t=512 d=1024 F=1024 H=8 E=4, full train step "
                                         f"(fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, ragged valid lengths: {wl['lens']}; encoder rows = valid "
-                                        "clips + the 3 padded clips per sample inside the conv heads' receptive field + valid text tokens (losses and "
-                                        "all gradients exactly the padded execution's)"
+                                        "clips + the 3 padded clips per sample inside the conv heads' receptive field + valid text tokens; the video "
+                                        "input projection runs on those clips only (losses and all gradients exactly the padded execution's)"
                                         if packed else f"{wl['what']}: padded execution",
                                baseline_config=args.config, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
                    world_size=world, comm_backend=(backend if world > 1 else None), comm_world_size=comm_size,
@@ -335,6 +335,7 @@ def main():
                                               "executed_*: the FLOPs of the rows the packed stream really runs, same time"),
                    encoder_rows_fraction=round(rows_halo if packed else 1.0, 4), all_clip_rows_fraction=round(rows_text, 4),
                    eval_packed_rows_fraction=round(rows_full, 4),
+                   projected_clip_rows_fraction=round(sum(sum(min(Lv, x + 3) for x in a) for a, _ in lens) / (len(lens) * B * Lv), 4) if packed else 1.0,
                    all_clip_rows_ms_per_step=None if allrows_ms is None else round(allrows_ms, 3),
                    padded_execution_ms_per_step=None if padded_ms is None else round(padded_ms, 3),
                    numerics="train-mode calls run the input projections on plain bf16 operands (saliency_scores within 3e-2 of fp32); the "

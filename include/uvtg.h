@@ -89,6 +89,10 @@ int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* params, void* 
  *              (receptive field +-3); every loss masks the padded positions (model/univtg.py:195-282).  Losses and ALL parameter
  *              gradients are therefore exactly the reference's; pred_* at padded positions beyond the halo come out as the heads'
  *              response to zero rows (finite, meaningless -- nothing reads them in training).
+ *          In every variant the VIDEO INPUT PROJECTION runs only on the clips that own a packed row (the feature LayerNorm gathers
+ *          them; dropout counters stay keyed by the padded row, so the masks are the padded execution's).  x0 keeps its padded
+ *          layout: the rows of the other padded clips are copies of the representative's row (first variant: bit-identical to
+ *          computing them) or zeros (loss-only variant: saliency at those positions is the masked constant + 0).
  *          The choice is a function of (dims, lens_host != NULL) only, so uvtg_backward -- which must get the same array -- makes the
  *          same one.  With memory != NULL: ignored in eval calls, error -24 in training calls. */
 int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wcache,

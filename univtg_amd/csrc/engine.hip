@@ -146,6 +146,8 @@ struct WSpace {
     pk.row_sample = a.take<int>(M); pk.row_src = a.take<int>(M); pk.row_pos = a.take<int>(M);
     pk.pad2pack = a.take<int>(M); pk.grad_map = a.take<int>(M); pk.kvalid = a.take<unsigned char>(M);
     pk.fstart = a.take<int>(B); pk.kept = a.take<int>(B); pk.frame_valid = a.take<float>((size_t)m.Rp + 1);
+    pk.vin_src = a.take<int>(m.Mv); pk.vin_dst = a.take<int>(m.Mv); pk.vin_x0 = a.take<int>(m.Mv); pk.vin_of = a.take<int>(m.Mv);
+    pk.tin_dst = a.take<int>(m.Mt); pk.vin_cnt = a.take<int>(B);
     xb0p = fast ? a.take<bf16_t>(M * d) : nullptr; ub0p = fast ? a.take<bf16_t>(M * d) : nullptr;
     g2p = (fast && tr) ? a.take<bf16_t>(M * d) : nullptr;
     for (int i = 0; i < 2; i++) {
@@ -280,6 +282,15 @@ int pack_mode(const uvtg_dims& c, const int* lens_host) {
 int halo_frame_rows(const Dm& m, const int* lens) {
   long long n = 0;
   for (int b = 0; b < m.c.B; b++) n += (lens[b] + HALO < m.c.Lv ? lens[b] + HALO : m.c.Lv) + 2;
+  return (int)n;
+}
+// clip rows that have a packed row (= rows of the compact video input projection): valid clips + representative / halo / all
+int compact_clip_rows(const Dm& m, const int* lens, int mode) {
+  long long n = 0;
+  for (int b = 0; b < m.c.B; b++) {
+    const int lv = lens[b];
+    n += mode == PACK_TEXT ? m.c.Lv : (mode == PACK_HALO ? (lv + HALO < m.c.Lv ? lv + HALO : m.c.Lv) : lv + (lv < m.c.Lv ? 1 : 0));
+  }
   return (int)n;
 }
 // rows of the packed encoder stream for these host-side lengths (lens[0..B) clips, lens[B..2B) text tokens per sample)
@@ -459,17 +470,23 @@ struct Fwd {
   bool fast, tr, pp;
   bool packed = false; int Mrows = 0;     // packed (ragged) encoder stream: Mrows <= B * S rows (see misc.hip)
   bool halo = false; int Rf = 0;          // loss-only stream: ragged conv-head frames of Rf rows in all (else B * (Lv + 2))
+  int Rv = 0;                             // packed: clip rows of the compact video input projection (pk.vin_*)
   int run_gemm(GemmArgs& g, bool x3) { return x3 ? launch_gemm_nt_f32x3(g, s) : launch_gemm_nt_bf16(g, s); }
   void set_out(GemmArgs& g, void* p, int ld) { if (fast) { g.outB = (bf16_t*)p; g.ldoB = ld; } else { g.outF = (float*)p; g.ldoF = ld; } }
 
   // one modality of the input projection (model/univtg.py:91-100,399-406) -> rows of x0 / xb[0] / ub[0]
   int project(int which, const float* src, float* x0) {
-    const int R = which == 0 ? m.Mv : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
+    // packed stream: the video projection runs on the clips that HAVE a packed row only (compact rows, tables pk.vin_*: the feature
+    // LayerNorm gathers them from src, dropout counters stay keyed by the padded row), and both modalities write x / x + pos
+    // straight into the packed layer-0 operands (text rows through pk.tin_dst); x0 keeps the padded layout.
+    const bool cv = packed && which == 0;
+    const int R = which == 0 ? (packed ? Rv : m.Mv) : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
     const int L = which == 0 ? m.c.Lv : m.c.Lt, d = m.c.d;
     const int t0 = which == 0 ? VP0G : TP0G, t1 = which == 0 ? VP1G : TP1G;
     const unsigned rs = which == 0 ? UVTG_RNG_IN_VID : UVTG_RNG_IN_TXT;
     const float p_in = tr ? m.c.p_in : 0.f;
     LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
+    if (cv) { ln.src_rows = ws.pk.vin_src; ln.gather_x = 1; }
     ln.x = src; ln.ldx = Din; ln.rows = R; ln.D = Din; ln.gamma = P[m.tail(t0)]; ln.beta = P[m.tail(t0 + 1)]; ln.eps = 1e-5f;
     ln.mean = ws.m0[which]; ln.rstd = ws.r0[which]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs; ln.Dpad = Kp;
     if (pp) { ln.yF2 = (float*)ws.a1[which]; ln.ldyF2 = Kp; ln.yB = ws.a1B[which]; ln.ldyB = Kp; }
@@ -480,6 +497,7 @@ struct Fwd {
     g.bias = P[m.tail(t0 + 3)]; g.act = 1; g.outF = ws.h1[which]; g.ldoF = d;
     TRY(run_gemm(g, pp));
     memset(&ln, 0, sizeof(ln));
+    if (cv) ln.src_rows = ws.pk.vin_src;
     ln.x = ws.h1[which]; ln.ldx = d; ln.rows = R; ln.D = d; ln.gamma = P[m.tail(t1)]; ln.beta = P[m.tail(t1 + 1)]; ln.eps = 1e-5f;
     ln.mean = ws.m1[which]; ln.rstd = ws.r1[which]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs + 1; ln.Dpad = d;
     if (pp) { ln.yF2 = (float*)ws.a2[which]; ln.ldyF2 = d; ln.yB = ws.a2B[which]; ln.ldyB = d; }
@@ -488,9 +506,10 @@ struct Fwd {
     GemmArgs g2 = gemm_base(ws.a2[which], d, pp ? (const void*)P[m.tail(t1 + 2)] : (const void*)(which == 0 ? w.vp1B : w.tp1B), d, R, d, d);
     g2.bias = P[m.tail(t1 + 3)];
     g2.bias2 = P[m.tail(TOK)] + (which == 0 ? d : 0);          // token-type row 1 = video, 0 = text (univtg.py:114-115)
-    g2.o_seg = L; g2.o_seg_stride = m.S; g2.o_off = which == 0 ? 0 : m.c.Lv;
+    if (cv) { g2.o_rows = ws.pk.vin_dst; g2.f_rows = ws.pk.vin_x0; g2.pos_map = ws.pk.vin_src; }
+    else { g2.o_seg = L; g2.o_seg_stride = m.S; g2.o_off = which == 0 ? 0 : m.c.Lv; if (packed) g2.o_rows = ws.pk.tin_dst; }
     g2.outF = x0; g2.ldoF = d;
-    if (fast) { g2.outB = (bf16_t*)ws.xb[0]; g2.ldoB = d; g2.outU = (bf16_t*)ws.ub[0]; }
+    if (fast) { g2.outB = packed ? ws.xb0p : (bf16_t*)ws.xb[0]; g2.ldoB = d; g2.outU = packed ? ws.ub0p : (bf16_t*)ws.ub[0]; }
     else g2.outUF = (float*)ws.ub[0];
     g2.ldoU = d;
     if (which == 0) { g2.pos = ws.pos; g2.ldpos = d; g2.pos_rows = R; }
@@ -643,6 +662,7 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
     TRY(packed_rows(m, lens_host, pmode, &mp));
     f.packed = true; f.Mrows = mp;
     f.halo = pmode == PACK_HALO; f.Rf = f.halo ? halo_frame_rows(m, lens_host) : m.Rp;
+    f.Rv = compact_clip_rows(m, lens_host, pmode);
     // the device-side tables are built from the MASKS (no copy out of the caller's pageable lens_host, which is only read here,
     // synchronously, for the row count): lens_host must be the masks' prefix lengths
     TRY(launch_pack_tables(src_vid_mask, src_txt_mask, ws.lens_dev, m.c.B, m.c.Lv, m.c.Lt, pmode == PACK_TEXT ? m.c.Lv : (pmode == PACK_HALO ? HALO : -1),
@@ -652,8 +672,8 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, s));
   if (f.tr && m.c.p_path > 0.f) TRY(launch_droppath_scales(ws.dps, 2 * m.c.E, m.c.B, m.c.p_path, m.c.seed, s));
   TRY(f.project(0, src_vid, x0));
+  if (f.packed && f.Rv < m.Mv) TRY(launch_fill_dropped_rows(x0, ws.pk, pmode == PACK_FULL, m.c.B, m.S, m.c.Lv, m.c.d, s));
   TRY(f.project(1, src_txt, x0));
-  if (f.packed) TRY(launch_pack_rows((const bf16_t*)ws.xb[0], (const bf16_t*)ws.ub[0], ws.pk.row_src, f.Mrows, m.c.d, ws.xb0p, ws.ub0p, s));
   uvtg_prof_section(0, 0, s);
   for (int l = 0; l < m.c.E; l++) TRY(f.layer(l, memory));
   uvtg_prof_section(0, 1, s);
@@ -848,12 +868,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // ---------------- saliency branch ----------------
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
   sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0B = dx0; sa.dw_pool = G(m.tail(POOL));
-  if (packed) sa.dx0_map = ws.pk.grad_map;
+  if (packed) { sa.dx0_map = ws.pk.grad_map; sa.vout_map = ws.pk.vin_of; }
   sa.dq = ws.sal_dq; sa.dlog = ws.sal_dlog; sa.out_vid = ws.dyP[0]; sa.out_txt = ws.dyP[1];
   TRY(launch_saliency_bwd(sa, s));
   // ---------------- input projections ----------------
   for (int which = 0; which < 2; which++) {
-    const int R = which == 0 ? m.Mv : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
+    const bool cv = packed && which == 0;      // compact clip rows (see Fwd::project)
+    const int R = which == 0 ? (packed ? compact_clip_rows(m, lens_host, pmode) : m.Mv) : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
     const int L = which == 0 ? Lv : m.c.Lt, roff = which == 0 ? 0 : Lv;
     const int t0 = which == 0 ? VP0G : TP0G, t1 = which == 0 ? VP1G : TP1G;
     const unsigned rs = which == 0 ? UVTG_RNG_IN_VID : UVTG_RNG_IN_TXT;
@@ -872,6 +893,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.g = ws.dA2[which]; lb.ldg = d; lb.x = ws.h1[which]; lb.ldx = d; lb.mean = ws.m1[which]; lb.rstd = ws.r1[which];
     lb.gamma = P[m.tail(t1)]; lb.rows = R; lb.D = d; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs + 1;
     lb.dgamma = G(m.tail(t1)); lb.dbeta = G(m.tail(t1 + 1)); lb.dxB = ws.dh1b[which]; lb.lddxB = d; lb.rs_seg = 1; lb.relu_from_x = 1;
+    if (cv) lb.src_rows = ws.pk.vin_src;
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
     TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
@@ -882,6 +904,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.g = ws.dA1[which]; lb.ldg = Kp; lb.x = src; lb.ldx = Din; lb.mean = ws.m0[which]; lb.rstd = ws.r0[which];
     lb.gamma = P[m.tail(t0)]; lb.rows = R; lb.D = Din; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs;
     lb.dgamma = G(m.tail(t0)); lb.dbeta = G(m.tail(t0 + 1)); lb.rs_seg = 1;
+    if (cv) { lb.src_rows = ws.pk.vin_src; lb.gather_x = 1; }
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
   }

@@ -183,10 +183,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     const int m = m0 + wm * 64 + row;
     if (m >= p.M) continue;
     f32x4 v = *(const f32x4*)(wbuf + row * 64 + c4);
-    const size_t orow = (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off);
+    size_t orow = (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off), frow = orow;
+    bool okB = true;                                // the non-outF outputs of this row are written (row tables: < 0 drops them)
+    if (p.o_rows) { const int t = p.o_rows[m]; okB = t >= 0; if (p.f_rows) frow = (size_t)p.f_rows[m]; orow = okB ? (size_t)t : 0; }
     v += bv;
     if (n < p.colscale_n) v *= p.colscale;
-    if (p.outPre) {
+    if (p.outPre && okB) {
       u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
       *(u32x2*)(p.outPre + go + orow * p.ldpre_out + n) = t;
     }
@@ -210,14 +212,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       v[0] += __uint_as_float(t[0] << 16); v[1] += __uint_as_float(t[0] & 0xffff0000u);
       v[2] += __uint_as_float(t[1] << 16); v[3] += __uint_as_float(t[1] & 0xffff0000u);
     }
-    if (p.outF) *(f32x4*)(p.outF + go + orow * p.ldoF + n) = v;
-    if (p.outB) {
+    if (p.outF) *(f32x4*)(p.outF + go + frow * p.ldoF + n) = v;
+    if (p.outB && okB) {
       u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
       *(u32x2*)(p.outB + go + orow * p.ldoB + n) = t;
     }
-    if (p.outU || p.outUF) {
+    if ((p.outU || p.outUF) && okB) {
       f32x4 u = v;
-      if (p.pos && m < p.pos_rows) { const f32x4 t = *(const f32x4*)(p.pos + (size_t)m * p.ldpos + n); u += t; }
+      if (p.pos && m < p.pos_rows) { const f32x4 t = *(const f32x4*)(p.pos + (size_t)(p.pos_map ? p.pos_map[m] : m) * p.ldpos + n); u += t; }
       if (p.outU) { u32x2 t; t[0] = pack_bf2(u[0], u[1]); t[1] = pack_bf2(u[2], u[3]); *(u32x2*)(p.outU + orow * p.ldoU + n) = t; }
       if (p.outUF) *(f32x4*)(p.outUF + orow * p.ldoU + n) = u;
     }
@@ -517,10 +519,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           const f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
           if (m >= p.M || !ncol) continue;
           float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          const size_t orow = GATHER ? (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off) : (size_t)m;
+          size_t orow = GATHER ? (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off) : (size_t)m, frow = orow;
+          bool okB = true;                          // the non-outF outputs of this row are written (row tables: < 0 drops them)
+          if constexpr (GATHER) {
+            if (p.o_rows) { const int t = p.o_rows[m]; okB = t >= 0; if (p.f_rows) frow = (size_t)p.f_rows[m]; orow = okB ? (size_t)t : 0; }
+          }
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = (v[e] + bv[e]) * cs;
-          if (p.outPre) {
+          if (p.outPre && okB) {
             u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
             *(u32x4*)(p.outPre + go + orow * p.ldpre_out + n) = t;
           }
@@ -558,17 +564,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(eop[e] << 16); v[2 * e + 1] += __uint_as_float(eop[e] & 0xffff0000u); }
           }
           if (p.outF) {
-            float* op = p.outF + go + orow * p.ldoF + n;
+            float* op = p.outF + go + frow * p.ldoF + n;
             *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
             *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
           }
-          if (p.outB) {
+          if (p.outB && okB) {
             u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
             *(u32x4*)(p.outB + go + orow * p.ldoB + n) = t;
           }
-          if (p.outU || p.outUF) {
+          if ((p.outU || p.outUF) && okB) {
             if (p.pos && m < p.pos_rows) {
-              const float* pp = p.pos + (size_t)m * p.ldpos + n;
+              const float* pp = p.pos + (size_t)((GATHER && p.pos_map) ? p.pos_map[m] : m) * p.ldpos + n;
               const f32x4 r0 = *(const f32x4*)pp, r1 = *(const f32x4*)(pp + 4);
 #pragma unroll
               for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
@@ -978,6 +984,8 @@ static int check_nt(const GemmArgs& a, int elem) {
   const int al = 16 / elem;   // elements per 16 bytes
   if (a.lda % al || a.ldb % al || a.ktap <= 0) return -2;
   if (a.ktap < a.K && (a.ktap % (elem == 2 ? 64 : 32))) return -2;
+  if ((a.o_rows || a.f_rows) && (a.residB || a.resid || a.gradPre || (a.groups > 1))) return -2;   // row tables: no epilogue operand
+  if (a.f_rows && !a.o_rows) return -2;
   if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return -3;
   if (a.N % 4 || a.ldoF % 4 || a.ldoB % 4 || a.ldoU % 4 || a.ldr % 4 || a.ldrB % 4 || a.ldgp % 4 || a.ldpre_out % 4 || a.ldpos % 4 ||
       a.colscale_n % 4) return -7;
@@ -1096,7 +1104,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   if (!best_tm) return -21;
   const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
   const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
-  const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1;
+  const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1 || b.o_rows || b.pos_map;
   const bool eop = b.residB || (b.actgrad && b.gradPre);
 #ifdef UVTG_NT_TRACE
   nt_trace_launch(b, best_tm, grid, gather, eop, s);

@@ -219,10 +219,14 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
   const int b = blockIdx.x, S = Lv + Lt;
   __shared__ int s_start;
   auto kept = [&](int lvr) { return keep_pad < 0 ? lvr : min(Lv, lvr + keep_pad); };
+  __shared__ int s_vstart;
   if (threadIdx.x == 0) {
-    int st = 0;
-    for (int i = 0; i < b; i++) { const int lvi = lens[i], lt = lens[B + i]; st += kept(lvi) + ((keep_pad < 0 && lvi < Lv) ? 1 : 0) + lt; }
-    s_start = st;
+    int st = 0, vs = 0;
+    for (int i = 0; i < b; i++) {
+      const int lvi = lens[i], lt = lens[B + i], nvi = kept(lvi) + ((keep_pad < 0 && lvi < Lv) ? 1 : 0);
+      st += nvi + lt; vs += nvi;
+    }
+    s_start = st; s_vstart = vs;
   }
   __syncthreads();
   const int lvr = lens[b], lt = lens[B + b];           // lvr: real number of valid clips
@@ -248,6 +252,14 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
     t.row_pos[r] = ps < Lv ? b * Lv + ps : -1;
     t.kvalid[r] = (ps < Lv && ps >= lvr) ? 0 : 1;      // padded clip positions (the representative included) are never keys
   }
+  // compact clip rows of the input projection: the sample's lv + rep leading clips, in order
+  for (int i = threadIdx.x; i < Lv; i += blockDim.x) {
+    const bool in = i < lv + rep;
+    t.vin_of[b * Lv + i] = in ? s_vstart + i : -1;
+    if (in) { t.vin_src[s_vstart + i] = b * Lv + i; t.vin_dst[s_vstart + i] = st + i; t.vin_x0[s_vstart + i] = b * S + i; }
+  }
+  if (threadIdx.x == 0) t.vin_cnt[b] = lv + rep;
+  for (int i = threadIdx.x; i < Lt; i += blockDim.x) t.tin_dst[b * Lt + i] = i < lt ? st + lv + rep + i : -1;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     int pk, gm;
     if (s < lv) { pk = st + s; gm = pk; }
@@ -257,16 +269,17 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
     t.pad2pack[b * S + s] = pk; t.grad_map[b * S + s] = gm;
   }
 }
-// gather rows of the padded bf16 operands into the packed order (both x and x + pos)
-__global__ __launch_bounds__(256) void pack_rows_kernel(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp) {
+// x0 rows of the clips the compact input projection drops (a suffix of each sample's clips; the saliency kernels read every row of
+// x0): without dropout every padded clip projects to the same vector, so they take the representative's row -- bit-identical to
+// the padded execution; on the loss-only stream (dropout: the padded clips differ, nothing reads them) zeros
+__global__ __launch_bounds__(256) void fill_dropped_rows_kernel(float* x0, const int* vin_of, const int* vin_cnt, int copy_rep, int B, int S, int Lv, int d) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= Mp) return;
-  const size_t src = (size_t)row_src[r] * d, dst = (size_t)r * d;
-  for (int c = lane * 8; c < d; c += 512) {
-    *(u32x4*)(xbp + dst + c) = *(const u32x4*)(xb + src + c);
-    *(u32x4*)(ubp + dst + c) = *(const u32x4*)(ub + src + c);
-  }
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, t) over B * Lv
+  if (row >= B * Lv || vin_of[row] >= 0) return;
+  const int b = row / Lv;
+  float* o = x0 + ((size_t)b * S + row % Lv) * d;
+  const float* rep = x0 + ((size_t)b * S + max(vin_cnt[b] - 1, 0)) * d;
+  for (int c = lane * 4; c < d; c += 256) *(f32x4*)(o + c) = copy_rep ? *(const f32x4*)(rep + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 // encoder output (packed) -> zero-framed conv input: every clip position of the padded layout, padded clips from the representative
 __global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, const int* pad2pack, const int* fstart, const int* kept, int B, int S, int Lv,
@@ -675,7 +688,9 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
       const int t = srow;
       const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
       const float vn = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f), cs = a.cosv[b * a.Lv + t];
-      bf16_t* out = a.out_vid + ((size_t)b * a.Lv + t) * d;
+      const int vo = a.vout_map ? a.vout_map[b * a.Lv + t] : b * a.Lv + t;
+      if (vo < 0) continue;                       // a clip the compact input projection dropped: no gradient row to write
+      bf16_t* out = a.out_vid + (size_t)vo * d;
 #pragma unroll
       for (int k = 0; k < KC; k++) {
         const int c = k * 256 + lane * 4;
@@ -734,7 +749,9 @@ __global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const Salien
     const int t = srow;
     const float gs = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
     const float vn = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f), cs = a.cosv[b * a.Lv + t];
-    bf16_t* out = a.out_vid + ((size_t)b * a.Lv + t) * d;
+    const int vo = a.vout_map ? a.vout_map[b * a.Lv + t] : b * a.Lv + t;
+    if (vo < 0) return;
+    bf16_t* out = a.out_vid + (size_t)vo * d;
     for (int c = lane; c < d; c += 64) {
       float g = g0(c);
       if (gs != 0.f) g += gs * (a.pooled[(size_t)b * d + c] / qn - cs * (x[c] / vn)) / vn;
@@ -770,9 +787,9 @@ int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_d
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp, hipStream_t s) {
-  if (d % 8) return -2;
-  hipLaunchKernelGGL(pack_rows_kernel, dim3(cdiv(Mp, 4)), dim3(256), 0, s, xb, ub, row_src, Mp, d, xbp, ubp);
+int launch_fill_dropped_rows(float* x0, const PackTables& t, int copy_rep, int B, int S, int Lv, int d, hipStream_t s) {
+  if (d % 4) return -2;
+  hipLaunchKernelGGL(fill_dropped_rows_kernel, dim3(cdiv(B * Lv, 4)), dim3(256), 0, s, x0, t.vin_of, t.vin_cnt, copy_rep, B, S, Lv, d);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

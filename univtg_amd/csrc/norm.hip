@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
   const int wpb = blockDim.x >> 6;
   const int D = a.D, D4 = (D + 3) >> 2;
   for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < a.rows; row += gridDim.x * wpb) {
-    const float* xr = a.x ? a.x + (size_t)row * a.ldx : nullptr;
-    const bf16_t* xbr = a.x ? nullptr : a.xB + (size_t)row * a.ldxB;
+    const int lrow = a.src_rows ? a.src_rows[row] : row;          // row of the padded layout: dropout counter key (+ x row if gather_x)
+    const int xrow = a.gather_x ? lrow : row;
+    const float* xr = a.x ? a.x + (size_t)xrow * a.ldx : nullptr;
+    const bf16_t* xbr = a.x ? nullptr : a.xB + (size_t)xrow * a.ldxB;
     float v[NV][VEC];
     float sum = 0.f;
 #pragma unroll
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * VEC;
       if constexpr (VEC == 2 && NV % 2 == 0) {            // all lanes take part in the exchange (outside the c < D guard)
-        if ((i & 1) == 0 && a.p_drop > 0.f) drop_pair2(a.seed, a.stream_id, row, i >> 1, lane, D4, a.p_drop, ks2);
+        if ((i & 1) == 0 && a.p_drop > 0.f) drop_pair2(a.seed, a.stream_id, lrow, i >> 1, lane, D4, a.p_drop, ks2);
       }
       if (c < D) {
         float y[VEC], gm[VEC], bt[VEC];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
             for (int e = 0; e < VEC; e++) y[e] *= ks2[i & 1][e];
           } else {
 #pragma unroll
-            for (int e = 0; e < VEC; e++) y[e] *= drop_scale(a.seed, a.stream_id, row, c + e, D4, a.p_drop);
+            for (int e = 0; e < VEC; e++) y[e] *= drop_scale(a.seed, a.stream_id, lrow, c + e, D4, a.p_drop);
           }
         }
         if (a.yF) storev<VEC>(a.yF + (size_t)row * a.ldyF + c, y);
@@ -211,18 +213,20 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512, (NV * VEC <= 16) ? UVTG_
     // ---- all loads of the RPW rows first, no control flow between them (so they are all in flight together) ----
     float xv[RPW][NV][VEC], gv[RPW][NV][VEC];
     float mean[RPW], rstd[RPW];
-    int rowi[RPW];
+    int rowi[RPW], lrow[RPW];
 #pragma unroll
     for (int rr = 0; rr < RPW; rr++) {
       rowi[rr] = min(row0 + rr * stride, a.rows - 1);      // clamped duplicate row: loaded, never stored / accumulated
       const size_t row = (size_t)rowi[rr];
+      lrow[rr] = a.src_rows ? a.src_rows[row] : rowi[rr];
+      const size_t xrow = a.gather_x ? (size_t)lrow[rr] : row;
       mean[rr] = a.mean[row]; rstd[rr] = a.rstd[row];
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         const int c = (i * 64 + lane) * VEC;
         if (c < D) {
-          if constexpr (BF) loadb<VEC>(a.xB + row * a.ldxB + c, xv[rr][i]);
-          else loadv<VEC>(a.x + row * a.ldx + c, xv[rr][i]);
+          if constexpr (BF) loadb<VEC>(a.xB + xrow * a.ldxB + c, xv[rr][i]);
+          else loadv<VEC>(a.x + xrow * a.ldx + c, xv[rr][i]);
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; e++) xv[rr][i][e] = 0.f;
@@ -295,12 +299,12 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512, (NV * VEC <= 16) ? UVTG_
           for (int e = 0; e < VEC; e++) pm[i] |= (xv[rr][i][e] > 0.f ? 1u : 0u) << e;
         }
         if constexpr (VEC == 2 && NV % 2 == 0) {
-          if ((i & 1) == 0 && a.p_drop > 0.f) drop_pair2(a.seed, a.stream_id, rowi[rr], i >> 1, lane, D4, a.p_drop, ks2);
+          if ((i & 1) == 0 && a.p_drop > 0.f) drop_pair2(a.seed, a.stream_id, lrow[rr], i >> 1, lane, D4, a.p_drop, ks2);
 #pragma unroll
           for (int e = 0; e < VEC; e++) gv[rr][i][e] *= ks2[i & 1][e];
         } else if (a.p_drop > 0.f && c < D) {
 #pragma unroll
-          for (int e = 0; e < VEC; e++) gv[rr][i][e] *= drop_scale(a.seed, a.stream_id, rowi[rr], c + e, D4, a.p_drop);
+          for (int e = 0; e < VEC; e++) gv[rr][i][e] *= drop_scale(a.seed, a.stream_id, lrow[rr], c + e, D4, a.p_drop);
         }
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
@@ -554,7 +558,8 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwdArgs a) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, D = a.D, D4 = (D + 3) >> 2;
   for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
-    const float* xr = a.x + (size_t)row * a.ldx;
+    const int lrow = a.src_rows ? a.src_rows[row] : row;
+    const float* xr = a.x + (size_t)(a.gather_x ? lrow : row) * a.ldx;
     float v[NVW][2];
     float sum = 0.f;
 #pragma unroll
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwdArgs a) {
 #pragma unroll
     for (int k = 0; k < NVW; k++) {
       const int c = (k * 256 + tid) * 2;
-      if ((k & 1) == 0 && a.p_drop > 0.f) drop_pair_wide(a.seed, a.stream_id, row, k >> 1, tid, D4, a.p_drop, ks);
+      if ((k & 1) == 0 && a.p_drop > 0.f) drop_pair_wide(a.seed, a.stream_id, lrow, k >> 1, tid, D4, a.p_drop, ks);
       if (c < D) {
         float gm[2], bt[2], y[2];
         loadv<2>(a.gamma + c, gm);
@@ -612,10 +617,11 @@ __global__ __launch_bounds__(256) void ln_dgb_wide_kernel(const LnBwdArgs a, int
     const int rb = min(r + 1, r1 - 1);             // second row of the pair (duplicate of the first on an odd tail: weight 0)
     const float wb = (r + 1 < r1) ? 1.f : 0.f;
     float ga[2], xa[2], gb[2], xb[2];
+    const int lr = a.src_rows ? a.src_rows[r] : r, lrb = a.src_rows ? a.src_rows[rb] : rb;
     loadv<2>(a.g + (size_t)r * a.ldg + cc, ga);
-    loadv<2>(a.x + (size_t)r * a.ldx + cc, xa);
+    loadv<2>(a.x + (size_t)(a.gather_x ? lr : r) * a.ldx + cc, xa);
     loadv<2>(a.g + (size_t)rb * a.ldg + cc, gb);
-    loadv<2>(a.x + (size_t)rb * a.ldx + cc, xb);
+    loadv<2>(a.x + (size_t)(a.gather_x ? lrb : rb) * a.ldx + cc, xb);
     const float ma = a.mean[r], sa = a.rstd[r], mb = a.mean[rb], sb = a.rstd[rb];
     float ka[2] = {1.f, 1.f}, kb[2] = {1.f, 1.f};
     if (a.p_drop > 0.f) {
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(256) void ln_dgb_wide_kernel(const LnBwdArgs a, int
       const int odd = tid & 1;
       const int c4 = c >> 2;                       // the even/odd pair covers columns 4*c4 .. 4*c4+3 (also when one of them is past D)
       unsigned q[4];
-      philox4(a.seed, (unsigned long long)(odd ? rb : r) * (unsigned long long)D4 + (unsigned long long)c4, a.stream_id, q);
+      philox4(a.seed, (unsigned long long)(odd ? lrb : lr) * (unsigned long long)D4 + (unsigned long long)c4, a.stream_id, q);
       const unsigned s0 = odd ? q[0] : q[2], s1 = odd ? q[1] : q[3];
       const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
       const float inv = 1.0f / (1.0f - a.p_drop);
@@ -663,7 +669,7 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
   if (!b.dgamma || b.partial_floats < (long long)blocks * 2 * b.D) b.partial = nullptr;
   if constexpr (VEC == 8 && NV <= 2) {
     static const bool lean_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
-    if (bf && a.gB && a.p_drop == 0.f && !a.relu_from_x && wpb == 8 && !lean_off) {
+    if (bf && a.gB && a.p_drop == 0.f && !a.relu_from_x && !a.gather_x && wpb == 8 && !lean_off) {
       hipLaunchKernelGGL((ln_bwd_lean_kernel<NV>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
       if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
       UVTG_CHECK_LAUNCH();

@@ -36,6 +36,9 @@ struct GemmArgs {
   bf16_t* outB; int ldoB;             // bf16 output
   const float* pos; int ldpos; int pos_rows;   // fp32 positional table indexed by m (< pos_rows)
   bf16_t* outU; float* outUF; int ldoU;        // (value + pos) in bf16 / fp32
+  // output-row tables (replace the affine scatter; no epilogue operand with these): row m's outPre / outB / outU / outUF go to row
+  // o_rows[m] (< 0: not written); outF goes to f_rows[m] (null: the affine o_seg row); pos is read at row pos_map[m] (null: m)
+  const int* o_rows; const int* f_rows; const int* pos_map;
 };
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s);
 int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s);
@@ -88,6 +91,9 @@ struct LnFwdArgs {
   bf16_t* yU; float* yUF; int ldyU;
   // copy of the video rows into the zero-framed conv layout [(b*(Lv+2) + s + 1), ldyP]
   bf16_t* yP; float* yPF; int ldyP;
+  // compact row streams (the input projection of the kept clips only): src_rows[row] = the row's index in the padded layout.  It keys
+  // the dropout counters (same mask as the padded execution) and, with gather_x, is the row of x that is read; outputs stay compact.
+  const int* src_rows; int gather_x;
 };
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
 
@@ -110,6 +116,7 @@ struct LnBwdArgs {
   const int* row_sample;        // packed rows: rowscale[row_sample[row]]
   int relu_from_x;              // 1: dx is masked by (x > 0): x is the output of a ReLU (input projections)
   float* partial; long long partial_floats;   // optional scratch for per-block dgamma / dbeta partials (else atomics)
+  const int* src_rows; int gather_x;          // as in LnFwdArgs (generic kernel and the wide dgamma / dbeta kernel)
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
 
@@ -149,12 +156,19 @@ struct PackTables {
   // conv-head frames (loss-only stream: ragged): sample b owns frame rows fstart[b] .. fstart[b] + kept[b] + 1 (first and last are the
   // zero rows of the k = 3 convolution); frame_valid [sum(kept + 2)] = 1 on clip rows, 0 on zero rows
   int* fstart; int* kept; float* frame_valid;
+  // compact clip rows of the input projection (the clips that have a packed row: valid + representative / halo, sample after sample):
+  // vin_src [Rv] = clip row b*Lv + t, vin_dst [Rv] = its packed-stream row, vin_x0 [Rv] = its row b*S + t of the padded x0;
+  // vin_of [B*Lv] = compact row of a clip or -1; tin_dst [B*Lt] = packed-stream row of a text token or -1 (padded)
+  int* vin_src; int* vin_dst; int* vin_x0; int* vin_of; int* tin_dst;
+  int* vin_cnt;                       // [B] clips of the sample that have a packed row (a prefix of its clips)
 };
 // keep_pad < 0: valid clips + ONE representative padded clip per sample; keep_pad >= 0: valid clips + the first keep_pad padded clips,
 // each its own row (keep_pad >= Lv: every clip row), no representative; padded clips beyond that are dropped (pad2pack = -1)
 int launch_pack_tables(const float* vid_mask, const float* txt_mask, int* lens_dev /* scratch [2B] */, int B, int Lv, int Lt, int keep_pad,
                        const PackTables& t, hipStream_t s);
-int launch_pack_rows(const bf16_t* xb, const bf16_t* ub, const int* row_src, int Mp, int d, bf16_t* xbp, bf16_t* ubp, hipStream_t s);
+// the fp32 rows of x0 [B*S, d] whose clip has no packed row (the compact projection never writes them): copy_rep = the sample's
+// last kept clip row (the representative padded clip: every padded clip projects to the same vector without dropout), else zeros
+int launch_fill_dropped_rows(float* x0, const PackTables& t, int copy_rep, int B, int S, int Lv, int d, hipStream_t s);
 // frames: null = uniform frames of Lv + 2 rows per sample; else t.fstart / t.kept
 int launch_unpack_vm(const bf16_t* packed, const PackTables& t, bool ragged_frames, int B, int S, int Lv, int d, bf16_t* vm_pad, hipStream_t s);
 // dvm: gradient wrt the clip rows, [B * Lv, d] (uniform frames) or in frame-row space (ragged_frames)
@@ -222,6 +236,7 @@ struct SaliencyArgs {             // weighted text pooling + cosine saliency (mo
   const int* dx0_map;             // packed encoder stream: token row (b*S + s) -> row of dx0 / dx0B, or -1 (no gradient)
   float* dq; float* dlog;         // scratch [B, d], [B, Lt]
   bf16_t* out_vid; bf16_t* out_txt;   // bf16 [B*Lv, d] / [B*Lt, d]: dx0 + saliency-branch gradients, re-packed per modality
+  const int* vout_map;            // clip row (b*Lv + t) -> row of out_vid (compact input projection), < 0: not written; null: identity
   float* dw_pool;                 // [d] atomically accumulated
 };
 int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s);
