@@ -41,6 +41,16 @@ for i in range(NL):
     if lib.uvtg_debug_nt_trace_info(i, info):
         break
     M, N, K, tm, eop, gather, grid, groups = list(info)
+    if M < 0:      # weight-gradient (TN) launch: -rows, tiles, splits, steps per unit, units
+        a = t[i].reshape(-1, 4)[:grid]
+        span = a[:, 2].max() - a[:, 0].min()
+        main, slab, steps = a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] * 100.0
+        print(f"{i:3d} TN rows={-M} tiles={N} splits={K} groups={groups} steps/unit<={tm} units={grid} span {span:7.1f} us | main median {np.median(main):6.1f} "
+              f"(max {main.max():6.1f}; {np.median(main / np.maximum(steps, 1)):.3f} us/step)  slab write median {np.median(slab):5.1f} (max {slab.max():5.1f})")
+        if "--xcd" in sys.argv:
+            print("      per-XCD median main:", " ".join(f"{np.median(main[x::8]):6.1f}" for x in range(8)), "| start skew (max - min):", f"{a[:, 0].max() - a[:, 0].min():.1f} us",
+                  "| slowest units:", np.argsort(-main)[:8].tolist())
+        continue
     a = t[i, :grid]
     used = a[..., 3] > 0
     span = a[..., 3][used].max() - a[..., 0][used].min()

@@ -806,6 +806,9 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = p.dbias && tile_k == 0 && wn == 0;
 
+#ifdef UVTG_NT_TRACE
+  if (g_nt_trace_dev && tid == 0 && blockIdx.x < 1024) g_nt_trace_dev[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
+#endif
   if (st0 < st1) stage(0);
   // K-step body: straight-line (the staging pieces of the next step are issued unconditionally -- past the last step they fetch rows
   // beyond this split into the idle stage, or zeros through the buffer bounds check -- so that the scheduling pins below see ONE basic
@@ -857,24 +860,32 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
         const s16x4 b0 = tb[ks & 1][j][0], b1 = tb[ks & 1][j][1];
         b[j] = (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
       }
+      // column sums of P (bias gradient): v_dot2c_f32_bf16 against (1, 1) adds both halves of a dword in ONE op; the four ops of
+      // fragment i sit behind the MFMAs that consumed it (no fragment is waited for earlier than the matrix cores need it) -- as 64
+      // convert + add pairs scheduled freely they made the bias units the launch's stragglers (+18 % on a quarter of the units)
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 4; i++) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-      if constexpr (BIAS) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int e = 0; e < 8; e++) bsum[i] += bf2f((bf16_t)a[i][e]);
+        if constexpr (BIAS) {
+          const u32x2 h0 = __builtin_bit_cast(u32x2, ta[ks & 1][i][0]), h1 = __builtin_bit_cast(u32x2, ta[ks & 1][i][1]);
+          // (inline asm: the v2bf16 builtin form read dword 0 of each pair twice under hipcc 7.2)
+          asm("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5"
+              : "+v"(bsum[i]) : "s"(0x3f803f80u), "v"(h0[0]), "v"(h0[1]), "v"(h1[0]), "v"(h1[1]));
+        }
       }
     }
     {   // pin the fragment pipeline: 12 transposing reads up front; per k-step 6 x (MFMA, 2 reads) + 2 MFMAs (the asm DMA statements keep
-        // their program order among the reads: 4 after the reads issued under k-step 0, 4 after those under k-step 1)
+        // their program order among the reads: 4 after the reads issued under k-step 0, 4 after those under k-step 1); BIAS: the 4 dot
+        // products of a fragment follow its two MFMAs
       __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
       for (int ks = 0; ks < 3; ks++) {
 #pragma unroll
-        for (int n = 0; n < 6; n++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        for (int n = 0; n < 3; n++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
@@ -882,6 +893,9 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
   }
   };
   if (do_bias) main_loop(std::true_type{}); else main_loop(std::false_type{});
+#ifdef UVTG_NT_TRACE
+  if (g_nt_trace_dev && tid == 0 && blockIdx.x < 1024) { g_nt_trace_dev[(size_t)blockIdx.x * 4 + 1] = wall_clock64(); g_nt_trace_dev[(size_t)blockIdx.x * 4 + 3] = (unsigned long long)(st1 - st0); }
+#endif
   // ---- partial tile -> fp32 slab [256 n][256 k] of this (split, tile) unit, row-contiguous 16-byte stores ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces issued past the last step must not land in the slabs below
   __syncthreads();
@@ -904,6 +918,9 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TNPlan plan) {
       *(f32x4*)(op + 4) = v1;
     }
   }
+#ifdef UVTG_NT_TRACE
+  if (g_nt_trace_dev && tid == 0 && blockIdx.x < 1024) g_nt_trace_dev[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
+#endif
   if (do_bias) {
     float* bpart = plan.scratch + plan.bias_base[gi] + (size_t)split * n_pad;
 #pragma unroll
@@ -1219,6 +1236,13 @@ int launch_gemm_tn_batch(const GemmTNBatch& b, hipStream_t s) {
     mx = tot > mx ? tot : mx;
   }
   uvtg_prof_begin_launch(2, flops, s);
+#ifdef UVTG_NT_TRACE
+  {
+    GemmArgs ti; memset(&ti, 0, sizeof(ti));
+    ti.M = -b.g[0].M; ti.N = pl.total_tiles; ti.K = pl.splits; ti.groups = b.count;
+    nt_trace_launch(ti, pl.steps_per, pl.total_tiles * pl.splits, false, false, s);
+  }
+#endif
   hipLaunchKernelGGL(gemm_tn256_kernel, dim3(pl.total_tiles * pl.splits), dim3(512), 131072, s, pl);
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mx + 255) / 256), b.count), dim3(256), 0, s, pl);
   uvtg_prof_end_launch(2, s);
