@@ -394,23 +394,24 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   TransposeOps to; to.count = 0;
   ConvWOps cv; cv.count = 0; cv.N = d; cv.C = d;
   auto cast = [&](const float* src, bf16_t* dst, long long n) { co.src[co.count] = src; co.dst[co.count] = dst; co.n[co.count] = n; co.count++; };
-  auto transp = [&](const float* src, int rows, int cols, bf16_t* dst, int ld) {
-    to.src[to.count] = src; to.dst[to.count] = dst; to.rows[to.count] = rows; to.cols[to.count] = cols; to.ld[to.count] = ld; to.count++;
+  auto transp = [&](const float* src, int rows, int cols, bf16_t* dst, int ld, bf16_t* plain = nullptr) {
+    to.src[to.count] = src; to.dst[to.count] = dst; to.plain[to.count] = plain; to.rows[to.count] = rows; to.cols[to.count] = cols; to.ld[to.count] = ld; to.count++;
   };
   auto convw = [&](const float* wsrc, bf16_t* dst, int ld, int ntot, int n_off, int kind) {
     cv.w[cv.count] = wsrc; cv.dst[cv.count] = dst; cv.ld[cv.count] = ld; cv.ntot[cv.count] = ntot; cv.n_off[cv.count] = n_off; cv.kind[cv.count] = kind; cv.count++;
   };
   if (4 * m.c.E + 4 > UVTG_MAX_PREP_OPS) return -17;
   for (int l = 0; l < m.c.E && fast; l++) {
-    cast(P[m.lay(l, IPW)], w.wqkv[l], 3LL * d * d);
-    cast(P[m.lay(l, OPW)], w.wo[l], (long long)d * d);
-    cast(P[m.lay(l, L1W)], w.w1[l], (long long)F * d);
-    cast(P[m.lay(l, L2W)], w.w2[l], (long long)d * F);
-    if (tr) {
-      transp(P[m.lay(l, IPW)], 3 * d, d, w.wqkvT[l], 3 * d);
-      transp(P[m.lay(l, OPW)], d, d, w.woT[l], d);
-      transp(P[m.lay(l, L1W)], F, d, w.w1T[l], F);
-      transp(P[m.lay(l, L2W)], d, F, w.w2T[l], d);
+    if (tr) {        // training: ONE pass over the fp32 master writes the forward operand and the dgrad operand
+      transp(P[m.lay(l, IPW)], 3 * d, d, w.wqkvT[l], 3 * d, w.wqkv[l]);
+      transp(P[m.lay(l, OPW)], d, d, w.woT[l], d, w.wo[l]);
+      transp(P[m.lay(l, L1W)], F, d, w.w1T[l], F, w.w1[l]);
+      transp(P[m.lay(l, L2W)], d, F, w.w2T[l], d, w.w2[l]);
+    } else {
+      cast(P[m.lay(l, IPW)], w.wqkv[l], 3LL * d * d);
+      cast(P[m.lay(l, OPW)], w.wo[l], (long long)d * d);
+      cast(P[m.lay(l, L1W)], w.w1[l], (long long)F * d);
+      cast(P[m.lay(l, L2W)], w.w2[l], (long long)d * F);
     }
   }
   // conv heads: layer 0 of both heads merged along N (span rows then class rows), layer 1 grouped
@@ -443,12 +444,14 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   } else {
     TRY(launch_cast_pad_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0B, m.Kpv, s));
     TRY(launch_cast_pad_bf16(P[m.tail(TP0W)], d, m.c.Dt, w.tp0B, m.Kpt, s));
-    cast(P[m.tail(VP1W)], w.vp1B, (long long)d * d);
-    cast(P[m.tail(TP1W)], w.tp1B, (long long)d * d);
+    if (!tr) {
+      cast(P[m.tail(VP1W)], w.vp1B, (long long)d * d);
+      cast(P[m.tail(TP1W)], w.tp1B, (long long)d * d);
+    }
   }
   if (tr) {
-    transp(P[m.tail(VP1W)], d, d, w.vp1T, d);
-    transp(P[m.tail(TP1W)], d, d, w.tp1T, d);
+    transp(P[m.tail(VP1W)], d, d, w.vp1T, d, w.vp1B);       // (vp1B / tp1B are null with split-bf16 projections: no plain copy then)
+    transp(P[m.tail(TP1W)], d, d, w.tp1T, d, w.tp1B);
     hipMemsetAsync(w.vp0T, 0, (size_t)m.Kpv * d * 2, s);
     hipMemsetAsync(w.tp0T, 0, (size_t)m.Kpt * d * 2, s);
     transp(P[m.tail(VP0W)], d, m.c.Dv, w.vp0T, d);

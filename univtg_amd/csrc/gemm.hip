@@ -331,6 +331,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   auto k_offsets = [&](int kt, unsigned& ka, unsigned& kb) {
     kb = (unsigned)kt * (KB * 2u);
     ka = kb;
+#ifdef UVTG_NT_TRACE
+    // latency probes (results are garbage): 101 = the A pieces always re-read K tile 0 (cache-hot after the first touch), 102 = the B
+    // pieces do, 103 = both -- against 100 (main loop only) they tell which operand's miss latency the two-stage ring fails to cover
+    if (p.act == 101 || p.act == 103) ka = 0;
+    if (p.act == 102 || p.act == 103) kb = 0;
+#endif
     if constexpr (GATHER) {
       const int k0 = kt * KB, tap = k0 / p.ktap;
       ka = (unsigned)(tap * p.lda + (k0 - tap * p.ktap)) * 2u;
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) bv[e] = 0.f;
-    if (ncol && p.act != 100) {
+    if (ncol && (p.act < 100 || p.act > 103)) {
       if (p.bias) {
         const float* bias = p.bias + (size_t)gz * p.gBias + n;
         const f32x4 b0 = *(const f32x4*)bias, b1 = *(const f32x4*)(bias + 4);
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     ktile(nk - 1, std::true_type{});
     NT_STAMP(2);
     // ---------------- epilogue of `tile`, out of the stage consumed last ----------------
-    if (p.act == 100) {   // measurement aid: main loop only
+    if (p.act >= 100 && p.act <= 103) {   // measurement aid: main loop only (101-103: latency probes of the measurement build)
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; i++)

@@ -114,22 +114,55 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastOps ops)
     }
   }
 }
-__global__ void transpose_bf16_multi_kernel(const TransposeOps ops) {
-  __shared__ float t[32][33];
-  const int op = blockIdx.z;
+// 64 x 64 tiles: 16-byte fp32 reads, 8-byte bf16 writes on both outputs (4 consecutive elements of a row of the plain copy, 4
+// consecutive source rows of a row of the transposed copy); shapes whose rows are not 16-byte aligned take the element path
+__global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const TransposeOps ops) {
+  __shared__ float t[64][65];
+  const int op = blockIdx.z, tid = threadIdx.x;
   const int rows = ops.rows[op], cols = ops.cols[op], ld = ops.ld[op];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
   if (c0 >= cols || r0 >= rows) return;
   const float* src = ops.src[op];
   bf16_t* dst = ops.dst[op];
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + threadIdx.x;
-    t[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
-  }
-  __syncthreads();
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + threadIdx.x;
-    if (c < cols && r < rows) dst[(size_t)c * ld + r] = f2bf(t[threadIdx.x][i]);
+  bf16_t* plain = ops.plain[op];
+  const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)dst) & 7) == 0) &&
+                   (!plain || (((uintptr_t)plain) & 7) == 0);
+  if (vec) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = r0 + (tid >> 4) + 16 * k, c = c0 + (tid & 15) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows && c < cols) {
+        v = *(const f32x4*)(src + (size_t)r * cols + c);
+        if (plain) { u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); *(u32x2*)(plain + (size_t)r * cols + c) = o; }
+      }
+      const int rl = (tid >> 4) + 16 * k, cl = (tid & 15) * 4;
+      t[rl][cl] = v[0]; t[rl][cl + 1] = v[1]; t[rl][cl + 2] = v[2]; t[rl][cl + 3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int cl = (tid >> 4) + 16 * k, rl = (tid & 15) * 4, c = c0 + cl, r = r0 + rl;
+      if (c >= cols || r >= rows) continue;
+      if (r + 3 < rows) {
+        u32x2 o; o[0] = pack_bf2(t[rl][cl], t[rl + 1][cl]); o[1] = pack_bf2(t[rl + 2][cl], t[rl + 3][cl]);
+        *(u32x2*)(dst + (size_t)c * ld + r) = o;
+      } else {
+        for (int e = 0; e < 4 && r + e < rows; e++) dst[(size_t)c * ld + r + e] = f2bf(t[rl + e][cl]);
+      }
+    }
+  } else {
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int rl = i >> 6, cl = i & 63, r = r0 + rl, c = c0 + cl;
+      float v = 0.f;
+      if (r < rows && c < cols) { v = src[(size_t)r * cols + c]; if (plain) plain[(size_t)r * cols + c] = f2bf(v); }
+      t[rl][cl] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int cl = i >> 6, rl = i & 63, r = r0 + rl, c = c0 + cl;
+      if (c < cols && r < rows) dst[(size_t)c * ld + r] = f2bf(t[rl][cl]);
+    }
   }
 }
 __global__ __launch_bounds__(256) void conv_w_multi_kernel(const ConvWOps ops, int tiled_bwd) {
@@ -219,14 +252,18 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
   const int b = blockIdx.x, S = Lv + Lt;
   __shared__ int s_start;
   auto kept = [&](int lvr) { return keep_pad < 0 ? lvr : min(Lv, lvr + keep_pad); };
-  __shared__ int s_vstart;
-  if (threadIdx.x == 0) {
-    int st = 0, vs = 0;
-    for (int i = 0; i < b; i++) {
+  __shared__ int s_vstart, s_f, s_red[2][3];
+  {   // exclusive prefix sums over the samples before b (packed rows, compact clip rows, frame rows): every thread sums a strided
+      // share, two wave sums -- a single thread walking up to B - 1 samples made this kernel 25 us of pure latency
+    int st = 0, vs = 0, f = 0;
+    for (int i = threadIdx.x; i < b; i += blockDim.x) {
       const int lvi = lens[i], lt = lens[B + i], nvi = kept(lvi) + ((keep_pad < 0 && lvi < Lv) ? 1 : 0);
-      st += nvi + lt; vs += nvi;
+      st += nvi + lt; vs += nvi; f += kept(lvi) + 2;
     }
-    s_start = st; s_vstart = vs;
+    for (int o = 32; o > 0; o >>= 1) { st += __shfl_xor(st, o, 64); vs += __shfl_xor(vs, o, 64); f += __shfl_xor(f, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = st; s_red[threadIdx.x >> 6][1] = vs; s_red[threadIdx.x >> 6][2] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) { s_start = s_red[0][0] + s_red[1][0]; s_vstart = s_red[0][1] + s_red[1][1]; s_f = s_red[0][2] + s_red[1][2]; }
   }
   __syncthreads();
   const int lvr = lens[b], lt = lens[B + b];           // lvr: real number of valid clips
@@ -234,13 +271,7 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
   const int rep = (keep_pad < 0 && lv < Lv) ? 1 : 0, n = lv + rep + lt, st = s_start;
   if (threadIdx.x == 0) { t.seq_start[b] = st; t.seq_count[b] = n; }
   if (keep_pad >= 0) {                                 // conv-head frames (ragged on the loss-only stream): kept clips + 2 zero rows per sample
-    __shared__ int s_f;
-    if (threadIdx.x == 0) {
-      int f = 0;
-      for (int i = 0; i < b; i++) f += kept(lens[i]) + 2;
-      s_f = f; t.fstart[b] = f; t.kept[b] = lv;
-    }
-    __syncthreads();
+    if (threadIdx.x == 0) { t.fstart[b] = s_f; t.kept[b] = lv; }
     for (int i = threadIdx.x; i < lv + 2; i += blockDim.x) t.frame_valid[s_f + i] = (i >= 1 && i <= lv) ? 1.f : 0.f;
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -854,7 +885,7 @@ int launch_transpose_bf16_multi(const TransposeOps& ops, hipStream_t s) {
   if (ops.count <= 0) return 0;
   int mr = 0, mc = 0;
   for (int i = 0; i < ops.count; i++) { mr = ops.rows[i] > mr ? ops.rows[i] : mr; mc = ops.cols[i] > mc ? ops.cols[i] : mc; }
-  hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3(cdiv(mc, 32), cdiv(mr, 32), ops.count), dim3(32, 8), 0, s, ops);
+  hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3(cdiv(mc, 64), cdiv(mr, 64), ops.count), dim3(256), 0, s, ops);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -186,7 +186,9 @@ int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int
 // batched forms for the per-step operand-cache rebuild: all casts / transposes / conv re-layouts of a step in one launch each
 constexpr int UVTG_MAX_PREP_OPS = 80;
 struct CastOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; long long n[UVTG_MAX_PREP_OPS]; int count; };
-struct TransposeOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; int rows[UVTG_MAX_PREP_OPS], cols[UVTG_MAX_PREP_OPS], ld[UVTG_MAX_PREP_OPS]; int count; };
+// dst[c][r] = bf16(src[r][c]) (leading dimension ld); plain (optional) additionally receives the untransposed bf16 copy [rows, cols]:
+// one read of the fp32 master feeds both GEMM operands (the forward's W and the dgrad's W^T)
+struct TransposeOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; bf16_t* plain[UVTG_MAX_PREP_OPS]; int rows[UVTG_MAX_PREP_OPS], cols[UVTG_MAX_PREP_OPS], ld[UVTG_MAX_PREP_OPS]; int count; };
 struct ConvWOps {     // kind 0: forward operand (dst[n][tap*C + c]), 1: dgrad operand (dst[c][tap'*Ntot + n_off + n] = w[n][c][2 - tap'])
   const float* w[16]; bf16_t* dst[16]; int ld[16], ntot[16], n_off[16], kind[16]; int N, C, count;
 };
