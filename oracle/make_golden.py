@@ -268,6 +268,41 @@ def run_detr_criterion(ref):
     print("detr_criterion: ok", store["losses"])
 
 
+def run_features(ref):
+    """Feature-file readers (main/dataset.py:325-358, :370-390) executed on temporary .npz files: inputs and the tensors the real
+    DatasetVLP methods return."""
+    import tempfile
+    DS = ref.dataset.DatasetVLP
+    rng = np.random.RandomState(31)
+    sf, clip = rng.randn(23, 40).astype(np.float32) * 3, rng.randn(21, 24).astype(np.float64)
+    q_last, q_pool = rng.randn(9, 16).astype(np.float32), rng.randn(16).astype(np.float32)
+    store = dict(slowfast=sf, clip=clip, q_last=q_last, q_pool=q_pool)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for sub, name, arrs in (("vid_slowfast", "v0", dict(features=sf)), ("vid_clip", "v0", dict(features=clip)),
+                                    ("txt_clip", "7", dict(last_hidden_state=q_last, pooler_output=q_pool))):
+                os.makedirs(os.path.join("data", "synthetic", sub), exist_ok=True)
+                np.savez(os.path.join("data", "synthetic", sub, name + ".npz"), **arrs)
+            ds = object.__new__(DS)
+            ds.use_cache, ds.v_feat_types, ds.v_feat_dirs = 0, ["vid_slowfast", "vid_clip"], ["vid_slowfast", "vid_clip"]
+            ds.q_feat_dir, ds.q_feat_dim, ds.txt_drop_ratio = "txt_clip", 16, 0
+            meta = dict(vid="v0", qid=7, dset_name="synthetic", v_feat_suffix="", q_feat_suffix="")
+            for norm in (True, False):
+                ds.normalize_v = ds.normalize_t = norm
+                store[f"video_{int(norm)}"] = ds._get_video_feat_by_vid(meta).numpy()
+                for ft in ("last_hidden_state", "pooler_output"):
+                    ds.q_feat_type = ft
+                    store[f"query_{ft}_{int(norm)}"] = ds._get_query_feat_by_qid(meta).numpy()
+            ds.q_feat_type, ds.normalize_t = "last_hidden_state", True
+            store["query_missing"] = ds._get_query_feat_by_qid(dict(meta, qid=8)).numpy()
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "features.npz"), **store)
+    print("features: ok", store["video_1"].shape, store["query_last_hidden_state_1"].shape)
+
+
 def run_span_utils(ref):
     """Doctest known answers of utils/span_utils.py:13-20,32-39,55-61,106-110 + random matrices."""
     g = torch.Generator().manual_seed(3)
@@ -407,6 +442,9 @@ def main():
     if sys.argv[1:] == ["detr_criterion"]:      # one fixture only (the others are unchanged)
         run_detr_criterion(ref)
         return
+    if sys.argv[1:] == ["features"]:
+        run_features(ref)
+        return
     tiny = dict(hidden_dim=64, nheads=2, dim_feedforward=96, enc_layers=2, v_feat_dim=34, t_feat_dim=24,
                 max_q_l=16, input_dropout=0.0, dropout=0.0, droppath=0.0)
     run_case(ref, "tiny_eval_ragged", O.make_cfg(**tiny), B=5, L_v=13, L_t=7, seed=11, ragged=True)
@@ -419,6 +457,7 @@ def main():
              real_feats=True)
     run_matcher(ref)
     run_detr_criterion(ref)
+    run_features(ref)
     run_span_utils(ref)
     run_nms(ref)
     run_dense_targets(ref)

@@ -139,6 +139,24 @@ def test_detr_criterion_matches_reference(golden_dir):
             assert np.abs(G[k] - r).max() <= tol * 10 * max(1.0, np.abs(r).max()), (dt, k)
 
 
+def test_feature_file_readers_match_reference(golden_dir, tmp_path):
+    """the .npz readers of main/dataset.py:325-358,370-390 (golden = the tensors the real DatasetVLP methods returned
+    on the same arrays): l2 normalisation per row, truncation to the shortest feature type, fp64 -> fp32, zeros((10, D)) placeholder."""
+    from univtg_amd import pipeline
+    z = np.load(os.path.join(golden_dir, "features.npz"))
+    np.savez(tmp_path / "sf.npz", features=z["slowfast"])
+    np.savez(tmp_path / "clip.npz", features=z["clip"])
+    np.savez(tmp_path / "q.npz", last_hidden_state=z["q_last"], pooler_output=z["q_pool"])
+    for norm in (True, False):
+        v = pipeline.read_video_features([tmp_path / "sf.npz", tmp_path / "clip.npz"], normalize=norm)
+        assert v.dtype == torch.float32 and np.array_equal(v.numpy(), z[f"video_{int(norm)}"])
+        for ft in ("last_hidden_state", "pooler_output"):
+            q = pipeline.read_query_features(tmp_path / "q.npz", ft, normalize=norm, feat_dim=16)
+            assert np.array_equal(q.numpy(), z[f"query_{ft}_{int(norm)}"]), (ft, norm)
+    q = pipeline.read_query_features(tmp_path / "missing.npz", "last_hidden_state", normalize=True, feat_dim=16)
+    assert np.array_equal(q.numpy(), z["query_missing"])
+
+
 def test_lsap_against_scipy_random():
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(0)

@@ -25,6 +25,7 @@ from __future__ import annotations
 import collections
 import time
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -199,3 +200,31 @@ class DevicePrefetcher:
             torch.cuda.synchronize(self.device)
             self.stats["upload_ms"] = sum(a.elapsed_time(b) for a, b in self._timers)
             self._timers = []
+
+
+# ---- feature files (main/dataset.py:325-358 query, :370-390 video) ------------------------------------------
+def _l2_normalize(a, eps=1e-5):
+    """utils/basic_utils.py:97-99"""
+    return a / (np.linalg.norm(a, axis=-1, keepdims=True) + eps)
+
+
+def read_video_features(paths, normalize=True):
+    """The reference's ``_get_video_feat_by_vid`` without the hdf5 cache: one ``.npz`` per feature type (key ``features``, e.g.
+    SlowFast + CLIP), each optionally l2-normalised per clip, truncated to the shortest ("some features are slightly longer than the
+    others") and concatenated along the feature axis -> fp32 tensor (L_v, sum D)."""
+    feats = []
+    for path in paths:
+        f = np.load(path)["features"].astype(np.float32)
+        feats.append(_l2_normalize(f) if normalize else f)
+    n = min(len(f) for f in feats)
+    return torch.from_numpy(np.concatenate([f[:n] for f in feats], axis=1))
+
+
+def read_query_features(path, feat_type="last_hidden_state", normalize=True, feat_dim=512):
+    """The reference's ``_get_query_feat_by_qid`` without the cache and without the (training-time, unused by the scripts) row drop:
+    key ``last_hidden_state`` (L_q, D) or ``pooler_output`` (D,); an unreadable file gives the reference's zeros((10, D)) placeholder."""
+    try:
+        q = np.load(path)[feat_type].astype(np.float32)
+    except Exception:
+        q = np.zeros((10, feat_dim), np.float32)
+    return torch.from_numpy(_l2_normalize(q) if normalize else q)
