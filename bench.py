@@ -245,13 +245,13 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch, on the launch stream ----
     lib = _lib.load()
-    roof, sect = None, None
+    roof, sect, roof_attn = None, None, None
     if rank == 0:
         lib.uvtg_profile_start()
     for i in range(args.profile_steps):          # EVERY rank runs these steps (they contain the gradient all-reduce); only rank 0 instruments them
         step.step(*batches[i % 2])
     if rank == 0:
-        ms, fl, n = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
+        ms, fl, n = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_longlong * 6)()
         _lib.check(lib.uvtg_profile_stop(ms, fl, n), "uvtg_profile_stop")
         floor = lib.uvtg_profile_event_floor_ms()
         fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel", "gemm_nt256_kernel"]
@@ -278,6 +278,20 @@ def main():
                     all_gemm_kernels={fam[i]: dict(ms_per_step=round(ms[i] / max(1, args.profile_steps), 3),
                                                    tflops=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else 0.0,
                                                    launches_per_step=int(n[i] // max(1, args.profile_steps))) for i in range(4)})
+        # attention kernels (families 4 / 5): FLOPs on the padded S as SURVEY 8d counts them, and on the rows the packed stream runs
+        lens_a = [bt[0]["_lens_host"] for bt in batches]
+        s2_pad = B * (Lv + Lt) ** 2
+        s2_exe = sum(sum((min(Lv, x + 3) + y) ** 2 for x, y in zip(a, b)) for a, b in lens_a) / len(lens_a) if packed else s2_pad
+        roof_attn = {}
+        for name, i, mult in (("forward", 4, 4.0), ("backward", 5, 10.0)):
+            t_ms = (ms[i] + floor * n[i]) / max(1, args.profile_steps)
+            alg = mult * MODEL["E"] * s2_pad * MODEL["d"]
+            roof_attn[name] = dict(ms_per_step=round(t_ms, 3), launches_per_step=int(n[i] // max(1, args.profile_steps)),
+                                   achieved=round(alg / max(t_ms * 1e-3, 1e-12) / 1e12, 1), frac=round(alg / max(t_ms * 1e-3, 1e-12) / 2.5e15, 4),
+                                   executed_tflops=round(mult * MODEL["E"] * s2_exe * MODEL["d"] / max(t_ms * 1e-3, 1e-12) / 1e12, 1))
+        roof_attn["note"] = ("attention kernels only (HIP event pairs around launch_attn_fwd / launch_attn_bwd incl. the delta pass): achieved = "
+                             "4 (fwd) / 10 (bwd) * E * B * S^2 * d FLOPs on the PADDED S over the measured time, peak 2.5 PFLOP/s; executed_tflops "
+                             "counts the rows the packed stream runs")
     # ---- section timing: encoder forward / backward (roofline.achieved = encoder fwd+bwd FLOPs / t_encoder / peak) ----
     if rank == 0:
         lib.uvtg_profile_sections_start()
@@ -340,7 +354,7 @@ def main():
                    padded_execution_ms_per_step=None if padded_ms is None else round(padded_ms, 3),
                    numerics="train-mode calls run the input projections on plain bf16 operands (saliency_scores within 3e-2 of fp32); the "
                             "1e-4 saliency clause holds for inference calls (split-bf16 projections)",
-                   losses=[round(x, 5) for x in losses], roofline=roof, cpu_baseline=cpu)
+                   losses=[round(x, 5) for x in losses], roofline=roof, roofline_attention=roof_attn, cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

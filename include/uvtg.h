@@ -243,7 +243,8 @@ int uvtg_adamw_clip_step(float* params, const float* grads, float* exp_avg, floa
 
 /* ---- measurement hooks (bench.py): HIP events around every launch of the GEMM kernels, recorded on the launch
  * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-bf16, 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,
- * persistent).  host arrays [4]. */
+ * persistent), 4: attention forward, 5: attention backward (all its kernels; FLOPs counted on the padded S: 4 S^2 hd per
+ * (sample, head) forward, 10 S^2 hd backward).  host arrays [6]. */
 int uvtg_profile_start(void);
 int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
 /* the empty-event-pair floor (ms) that uvtg_profile_stop measured on the launch stream and subtracted from every launch */
