@@ -23,6 +23,19 @@ def main():
     print(f"# rocprofv3 --kernel-trace summary of {db.split('/')[-1]}")
     print(f"\ntotal kernel time {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches; first-to-last span {(span[1] - span[0]) / 1e6:.3f} ms"
           + (f"; {steps} steps traced -> {tot / 1e6 / steps:.3f} ms kernel time per step" if steps else ""))
+    # idle time between consecutive dispatches INSIDE a training step (a step ends with adamw_kernel): what a graph launch could remove
+    seq = c.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
+    ends = [i for i, r in enumerate(seq) if "adamw_kernel" in (r[0] or "")]
+    if len(ends) >= 3:
+        gaps, busy, wall, n = [], [], [], []
+        for a, b in zip(ends[1:-1], ends[2:]):
+            st = seq[a + 1: b + 1]
+            gaps.append(sum(max(0, st[i + 1][1] - st[i][2]) for i in range(len(st) - 1)))
+            busy.append(sum(r[2] - r[1] for r in st)); wall.append(st[-1][2] - st[0][1]); n.append(len(st))
+        k = len(gaps)
+        print(f"\nper step (median of {k}): {sorted(n)[k // 2]} dispatches, first-start to last-end {sorted(wall)[k // 2] / 1e6:.3f} ms, kernel time "
+              f"{sorted(busy)[k // 2] / 1e6:.3f} ms, idle between dispatches {sorted(gaps)[k // 2] / 1e6:.3f} ms "
+              f"({sorted(gaps)[k // 2] / max(sorted(n)[k // 2] - 1, 1) / 1e3:.2f} us per gap)")
     print("\n| kernel | calls | total ms | avg us | min us | max us | % | vgpr | agpr | sgpr | lds B | scratch B |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     for n, cnt, t, mn, mx, vg, ag, sg, lds, scr in rows:

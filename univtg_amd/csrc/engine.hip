@@ -672,7 +672,7 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
                            ws.pk, s));
   }
   uvtg_prof_section(2, 0, s);
-  TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, s));
+  TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, f.packed ? ws.pk.vin_of : nullptr, s));
   if (f.tr && m.c.p_path > 0.f) TRY(launch_droppath_scales(ws.dps, 2 * m.c.E, m.c.B, m.c.p_path, m.c.seed, s));
   TRY(f.project(0, src_vid, x0));
   if (f.packed && f.Rv < m.Mv) TRY(launch_fill_dropped_rows(x0, ws.pk, pmode == PACK_FULL, m.c.B, m.S, m.c.Lv, m.c.d, s));
@@ -1043,5 +1043,5 @@ extern "C" int uvtg_ragged_to_padded(const void* packed, int src_bf16, const int
 extern "C" int uvtg_sine_position(const float* vid_mask, const float* txt_mask, const float* dim_t, float* pos, unsigned char* kvalid,
                                   int B, int Lv, int Lt, int d, uvtg_stream_t st) {
   if (!vid_mask || !txt_mask || !dim_t || !pos || !kvalid) return -20;
-  return launch_seq_prep(vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, (hipStream_t)st);
+  return launch_seq_prep(vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, nullptr, (hipStream_t)st);
 }

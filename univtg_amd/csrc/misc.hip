@@ -8,10 +8,17 @@
 namespace {
 
 // ---------------- position table + key validity ----------------
+// skip (optional, [B*Lv]): rows with skip[row] < 0 have no packed row and nobody reads their table entry (pk.vin_of)
 __global__ void seq_prep_kernel(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
-                                const float* dim_t, float* pos, unsigned char* kvalid) {
+                                const float* dim_t, float* pos, unsigned char* kvalid, const int* skip) {
   const int row = blockIdx.x;             // (b, t) over B*Lv
   const int b = row / Lv, t = row % Lv;
+  if (t == 0) {
+    const int S = Lv + Lt;
+    for (int s = threadIdx.x; s < S; s += blockDim.x)
+      kvalid[b * S + s] = (s < Lv ? vid_mask[b * Lv + s] : txt_mask[b * Lt + (s - Lv)]) != 0.f;
+  }
+  if (skip && skip[row] < 0) return;
   __shared__ float s_c, s_last;
   if (threadIdx.x < 64) {
     float c = 0.f, tot = 0.f;
@@ -26,14 +33,20 @@ __global__ void seq_prep_kernel(const float* vid_mask, const float* txt_mask, in
   __syncthreads();
   // x_embed / (x_embed[:, -1:] + eps) * scale, all in fp32 (position_encoding.py:70-73)
   const float e = s_c / (s_last + 1e-6f) * 6.283185307179586f;
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    const float ang = e / dim_t[c];
-    pos[(size_t)row * d + c] = (c & 1) ? cosf(ang) : sinf(ang);
-  }
-  if (t == 0) {
-    const int S = Lv + Lt;
-    for (int s = threadIdx.x; s < S; s += blockDim.x)
-      kvalid[b * S + s] = (s < Lv ? vid_mask[b * Lv + s] : txt_mask[b * Lt + (s - Lv)]) != 0.f;
+  if ((d & 1) == 0) {
+    // columns 2j (sin) and 2j + 1 (cos) share their denominator (dim_t[2j] == dim_t[2j + 1], position_encoding.py:75-78): one angle,
+    // one sincosf, one 8-byte store per pair
+    for (int c = threadIdx.x * 2; c < d; c += blockDim.x * 2) {
+      const float a0 = e / dim_t[c], a1 = e / dim_t[c + 1];
+      float sv, cv;
+      if (a0 == a1) sincosf(a0, &sv, &cv); else { sv = sinf(a0); cv = cosf(a1); }
+      *(f32x2*)(pos + (size_t)row * d + c) = (f32x2){sv, cv};
+    }
+  } else {
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+      const float ang = e / dim_t[c];
+      pos[(size_t)row * d + c] = (c & 1) ? cosf(ang) : sinf(ang);
+    }
   }
 }
 
@@ -417,6 +430,9 @@ __device__ __forceinline__ void head_dz(const HeadsFinalArgs& a, int b, int t, f
 
 // dh2[b, u, :] (zero-framed, relu' applied) : dh[u][c] = sum_tap sum_j w[j][c][tap] * dz_j[u - tap + 1]
 // one wave per (b, u) row, lane owns 8 channels of the 2d-wide row per pass
+// NP > 0: 2 d == 512 NP -- the row's NP passes are unrolled with every hidden-row load issued before the first store (the output may
+// alias nothing, but the compiler cannot know: with the rolled loop each pass waited for the previous pass's store)
+template <int NP>
 __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFinalArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, u)
@@ -424,16 +440,21 @@ __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFina
   const int b = row / a.Lv, u = row % a.Lv, d = a.d;
   if (a.kept && u >= a.kept[b]) return;
   const int fs = a.fstart ? a.fstart[b] : b * (a.Lv + 2);
+  const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(fs + u + 1) * a.ldh;
+  bf16_t* out = a.dh2 + (size_t)(fs + u + 1) * a.lddh;
+  constexpr int NPP = NP > 0 ? NP : 1;
+  u32x4 hraw[NPP];
+  if constexpr (NP > 0) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) hraw[k] = *(const u32x4*)(h2 + lane * 8 + 512 * k);
+  }
   float dz0[3], dz1[3], dzc[3];
 #pragma unroll
   for (int tap = 0; tap < 3; tap++) head_dz(a, b, u - tap + 1, dz0[tap], dz1[tap], dzc[tap]);
-  const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(fs + u + 1) * a.ldh;
-  bf16_t* out = a.dh2 + (size_t)(fs + u + 1) * a.lddh;
-  for (int c2 = lane * 8; c2 < 2 * d; c2 += 512) {
+  auto pass = [&](int c2, const float (&h)[8]) {
     const bool cls = c2 >= d;
     const int c = cls ? c2 - d : c2;
-    float h[8], g[8];
-    ld8<bf16_t>(h2 + c2, h);
+    float g[8];
     if (!cls) {
       float w0[24], w1[24];
       ldw24(a.w_span + (size_t)c * 3, w0); ldw24(a.w_span + ((size_t)d + c) * 3, w1);
@@ -457,6 +478,21 @@ __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFina
     }
     u32x4 o; o[0] = pack_bf2(g[0], g[1]); o[1] = pack_bf2(g[2], g[3]); o[2] = pack_bf2(g[4], g[5]); o[3] = pack_bf2(g[6], g[7]);
     *(u32x4*)(out + c2) = o;
+  };
+  if constexpr (NP > 0) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      float h[8];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { h[2 * e] = __uint_as_float(hraw[k][e] << 16); h[2 * e + 1] = __uint_as_float(hraw[k][e] & 0xffff0000u); }
+      pass(lane * 8 + 512 * k, h);
+    }
+  } else {
+    for (int c2 = lane * 8; c2 < 2 * d; c2 += 512) {
+      float h[8];
+      ld8<bf16_t>(h2 + c2, h);
+      pass(c2, h);
+    }
   }
 }
 
@@ -689,7 +725,9 @@ __global__ __launch_bounds__(1024) void saliency_dlog_kernel(const SaliencyArgs 
   for (int t = 0; t < a.Lt; t++) dot += a.alpha[b * a.Lt + t] * sm[t];
   for (int t = tid; t < a.Lt; t += 1024) a.dlog[b * a.Lt + t] = a.alpha[b * a.Lt + t] * (sm[t] - dot);
 }
-// one block per (sample, 32-row chunk); 4 waves, each walks rows chunk*32 + wave, +4, ...; lane owns columns 4*lane + 256*k
+// one block per (sample, SAL_CHUNK-row chunk); 4 waves, each walks rows chunk*SAL_CHUNK + wave, +4, ...; lane owns columns 4*lane + 256*k
+// (16-row chunks: twice the blocks of the 32-row version, all still resident at once -- the kernel is a per-row latency chain)
+constexpr int SAL_CHUNK = 16;
 template <int KC>    // d = 256 * KC
 __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a) {
   __shared__ float s_dw[4][256 * KC];
@@ -702,8 +740,8 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
 #pragma unroll
     for (int e = 0; e < 4; e++) dw[k][e] = 0.f;
   bool any_txt = false;
-  const int s_end = min(a.S, chunk * 32 + 32);
-  for (int srow = chunk * 32 + wave; srow < s_end; srow += 4) {
+  const int s_end = min(a.S, chunk * SAL_CHUNK + SAL_CHUNK);
+  for (int srow = chunk * SAL_CHUNK + wave; srow < s_end; srow += 4) {
     const size_t row = (size_t)b * a.S + srow;
     const float* x = a.x0 + row * d;
     const long long grow = a.dx0_map ? (long long)a.dx0_map[row] : (long long)row;      // row of the (possibly packed) encoder gradient
@@ -839,8 +877,8 @@ int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S,
   return 0;
 }
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
-                    const float* dim_t, float* pos, unsigned char* kvalid, hipStream_t s) {
-  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid);
+                    const float* dim_t, float* pos, unsigned char* kvalid, const int* skip, hipStream_t s) {
+  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, skip);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -923,7 +961,9 @@ int launch_heads_final_fwd(const HeadsFinalArgs& a, hipStream_t s) {
 }
 int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s) {
   if (a.precise) return -6;
-  hipLaunchKernelGGL(heads_final_bwd_dh_kernel, dim3(cdiv(a.B * a.Lv, 4)), dim3(256), 0, s, a);
+  if (a.d == 1024) hipLaunchKernelGGL(heads_final_bwd_dh_kernel<4>, dim3(cdiv(a.B * a.Lv, 4)), dim3(256), 0, s, a);
+  else if (a.d == 512) hipLaunchKernelGGL(heads_final_bwd_dh_kernel<2>, dim3(cdiv(a.B * a.Lv, 4)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(heads_final_bwd_dh_kernel<0>, dim3(cdiv(a.B * a.Lv, 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   static bool attr = false;
   if (!attr) {
@@ -948,7 +988,7 @@ int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 64)), dim3(256), (3 * a.Lv + 256) * sizeof(float), s, a);
   hipLaunchKernelGGL(saliency_dlog_kernel, dim3(a.B), dim3(1024), a.Lt * sizeof(float), s, a);
-  const dim3 grid(a.B, cdiv(a.S, 32));
+  const dim3 grid(a.B, cdiv(a.S, SAL_CHUNK));
   if (a.d == 1024) hipLaunchKernelGGL(saliency_rows_kernel<4>, grid, dim3(256), 0, s, a);
   else if (a.d == 512) hipLaunchKernelGGL(saliency_rows_kernel<2>, grid, dim3(256), 0, s, a);
   else if (a.d == 256) hipLaunchKernelGGL(saliency_rows_kernel<1>, grid, dim3(256), 0, s, a);

@@ -177,7 +177,7 @@ int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S,
 
 int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask, hipStream_t s);
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
-                    const float* dim_t, float* pos, unsigned char* kvalid, hipStream_t s);
+                    const float* dim_t, float* pos, unsigned char* kvalid, const int* skip /* [B*Lv], < 0: row not needed; may be NULL */, hipStream_t s);
 int launch_droppath_scales(float* scales, int n_layers2, int B, float p, unsigned long long seed, hipStream_t s);
 int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
 int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s);
