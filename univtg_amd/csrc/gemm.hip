@@ -295,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   // fetched inside the epilogue one group ahead, into the registers the fragments no longer need
   constexpr int NPF = !EOP ? 0 : (TM == 4 ? 0 : (TM == 3 ? 1 : 2));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
+  __shared__ float s_rs[256];               // per-row factors (DropPath / frame mask) of the tile in its epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + BM - 1) / BM;
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     const bool ncol = n < p.N;
     // bias of the lane's columns, fetched at the head of the tile (in the epilogue the load would sit behind the barrier with
     // every wave of the block waiting on it); consumed here on every path (see the note on pending loads in the epilogue)
+    float rs_reg = 1.f;       // (set in the last K tile)
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) bv[e] = 0.f;
@@ -423,6 +425,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       k_offsets(LAST ? 0 : kt + 1, ka, kb);
       unsigned char* sbase = smem256 + (cur ^ 1) * SSTR;
       const unsigned char* base = smem256 + cur * SSTR;
+      if constexpr (LAST) {
+        // row factor of tile row (tid & 255), fetched under the last K tile: in the epilogue the lookup -- two DEPENDENT loads per
+        // q iteration, rowscale[row_sample[m]] -- was a latency chain of its own (8.5-10 us epilogues with DropPath vs 5 without).
+        // Branch-free (this block is scheduled as one): without a table the loads hit a valid dummy address and are not used.
+        const int mr = min(m0 + (tid & 255), p.M - 1);
+        const int* rsm = p.row_sample ? p.row_sample : (const int*)p.B;
+        const int i1 = rsm[p.row_sample ? mr : 0];
+        const float* rsp = p.rowscale ? p.rowscale : (const float*)p.B;
+        rs_reg = rsp[p.rowscale ? (p.row_sample ? i1 : mr / p.rs_seg) : 0];
+      }
       s16x8 fa[2][TM], fb[2][TN];
       if (ORD == 0) {
 #pragma unroll
@@ -493,6 +505,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           for (int r = 0; r < 16; r++) t += acc[i][j][r];
       if (t == 123.456f) p.outF[0] = t;
     } else {
+      if (tid < 256) s_rs[tid] = rs_reg;
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             }
           }
           if (p.rowscale) {      // (a zero factor SELECTS zero: the masked frame rows of the conv heads may have accumulated garbage)
-            const float rs = p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg];
+            const float rs = s_rs[wm * (32 * TM) + i * 32 + row];
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = rs == 0.f ? 0.f : v[e] * rs;
           }
