@@ -296,6 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   constexpr int NPF = !EOP ? 0 : (TM == 4 ? 0 : (TM == 3 ? 1 : 2));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   __shared__ float s_rs[256];               // per-row factors (DropPath / frame mask) of the tile in its epilogue
+  __shared__ int s_tab[GATHER ? 3 : 1][256]; // GATHER: the tile rows' entries of the output-row tables (o_rows, f_rows, pos_map)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + BM - 1) / BM;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     // bias of the lane's columns, fetched at the head of the tile (in the epilogue the load would sit behind the barrier with
     // every wave of the block waiting on it); consumed here on every path (see the note on pending loads in the epilogue)
     float rs_reg = 1.f;       // (set in the last K tile)
+    [[maybe_unused]] int tab_reg[3] = {0, 0, 0};
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) bv[e] = 0.f;
@@ -434,6 +436,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         const int i1 = rsm[p.row_sample ? mr : 0];
         const float* rsp = p.rowscale ? p.rowscale : (const float*)p.B;
         rs_reg = rsp[p.rowscale ? (p.row_sample ? i1 : mr / p.rs_seg) : 0];
+        if constexpr (GATHER) {             // the row tables likewise (same dummy-address trick)
+          const int* t0 = p.o_rows ? p.o_rows : (const int*)p.B;
+          const int* t1 = p.f_rows ? p.f_rows : (const int*)p.B;
+          const int* t2 = p.pos_map ? p.pos_map : (const int*)p.B;
+          tab_reg[0] = t0[p.o_rows ? mr : 0]; tab_reg[1] = t1[p.f_rows ? mr : 0]; tab_reg[2] = t2[p.pos_map ? mr : 0];
+        }
       }
       s16x8 fa[2][TM], fb[2][TN];
       if (ORD == 0) {
@@ -506,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       if (t == 123.456f) p.outF[0] = t;
     } else {
       if (tid < 256) s_rs[tid] = rs_reg;
+      if constexpr (GATHER) { if (tid < 256) { s_tab[0][tid] = tab_reg[0]; s_tab[1][tid] = tab_reg[1]; s_tab[2][tid] = tab_reg[2]; } }
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
@@ -541,7 +550,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           size_t orow = GATHER ? (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off) : (size_t)m, frow = orow;
           bool okB = true;                          // the non-outF outputs of this row are written (row tables: < 0 drops them)
           if constexpr (GATHER) {
-            if (p.o_rows) { const int t = p.o_rows[m]; okB = t >= 0; if (p.f_rows) frow = (size_t)p.f_rows[m]; orow = okB ? (size_t)t : 0; }
+            if (p.o_rows) {
+              const int rl = wm * (32 * TM) + i * 32 + row;
+              const int t = s_tab[0][rl]; okB = t >= 0; if (p.f_rows) frow = (size_t)s_tab[1][rl]; orow = okB ? (size_t)t : 0;
+            }
           }
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = (v[e] + bv[e]) * cs;
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           }
           if ((p.outU || p.outUF) && okB) {
             if (p.pos && m < p.pos_rows) {
-              const float* pp = p.pos + (size_t)((GATHER && p.pos_map) ? p.pos_map[m] : m) * p.ldpos + n;
+              const float* pp = p.pos + (size_t)((GATHER && p.pos_map) ? s_tab[GATHER ? 2 : 0][wm * (32 * TM) + i * 32 + row] : m) * p.ldpos + n;
               const f32x4 r0 = *(const f32x4*)pp, r1 = *(const f32x4*)(pp + 4);
 #pragma unroll
               for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
