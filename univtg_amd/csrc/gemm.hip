@@ -29,6 +29,7 @@ __device__ __forceinline__ int map_row(int m, int seg, int stride, int off) {
 
 template <bool X3>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
+#pragma clang fp contract(off)            // (epilogue rounding identical to the persistent kernel's)
   constexpr int BK = X3 ? 32 : 64;
   constexpr int TILE = BM * BK;
   constexpr int NT = X3 ? 4 : 2;            // operand tiles per stage (A,B[,Alo,Blo])
@@ -287,8 +288,18 @@ __global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = 
 #else
 #define NT_STAMP(k) do { } while (0)
 #endif
-template <bool GATHER, int TM, bool EOP, int ORD>
+// EPI (plain row mapping only): the epilogue is VALU-issue-bound (8 waves x 4 TM iterations x ~80 instructions, most of them the
+// run-time feature tests and 64-bit address arithmetic of paths the launch does not take), so the step's recurring feature sets get
+// bodies without the rest: 0 = general; 1 = bias, column scale, row factor, bf16 residual (EOP), bf16 out (q,k,v / out-proj / FFN2 /
+// dgrads: 24 of the 40 launches); 2 = bias, pre-activation copy, GELU, bf16 out (FFN1); 3 = GELU' of the bf16 pre-activation (EOP),
+// bf16 out (the activation-gradient GEMM).
+template <bool GATHER, int TM, bool EOP, int ORD, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
+#pragma clang fp contract(off)            // every instantiation must round the epilogue alike (the tile paths are compared bit for bit)
+  static_assert(!(EPI != 0 && GATHER), "the specialised epilogues have the plain row mapping");
+  static_assert(EPI != 2 || !EOP, "FFN1 has no epilogue operand");
+  static_assert(EPI != 3 || EOP, "the activation gradient reads its pre-activation");
+  constexpr bool SIMPLE = EPI != 0;
   constexpr int TB = 256, KB = 64, TN = 2, BM = 64 * TM, PA = TM, PB = 4, NP = PA + PB;
   constexpr int BOFF = 32768, SSTR = 65536;
   // epilogue-operand groups (32 rows x 64 columns = 4 x 16 B per lane each) fetched during the last K tile; the remaining ones are
@@ -557,53 +568,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           }
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = (v[e] + bv[e]) * cs;
-          if (p.outPre && okB) {
+          if ((EPI == 2 || (EPI == 0 && p.outPre)) && okB) {
             u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
             *(u32x4*)(p.outPre + go + orow * p.ldpre_out + n) = t;
           }
-          if (p.act == 1) {
+          if (EPI == 0 && p.act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-          } else if (p.act == 2) {
+          } else if (EPI == 2 || (EPI == 0 && p.act == 2)) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = gelu_fast(v[e]);
           }
           u32x4 eop = {0, 0, 0, 0};
           if constexpr (GROUPS) eop = ecur;
           else if constexpr (EOP) eop = *(const u32x4*)(esrc + orow * eld + n);
-          if (EOP && p.actgrad && !p.residB) {
+          if (EOP && (EPI == 3 || (EPI == 0 && p.actgrad && !p.residB))) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
               const float q0 = __uint_as_float(eop[e] << 16), q1 = __uint_as_float(eop[e] & 0xffff0000u);
-              if (p.actgrad == 1) { v[2 * e] = q0 > 0.f ? v[2 * e] : 0.f; v[2 * e + 1] = q1 > 0.f ? v[2 * e + 1] : 0.f; }
+              if (EPI == 0 && p.actgrad == 1) { v[2 * e] = q0 > 0.f ? v[2 * e] : 0.f; v[2 * e + 1] = q1 > 0.f ? v[2 * e + 1] : 0.f; }
               else { v[2 * e] *= gelu_fast_grad(q0); v[2 * e + 1] *= gelu_fast_grad(q1); }
             }
           }
-          if (p.rowscale) {      // (a zero factor SELECTS zero: the masked frame rows of the conv heads may have accumulated garbage)
+          if (EPI <= 1 && p.rowscale) {      // (a zero factor SELECTS zero: the masked frame rows of the conv heads may have accumulated garbage)
             const float rs = s_rs[wm * (32 * TM) + i * 32 + row];
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = rs == 0.f ? 0.f : v[e] * rs;
           }
-          if (p.resid) {
+          if (!SIMPLE && p.resid) {
             const float* rp = p.resid + orow * p.ldr + n;
             const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
             for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
           }
-          if (EOP && p.residB) {
+          if (EOP && (EPI == 1 || (EPI == 0 && p.residB))) {
 #pragma unroll
             for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(eop[e] << 16); v[2 * e + 1] += __uint_as_float(eop[e] & 0xffff0000u); }
           }
-          if (p.outF) {
+          if (!SIMPLE && p.outF) {
             float* op = p.outF + go + frow * p.ldoF + n;
             *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
             *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
           }
-          if (p.outB && okB) {
+          if ((SIMPLE || p.outB) && okB) {
             u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
             *(u32x4*)(p.outB + go + orow * p.ldoB + n) = t;
           }
-          if ((p.outU || p.outUF) && okB) {
+          if (!SIMPLE && (p.outU || p.outUF) && okB) {
             if (p.pos && m < p.pos_rows) {
               const float* pp = p.pos + (size_t)((GATHER && p.pos_map) ? s_tab[GATHER ? 2 : 0][wm * (32 * TM) + i * 32 + row] : m) * p.ldpos + n;
               const f32x4 r0 = *(const f32x4*)pp, r1 = *(const f32x4*)(pp + 4);
@@ -1072,23 +1083,23 @@ static int eff_cus() { return (g_cu_cap > 0 && g_cu_cap < g_num_cu) ? g_cu_cap :
 #define UVTG_NT_F3 1.07
 #define UVTG_NT_F2 1.20
 #endif
-template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, bool eop, hipStream_t s) {
+template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, bool eop, int epi, hipStream_t s) {
   constexpr int smem = 131072;
   static bool attr = false;
+#define NT256_ATTR(G, E, P) if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<G, TM, E, ORD, P>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
   if (!attr) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, false, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, true, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, false, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, true, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    NT256_ATTR(false, false, 0) NT256_ATTR(false, true, 0) NT256_ATTR(false, false, 1) NT256_ATTR(false, true, 1)
+    NT256_ATTR(false, false, 2) NT256_ATTR(false, true, 3) NT256_ATTR(true, false, 0) NT256_ATTR(true, true, 0)
     attr = true;
   }
-  if (gather) {
-    if (eop) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, true, ORD>), dim3(grid), dim3(512), smem, s, b);
-    else hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, false, ORD>), dim3(grid), dim3(512), smem, s, b);
-  } else {
-    if (eop) hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, true, ORD>), dim3(grid), dim3(512), smem, s, b);
-    else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, false, ORD>), dim3(grid), dim3(512), smem, s, b);
-  }
+#undef NT256_ATTR
+#define NT256_GO(G, E, P) hipLaunchKernelGGL((gemm_nt256_kernel<G, TM, E, ORD, P>), dim3(grid), dim3(512), smem, s, b)
+  if (gather) { if (eop) NT256_GO(true, true, 0); else NT256_GO(true, false, 0); }
+  else if (epi == 1) { if (eop) NT256_GO(false, true, 1); else NT256_GO(false, false, 1); }
+  else if (epi == 2 && !eop) NT256_GO(false, false, 2);
+  else if (epi == 3 && eop) NT256_GO(false, true, 3);
+  else { if (eop) NT256_GO(false, true, 0); else NT256_GO(false, false, 0); }
+#undef NT256_GO
   return 0;
 }
 // Staging order per tile height (TM = 2, 3, 4).  Measured on the whole training step (tools/ord_ab.sh, same box, two rounds): the
@@ -1154,15 +1165,24 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1 || b.o_rows || b.pos_map;
   const bool eop = b.residB || (b.actgrad && b.gradPre);
+  static const bool epi_off = getenv("UVTG_NT_EPI_OFF") != nullptr;       // experiment: the general epilogue everywhere
+  static const int epi_mask = getenv("UVTG_NT_EPI_MASK") ? atoi(getenv("UVTG_NT_EPI_MASK")) : 14;      // bit e: specialisation e allowed
+  int epi = 0;
+  if (!epi_off && !gather && b.outB && !b.resid && !b.outF && !b.outU && !b.outUF && !b.pos) {
+    if (!b.outPre && !b.act && !b.actgrad && (!eop || b.residB)) epi = 1;
+    else if (b.outPre && b.act == 2 && !b.actgrad && !eop && !b.rowscale) epi = 2;
+    else if (!b.outPre && !b.act && b.actgrad == 2 && eop && !b.residB && !b.rowscale) epi = 3;
+  }
+  if (!((epi_mask >> epi) & 1)) epi = 0;
 #ifdef UVTG_NT_TRACE
   nt_trace_launch(b, best_tm, grid, gather, eop, s);
 #endif
   uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
   int rc;
   if (nt_order(best_tm) == 0)
-    rc = best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, s));
+    rc = best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
   else
-    rc = best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, s));
+    rc = best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, epi, s));
   uvtg_prof_end_launch(3, s);
   if (rc) return rc;
   UVTG_CHECK_LAUNCH();

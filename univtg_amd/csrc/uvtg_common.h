@@ -52,6 +52,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // rounding of the result), one v_rcp + one v_exp shared by value and derivative -- erff() plus a second exponential made the
 // activation-gradient epilogue ALU-bound (18 us per 192 x 256 tile against 8.5 us for the same bytes without it).
 __device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& pdf_x) {
+#pragma clang fp contract(off)      // the same bits from every kernel instantiation that inlines this (contraction is a per-site scheduling choice)
   const float ax = fabsf(x) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   const float e = __expf(-ax * ax);                         // exp(-x^2 / 2)
@@ -63,8 +64,14 @@ __device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& pdf_
   cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
   pdf_x = x * 0.3989422804014327f * e;
 }
-__device__ __forceinline__ float gelu_fast(float x) { float c, p; gelu_fast_parts(x, c, p); return x * c; }
-__device__ __forceinline__ float gelu_fast_grad(float x) { float c, p; gelu_fast_parts(x, c, p); return c + p; }
+__device__ __forceinline__ float gelu_fast(float x) {
+#pragma clang fp contract(off)
+  float c, p; gelu_fast_parts(x, c, p); return x * c;
+}
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+#pragma clang fp contract(off)
+  float c, p; gelu_fast_parts(x, c, p); return c + p;
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // Counter-based RNG (Philox-4x32-10) for dropout / DropPath: stateless, reproducible in backward.
