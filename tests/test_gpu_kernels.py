@@ -146,7 +146,8 @@ def test_attention_softmax_rescale_branch(dev):
     assert float((o.cpu() - ref_o).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("B,S,H,hd", [(2, 27, 2, 32), (2, 107, 2, 64), (2, 107, 4, 128), (1, 200, 2, 128), (2, 128, 2, 128), (3, 33, 1, 128)])
+@pytest.mark.parametrize("B,S,H,hd", [(2, 27, 2, 32), (2, 107, 2, 64), (2, 107, 4, 128), (1, 200, 2, 128), (2, 128, 2, 128), (3, 33, 1, 128),
+                                       (2, 160, 8, 128), (1, 256, 2, 64), (2, 129, 2, 32), (1, 300, 2, 128)])   # 129..256: the 8-wave fused kernel; 300: split kernels
 def test_attention_bwd(dev, B, S, H, hd):
     from univtg_amd import ops
     g = torch.Generator().manual_seed(S * hd)

@@ -582,7 +582,7 @@ def test_edge_shapes_vs_oracle(dev, B, Lv, Lt, d, H, ragged):
     assert worst > 0.95, worst
 
 
-@pytest.mark.parametrize("B,Lv,Lt,d,H,E", [(6, 30, 10, 256, 4, 2), (256, 75, 32, 1024, 8, 4), (3, 150, 12, 128, 2, 2)])
+@pytest.mark.parametrize("B,Lv,Lt,d,H,E", [(6, 30, 10, 256, 4, 2), (256, 75, 32, 1024, 8, 4), (3, 150, 12, 128, 2, 2), (5, 128, 32, 256, 2, 2)])
 def test_packed_ragged_stream_matches_padded(dev, B, Lv, Lt, d, H, E):
     """Packed encoder stream (valid clips + ONE representative padded clip + valid text per sample, include/uvtg.h lens_host)
     against the padded execution of the same ragged batch: same outputs at every clip position (padded ones included), same

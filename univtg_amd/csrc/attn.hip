@@ -547,10 +547,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 // halve the occupancy); with p_drop > 0 -- never the case in the reference scripts, scripts/pretrain.sh:34 -- the split
 // kernels run instead.
 // ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a) {
-  constexpr int KSTR = HD + 8, QSTR = HD + 8, DSTR = 128 + 8, CH = HD / 8;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[128 * KSTR];
+// NW = 4: up to 128 keys, two workgroups per CU.  NW = 8 (128 < S <= 256, e.g. the pretraining shape L_v = 128 + 32 text tokens): 256 keys,
+// 8 waves, one workgroup per CU (the same two waves per SIMD); the dQ^T tile of a query block is summed over two key halves by two
+// wave groups and folded through an fp32 LDS slab.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kernel(const AttnArgs a) {
+  constexpr int KROWS = 32 * NW, T = 64 * NW;
+  constexpr int KSTR = HD + 8, QSTR = HD + 8, DSTR = KROWS + 8, CH = HD / 8;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[KROWS * KSTR];
+  __shared__ float sPart[NW == 8 ? 4 * 16 * 64 : 1];     // NW = 8: dQ^T partials of the upper key half, [hd tile][acc register][lane]
   __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * QSTR];
   __shared__ __attribute__((aligned(16))) bf16_t sO[32 * QSTR];
   __shared__ __attribute__((aligned(16))) bf16_t sDS[32 * DSTR];
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
   for (int i = 0; i < HD / 32; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-  constexpr int NP = (32 * CH + 255) / 256;          // staging pieces per thread per operand
+  constexpr int NP = (32 * CH + T - 1) / T;          // staging pieces per thread per operand
   u32x4 pq[NP], po[NP];
   float pl = 0.f, pdl = 0.f;                         // lse / delta of query qb*32 + tid (tid < 32), fetched with the block's rows
   auto prefetch = [&](int qb) {
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
     }
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int q = tid + 256 * i, r = q / CH, c = q % CH, qi = qb * 32 + r;
+      const int q = tid + T * i, r = q / CH, c = q % CH, qi = qb * 32 + r;
       pq[i] = (u32x4){0, 0, 0, 0}; po[i] = (u32x4){0, 0, 0, 0};
       if (q < 32 * CH && qi < S) {
         pq[i] = *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8);
@@ -593,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
   prefetch(0);                                       // first query block's rows are in flight while K is staged
   // K (all keys) -> LDS, zero rows beyond S
 #pragma unroll
-  for (int i = 0; i < (128 * CH) / 256; i++) {
-    const int q = tid + 256 * i, r = q / CH, c = q % CH;
+  for (int i = 0; i < (KROWS * CH) / T; i++) {
+    const int q = tid + T * i, r = q / CH, c = q % CH;
     u32x4 kv = {0, 0, 0, 0};
     if (r < S) kv = *(const u32x4*)(qkv + (rowbase + r) * a.ldqkv + d + h * HD + c * 8);
     *(u32x4*)(&sK[r * KSTR + c * 8]) = kv;
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
   auto flush_dq = [&](int qbp) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int q = tid + 256 * i, r = q / CH, c = q % CH, qi = qbp * 32 + r;
+      const int q = tid + T * i, r = q / CH, c = q % CH, qi = qbp * 32 + r;
       if (q < 32 * CH && qi < S) *(u32x4*)(a.dqkv + (rowbase + qi) * a.lddqkv + h * HD + c * 8) = *(const u32x4*)(&sDQ[r * QSTR + c * 8]);
     }
   };
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
     if (qb > 0) flush_dq(qb - 1);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int q = tid + 256 * i, r = q / CH, c = q % CH;
+      const int q = tid + T * i, r = q / CH, c = q % CH;
       if (q < 32 * CH) { *(u32x4*)(&sQ[r * QSTR + c * 8]) = pq[i]; *(u32x4*)(&sO[r * QSTR + c * 8]) = po[i]; }
     }
     if (tid < 32) { sL[tid] = pl; sD[tid] = pdl; }   // rows beyond S: clamped duplicates, masked by qi < S below
@@ -661,26 +666,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnArgs a
       }
     }
     __syncthreads();                                 // every wave's dS tile of this query block is in sDS
-    // dQ^T tile (head dims 32 wave .. +31) x (32 queries) = sum over all 128 keys of K^T dS^T
-    if (wave * 32 < HD) {
+    // dQ^T tile (head dims 32 t .. +31) x (32 queries) = sum over the keys of K^T dS^T: wave w takes tile t = w % 4 over the keys
+    // 128 (w / 4) .. + 127; with 8 waves the upper half's partial goes through sPart and the lower half's waves finish the tile
+    {
+      const int tile_hd = wave & 3, khalf = wave >> 2;
+      const bool dq_on = tile_hd * 32 < HD;
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; r++) dq[r] = 0.f;
-      const int col = wave * 32 + 16 * qd + 4 * (i16 & 3);
+      if (dq_on) {
+        const int col = tile_hd * 32 + 16 * qd + 4 * (i16 & 3);
 #pragma unroll
-      for (int kk = 0; kk < 8; kk++) {
-        const int kr = 16 * kk + 8 * g + (i16 >> 2);
-        const s16x8 kt_ = cat4(lds_tr16(&sK[kr * KSTR + col]), lds_tr16(&sK[(kr + 4) * KSTR + col]));
-        const s16x8 db = *(const s16x8*)(&sDS[l31 * DSTR + 16 * kk + 8 * g]);
-        dq = mfma32(kt_, db, dq);
+        for (int kk = 0; kk < 8; kk++) {
+          const int kr = khalf * 128 + 16 * kk + 8 * g + (i16 >> 2);
+          const s16x8 kt_ = cat4(lds_tr16(&sK[kr * KSTR + col]), lds_tr16(&sK[(kr + 4) * KSTR + col]));
+          const s16x8 db = *(const s16x8*)(&sDS[l31 * DSTR + khalf * 128 + 16 * kk + 8 * g]);
+          dq = mfma32(kt_, db, dq);
+        }
       }
+      if constexpr (NW == 8) {
+        if (dq_on && khalf == 1) {
 #pragma unroll
-      for (int rq = 0; rq < 4; rq++) {
-        const int c = wave * 32 + 8 * rq + 4 * g;
-        u32x2 t;
-        t[0] = pack_bf2(dq[4 * rq] * a.qscale, dq[4 * rq + 1] * a.qscale);
-        t[1] = pack_bf2(dq[4 * rq + 2] * a.qscale, dq[4 * rq + 3] * a.qscale);
-        *(u32x2*)(&sDQ[l31 * QSTR + c]) = t;
+          for (int r = 0; r < 16; r++) sPart[(tile_hd * 16 + r) * 64 + lane] = dq[r];
+        }
+        __syncthreads();
+        if (dq_on && khalf == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) dq[r] += sPart[(tile_hd * 16 + r) * 64 + lane];
+        }
+      }
+      if (dq_on && khalf == 0) {
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+          const int c = tile_hd * 32 + 8 * rq + 4 * g;
+          u32x2 t;
+          t[0] = pack_bf2(dq[4 * rq] * a.qscale, dq[4 * rq + 1] * a.qscale);
+          t[1] = pack_bf2(dq[4 * rq + 2] * a.qscale, dq[4 * rq + 3] * a.qscale);
+          *(u32x2*)(&sDQ[l31 * QSTR + c]) = t;
+        }
       }
     }
   }
@@ -741,9 +764,19 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   UVTG_CHECK_LAUNCH();
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
   if (a.S <= 128 && a.p_drop <= 0.f) {   // whole (sample, head) problem in one workgroup: one pass over q, k, v, dO
-    if (a.hd == 128) hipLaunchKernelGGL((attn_bwd_fused_kernel<128>), grid, blk, 0, s, a);
-    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32>), grid, blk, 0, s, a);
+    if (a.hd == 128) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4>), grid, blk, 0, s, a);
+    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 4>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 4>), grid, blk, 0, s, a);
+    uvtg_prof_end_launch(5, s);
+    UVTG_CHECK_LAUNCH();
+    return 0;
+  }
+  static const bool fused8_off = getenv("UVTG_ATTN_FUSED8_OFF") != nullptr;      // experiment: the split kernels for 128 < S <= 256
+  if (a.S <= 256 && a.p_drop <= 0.f && !fused8_off) {   // the same with 8 waves / 256 keys (one workgroup per CU)
+    const dim3 g8(1, a.H, a.B), b8(512);
+    if (a.hd == 128) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 8>), g8, b8, 0, s, a);
+    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 8>), g8, b8, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 8>), g8, b8, 0, s, a);
     uvtg_prof_end_launch(5, s);
     UVTG_CHECK_LAUNCH();
     return 0;
