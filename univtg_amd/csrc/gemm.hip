@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
       }
       float* op = p.out + (size_t)n * p.ldo + (size_t)kk * taps;
       for (int j = 0; j < taps; j++) {
-        f32x4 o = *(f32x4*)(op + 4 * j);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (!p.assign) o = *(f32x4*)(op + 4 * j);
         o[0] += v[4 * j]; o[1] += v[4 * j + 1]; o[2] += v[4 * j + 2]; o[3] += v[4 * j + 3];
         *(f32x4*)(op + 4 * j) = o;
       }
@@ -1018,10 +1019,12 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
     for (int sidx = 0; sidx < splits; sidx++) s += *(const f32x4*)(sp + (size_t)sidx * tiles * 65536);
     const int tap = p.ktap > 0 ? k / p.ktap : 0;
     float* op = p.out + (size_t)n * p.ldo + (size_t)(k - tap * (p.ktap > 0 ? p.ktap : 0)) * p.col_stride + tap;
-    if (p.col_stride == 1 && p.ktap == 0 && k + 3 < p.K && ((((uintptr_t)op) & 15) == 0)) { f32x4 o = *(f32x4*)op; o += s; *(f32x4*)op = o; }
-    else {
+    if (p.col_stride == 1 && p.ktap == 0 && k + 3 < p.K && ((((uintptr_t)op) & 15) == 0)) {
+      if (p.assign) *(f32x4*)op = s;
+      else { f32x4 o = *(f32x4*)op; o += s; *(f32x4*)op = o; }
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) if (k + e < p.K) op[(size_t)e * p.col_stride] += s[e];
+      for (int e = 0; e < 4; e++) if (k + e < p.K) { if (p.assign) op[(size_t)e * p.col_stride] = s[e]; else op[(size_t)e * p.col_stride] += s[e]; }
     }
   }
   if (p.dbias && idx < p.N) {
@@ -1319,6 +1322,10 @@ int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s) {
   if (tn256_ok(a)) return launch_tn256(a, s);
   if (a.ktap > 0) return -2;      // taps exist only in the 256-tile kernel: callers check gemm_tn_taps_ok() first
   if (a.ldp % 8 || a.ldq % 8 || ((uintptr_t)a.P & 15) || ((uintptr_t)a.Q & 15)) return -2;
+  if (a.assign) {                 // the atomic kernel accumulates: give it a zeroed output (contiguous outputs only)
+    if (a.col_stride != 1) return -2;
+    if (hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.N * a.ldo * sizeof(float), s)) return (int)e;
+  }
   dim3 grid(cdiv(a.N, 128) * cdiv(a.K, 128), a.splits, 1);
   uvtg_prof_begin_launch(2, 2.0 * a.M * a.N * a.K, s);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, a);

@@ -59,6 +59,10 @@ __global__ void droppath_kernel(float* scales, int n, int B, float p, unsigned l
   scales[i] = floorf(keep + u01(r[0])) / keep;     // drop_path(): mask = floor(keep + U[0,1)), x / keep * mask
 }
 
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const ZeroRanges r) {
+  float* p = base + r.off[blockIdx.x];
+  for (int i = threadIdx.x; i < r.n[blockIdx.x]; i += 256) p[i] = 0.f;
+}
 __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, long long n) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -884,6 +888,12 @@ int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv,
 }
 int launch_droppath_scales(float* scales, int n, int B, float p, unsigned long long seed, hipStream_t s) {
   hipLaunchKernelGGL(droppath_kernel, dim3(cdiv(n * B, 256)), dim3(256), 0, s, scales, n, B, p, seed);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s) {
+  if (r.count <= 0) return 0;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count), dim3(256), 0, s, base, r);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -58,6 +58,8 @@ struct GemmTNArgs {
   // 256-tile kernel only: K is `K / ktap` conv taps of ktap columns; tap t reads Q rows m + q_row_off + t, columns k % ktap,
   // and lands at out[n * ldo + (k % ktap) * col_stride + t]   (0: no taps)
   int ktap;
+  // 1: out = the product (the caller does NOT zero `out`; dbias is still accumulated); 0: out += the product
+  int assign;
 };
 // several weight gradients over the SAME reduction rows (M, splits plan) in one launch: the tiles of all groups share the M splits,
 // so there are more tiles per launch, fewer splits, and far less split-partial traffic than one launch per gradient
@@ -180,6 +182,10 @@ int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv,
                     const float* dim_t, float* pos, unsigned char* kvalid, const int* skip /* [B*Lv], < 0: row not needed; may be NULL */, hipStream_t s);
 int launch_droppath_scales(float* scales, int n_layers2, int B, float p, unsigned long long seed, hipStream_t s);
 int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
+// zero the float ranges [off[i], off[i] + n[i]) of base (the gradients no weight-gradient launch assigns)
+constexpr int UVTG_MAX_ZERO_RANGES = 224;
+struct ZeroRanges { long long off[UVTG_MAX_ZERO_RANGES]; int n[UVTG_MAX_ZERO_RANGES]; int count; };
+int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s);
 int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s);
 int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);
 int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);  // dst[c][r]
