@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
       px[i] = (u32x4){0, 0, 0, 0}; pg[i] = (u32x4){0, 0, 0, 0}; pg2[i] = (u32x4){0, 0, 0, 0};
       if (c < D) {
         px[i] = *(const u32x4*)(a.xB + row * a.ldxB + c);
-        pg[i] = *(const u32x4*)(a.gB + row * a.ldgB + c);
+        if (a.gB) pg[i] = *(const u32x4*)(a.gB + row * a.ldgB + c);       // (the top layer has only the heads' gradient: g2)
       }
     }
     if (have_g2) {
@@ -669,7 +669,7 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
   if (!b.dgamma || b.partial_floats < (long long)blocks * 2 * b.D) b.partial = nullptr;
   if constexpr (VEC == 8 && NV <= 2) {
     static const bool lean_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
-    if (bf && a.gB && a.p_drop == 0.f && !a.relu_from_x && !a.gather_x && wpb == 8 && !lean_off) {
+    if (bf && (a.gB || a.g2B) && a.p_drop == 0.f && !a.relu_from_x && !a.gather_x && wpb == 8 && !lean_off) {
       hipLaunchKernelGGL((ln_bwd_lean_kernel<NV>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
       if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
       UVTG_CHECK_LAUNCH();
