@@ -240,6 +240,14 @@ int uvtg_postprocess_mr(const float* pred_logits, const float* pred_spans, const
 int uvtg_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float max_norm, float grad_scale, float* scratch, uvtg_stream_t stream);
+/* The same with the squared gradient norm already on the device: uvtg_backward accumulates it while it writes the gradients
+ * (uvtg_backward_gradnorm2 returns its address inside the workspace), so a single-rank step needs no extra pass over the
+ * gradient buffer.  NOT valid after a gradient all-reduce (the norm must be the reduced gradients'): use uvtg_adamw_clip_step there. */
+int uvtg_adamw_clip_step_prenorm(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                 float max_norm, float grad_scale, const float* sqnorm_dev, uvtg_stream_t stream);
+const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* workspace);
+
 
 /* ---- measurement hooks (bench.py): HIP events around every launch of the GEMM kernels, recorded on the launch
  * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-bf16, 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,

@@ -49,6 +49,8 @@ SIGNATURES = {
     "uvtg_ragged_to_padded": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "uvtg_sine_position": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "uvtg_adamw_clip_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
+    "uvtg_adamw_clip_step_prenorm": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P]),
+    "uvtg_backward_gradnorm2": (_P, [_P, _P]),
     "uvtg_debug_force_nt_tile": (_I, [_I]),
     "uvtg_debug_force_nt_bm": (_I, [_I]),
     "uvtg_debug_gemm_cus": (_I, [_I]),

@@ -132,6 +132,7 @@ struct WSpace {
   float *alpha, *cosv, *vnorm, *qnorm, *sal_dq, *sal_dlog;
   // backward scratch
   float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2], *tn_scratch; long long tn_scratch_floats;
+  float* gnorm2;       // sum of squares of the step's gradients, accumulated by uvtg_backward (uvtg_backward_gradnorm2)
   bf16_t *dh2_pad, *dh1_pad, *dyB, *dyR, *dvmB, *gxb[2], *da, *dOb, *dqkv, *dyP[2], *dh1b[2];
   size_t bytes;
   WSpace(const Dm& m, void* base, float* x0) {
@@ -201,6 +202,7 @@ struct WSpace {
       dvmB = a.take<bf16_t>((size_t)(m.Rp + 1) * d); gxb[0] = a.take<bf16_t>(M * d); gxb[1] = a.take<bf16_t>(M * d);     // (frame-row space on the loss-only stream)
       dyR = a.take<bf16_t>(M * d); delta = a.take<float>(B * m.c.H * m.S);
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
+      gnorm2 = a.take<float>(4);
       {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
         long long need = 0;
         const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d}, {m.Rp, (int)d, 3 * (int)d},
@@ -718,6 +720,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   { long long o = 0; for (int i = 0; i < m.np; i++) { off[i] = o; o += (pnumel(m, i) + 3) / 4 * 4; } off[m.np] = o; }
   auto G = [&](int idx) { return grads + off[idx]; };
   uvtg_prof_section(3, 0, s);
+  ZeroRanges zr_keep; zr_keep.count = 0;
   // The weight-gradient launches ASSIGN their matrices (99.6 % of the buffer: no zero fill, no read-modify-write in the reduce pass);
   // every other gradient (biases, LayerNorm, token-type rows, pooling vector, the heads' last layer) is accumulated into zeros.
   {
@@ -731,13 +734,15 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       zr.off[zr.count] = off[i]; zr.n[zr.count] = (int)(off[i + 1] - off[i]); zr.count++;
     }
     TRY(launch_zero_ranges(grads, zr, s));
+    zr_keep = zr;
   }
+  if (hipError_t e = hipMemsetAsync(ws.gnorm2, 0, sizeof(float), s)) return (int)e;
   const int splits_M = 8, splits_v = 8;
   auto wgrad = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, int cs,
                    float* dbias, int q_off, int Mq, int splits) {
     GemmTNArgs t; memset(&t, 0, sizeof(t));
     t.P = Pm; t.ldp = ldp; t.Q = Q; t.ldq = ldq; t.M = rows; t.N = N; t.K = K; t.q_row_off = q_off; t.Mq = Mq;
-    t.out = out; t.ldo = ldo; t.col_stride = cs; t.dbias = dbias; t.splits = splits; t.assign = cs == 1;
+    t.out = out; t.ldo = ldo; t.col_stride = cs; t.dbias = dbias; t.splits = splits; t.assign = cs == 1; t.sqsum = ws.gnorm2;
     t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
     return launch_gemm_tn_bf16(t, s);
   };
@@ -746,7 +751,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   auto tn_group = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, float* dbias) {
     GemmTNArgs t; memset(&t, 0, sizeof(t));
     t.P = Pm; t.ldp = ldp; t.Q = Q; t.ldq = ldq; t.M = rows; t.N = N; t.K = K; t.Mq = rows;
-    t.out = out; t.ldo = ldo; t.col_stride = 1; t.dbias = dbias; t.splits = splits_M; t.assign = 1;
+    t.out = out; t.ldo = ldo; t.col_stride = 1; t.dbias = dbias; t.splits = splits_M; t.assign = 1; t.sqsum = ws.gnorm2;
     t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
     return t;
   };
@@ -760,13 +765,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   auto conv_wgrad = [&](const bf16_t* dY, int ldp, const bf16_t* X, int ldq, float* dW, float* dBi, int rows) -> int {
     GemmTNArgs t; memset(&t, 0, sizeof(t));
     t.P = dY; t.ldp = ldp; t.Q = X; t.ldq = ldq; t.M = rows; t.N = d; t.K = 3 * d; t.q_row_off = -1; t.Mq = rows;
-    t.out = dW; t.ldo = 3 * d; t.col_stride = 3; t.dbias = dBi; t.splits = splits_v; t.ktap = d; t.assign = 1;
+    t.out = dW; t.ldo = 3 * d; t.col_stride = 3; t.dbias = dBi; t.splits = splits_v; t.ktap = d; t.assign = 1; t.sqsum = ws.gnorm2;
     t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
     if (gemm_tn_taps_ok(t)) return launch_gemm_tn_bf16(t, s);
     if (hipError_t e = hipMemsetAsync(dW, 0, (size_t)d * 3 * d * sizeof(float), s)) return (int)e;      // per-tap launches accumulate (stride-3 outputs)
     for (int tap = 0; tap < 3; tap++)
       TRY(wgrad(dY, ldp, X, ldq, rows, d, d, dW + tap, 3 * d, 3, tap == 1 ? dBi : nullptr, tap - 1, rows, splits_v));
-    return 0;
+    return launch_sqsum(dW, (long long)d * 3 * d, ws.gnorm2, s);
   };
   // ---------------- heads ----------------
   const bool halo = pmode == PACK_HALO;          // ragged conv-head frames (see Fwd::heads)
@@ -925,8 +930,18 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
   }
+  TRY(launch_sqsum_ranges(grads, zr_keep, ws.gnorm2, s));      // the gradients no weight-gradient launch assigned
   uvtg_prof_section(3, 1, s);
   return 0;
+}
+
+// device address of the squared L2 norm of ALL gradients of the last uvtg_backward on this workspace (single-rank steps hand it to
+// uvtg_adamw_clip_step_prenorm instead of re-reading the gradient buffer; after a gradient all-reduce it is stale)
+extern "C" const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* workspace) {
+  if (check_dims(dm) || !workspace || !dm->training || dm->precise) return nullptr;
+  Dm m(*dm);
+  WSpace ws(m, workspace, nullptr);
+  return ws.gnorm2;
 }
 
 // =================================================================================================

@@ -982,6 +982,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
   const long long total = (long long)p.N * kq;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int taps = p.ktap > 0 ? p.K / p.ktap : 0;
+  float sq = 0.f;          // sum of squares of the values this thread assigns (p.sqsum)
   if (taps >= 2 && taps <= 4 && p.col_stride == taps && p.ktap % 4 == 0 && taps * p.ktap == p.K && p.ldo % 4 == 0 &&
       (((uintptr_t)p.out) & 15) == 0) {
     // conv taps: a thread folds the `taps` tiles that hold columns kk .. kk + 3 of every tap and writes the 4 x taps floats of
@@ -1009,6 +1010,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
         if (!p.assign) o = *(f32x4*)(op + 4 * j);
         o[0] += v[4 * j]; o[1] += v[4 * j + 1]; o[2] += v[4 * j + 2]; o[3] += v[4 * j + 3];
         *(f32x4*)(op + 4 * j) = o;
+        sq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
       }
     }
   } else if (idx < total) {
@@ -1022,10 +1024,18 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
     if (p.col_stride == 1 && p.ktap == 0 && k + 3 < p.K && ((((uintptr_t)op) & 15) == 0)) {
       if (p.assign) *(f32x4*)op = s;
       else { f32x4 o = *(f32x4*)op; o += s; *(f32x4*)op = o; }
+      sq += (s[0] * s[0] + s[1] * s[1]) + (s[2] * s[2] + s[3] * s[3]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) if (k + e < p.K) { if (p.assign) op[(size_t)e * p.col_stride] = s[e]; else op[(size_t)e * p.col_stride] += s[e]; }
+      for (int e = 0; e < 4; e++) if (k + e < p.K) { if (p.assign) op[(size_t)e * p.col_stride] = s[e]; else op[(size_t)e * p.col_stride] += s[e]; sq += s[e] * s[e]; }
     }
+  }
+  if (p.sqsum && p.assign) {      // (block-uniform condition; with assign the values above ARE the final gradient)
+    __shared__ float red[4];
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float t = (red[0] + red[1]) + (red[2] + red[3]); if (t != 0.f) atomicAdd(p.sqsum, t); }
   }
   if (p.dbias && idx < p.N) {
     const float* bp = plan.scratch + plan.bias_base[gi] + idx;
@@ -1331,5 +1341,6 @@ int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, a);
   uvtg_prof_end_launch(2, s);
   UVTG_CHECK_LAUNCH();
+  if (a.assign && a.sqsum) return launch_sqsum(a.out, (long long)a.N * a.ldo, a.sqsum, s);      // (small shapes: a pass over the matrix)
   return 0;
 }

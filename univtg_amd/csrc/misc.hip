@@ -63,6 +63,25 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const Zer
   float* p = base + r.off[blockIdx.x];
   for (int i = threadIdx.x; i < r.n[blockIdx.x]; i += 256) p[i] = 0.f;
 }
+__global__ __launch_bounds__(256) void sqsum_ranges_kernel(const float* base, const ZeroRanges r, float* out) {
+  __shared__ float red[4];
+  const float* p = base + r.off[blockIdx.x];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < r.n[blockIdx.x]; i += 256) acc += p[i] * p[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void sqsum_kernel(const float* x, long long n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
 __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, long long n) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -894,6 +913,19 @@ int launch_droppath_scales(float* scales, int n, int B, float p, unsigned long l
 int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s) {
   if (r.count <= 0) return 0;
   hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count), dim3(256), 0, s, base, r);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_sqsum_ranges(const float* base, const ZeroRanges& r, float* sqsum, hipStream_t s) {
+  if (r.count <= 0 || !sqsum) return 0;
+  hipLaunchKernelGGL(sqsum_ranges_kernel, dim3(r.count), dim3(256), 0, s, base, r, sqsum);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_sqsum(const float* x, long long n, float* sqsum, hipStream_t s) {
+  if (n <= 0 || !sqsum) return 0;
+  const long long b = (n + 2047) / 2048;
+  hipLaunchKernelGGL(sqsum_kernel, dim3((unsigned)(b < 1024 ? b : 1024)), dim3(256), 0, s, x, n, sqsum);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

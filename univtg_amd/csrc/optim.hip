@@ -74,6 +74,19 @@ extern "C" int uvtg_adamw_clip_step(float* params, const float* grads, float* m,
   return 0;
 }
 
+extern "C" int uvtg_adamw_clip_step_prenorm(float* params, const float* grads, float* m, float* v, long long n, float lr, float beta1,
+                                            float beta2, float eps, float wd, int step, float max_norm, float grad_scale,
+                                            const float* sqnorm_dev, uvtg_stream_t stream) {
+  if (!params || !grads || !m || !v || !sqnorm_dev) return -20;
+  if (n <= 0 || n % 4 || step <= 0) return -11;
+  hipStream_t s = (hipStream_t)stream;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2s,
+                     max_norm, grad_scale, sqnorm_dev);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- timing hooks: HIP events around every launch of one kernel family, on the launch stream ----
 void uvtg_prof_begin_launch(int family, double flops, hipStream_t s) {
   if (!g_prof.on) return;

@@ -12,6 +12,7 @@ buffer (``torch.distributed`` backend "nccl" == RCCL on ROCm).  NCE negatives st
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -144,9 +145,16 @@ class TrainStep:
             self._exchange_gradients(dims)
         if optimize:
             self.t += 1
-            chk(lib.uvtg_adamw_clip_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.flat.numel(),
-                                         self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, float(self.clip),
-                                         1.0 / self.world, _ptr(self.scratch), st), "uvtg_adamw_clip_step")
+            if self.world == 1 and not self.overlap and not os.environ.get("UVTG_PRENORM_OFF"):
+                # single rank: uvtg_backward accumulated the squared gradient norm while writing the gradients
+                gn2 = lib.uvtg_backward_gradnorm2(C.byref(dims), _ptr(self.ws))
+                chk(lib.uvtg_adamw_clip_step_prenorm(_ptr(self.flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.flat.numel(),
+                                                     self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, float(self.clip),
+                                                     1.0, gn2, st), "uvtg_adamw_clip_step_prenorm")
+            else:
+                chk(lib.uvtg_adamw_clip_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.flat.numel(),
+                                             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, float(self.clip),
+                                             1.0 / self.world, _ptr(self.scratch), st), "uvtg_adamw_clip_step")
             model.invalidate_operand_cache()      # the raw kernel rewrote the parameters: model(...) must rebuild its bf16 operands
         return self.losses[:5].clone()            # (the internal buffer is overwritten by the next step)
 
