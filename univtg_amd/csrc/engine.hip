@@ -202,7 +202,7 @@ struct WSpace {
       dvmB = a.take<bf16_t>((size_t)(m.Rp + 1) * d); gxb[0] = a.take<bf16_t>(M * d); gxb[1] = a.take<bf16_t>(M * d);     // (frame-row space on the loss-only stream)
       dyR = a.take<bf16_t>(M * d); delta = a.take<float>(B * m.c.H * m.S);
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
-      gnorm2 = a.take<float>(4);
+      gnorm2 = a.take<float>(UVTG_SQSUM_FLOATS);
       {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
         long long need = 0;
         const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d}, {m.Rp, (int)d, 3 * (int)d},
@@ -736,7 +736,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     TRY(launch_zero_ranges(grads, zr, s));
     zr_keep = zr;
   }
-  if (hipError_t e = hipMemsetAsync(ws.gnorm2, 0, sizeof(float), s)) return (int)e;
+  if (hipError_t e = hipMemsetAsync(ws.gnorm2, 0, UVTG_SQSUM_FLOATS * sizeof(float), s)) return (int)e;
   const int splits_M = 8, splits_v = 8;
   auto wgrad = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, int cs,
                    float* dbias, int q_off, int Mq, int splits) {
@@ -771,7 +771,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     if (hipError_t e = hipMemsetAsync(dW, 0, (size_t)d * 3 * d * sizeof(float), s)) return (int)e;      // per-tap launches accumulate (stride-3 outputs)
     for (int tap = 0; tap < 3; tap++)
       TRY(wgrad(dY, ldp, X, ldq, rows, d, d, dW + tap, 3 * d, 3, tap == 1 ? dBi : nullptr, tap - 1, rows, splits_v));
-    return launch_sqsum(dW, (long long)d * 3 * d, ws.gnorm2, s);
+    return launch_sqsum(dW, (long long)d * 3 * d, ws.gnorm2 + 32, s);
   };
   // ---------------- heads ----------------
   const bool halo = pmode == PACK_HALO;          // ragged conv-head frames (see Fwd::heads)

@@ -65,9 +65,13 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const Zer
 }
 __global__ __launch_bounds__(256) void sqsum_ranges_kernel(const float* base, const ZeroRanges r, float* out) {
   __shared__ float red[4];
-  const float* p = base + r.off[blockIdx.x];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < r.n[blockIdx.x]; i += 256) acc += p[i] * p[i];
+  if ((int)blockIdx.x == r.count) {          // last block: the 64 slots the reduce passes added into (128 bytes apart)
+    if (threadIdx.x < 64) acc = out[32 + threadIdx.x * 32];
+  } else {
+    const float* p = base + r.off[blockIdx.x];
+    for (int i = threadIdx.x; i < r.n[blockIdx.x]; i += 256) acc += p[i] * p[i];
+  }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -917,8 +921,8 @@ int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s) {
   return 0;
 }
 int launch_sqsum_ranges(const float* base, const ZeroRanges& r, float* sqsum, hipStream_t s) {
-  if (r.count <= 0 || !sqsum) return 0;
-  hipLaunchKernelGGL(sqsum_ranges_kernel, dim3(r.count), dim3(256), 0, s, base, r, sqsum);
+  if (!sqsum) return 0;
+  hipLaunchKernelGGL(sqsum_ranges_kernel, dim3(r.count + 1), dim3(256), 0, s, base, r, sqsum);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

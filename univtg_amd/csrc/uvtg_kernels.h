@@ -60,7 +60,8 @@ struct GemmTNArgs {
   int ktap;
   // 1: out = the product (the caller does NOT zero `out`; dbias is still accumulated); 0: out += the product
   int assign;
-  // optional (assign only): *sqsum += the sum of squares of the assigned matrix (the clipping norm without a pass over the gradients)
+  // optional (assign only): the sum of squares of the assigned matrix is added into the slot array sqsum[32 + 32 s], s < 64 (the clipping
+  // norm without a pass over the gradients; UVTG_SQSUM_FLOATS floats, zeroed by the caller, folded by launch_sqsum_ranges into sqsum[0])
   float* sqsum;
 };
 // several weight gradients over the SAME reduction rows (M, splits plan) in one launch: the tiles of all groups share the M splits,
@@ -188,7 +189,8 @@ int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
 constexpr int UVTG_MAX_ZERO_RANGES = 224;
 struct ZeroRanges { long long off[UVTG_MAX_ZERO_RANGES]; int n[UVTG_MAX_ZERO_RANGES]; int count; };
 int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s);
-int launch_sqsum_ranges(const float* base, const ZeroRanges& r, float* sqsum, hipStream_t s);     // *sqsum += sum of squares over the ranges
+constexpr int UVTG_SQSUM_FLOATS = 32 + 64 * 32;
+int launch_sqsum_ranges(const float* base, const ZeroRanges& r, float* sqsum, hipStream_t s);     // sqsum[0] += sum of squares over the ranges + the 64 slots
 int launch_sqsum(const float* x, long long n, float* sqsum, hipStream_t s);
 int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s);
 int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);
