@@ -767,8 +767,12 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
 #pragma unroll
     for (int e = 0; e < 4; e++) dw[k][e] = 0.f;
   bool any_txt = false;
-  const int s_end = min(a.S, chunk * SAL_CHUNK + SAL_CHUNK);
-  for (int srow = chunk * SAL_CHUNK + wave; srow < s_end; srow += 4) {
+  // clip chunks of SAL_CHUNK rows, then ONE chunk with all the text rows of the sample (the pooling-weight gradient leaves as one set of
+  // atomics per sample instead of one per 16-row chunk that happens to contain text rows)
+  const int nvc = (a.Lv + SAL_CHUNK - 1) / SAL_CHUNK;
+  const int s_begin = chunk < nvc ? chunk * SAL_CHUNK : a.Lv;
+  const int s_end = chunk < nvc ? min(a.Lv, chunk * SAL_CHUNK + SAL_CHUNK) : a.S;
+  for (int srow = s_begin + wave; srow < s_end; srow += 4) {
     const size_t row = (size_t)b * a.S + srow;
     const float* x = a.x0 + row * d;
     const long long grow = a.dx0_map ? (long long)a.dx0_map[row] : (long long)row;      // row of the (possibly packed) encoder gradient
@@ -1034,7 +1038,7 @@ int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 64)), dim3(256), (3 * a.Lv + 256) * sizeof(float), s, a);
   hipLaunchKernelGGL(saliency_dlog_kernel, dim3(a.B), dim3(1024), a.Lt * sizeof(float), s, a);
-  const dim3 grid(a.B, cdiv(a.S, SAL_CHUNK));
+  const dim3 grid(a.B, cdiv(a.Lv, SAL_CHUNK) + 1);
   if (a.d == 1024) hipLaunchKernelGGL(saliency_rows_kernel<4>, grid, dim3(256), 0, s, a);
   else if (a.d == 512) hipLaunchKernelGGL(saliency_rows_kernel<2>, grid, dim3(256), 0, s, a);
   else if (a.d == 256) hipLaunchKernelGGL(saliency_rows_kernel<1>, grid, dim3(256), 0, s, a);
