@@ -245,13 +245,13 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch, on the launch stream ----
     lib = _lib.load()
-    roof, sect, roof_attn = None, None, None
+    roof, sect, roof_attn, roof_hbm = None, None, None, None
     if rank == 0:
         lib.uvtg_profile_start()
     for i in range(args.profile_steps):          # EVERY rank runs these steps (they contain the gradient all-reduce); only rank 0 instruments them
         step.step(*batches[i % 2])
     if rank == 0:
-        ms, fl, n = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_longlong * 6)()
+        ms, fl, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_longlong * 8)()
         _lib.check(lib.uvtg_profile_stop(ms, fl, n), "uvtg_profile_stop")
         floor = lib.uvtg_profile_event_floor_ms()
         fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel", "gemm_nt256_kernel"]
@@ -292,6 +292,22 @@ def main():
         roof_attn["note"] = ("attention kernels only (HIP event pairs around launch_attn_fwd / launch_attn_bwd incl. the delta pass): achieved = "
                              "4 (fwd) / 10 (bwd) * E * B * S^2 * d FLOPs on the PADDED S over the measured time, peak 2.5 PFLOP/s; executed_tflops "
                              "counts the rows the packed stream runs")
+        # HBM-bound kernels: LayerNorm launches (bytes counted by the library) and the attention kernels (bytes of the rows the stream runs)
+        rows_exe = (sum(sum(min(Lv, x + 3) + y for x, y in zip(a, b)) for a, b in lens_a) / len(lens_a)) if packed else B * (Lv + Lt)
+        roof_hbm = {}
+        for name, i in (("layernorm_forward", 6), ("layernorm_backward", 7)):
+            t_ms = (ms[i] + floor * n[i]) / max(1, args.profile_steps)
+            gb = fl[i] / max(1, args.profile_steps) / 1e9
+            roof_hbm[name] = dict(ms_per_step=round(t_ms, 3), launches_per_step=int(n[i] // max(1, args.profile_steps)), gbytes_per_step=round(gb, 3),
+                                  achieved=round(gb / max(t_ms * 1e-3, 1e-12), 0), peak=8000.0, unit="GB/s", frac=round(gb / max(t_ms * 1e-3, 1e-12) / 8000.0, 3))
+        for name, i, streams in (("attention_forward", 4, 4), ("attention_backward", 5, 8)):
+            t_ms = (ms[i] + floor * n[i]) / max(1, args.profile_steps)
+            gb = MODEL["E"] * streams * rows_exe * MODEL["d"] * 2 / 1e9
+            roof_hbm[name] = dict(ms_per_step=round(t_ms, 3), gbytes_per_step=round(gb, 3), achieved=round(gb / max(t_ms * 1e-3, 1e-12), 0), peak=8000.0,
+                                  unit="GB/s", frac=round(gb / max(t_ms * 1e-3, 1e-12) / 8000.0, 3))
+        roof_hbm["note"] = ("HBM-bound kernels against the 8 TB/s peak: algorithmic bytes per step (LayerNorm: input + every output row stream of every "
+                            "launch, incl. the feature LayerNorms and their parameter-gradient reduce passes in the time; attention: q,k,v + o forward, "
+                            "q,k,v,dO,O + dq,dk,dv backward, bf16, executed rows) over the event-pair time of the launches")
     # ---- section timing: encoder forward / backward (roofline.achieved = encoder fwd+bwd FLOPs / t_encoder / peak) ----
     if rank == 0:
         lib.uvtg_profile_sections_start()
@@ -354,7 +370,7 @@ def main():
                    padded_execution_ms_per_step=None if padded_ms is None else round(padded_ms, 3),
                    numerics="train-mode calls run the input projections on plain bf16 operands (saliency_scores within 3e-2 of fp32); the "
                             "1e-4 saliency clause holds for inference calls (split-bf16 projections)",
-                   losses=[round(x, 5) for x in losses], roofline=roof, roofline_attention=roof_attn, cpu_baseline=cpu)
+                   losses=[round(x, 5) for x in losses], roofline=roof, roofline_attention=roof_attn, roofline_hbm=roof_hbm, cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

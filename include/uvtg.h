@@ -252,7 +252,9 @@ const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* workspace);
 /* ---- measurement hooks (bench.py): HIP events around every launch of the GEMM kernels, recorded on the launch
  * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-bf16, 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,
  * persistent), 4: attention forward, 5: attention backward (all its kernels; FLOPs counted on the padded S: 4 S^2 hd per
- * (sample, head) forward, 10 S^2 hd backward).  host arrays [6]. */
+ * (sample, head) forward, 10 S^2 hd backward), 6: LayerNorm forward launches, 7: LayerNorm backward launches (for 6 / 7 the
+ * "flops" entry carries the algorithmic BYTES of the row streams: input + every output, position-table reads not counted).
+ * host arrays [8]. */
 int uvtg_profile_start(void);
 int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
 /* the empty-event-pair floor (ms) that uvtg_profile_stop measured on the launch stream and subtracted from every launch */

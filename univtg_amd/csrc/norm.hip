@@ -712,7 +712,7 @@ static bool al(const void* p, int ld_elems, int bytes_per, int want) {
   return p == nullptr || ((((uintptr_t)p) % want == 0) && ((size_t)ld_elems * bytes_per) % want == 0);
 }
 
-int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
+static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
   const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.xB, a.ldxB, 2, 8) && al(a.yF, a.ldyF, 4, 16) && al(a.yF2, a.ldyF2, 4, 16) &&
                        al(a.yB, a.ldyB, 2, 8) && al(a.yU, a.ldyU, 2, 8) && al(a.yUF, a.ldyU, 4, 16) &&
@@ -731,7 +731,7 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
   LN_DISPATCH(run_fwd, a)
 }
 
-int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
+static int launch_ln_bwd_impl(const LnBwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
   const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.g, a.ldg, 4, 16) && al(a.g2, a.ldg2, 4, 16) && al(a.xB, a.ldxB, 2, 8) &&
                        al(a.gB, a.ldgB, 2, 8) && al(a.g2B, a.ldg2B, 2, 8) && al(a.dxB2, a.lddxB2, 2, 8) &&
@@ -755,4 +755,34 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     }
   }
   LN_DISPATCH(run_bwd, a)
+}
+
+// measurement hooks (uvtg_profile_start / stop, families 6 / 7): event pairs around every LayerNorm launch; the "flops" slot carries the
+// algorithmic bytes of the row streams (input + every output; the position-table reads of the +pos outputs are not counted)
+void uvtg_prof_begin_launch(int family, double flops, hipStream_t s);
+void uvtg_prof_end_launch(int family, hipStream_t s);
+
+int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
+  const double rd = (double)a.rows * a.D;
+  double bytes = rd * (a.x ? 4 : 2);
+  if (a.yF) bytes += rd * 4;
+  if (a.yF2) bytes += (double)a.rows * (a.Dpad > a.D ? a.Dpad : a.D) * 4;
+  if (a.yB) bytes += (double)a.rows * (a.Dpad > a.D ? a.Dpad : a.D) * 2;
+  if (a.yU) bytes += rd * 2;
+  if (a.yUF) bytes += rd * 4;
+  uvtg_prof_begin_launch(6, bytes, s);
+  const int rc = launch_ln_fwd_impl(a, s);
+  uvtg_prof_end_launch(6, s);
+  return rc;
+}
+int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
+  const double rd = (double)a.rows * a.D;
+  double bytes = rd * (a.x ? 4 : 2) + ((a.g || a.gB) ? rd * (a.g ? 4 : 2) : 0.0) + ((a.g2 || a.g2B) ? rd * (a.g2 ? 4 : 2) : 0.0);
+  if (a.dxF) bytes += rd * 4;
+  if (a.dxB) bytes += rd * 2;
+  if (a.dxB2) bytes += rd * 2;
+  uvtg_prof_begin_launch(7, bytes, s);
+  const int rc = launch_ln_bwd_impl(a, s);
+  uvtg_prof_end_launch(7, s);
+  return rc;
 }

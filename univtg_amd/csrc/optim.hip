@@ -48,9 +48,9 @@ struct Prof {
   bool on = false;
   hipStream_t last = nullptr;
   double floor_ms = 0;
-  std::vector<hipEvent_t> ev[6];
-  size_t used[6] = {0, 0, 0, 0, 0, 0};
-  double flops[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<hipEvent_t> ev[8];
+  size_t used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double flops[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // section timing (its own pass: the per-launch events above would sit inside the sections)
   bool sec_on = false;
   std::vector<hipEvent_t> sev[4];
@@ -104,7 +104,7 @@ void uvtg_prof_end_launch(int family, hipStream_t s) {
   u += 2;
 }
 extern "C" int uvtg_profile_start(void) {
-  for (int f = 0; f < 6; f++) { g_prof.used[f] = 0; g_prof.flops[f] = 0; }
+  for (int f = 0; f < 8; f++) { g_prof.used[f] = 0; g_prof.flops[f] = 0; }
   g_prof.on = true;
   return 0;
 }
@@ -125,7 +125,7 @@ extern "C" int uvtg_profile_stop(double* ms, double* flops, long long* launches)
     if (t < floor_ms) floor_ms = t;
     hipEventDestroy(ca[i]); hipEventDestroy(cb[i]);
   }
-  for (int f = 0; f < 6; f++) {
+  for (int f = 0; f < 8; f++) {
     double tot = 0;
     for (size_t i = 0; i + 1 < g_prof.used[f]; i += 2) {
       float t = 0;
