@@ -253,7 +253,7 @@ const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* workspace);
  * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-bf16, 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,
  * persistent), 4: attention forward, 5: attention backward (all its kernels; FLOPs counted on the padded S: 4 S^2 hd per
  * (sample, head) forward, 10 S^2 hd backward), 6: LayerNorm forward launches, 7: LayerNorm backward launches (for 6 / 7 the
- * "flops" entry carries the algorithmic BYTES of the row streams: input + every output, position-table reads not counted).
+ * "flops" entry carries the algorithmic BYTES of the row streams: input + every output + the position rows added into the +pos outputs).
  * host arrays [8]. */
 int uvtg_profile_start(void);
 int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);

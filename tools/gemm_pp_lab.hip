@@ -437,6 +437,203 @@ template <int V = 0, int ABL = 0> void launch_r1(const LabArgs& a, int grid_cap 
   hipLaunchKernelGGL((gemm_r1_kernel<V, ABL>), dim3(grid), dim3(512), 131072, 0, a);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// RING: K tiles of 32 (32 KB: A [256][32] | B [256][32] bf16, 64-byte rows) in a ring of 4 stages, staging distance 3 K tiles
+// (64-96 KB of operands in flight instead of one 64 KB burst per K tile), ONE barrier per K tile placed between its two k-steps:
+//   k-step 0 MFMAs (fragments read during the previous k-step) + fragment reads of k-step 1
+//   s_waitcnt vmcnt(4) (own pieces of K tile it+1 have landed) ; barrier (=> everybody's have, and K tile it-1 is read out)
+//   pieces of K tile it+3 -> stage (it-1) & 3 ; k-step 1 MFMAs + fragment reads of k-step 0 of K tile it+1
+// so no fragment read ever waits behind a barrier.  16-byte chunk c of row r sits at chunk position c ^ ((r >> 2) & 3)
+// (conflict-free for the ds_read_b128 lane groups).  ABL: 1 no pieces in the loop, 8 no MFMA.
+// ------------------------------------------------------------------------------------------------
+template <int ABL>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(const LabArgs p) {
+  constexpr int TM = 4, TN = 2, SB = 32768;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / 4, wn = wave % 4, g = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = p.K / 32;
+  const int G = gridDim.x;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int ntw = (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int total = ntw * nk;
+  const int sr = lane >> 2, sc = lane & 3;
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    m0 = (l / tiles_n) * 256; n0 = (l % tiles_n) * 256;
+  };
+  unsigned aofs[2], bofs[2];
+  auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int r = (wave * 2 + i) * 16 + sr;
+      const int c = (sc ^ ((sr >> 2) & 3)) * 8;
+      aofs[i] = ((unsigned)min(m0 + r, p.M - 1) * p.lda + c) * 2;
+      bofs[i] = ((unsigned)min(n0 + r, p.N - 1) * p.ldb + c) * 2;
+    }
+  };
+  auto pieces = [&](int stage, int kt) {
+    unsigned char* sb = smem + stage * SB + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)p.A + aofs[i] + kt * 64), (lds_void*)(sb + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)p.B + bofs[i] + kt * 64), (lds_void*)(sb + 16384 + i * 1024), 16, 0, 0);
+    }
+  };
+  int aoff[TM], boff[TN];
+  const int swz = (l31 >> 2) & 3;
+#pragma unroll
+  for (int i = 0; i < TM; i++) aoff[i] = (wm * 128 + i * 32 + l31) * 64;
+#pragma unroll
+  for (int j = 0; j < TN; j++) boff[j] = 16384 + (wn * 64 + j * 32 + l31) * 64;
+  const int x0 = (g ^ swz) << 4, x1 = ((2 + g) ^ swz) << 4;       // chunk positions of k-step 0 / 1
+
+  // issue side of the K-tile stream
+  int i_kt = 0, i_tile = blockIdx.x, im0, in0;
+  tile_origin(i_tile, im0, in0);
+  set_offsets(im0, in0);
+  auto issue_wrap = [&]() {          // called outside the pinned blocks
+    if (i_kt == nk) {
+      i_kt = 0;
+      if (i_tile + G < ntiles) i_tile += G;        // past the end: the last tile is re-loaded into idle stages
+      tile_origin(i_tile, im0, in0);
+      set_offsets(im0, in0);
+    }
+  };
+  for (int s = 0; s < 3; s++) { issue_wrap(); pieces(s, i_kt); i_kt++; }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  BAR();
+  s16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(smem + aoff[i] + x0);
+#pragma unroll
+  for (int j = 0; j < TN; j++) fb[0][j] = *(const s16x8*)(smem + boff[j] + x0);
+
+  int tile = blockIdx.x, m0, n0, kt = 0;
+  tile_origin(tile, m0, n0);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  for (int it = 0; it < total; it++) {
+    issue_wrap();
+    const unsigned char* base = smem + (it & 3) * SB;
+    const unsigned char* nbase = smem + ((it + 1) & 3) * SB;
+    unsigned char* const istage_dummy = nullptr; (void)istage_dummy;
+    // ---- k-step 0 : reads of k-step 1 under its MFMAs ----
+#pragma unroll
+    for (int i = 0; i < TM; i++) fa[1][i] = *(const s16x8*)(base + aoff[i] + x1);
+#pragma unroll
+    for (int j = 0; j < TN; j++) fb[1][j] = *(const s16x8*)(base + boff[j] + x1);
+    if (!(ABL & 8)) {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[0][i], fb[0][j], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; i++) acc[i][0][0] += __builtin_bit_cast(float, (int)fa[0][i][0] | ((int)fb[0][i & 1][1] << 16));
+    }
+    if (ABL == 0) {          // MFMA first: its operands were read a k-step ago, so the wait in front of it finds nothing outstanding
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+      for (int n = 0; n < TM + TN; n++) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN) - 1, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    BAR();
+    // ---- k-step 1 : the pieces of K tile it+3, the reads of k-step 0 of K tile it+1 ----
+    if (!(ABL & 1)) pieces((it + 3) & 3, i_kt);
+    i_kt++;
+#pragma unroll
+    for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(nbase + aoff[i] + x0);
+#pragma unroll
+    for (int j = 0; j < TN; j++) fb[0][j] = *(const s16x8*)(nbase + boff[j] + x0);
+    if (!(ABL & 8)) {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[1][i], fb[1][j], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; i++) acc[i][0][0] += __builtin_bit_cast(float, (int)fa[1][i][0] | ((int)fb[1][i & 1][1] << 16));
+    }
+    if (ABL == 0) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+      for (int n = 0; n < TM + TN; n++) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kt < nk) continue;
+    // ---- the output tile is complete ----
+    kt = 0;
+    if (p.mode == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) t += acc[i][j][r];
+      if (t == 123.456f) p.outF[0] = t;
+    } else {
+      __builtin_amdgcn_s_barrier();                    // every wave is past its reads of stage it & 3: 4 KB of it per wave as fp32 slab
+      float* wbuf = (float*)(smem + (it & 3) * SB) + wave * 1024;
+      const int c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) wbuf[((r & 3) + 8 * (r >> 2) + 4 * g) * 32 + l31] = acc[i][j][r];
+          const int mb = m0 + wm * 128 + i * 32, n = n0 + wn * 64 + j * 32 + c4;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int row = q * 8 + (lane >> 3), m = mb + row;
+            f32x4 v = *(const f32x4*)(wbuf + row * 32 + c4);
+            if (m < p.M && n < p.N) {
+              if (p.bias) v += *(const f32x4*)(p.bias + n);
+              if (p.resid) {
+                const u32x2 t = *(const u32x2*)(p.resid + (size_t)m * p.ldo + n);
+                v[0] += __uint_as_float(t[0] << 16); v[1] += __uint_as_float(t[0] & 0xffff0000u);
+                v[2] += __uint_as_float(t[1] << 16); v[3] += __uint_as_float(t[1] & 0xffff0000u);
+              }
+              u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
+              *(u32x2*)(p.outB + (size_t)m * p.ldo + n) = t;
+            }
+          }
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores count in vmcnt: restart the piece accounting from zero
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    tile += G;
+    if (tile < ntiles) tile_origin(tile, m0, n0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int ABL = 0> void launch_ring(const LabArgs& a, int grid_cap = 256) {
+  static bool once = false;
+  if (!once) { CK(hipFuncSetAttribute((const void*)gemm_ring_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); once = true; }
+  int grid = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (grid > grid_cap) grid = grid_cap;
+  hipLaunchKernelGGL((gemm_ring_kernel<ABL>), dim3(grid), dim3(512), 131072, 0, a);
+}
+
 // naive reference (bf16 output path: fp32 accumulate + bias + resid)
 __global__ void ref_kernel(const bf16_t* A, const bf16_t* B, const float* bias, const bf16_t* resid, float* C, int M, int N, int K) {
   const int n = blockIdx.x * 16 + threadIdx.x, m = blockIdx.y * 16 + threadIdx.y;
@@ -484,6 +681,58 @@ static double check(const LabArgs& a, const float* R, int runs, const char* name
 }
 
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "ring")) {       // ring-of-4 K loop vs the one-barrier 2-stage structure
+    const int cshapes[][3] = {{700, 520, 192}, {1000, 256, 1024}, {5000, 1032, 256}, {27392, 1024, 1024}};
+    for (auto& s : cshapes) {
+      const int M = s[0], N = s[1], K = s[2];
+      bf16_t *A, *B, *Cb, *Rs; float *R, *bias;
+      CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&Cb, (size_t)M * N * 2)); CK(hipMalloc(&Rs, (size_t)M * N * 2));
+      CK(hipMalloc(&R, (size_t)M * N * 4)); CK(hipMalloc(&bias, N * 4));
+      fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1, 1.0f);
+      fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2, 0.05f);
+      fill_kernel<<<(unsigned)(((size_t)M * N + 255) / 256), 256>>>(Rs, (size_t)M * N, 3, 1.0f);
+      std::vector<float> hb(N); for (int i = 0; i < N; i++) hb[i] = 0.01f * (i % 97);
+      CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
+      ref_kernel<<<dim3((N + 15) / 16, (M + 15) / 16), dim3(16, 16)>>>(A, B, bias, Rs, R, M, N, K);
+      CK(hipDeviceSynchronize());
+      LabArgs a{A, B, M, N, K, K, K, bias, Rs, nullptr, Cb, N, 1};
+      for (int cap : {256, 3}) {
+        if (cap < 256 && M > 20000) continue;
+        check(a, R, M > 20000 ? 3 : 5, "ring", [](const LabArgs& x, int c) { launch_ring<0>(x, c); }, cap);
+      }
+      hipFree(A); hipFree(B); hipFree(Cb); hipFree(Rs); hipFree(R); hipFree(bias);
+    }
+    const int shapes[][3] = {{27392, 1024, 1024}, {20158, 1024, 1024}, {20158, 3072, 1024}, {20158, 1024, 3072}, {4096, 4096, 4096}};
+    for (auto& s : shapes) {
+      const int M = s[0], N = s[1], K = s[2];
+      bf16_t *A, *B, *Cb, *Rs; float* C;
+      CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, 1024)); CK(hipMalloc(&Cb, (size_t)M * N * 2)); CK(hipMalloc(&Rs, (size_t)M * N * 2));
+      fill_kernel<<<(unsigned)(((size_t)M * K + 255) / 256), 256>>>(A, (size_t)M * K, 1, 1.0f);
+      fill_kernel<<<(unsigned)(((size_t)N * K + 255) / 256), 256>>>(B, (size_t)N * K, 2, 1.0f);
+      fill_kernel<<<(unsigned)(((size_t)M * N + 255) / 256), 256>>>(Rs, (size_t)M * N, 3, 1.0f);
+      const double fl = 2.0 * M * N * K;
+      for (int mode : {0, 2}) {
+        LabArgs a{A, B, M, N, K, K, K, nullptr, mode == 2 ? Rs : nullptr, C, Cb, N, mode ? 1 : 0};
+        float t[3] = {0, 0, 0};
+        for (int round = 0; round < 3; round++) {
+          t[0] += time_us([&] { launch_r1<0, 0>(a); }, 10);
+          t[1] += time_us([&] { launch_r1<1, 0>(a); }, 10);
+          t[2] += time_us([&] { launch_ring<0>(a); }, 10);
+        }
+        for (int i = 0; i < 3; i++) t[i] /= 3;
+        printf("%5dx%4dx%4d mode %d: r1 V0 %7.1f us %6.0f TF | V1 %7.1f us %6.0f TF | ring %7.1f us %6.0f TF\n", M, N, K, mode,
+               t[0], fl / t[0] / 1e6, t[1], fl / t[1] / 1e6, t[2], fl / t[2] / 1e6);
+      }
+      if (K == 1024 && N == 1024 && M == 27392) {
+        LabArgs a{A, B, M, N, K, K, K, nullptr, nullptr, C, Cb, N, 0};
+        const float t0 = time_us([&] { launch_ring<0>(a); }, 20), t1 = time_us([&] { launch_ring<1>(a); }, 20), t8 = time_us([&] { launch_ring<8>(a); }, 20),
+                    r8 = time_us([&] { launch_r1<0, 8>(a); }, 20), r7 = time_us([&] { launch_r1<0, 7>(a); }, 20);
+        printf("ring ablation 27392x1024x1024 (us): full %.1f | no pieces %.1f | no MFMA %.1f   (r1: no MFMA %.1f, MFMA only %.1f)\n", t0, t1, t8, r8, r7);
+      }
+      hipFree(A); hipFree(B); hipFree(C); hipFree(Cb); hipFree(Rs);
+    }
+    return 0;
+  }
   // ---- correctness + race screen (several runs, awkward and production shapes, small and full grids) ----
   const int cshapes[][3] = {{700, 520, 192}, {1000, 256, 1024}, {5000, 1032, 256}, {27392, 1024, 1024}};
   for (auto& s : cshapes) {

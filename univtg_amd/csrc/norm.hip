@@ -557,6 +557,8 @@ template <int NVW>      // NVW even: column iterations of 512 columns each
 __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwdArgs a) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, D = a.D, D4 = (D + 3) >> 2;
+  // (measured: issuing the next row's loads before the reductions of the current one changes nothing -- the kernel is bound by the
+  // Philox draws of the input dropout, 20 quarter-rate 32 x 32 -> 64 bit multiplies per 4 columns, not by the load -> reduce chain)
   for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
     const int lrow = a.src_rows ? a.src_rows[row] : row;
     const float* xr = a.x + (size_t)(a.gather_x ? lrow : row) * a.ldx;
@@ -758,7 +760,7 @@ static int launch_ln_bwd_impl(const LnBwdArgs& a, hipStream_t s) {
 }
 
 // measurement hooks (uvtg_profile_start / stop, families 6 / 7): event pairs around every LayerNorm launch; the "flops" slot carries the
-// algorithmic bytes of the row streams (input + every output; the position-table reads of the +pos outputs are not counted)
+// algorithmic bytes of the row streams (input + every output + the fp32 position rows the +pos outputs add)
 void uvtg_prof_begin_launch(int family, double flops, hipStream_t s);
 void uvtg_prof_end_launch(int family, hipStream_t s);
 
@@ -770,6 +772,7 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
   if (a.yB) bytes += (double)a.rows * (a.Dpad > a.D ? a.Dpad : a.D) * 2;
   if (a.yU) bytes += rd * 2;
   if (a.yUF) bytes += rd * 4;
+  if (a.pos && (a.yU || a.yUF) && a.S > 0) bytes += rd * 4 * a.Lv / a.S;      // fp32 position rows of the clip rows (packed streams: >= this share)
   uvtg_prof_begin_launch(6, bytes, s);
   const int rc = launch_ln_fwd_impl(a, s);
   uvtg_prof_end_launch(6, s);
