@@ -217,7 +217,7 @@ def test_nt256_tile_heights_agree(dev):
             w = bf((torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev))
             b = torch.randn(N, generator=g).to(dev)
             outs = []
-            for bm in (256, 192, 128):
+            for bm in (256, 320, 192, 128):
                 _lib.check(lib.uvtg_debug_force_nt_bm(bm))
                 outs.append(ops.linear_bf16(a, w, b, act))
             ref = a.double() @ w.double().t() + b.double()

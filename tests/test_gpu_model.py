@@ -443,7 +443,7 @@ def test_nt256_engine_path_matches_nt128(dev):
     step = TrainStep(model, crit, grad_clip=0.1)
     res = {}
     try:
-        for tile, bm in ((128, 0), (256, 0), (256, 256), (256, 192), (256, 128)):     # every tile height of the persistent kernel,
+        for tile, bm in ((128, 0), (256, 0), (256, 320), (256, 256), (256, 192), (256, 128)):     # every tile height of the persistent kernel,
             _lib.check(lib.uvtg_debug_force_nt_tile(tile))                             # with its fused epilogues (residual, act-grad, ...)
             _lib.check(lib.uvtg_debug_force_nt_bm(bm))
             losses = step.step(ind, tgd, optimize=False).clone()
@@ -453,7 +453,7 @@ def test_nt256_engine_path_matches_nt128(dev):
         lib.uvtg_debug_force_nt_tile(0)
         lib.uvtg_debug_force_nt_bm(0)
     l1, g1, pl1, ps1 = res[(128, 0)]
-    for key in ((256, 256), (256, 192), (256, 128)):
+    for key in ((256, 320), (256, 256), (256, 192), (256, 128)):
         lk, gk, plk, psk = res[key]
         assert float((pl1 - plk).abs().max()) < 1e-6 and float((ps1 - psk).abs().max()) < 1e-6, key
         assert float((l1 - lk).abs().max()) < 1e-5 * max(1.0, float(l1.abs().max())), key

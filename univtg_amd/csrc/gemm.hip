@@ -274,6 +274,17 @@ template <int Mf, int R, bool READS, int NV> __device__ __forceinline__ void sgb
   sgb_vmem_mfma<NV, Mf - PAIRS>();
 }
 
+// 320-row tiles (single-buffered A fragments): per A fragment i its TN MFMAs, then the read that refills it for the next k-step (the
+// first TN groups also take one B fragment of the next k-step), then one of the NV (<= TM) VMEM issues
+template <int I, int TM_, int TN_, bool READS, int NV> __device__ __forceinline__ void sgb_sb() {
+  if constexpr (I < TM_) {
+    __builtin_amdgcn_sched_group_barrier(0x008, TN_, 0);
+    if constexpr (READS) __builtin_amdgcn_sched_group_barrier(0x100, I < TN_ ? 2 : 1, 0);
+    if constexpr (I < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    sgb_sb<I + 1, TM_, TN_, READS, NV>();
+  }
+}
+
 // GATHER: row gather / scatter / conv taps / groups present (integer divisions per row); the plain variant has none.
 // TM: 32-row fragments per wave along M -> tile height BM = 64 TM (256 / 192 / 128): the launcher picks the height that
 // wastes the fewest CU-rounds for the launch's tile count (ragged batches give awkward row counts).
@@ -299,15 +310,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   static_assert(!(EPI != 0 && GATHER), "the specialised epilogues have the plain row mapping");
   static_assert(EPI != 2 || !EOP, "FFN1 has no epilogue operand");
   static_assert(EPI != 3 || EOP, "the activation gradient reads its pre-activation");
+  static_assert(TM < 5 || ((TM + 4 + 1) / 2 <= TM), "320-row tiles: at most one staging piece per A-fragment group of a k-step");
   constexpr bool SIMPLE = EPI != 0;
   constexpr int TB = 256, KB = 64, TN = 2, BM = 64 * TM, PA = TM, PB = 4, NP = PA + PB;
-  constexpr int BOFF = 32768, SSTR = 65536;
+  constexpr int BOFF = BM * 128 > 32768 ? BM * 128 : 32768, SSTR = BOFF + 32768;      // (320-row tiles: 40 KB of A rows per stage)
+  constexpr int RT = BM > 256 ? 512 : 256;       // tile rows covered by the per-row staging tables (one thread per row)
   // epilogue-operand groups (32 rows x 64 columns = 4 x 16 B per lane each) fetched during the last K tile; the remaining ones are
   // fetched inside the epilogue one group ahead, into the registers the fragments no longer need
-  constexpr int NPF = !EOP ? 0 : (TM == 4 ? 0 : (TM == 3 ? 1 : 2));
+  constexpr int NPF = !EOP ? 0 : (TM >= 4 ? 0 : (TM == 3 ? 1 : 2));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
-  __shared__ float s_rs[256];               // per-row factors (DropPath / frame mask) of the tile in its epilogue
-  __shared__ int s_tab[GATHER ? 3 : 1][256]; // GATHER: the tile rows' entries of the output-row tables (o_rows, f_rows, pos_map)
+  __shared__ float s_rs[RT];               // per-row factors (DropPath / frame mask) of the tile in its epilogue
+  __shared__ int s_tab[GATHER ? 3 : 1][RT]; // GATHER: the tile rows' entries of the output-row tables (o_rows, f_rows, pos_map)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + BM - 1) / BM;
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         // row factor of tile row (tid & 255), fetched under the last K tile: in the epilogue the lookup -- two DEPENDENT loads per
         // q iteration, rowscale[row_sample[m]] -- was a latency chain of its own (8.5-10 us epilogues with DropPath vs 5 without).
         // Branch-free (this block is scheduled as one): without a table the loads hit a valid dummy address and are not used.
-        const int mr = min(m0 + (tid & 255), p.M - 1);
+        const int mr = min(m0 + (tid & (RT - 1)), p.M - 1);
         const int* rsm = p.row_sample ? p.row_sample : (const int*)p.B;
         const int i1 = rsm[p.row_sample ? mr : 0];
         const float* rsp = p.rowscale ? p.rowscale : (const float*)p.B;
@@ -454,6 +467,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           tab_reg[0] = t0[p.o_rows ? mr : 0]; tab_reg[1] = t1[p.f_rows ? mr : 0]; tab_reg[2] = t2[p.pos_map ? mr : 0];
         }
       }
+      constexpr int G0 = ORD == 0 ? 0 : (NP + 1) / 2, G1 = ORD == 0 ? 0 : NP - (NP + 1) / 2;          // pieces issued under k-step 0 / 1
+      constexpr int E2 = (NPF * 4 + 1) / 2, E3 = NPF * 4 - E2;  // epilogue-operand loads under k-step 2 / 3
+      constexpr int Mf = TM * TN, R = TM + TN;
+      if constexpr (TM >= 5) {
+        // 320-row tiles: 160 accumulator registers leave no room for two sets of A fragments.  Each A fragment is refilled for the
+        // next k-step right behind its own TN MFMAs (the refill then has the other (TM - 1) TN MFMAs of this k-step and i TN of the
+        // next one to land: >= 8 MFMAs); only the B fragments, used by every MFMA of a k-step, stay double-buffered.
+        s16x8 fa[TM], fb[2][TN];
+        if (ORD == 0) {
+#pragma unroll
+          for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) fa[i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb[0][j] = *(const s16x8*)(base + boff[j] + ((g ^ swz) << 4));
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[i], fb[ks & 1][j], acc[i][j]);
+            if (ks < 3) {
+              fa[i] = *(const s16x8*)(base + aoff[i] + (((2 * ks + 2 + g) ^ swz) << 4));
+              if (i < TN) fb[(ks + 1) & 1][i] = *(const s16x8*)(base + boff[i] + (((2 * ks + 2 + g) ^ swz) << 4));
+            }
+            // (LDS-DMA and fragment reads keep their source order -- both touch LDS as far as the compiler knows -- so a piece goes
+            // where the pinned sequence wants it: one behind the reads of each group of k-steps 0 and 1)
+            if (ORD == 1 && ks == 0 && i < G0) piece(sbase, ka, kb, i);
+            if (ORD == 1 && ks == 1 && G0 + i < NP) piece(sbase, ka, kb, G0 + i);
+          }
+        }
+        if (ORD == 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+        sgb_sb<0, TM, TN, true, G0>();
+        sgb_sb<0, TM, TN, true, G1>();
+        sgb_sb<0, TM, TN, true, 0>();
+        sgb_sb<0, TM, TN, false, 0>();
+      } else {
       s16x8 fa[2][TM], fb[2][TN];
       if (ORD == 0) {
 #pragma unroll
@@ -463,8 +515,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
 #pragma unroll
       for (int j = 0; j < TN; j++) fb[0][j] = *(const s16x8*)(base + boff[j] + ((g ^ swz) << 4));
-      constexpr int G0 = ORD == 0 ? 0 : (NP + 1) / 2, G1 = ORD == 0 ? 0 : NP - (NP + 1) / 2;          // pieces issued under k-step 0 / 1
-      constexpr int E2 = (NPF * 4 + 1) / 2, E3 = NPF * 4 - E2;  // epilogue-operand loads under k-step 2 / 3
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         if (ks < 3) {
@@ -494,13 +544,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       }
       // pin the software pipeline the source expresses (hipcc otherwise sinks every fragment read next to its MFMAs and moves the
       // pieces to the head): R reads up front; per k-step (MFMA, read) pairs, then the VMEM issues two at a time between MFMAs
-      constexpr int Mf = TM * TN, R = TM + TN;
       if (ORD == 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
       sgb_kstep<Mf, R, true, G0>();
       sgb_kstep<Mf, R, true, G1>();
       sgb_kstep<Mf, R, true, LAST ? E2 : 0>();
       sgb_kstep<Mf, R, false, LAST ? E3 : 0>();
+      }
       it++;
     };
 #ifdef UVTG_NT_TRACE
@@ -524,8 +574,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           for (int r = 0; r < 16; r++) t += acc[i][j][r];
       if (t == 123.456f) p.outF[0] = t;
     } else {
-      if (tid < 256) s_rs[tid] = rs_reg;
-      if constexpr (GATHER) { if (tid < 256) { s_tab[0][tid] = tab_reg[0]; s_tab[1][tid] = tab_reg[1]; s_tab[2][tid] = tab_reg[2]; } }
+      if (tid < RT) s_rs[tid] = rs_reg;
+      if constexpr (GATHER) { if (tid < RT) { s_tab[0][tid] = tab_reg[0]; s_tab[1][tid] = tab_reg[1]; s_tab[2][tid] = tab_reg[2]; } }
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
@@ -1069,7 +1119,7 @@ static int check_nt(const GemmArgs& a, int elem) {
 // touches 8 columns at a time, 32-bit byte offsets, and enough work that 256 x 256 tiles do not waste the chip
 static int g_force_tile = 0;   // 0: automatic, 128 / 256: force that NT tile size where it is legal (parity tests)
 static int g_force_bm = 0;     // 0: automatic, 128 / 192 / 256: force the tile height of the 256-wide persistent kernel
-extern "C" int uvtg_debug_force_nt_bm(int bm) { if (bm != 0 && bm != 128 && bm != 192 && bm != 256) return -21; g_force_bm = bm; return 0; }
+extern "C" int uvtg_debug_force_nt_bm(int bm) { if (bm != 0 && bm != 128 && bm != 192 && bm != 256 && bm != 320) return -21; g_force_bm = bm; return 0; }
 extern "C" int uvtg_debug_force_nt_tile(int tile) { if (tile != 0 && tile != 128 && tile != 256) return -21; g_force_tile = tile; return 0; }
 static bool nt256_ok(const GemmArgs& a) {
   if (g_force_tile == 128) return false;
@@ -1093,23 +1143,27 @@ extern "C" int uvtg_debug_gemm_cus(int n) { g_cu_cap = n > 0 ? n : 0; return 0; 
 static int eff_cus() { return (g_cu_cap > 0 && g_cu_cap < g_num_cu) ? g_cu_cap : g_num_cu; }
 // relative time per output element of the persistent NT structure at the three tile heights
 #ifndef UVTG_NT_F4
+#define UVTG_NT_F5 1.02
 #define UVTG_NT_F4 1.00
 #define UVTG_NT_F3 1.07
 #define UVTG_NT_F2 1.20
 #endif
 template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, bool eop, int epi, hipStream_t s) {
-  constexpr int smem = 131072;
+  constexpr int smem = TM == 5 ? 147456 : 131072;
   static bool attr = false;
 #define NT256_ATTR(G, E, P) if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<G, TM, E, ORD, P>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
   if (!attr) {
     NT256_ATTR(false, false, 0) NT256_ATTR(false, true, 0) NT256_ATTR(false, false, 1) NT256_ATTR(false, true, 1)
-    NT256_ATTR(false, false, 2) NT256_ATTR(false, true, 3) NT256_ATTR(true, false, 0) NT256_ATTR(true, true, 0)
+    NT256_ATTR(false, false, 2) NT256_ATTR(false, true, 3)
+    if constexpr (TM < 5) { NT256_ATTR(true, false, 0) NT256_ATTR(true, true, 0) }
     attr = true;
   }
 #undef NT256_ATTR
 #define NT256_GO(G, E, P) hipLaunchKernelGGL((gemm_nt256_kernel<G, TM, E, ORD, P>), dim3(grid), dim3(512), smem, s, b)
-  if (gather) { if (eop) NT256_GO(true, true, 0); else NT256_GO(true, false, 0); }
-  else if (epi == 1) { if (eop) NT256_GO(false, true, 1); else NT256_GO(false, false, 1); }
+  if (gather) {
+    if constexpr (TM < 5) { if (eop) NT256_GO(true, true, 0); else NT256_GO(true, false, 0); }
+    else return -21;
+  } else if (epi == 1) { if (eop) NT256_GO(false, true, 1); else NT256_GO(false, false, 1); }
   else if (epi == 2 && !eop) NT256_GO(false, false, 2);
   else if (epi == 3 && eop) NT256_GO(false, true, 3);
   else { if (eop) NT256_GO(false, true, 0); else NT256_GO(false, false, 0); }
@@ -1121,11 +1175,11 @@ template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int gri
 // real epilogues run (conv / K = 3072 launches -7 %); 192-row tiles LOSE 3 % (their K tile has 24 MFMAs to cover the same pieces), so
 // they stay on the round-1 order.  Experiment override: UVTG_NT_ORD="<o2><o3><o4>".
 static int nt_order(int tm) {
-  static int ord[3] = {-1, -1, -1};
+  static int ord[4] = {-1, -1, -1, -1};
   if (ord[0] < 0) {
-    static const int dflt[3] = {0, 0, 1};
+    static const int dflt[4] = {0, 0, 1, 1};
     const char* e = getenv("UVTG_NT_ORD");
-    for (int i = 0; i < 3; i++) ord[i] = (e && strlen(e) == 3 && (e[i] == '0' || e[i] == '1')) ? e[i] - '0' : dflt[i];
+    for (int i = 0; i < 4; i++) ord[i] = (e && strlen(e) >= 3 && (int)strlen(e) > i && (e[i] == '0' || e[i] == '1')) ? e[i] - '0' : dflt[i];
   }
   return ord[tm - 2];
 }
@@ -1162,21 +1216,8 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
-  // Candidates: 256-wide tiles of 256 / 192 / 128 rows, one workgroup per CU.
+  // Candidates: 256-wide tiles of 320 / 256 / 192 / 128 rows, one workgroup per CU.
   // Cost = tiles per CU x rows of a tile x a per-height factor (measured relative time per output element).
-  struct Cand { int tm; double f; };
-  static const Cand cands[] = {{4, UVTG_NT_F4}, {3, UVTG_NT_F3}, {2, UVTG_NT_F2}};
-  int best_tm = 0; double best = 1e30;
-  for (const Cand& c : cands) {
-    if (g_force_bm && c.tm * 64 != g_force_bm) continue;
-    const long long tiles = (long long)cdiv(b.M, 64 * c.tm) * cdiv(b.N, 256) * b.groups;
-    const double rounds = (double)((tiles + eff_cus() - 1) / eff_cus());
-    const double cost = rounds * (64.0 * c.tm) * c.f;
-    if (cost < best) { best = cost; best_tm = c.tm; }
-  }
-  if (!best_tm) return -21;
-  const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
-  const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1 || b.o_rows || b.pos_map;
   const bool eop = b.residB || (b.actgrad && b.gradPre);
   static const bool epi_off = getenv("UVTG_NT_EPI_OFF") != nullptr;       // experiment: the general epilogue everywhere
@@ -1188,15 +1229,36 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
     else if (!b.outPre && !b.act && b.actgrad == 2 && eop && !b.residB && !b.rowscale) epi = 3;
   }
   if (!((epi_mask >> epi) & 1)) epi = 0;
+  struct Cand { int tm; double f; };
+  static const bool tm5_off = getenv("UVTG_NT_TM5_OFF") != nullptr;          // experiment: no 320-row tiles
+  static const Cand cands[] = {{5, UVTG_NT_F5}, {4, UVTG_NT_F4}, {3, UVTG_NT_F3}, {2, UVTG_NT_F2}};
+  int best_tm = 0; double best = 1e30;
+  // (320-row tiles: plain row mapping only -- the gather variants have no registers left for them; a forced 320 falls back to 256 there)
+  const int force_bm = (g_force_bm == 320 && gather) ? 256 : g_force_bm;
+  for (const Cand& c : cands) {
+    if (force_bm && c.tm * 64 != force_bm) continue;
+    if (c.tm == 5 && (gather || (tm5_off && force_bm != 320))) continue;
+    const long long tiles = (long long)cdiv(b.M, 64 * c.tm) * cdiv(b.N, 256) * b.groups;
+    // rounds: a partly filled last round costs ~0.84 of a full one up to ~70 % fill (fewer active CUs run their K loops faster), then
+    // rises to a full round (fitted on the per-height timings of tools/tm5_ab.sh at the step's shapes)
+    const long long full = tiles / eff_cus(), rem = tiles % eff_cus();
+    const double fill = (double)rem / eff_cus();
+    const double rounds = (double)full + (rem ? 0.84 + 0.16 * (fill > 0.7 ? (fill - 0.7) / 0.3 : 0.0) : 0.0);
+    const double cost = rounds * (64.0 * c.tm) * c.f;
+    if (cost < best) { best = cost; best_tm = c.tm; }
+  }
+  if (!best_tm) return -21;
+  const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
+  const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
 #ifdef UVTG_NT_TRACE
   nt_trace_launch(b, best_tm, grid, gather, eop, s);
 #endif
   uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
   int rc;
   if (nt_order(best_tm) == 0)
-    rc = best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
+    rc = best_tm == 5 ? launch_nt256_tm<5, 0>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
   else
-    rc = best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, epi, s));
+    rc = best_tm == 5 ? launch_nt256_tm<5, 1>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, epi, s));
   uvtg_prof_end_launch(3, s);
   if (rc) return rc;
   UVTG_CHECK_LAUNCH();
