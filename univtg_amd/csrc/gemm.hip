@@ -286,7 +286,7 @@ template <int I, int TM_, int TN_, bool READS, int NV> __device__ __forceinline_
 }
 
 // GATHER: row gather / scatter / conv taps / groups present (integer divisions per row); the plain variant has none.
-// TM: 32-row fragments per wave along M -> tile height BM = 64 TM (256 / 192 / 128): the launcher picks the height that
+// TM: 32-row fragments per wave along M -> tile height BM = 64 TM (320 / 256 / 192 / 128; 320 without GATHER only): the launcher picks the height that
 // wastes the fewest CU-rounds for the launch's tile count (ragged batches give awkward row counts).
 // EOP: the launch has a bf16 epilogue operand (residB / gradPre).
 // ORD: 0 = all staging pieces of the next K tile right behind the barrier (round-1 order), 1 = behind the fragment reads of k-step 0,
@@ -1141,7 +1141,7 @@ static int g_num_cu = 0;
 static int g_cu_cap = 0;       // experiment knob: the persistent GEMM grids use at most this many CUs (0 = all)
 extern "C" int uvtg_debug_gemm_cus(int n) { g_cu_cap = n > 0 ? n : 0; return 0; }
 static int eff_cus() { return (g_cu_cap > 0 && g_cu_cap < g_num_cu) ? g_cu_cap : g_num_cu; }
-// relative time per output element of the persistent NT structure at the three tile heights
+// relative time per output element of the persistent NT structure at the four tile heights
 #ifndef UVTG_NT_F4
 #define UVTG_NT_F5 1.02
 #define UVTG_NT_F4 1.00
@@ -1170,7 +1170,7 @@ template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int gri
 #undef NT256_GO
   return 0;
 }
-// Staging order per tile height (TM = 2, 3, 4).  Measured on the whole training step (tools/ord_ab.sh, same box, two rounds): the
+// Staging order per tile height (TM = 2, 3, 4, 5; the 320-row tiles were only measured interleaved).  Measured on the whole training step (tools/ord_ab.sh, same box, two rounds): the
 // interleaved order wins 5-10 % on the bare main loop at every height (tools/nt_ab.py) but only the 256-row tiles keep a gain once the
 // real epilogues run (conv / K = 3072 launches -7 %); 192-row tiles LOSE 3 % (their K tile has 24 MFMAs to cover the same pieces), so
 // they stay on the round-1 order.  Experiment override: UVTG_NT_ORD="<o2><o3><o4>".
