@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
   const int nk = p.K / KB;
-  const int sr = lane >> 3, sc = lane & 7;
+  const int sr_ = lane >> 3, sc_ = lane & 7;
 
   auto tile_origin = [&](int t, int& gz, int& m0, int& n0) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
@@ -339,6 +339,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   const char* Abase = (const char*)p.A;      // A operand of the tile being loaded (A2 for the column tiles from a2_n0 on)
   auto set_offsets = [&](int gz, int m0, int n0) {
     Abase = (const char*)((p.A2 && n0 >= p.a2_n0) ? p.A2 : p.A);
+    // 320-row tiles: the per-piece swizzled chunk columns are lane constants the compiler would keep in NP registers for the whole
+    // kernel; behind an opaque move they are recomputed here, once per tile
+    int sr = sr_, sc = sc_;
+    if constexpr (TM >= 5) asm volatile("" : "+v"(sr), "+v"(sc));
 #pragma unroll
     for (int i = 0; i < PA; i++) {
       const int r = (wave * PA + i) * 8 + sr;
@@ -574,6 +578,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           for (int r = 0; r < 16; r++) t += acc[i][j][r];
       if (t == 123.456f) p.outF[0] = t;
     } else {
+      // 320-row tiles: the lane's column index is re-derived here behind an opaque move, so that the 64-bit output / operand addresses
+      // built from it are computed after the K loop instead of living through it (they were the values the register allocator spilled)
+      int c8e = c8;
+      if constexpr (TM >= 5) asm volatile("" : "+v"(c8e));
+      const int n = n0 + wn * 64 + c8e;
+      const bool ncol = n < p.N;
       if (tid < RT) s_rs[tid] = rs_reg;
       if constexpr (GATHER) { if (tid < RT) { s_tab[0][tid] = tab_reg[0]; s_tab[1][tid] = tab_reg[1]; s_tab[2][tid] = tab_reg[2]; } }
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
