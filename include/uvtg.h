@@ -269,8 +269,12 @@ int uvtg_profile_sections_stop(double* total_ms, long long* counts);
 /* Test knob: force the NT GEMM tile size (0 = automatic choice, 128, 256) so that both kernels can be compared on
  * identical inputs.  Process-wide. */
 int uvtg_debug_force_nt_tile(int tile);
-/* ... and the tile HEIGHT of the persistent 256-wide kernel (0 = automatic per launch, 128, 192, 256) */
+/* ... and the tile HEIGHT of the persistent 256-wide kernel (0 = automatic per launch, 128, 192, 256, 320; 320 applies to the launches
+ * with the plain row mapping, the gather launches run 256 rows then) */
 int uvtg_debug_force_nt_bm(int bm);
+/* Host arithmetic only (no device needed): the tile height the persistent NT GEMM picks for an M x N launch of `groups` groups on `cus`
+ * compute units, gather != 0 for launches with row gather / scatter / conv taps / row tables.  Returns 128, 192, 256 or 320. */
+int uvtg_debug_nt_tile_rows(int M, int N, int groups, int gather, int cus);
 /* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
  * launches on different streams can run side by side. */
 int uvtg_debug_gemm_cus(int n);

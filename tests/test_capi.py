@@ -98,3 +98,20 @@ def test_hot_kernels_resources():
         # its prologue/epilogue are tolerated (its parity tests are the gate), the GEMMs must stay spill-free
         assert k["scratch"] <= (32 if "attn_bwd_fused" in k["name"] else 0), (k["name"], k["scratch"])
         assert k["waves_per_simd"] >= 2, (k["name"], k["vgpr"])
+
+
+def test_nt_tile_height_choice(lib):
+    """The persistent NT GEMM's tile-height choice is host arithmetic: pin the decisions the measured shapes rest on
+    (tools/tm5_ab.sh) so that a change of the cost model shows up here, without a GPU."""
+    pick = lambda M, N, gather=0, groups=1, cus=256: lib.uvtg_debug_nt_tile_rows(M, N, groups, gather, cus)
+    assert pick(20158, 1024) == 320          # 252 tiles = one round of 256 CUs (192 rows: 420 tiles = 1.66 rounds)
+    assert pick(20470, 1024) == 320          # 256 tiles: exactly one round
+    assert pick(20500, 1024) == 192          # 260 tiles of 320 rows would need a second round for 4 tiles
+    assert pick(20158, 3072) == 320          # 768 tiles = exactly three rounds
+    assert pick(15691, 1024) == 256          # 248 tiles of 256 rows fill one round better than 200 of 320
+    assert pick(8192, 1024) == 128           # text rows: 256 tiles of 128 rows = one full round of short tiles
+    for M in (15179, 15691, 20158, 27392):   # gather launches (conv taps, row tables) never get 320-row tiles
+        assert pick(M, 1024, gather=1) in (128, 192, 256)
+        assert pick(M, 2048, gather=1) in (128, 192, 256)
+    assert pick(20158, 1024, cus=64) in (128, 192, 256, 320)
+    assert lib.uvtg_debug_nt_tile_rows(0, 1024, 1, 0, 256) < 0

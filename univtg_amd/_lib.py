@@ -54,6 +54,7 @@ SIGNATURES = {
     "uvtg_debug_force_nt_tile": (_I, [_I]),
     "uvtg_debug_force_nt_bm": (_I, [_I]),
     "uvtg_debug_gemm_cus": (_I, [_I]),
+    "uvtg_debug_nt_tile_rows": (_I, [_I, _I, _I, _I, _I]),
     "uvtg_profile_start": (_I, []),
     "uvtg_profile_stop": (_I, [_P, _P, _P]),
     "uvtg_profile_event_floor_ms": (C.c_double, []),

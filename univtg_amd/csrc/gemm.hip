@@ -1158,6 +1158,34 @@ static int eff_cus() { return (g_cu_cap > 0 && g_cu_cap < g_num_cu) ? g_cu_cap :
 #define UVTG_NT_F3 1.07
 #define UVTG_NT_F2 1.20
 #endif
+// Tile height (TM = rows / 64) of a persistent NT launch, pure host arithmetic.  Candidates: 256-wide tiles of 320 / 256 / 192 / 128 rows,
+// one workgroup per CU; cost = rounds x rows of a tile x the per-height factor.  A partly filled last round costs ~0.84 of a full one up to
+// ~70 % fill (fewer active CUs run their K loops faster), then rises to a full round (fitted on the per-height timings of tools/tm5_ab.sh at
+// the step's shapes).  320-row tiles: plain row mapping only -- the gather variants have no registers left for them; a forced 320 falls back
+// to 256 there.  Returns 0 when the forced height is not a candidate.
+static int nt256_pick_tm(int M, int N, int groups, bool gather, int cus, int force) {
+  struct Cand { int tm; double f; };
+  static const bool tm5_off = getenv("UVTG_NT_TM5_OFF") != nullptr;          // experiment: no 320-row tiles
+  static const Cand cands[] = {{5, UVTG_NT_F5}, {4, UVTG_NT_F4}, {3, UVTG_NT_F3}, {2, UVTG_NT_F2}};
+  int best_tm = 0; double best = 1e30;
+  const int force_bm = (force == 320 && gather) ? 256 : force;
+  if (cus < 1) cus = 1;
+  for (const Cand& c : cands) {
+    if (force_bm && c.tm * 64 != force_bm) continue;
+    if (c.tm == 5 && (gather || (tm5_off && force_bm != 320))) continue;
+    const long long tiles = (long long)cdiv(M, 64 * c.tm) * cdiv(N, 256) * groups;
+    const long long full = tiles / cus, rem = tiles % cus;
+    const double fill = (double)rem / cus;
+    const double rounds = (double)full + (rem ? 0.84 + 0.16 * (fill > 0.7 ? (fill - 0.7) / 0.3 : 0.0) : 0.0);
+    const double cost = rounds * (64.0 * c.tm) * c.f;
+    if (cost < best) { best = cost; best_tm = c.tm; }
+  }
+  return best_tm;
+}
+extern "C" int uvtg_debug_nt_tile_rows(int M, int N, int groups, int gather, int cus) {
+  if (M <= 0 || N <= 0 || groups <= 0 || cus <= 0) return -20;
+  return 64 * nt256_pick_tm(M, N, groups, gather != 0, cus, 0);
+}
 template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, bool eop, int epi, hipStream_t s) {
   constexpr int smem = TM == 5 ? 147456 : 131072;
   static bool attr = false;
@@ -1226,8 +1254,6 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
-  // Candidates: 256-wide tiles of 320 / 256 / 192 / 128 rows, one workgroup per CU.
-  // Cost = tiles per CU x rows of a tile x a per-height factor (measured relative time per output element).
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1 || b.o_rows || b.pos_map;
   const bool eop = b.residB || (b.actgrad && b.gradPre);
   static const bool epi_off = getenv("UVTG_NT_EPI_OFF") != nullptr;       // experiment: the general epilogue everywhere
@@ -1239,24 +1265,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
     else if (!b.outPre && !b.act && b.actgrad == 2 && eop && !b.residB && !b.rowscale) epi = 3;
   }
   if (!((epi_mask >> epi) & 1)) epi = 0;
-  struct Cand { int tm; double f; };
-  static const bool tm5_off = getenv("UVTG_NT_TM5_OFF") != nullptr;          // experiment: no 320-row tiles
-  static const Cand cands[] = {{5, UVTG_NT_F5}, {4, UVTG_NT_F4}, {3, UVTG_NT_F3}, {2, UVTG_NT_F2}};
-  int best_tm = 0; double best = 1e30;
-  // (320-row tiles: plain row mapping only -- the gather variants have no registers left for them; a forced 320 falls back to 256 there)
-  const int force_bm = (g_force_bm == 320 && gather) ? 256 : g_force_bm;
-  for (const Cand& c : cands) {
-    if (force_bm && c.tm * 64 != force_bm) continue;
-    if (c.tm == 5 && (gather || (tm5_off && force_bm != 320))) continue;
-    const long long tiles = (long long)cdiv(b.M, 64 * c.tm) * cdiv(b.N, 256) * b.groups;
-    // rounds: a partly filled last round costs ~0.84 of a full one up to ~70 % fill (fewer active CUs run their K loops faster), then
-    // rises to a full round (fitted on the per-height timings of tools/tm5_ab.sh at the step's shapes)
-    const long long full = tiles / eff_cus(), rem = tiles % eff_cus();
-    const double fill = (double)rem / eff_cus();
-    const double rounds = (double)full + (rem ? 0.84 + 0.16 * (fill > 0.7 ? (fill - 0.7) / 0.3 : 0.0) : 0.0);
-    const double cost = rounds * (64.0 * c.tm) * c.f;
-    if (cost < best) { best = cost; best_tm = c.tm; }
-  }
+  const int best_tm = nt256_pick_tm(b.M, b.N, b.groups, gather, eff_cus(), g_force_bm);
   if (!best_tm) return -21;
   const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
   const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
