@@ -436,6 +436,26 @@ def run_collate(ref):
     print("collate: ok", {k: tuple(v.shape) for k, v in model_inputs.items()})
 
 
+def run_feature_cache(ref):
+    """SURVEY 8f row 2, cache path: the real ``DatasetVLP._get_video_feat_by_vid`` / ``_get_query_feat_by_qid`` with ``use_cache`` on
+    (main/dataset.py:335-340,375-376) over in-memory caches of the shape ``DatasetVLP.__init__`` builds from the hdf5 files
+    (main/dataset.py:113-131: ``{feat_type: {vid: array}}``, ``{qid: array}``)."""
+    DS = ref.dataset.DatasetVLP
+    rng = np.random.RandomState(23)
+    sf = rng.randn(39, 24).astype(np.float32)          # stored the way data/create_h5py.py wrote them
+    clip = rng.randn(37, 16).astype(np.float32)
+    q = rng.randn(9, 16).astype(np.float32)
+    ds = object.__new__(DS)
+    ds.use_cache, ds.v_feat_types, ds.v_feat_dirs, ds.normalize_v = 1, ["vid_slowfast", "vid_clip"], ["unused_a", "unused_b"], True
+    ds.vid_cache = {"vid_slowfast": {7: sf}, "vid_clip": {7: clip}}
+    ds.txt_cache, ds.q_feat_dir, ds.q_feat_dim, ds.q_feat_type, ds.normalize_t, ds.txt_drop_ratio = {"q3": q}, "unused", 16, "last_hidden_state", True, 0
+    meta = dict(dset_name="d", v_feat_suffix="", q_feat_suffix="", vid=7, qid="q3")
+    store = {"slowfast": sf, "clip": clip, "q": q, "video": ds._get_video_feat_by_vid(meta).numpy(), "query": ds._get_query_feat_by_qid(meta).numpy(),
+             "query_missing": ds._get_query_feat_by_qid(dict(meta, qid="absent")).numpy()}
+    np.savez_compressed(os.path.join(OUT, "features_cache.npz"), **store)
+    print("features_cache: ok", {k: v.shape for k, v in store.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -444,6 +464,9 @@ def main():
         return
     if sys.argv[1:] == ["features"]:
         run_features(ref)
+        return
+    if sys.argv[1:] == ["feature_cache"]:
+        run_feature_cache(ref)
         return
     tiny = dict(hidden_dim=64, nheads=2, dim_feedforward=96, enc_layers=2, v_feat_dim=34, t_feat_dim=24,
                 max_q_l=16, input_dropout=0.0, dropout=0.0, droppath=0.0)
@@ -458,6 +481,7 @@ def main():
     run_matcher(ref)
     run_detr_criterion(ref)
     run_features(ref)
+    run_feature_cache(ref)
     run_span_utils(ref)
     run_nms(ref)
     run_dense_targets(ref)

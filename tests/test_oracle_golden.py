@@ -157,6 +157,27 @@ def test_feature_file_readers_match_reference(golden_dir, tmp_path):
     assert np.array_equal(q.numpy(), z["query_missing"])
 
 
+def test_feature_cache_readers_match_reference(golden_dir):
+    """SURVEY 8f row 2, hdf5 cache path (main/dataset.py:113-131,335-340,375-376): the store is any mapping whose items slice to arrays
+    (an open h5py.File where h5py exists -- emulated here by a dict behind a str-keyed view), entries are used as stored."""
+    from univtg_amd import pipeline
+    z = np.load(os.path.join(golden_dir, "features_cache.npz"))
+
+    class Store(dict):                      # what an h5py.File looks like to the loader: str keys, datasets that slice to ndarrays
+        def __getitem__(self, k):
+            assert isinstance(k, str)
+            return dict.__getitem__(self, k)
+    caches = [pipeline.load_feature_cache(Store({"7": z["slowfast"]}), [7]), pipeline.load_feature_cache(Store({"7": z["clip"]}), [7])]
+    v = pipeline.read_video_features_cached(caches, 7)
+    assert v.dtype == torch.float32 and np.array_equal(v.numpy(), z["video"])
+    tc = pipeline.load_feature_cache(Store({"q3": z["q"]}), ["q3", "absent"], optional=True)
+    assert set(tc) == {"q3"}
+    assert np.array_equal(pipeline.read_query_features_cached(tc, "q3", feat_dim=16).numpy(), z["query"])
+    assert np.array_equal(pipeline.read_query_features_cached(tc, "absent", feat_dim=16).numpy(), z["query_missing"])
+    with pytest.raises(KeyError):
+        pipeline.load_feature_cache(Store({}), [1])
+
+
 def test_lsap_against_scipy_random():
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(0)

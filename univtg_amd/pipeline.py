@@ -228,3 +228,37 @@ def read_query_features(path, feat_type="last_hidden_state", normalize=True, fea
     except Exception:
         q = np.zeros((10, feat_dim), np.float32)
     return torch.from_numpy(_l2_normalize(q) if normalize else q)
+
+
+def load_feature_cache(store, keys, optional=False):
+    """The reference's in-memory feature cache (``DatasetVLP.__init__`` with ``use_cache``, main/dataset.py:113-131): ``store`` is any
+    mapping whose items slice to arrays -- an open ``h5py.File`` of ``data/<dset>/h5py/<feat_type>.hdf5`` when the caller has h5py (this
+    package does not import it), or a dict of arrays -- and the result holds ``store[str(key)][:]`` for every key.  ``optional`` skips keys
+    the store does not have (the reference does that for the text cache and substitutes zeros at read time)."""
+    out = {}
+    for key in keys:
+        try:
+            out[key] = np.asarray(store[str(key)][:])
+        except Exception:
+            if not optional:
+                raise
+    return out
+
+
+def read_video_features_cached(caches, vid):
+    """``_get_video_feat_by_vid`` on the cache path (main/dataset.py:375-376,382-386): one cache per feature type, entries taken AS STORED
+    (the hdf5 files hold the features the way ``data/create_h5py.py`` wrote them: no cast, no normalisation here), truncated to the
+    shortest and concatenated along the feature axis."""
+    feats = [np.asarray(c[vid]) for c in caches]
+    n = min(len(f) for f in feats)
+    return torch.from_numpy(np.concatenate([f[:n] for f in feats], axis=1))
+
+
+def read_query_features_cached(cache, qid, feat_dim=512):
+    """``_get_query_feat_by_qid`` on the cache path (main/dataset.py:335-340): the stored array as is, zeros((10, D)) for a missing qid."""
+    try:
+        q = np.asarray(cache[qid])
+    except Exception:
+        q = np.zeros((10, feat_dim), np.float32)
+    return torch.from_numpy(q)
+
