@@ -29,6 +29,8 @@ typedef void* uvtg_stream_t;   /* hipStream_t */
 /* Geometry + mode of one forward/backward call.  Mirrors the fields build_model() reads from `args`
  * (model/univtg.py:409-450) plus the batch shape. */
 typedef struct uvtg_dims {
+  int struct_size;           /* = sizeof(uvtg_dims) of the header the caller was built against; every entry point rejects a
+                                mismatch (-18) instead of reading a shorter / differently laid out struct (ABI break guard)  */
   int B, Lv, Lt;             /* batch, padded #clips, padded #text tokens (S = Lv + Lt)            */
   int d, H, F, E;            /* hidden_dim, nheads, dim_feedforward, enc_layers                    */
   int Dv, Dt;                /* v_feat_dim (incl. TEF), t_feat_dim                                 */
@@ -162,6 +164,8 @@ long long uvtg_wgrad_scratch_floats(int M, int N, int K);
 int uvtg_wgrad_bf16_ws(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, float* scratch,
                        long long scratch_floats, uvtg_stream_t stream);
 int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t stream);
+/* bf16 -> fp32 (exact).  With uvtg_cast_bf16: the optional bf16 gradient buckets of the data-parallel exchange. */
+int uvtg_cast_f32(const void* src, float* dst, long long n, uvtg_stream_t stream);
 /* LayerNorm rows (eps 1e-5): y fp32, optional mean/rstd */
 int uvtg_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int rows, int D, uvtg_stream_t stream);
@@ -257,6 +261,9 @@ const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* workspace);
  * host arrays [8]. */
 int uvtg_profile_start(void);
 int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
+/* algorithmic bytes of the launches between uvtg_profile_start and _stop, per family (host array [8]; filled for family 3, the persistent
+ * NT GEMM: A and W once, every output once, residual / pre-activation / position operands once) */
+int uvtg_profile_bytes(double* bytes);
 /* the empty-event-pair floor (ms) that uvtg_profile_stop measured on the launch stream and subtracted from every launch */
 double uvtg_profile_event_floor_ms(void);
 
@@ -278,6 +285,11 @@ int uvtg_debug_nt_tile_rows(int M, int N, int groups, int gather, int cus);
 /* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
  * launches on different streams can run side by side. */
 int uvtg_debug_gemm_cus(int n);
+/* Data-parallel runs: leave k compute units out of every persistent GEMM grid (NT tiles and weight-gradient units are sized for
+ * CUs - k), so that RCCL's all-reduce kernels on the communication stream always find free CUs while backward runs (the reference
+ * gets this from DDP's bucket hooks running beside cuBLAS kernels that do not fill the chip, main/train_vlp_ddp.py:272-275).
+ * k = 0 (default): whole chip.  Process-wide; returns the number of CUs the grids will use. */
+int uvtg_set_reserved_cus(int k);
 const char* uvtg_strerror(int code);
 int uvtg_version(void);
 

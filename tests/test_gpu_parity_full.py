@@ -113,10 +113,17 @@ def test_config2_full_size_fp32x3_forward_and_post_nms_indices(dev, config2):
             if clip_length > 0:
                 assert np.all(np.mod(win[b, :, :2], clip_length) == 0)          # integer clip multiples (eval/postprocessing.py:46-51)
     # ---- (b) the fp32x3 forward in front of it ----
-    model, _ = build(cfg, params, dev, "fp32x3")
+    # the DEFAULT drop-in model (precision="auto", what a maintainer following INTEGRATION section 1 gets): inference calls run fp32x3
+    model, _ = build(cfg, params, dev, "auto", proj_precise="auto")
     model.eval()
     with torch.no_grad():
         out = model(**to_dev(inputs, dev))
+    m32, _ = build(cfg, params, dev, "fp32x3")
+    m32.eval()
+    with torch.no_grad():
+        o32 = m32(**to_dev(inputs, dev))
+    for k in ("pred_logits", "pred_spans", "saliency_scores"):
+        assert torch.equal(out[k], o32[k]), k                                    # "auto" under no_grad IS the fp32x3 path
     valid = inputs["src_vid_mask"].bool()
     e_sal = float((out["saliency_scores"].cpu() - ref["saliency_scores"])[valid].abs().max())
     e_log = float((out["pred_logits"].cpu() - ref["pred_logits"]).abs().max())
@@ -154,7 +161,9 @@ def test_config2_full_size_fp32x3_forward_and_post_nms_indices(dev, config2):
         print(f"[config2 fp32x3 forward + tail, clip_length={clip_length}] identical ranking + keep-set: {exact}/{B}; boundary cases of the "
               f"reference's own decisions: {explained}; unexplained: {len(unexplained)}")
         assert not unexplained, unexplained
-        assert exact >= (0.85 if clip_length == 0 else 0.5) * B
+        # measured 254/256 for both settings (the other two: score near-ties of the reference's own ranking, counted above); every
+        # sample that is not bit-identical must be such a boundary case, and there may be at most four of them
+        assert exact >= B - 4 and exact + sum(explained.values()) == B
 
 
 def test_config2_full_size_bf16_losses_gradients_and_index_agreement(dev, config2):
@@ -200,26 +209,36 @@ def test_config2_full_size_bf16_losses_gradients_and_index_agreement(dev, config
         same_set += set(got) == set(want)
     print(f"[config2 bf16] post-NMS top-10 clip indices vs fp32 reference algorithm: identical ordered list {same_list}/{B}, "
           f"identical set {same_set}/{B}, identical top-1 {top1}/{B}")
-    assert top1 >= 0.9 * B
+    # measured 251 / 226 / 219 of 256 (profiles): floors a few samples below the measurement.  precision="bf16" is the
+    # OPT-IN fast inference mode; the default ("auto") runs inference calls in fp32x3, where the index clause holds (test above)
+    assert top1 >= B - 10 and same_set >= B - 40 and same_list >= B - 48
 
 
-def test_bench_path_trainstep_dropout_replayed_through_oracle(dev):
-    """The EXACT bench.py path: native TrainStep, train mode, config 2 full size (B=256, E=4), input dropout 0.5 + DropPath 0.1,
-    packed="auto" with the collate's host-side lengths.  The device Philox masks are regenerated on the host and handed to the
-    oracle; losses and every parameter gradient must agree.  (Under input dropout the native step's packed stream keeps the valid clips,
-    the three padded clips inside the conv heads' receptive field of a valid position -- each with its own mask -- and the valid text
-    tokens: exact for everything a loss can see, unlike round 1's shared-mask representative.)"""
+def _philox_rng(seed, cfg, B, Lv, Lt, p_in, p_path):
+    """The device Philox masks of one TrainStep call, regenerated on the host in the oracle's rng layout."""
     import philox_ref as R
+    Dv, Dt, d, E = cfg.v_feat_dim, cfg.t_feat_dim, cfg.hidden_dim, cfg.enc_layers
+    t = lambda a: torch.from_numpy(a)
+    return {"vid_keep": [t(R.row_keep(seed, R.RNG_IN_VID, B * Lv, Dv, p_in)).view(B, Lv, Dv),
+                         t(R.row_keep(seed, R.RNG_IN_VID + 1, B * Lv, d, p_in)).view(B, Lv, d)],
+            "txt_keep": [t(R.row_keep(seed, R.RNG_IN_TXT, B * Lt, Dt, p_in)).view(B, Lt, Dt),
+                         t(R.row_keep(seed, R.RNG_IN_TXT + 1, B * Lt, d, p_in)).view(B, Lt, d)],
+            "dp_scale": t(R.droppath_scales(seed, E, B, p_path))}
+
+
+def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True):
+    """The EXACT bench.py path at one BASELINE shape: native TrainStep, train mode, input dropout 0.5 + DropPath 0.1, packed="auto" with
+    the collate's host-side lengths (loss-only packing).  The device Philox masks are regenerated on the host and handed to the oracle;
+    the five losses, pred_logits at the valid positions and EVERY parameter gradient must agree."""
     from oracle import univtg_oracle as O
     from univtg_amd.trainer import TrainStep
     _threads()
-    cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
-    params = O.init_params(cfg, seed=201)
-    B, Lv, Lt = 256, 75, 32
-    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=202, ragged=True)
+    cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1, max_v_l=Lv)
+    params = O.init_params(cfg, seed=seeds[0])
+    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=seeds[1], ragged=True)
     res = {}
-    for packed in (False, "auto"):
-        model, crit = build(cfg, params, dev, "bf16", proj_precise="auto")
+    for packed in ((False, "auto") if compare_padded else ("auto",)):
+        model, crit = build(cfg, params, dev, "auto", proj_precise="auto")      # the default drop-in model, as bench.py builds it
         model.train()
         model.set_seed(777)
         step = TrainStep(model, crit, grad_clip=0.1, packed=packed)
@@ -228,41 +247,109 @@ def test_bench_path_trainstep_dropout_replayed_through_oracle(dev):
         losses = step.step(batch, to_dev(tg, dev), optimize=False)
         torch.cuda.synchronize()
         res[packed] = (losses.cpu(), step.grads.clone(), model, step.pred_logits.clone())
-    # the two executions draw the same masks and compute the same rows: equal to re-association noise
-    l0, g0, _, pl0 = res[False]
     l1, g1, model, pl1 = res["auto"]
-    assert float((l0 - l1).abs().max()) < 2e-3 * max(1.0, float(l0.abs().max()))
-    gg0, gg1 = g0.double(), g1.double()
-    assert float((gg0 @ gg1) / (gg0.norm() * gg1.norm())) > 0.9995
+    if compare_padded:      # the two executions draw the same masks and compute the same rows: equal to re-association noise
+        l0, g0, _, pl0 = res[False]
+        assert float((l0 - l1).abs().max()) < 2e-3 * max(1.0, float(l0.abs().max()))
+        gg0, gg1 = g0.double(), g1.double()
+        assert float((gg0 @ gg1) / (gg0.norm() * gg1.norm())) > 0.9995
     # ---- replay through the oracle ----
     seed = (777 * 1000003 + 1) & 0xFFFFFFFFFFFFFFFF
-    Dv, Dt, d, E = cfg.v_feat_dim, cfg.t_feat_dim, cfg.hidden_dim, cfg.enc_layers
-    t = lambda a: torch.from_numpy(a)
-    rng = {"vid_keep": [t(R.row_keep(seed, R.RNG_IN_VID, B * Lv, Dv, 0.5)).view(B, Lv, Dv),
-                        t(R.row_keep(seed, R.RNG_IN_VID + 1, B * Lv, d, 0.5)).view(B, Lv, d)],
-           "txt_keep": [t(R.row_keep(seed, R.RNG_IN_TXT, B * Lt, Dt, 0.5)).view(B, Lt, Dt),
-                        t(R.row_keep(seed, R.RNG_IN_TXT + 1, B * Lt, d, 0.5)).view(B, Lt, d)],
-           "dp_scale": t(R.droppath_scales(seed, E, B, 0.1))}
+    rng = _philox_rng(seed, cfg, B, Lv, Lt, 0.5, 0.1)
     p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref = O.forward(p2, cfg, inputs["src_txt"], inputs["src_txt_mask"], inputs["src_vid"], inputs["src_vid_mask"], rng=rng)
     ref_losses = O.criterion(ref, tg, cfg)
     O.total_loss(ref_losses, cfg).backward()
     vmask = inputs["src_vid_mask"].bool()
     e = float((pl1.cpu() - ref["pred_logits"].detach())[vmask].abs().max())     # (loss-only packing: padded positions beyond the conv halo differ)
-    assert e < 4e-2, e
+    lerr = {}
     for i, k in enumerate(("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")):
         got, want = float(l1[i]), float(ref_losses[k])
-        assert abs(got - want) < 3e-2 * max(1.0, abs(want)), (k, got, want)
+        lerr[k] = abs(got - want) / max(1.0, abs(want))
+    Dv, Dt = cfg.v_feat_dim, cfg.t_feat_dim
     offs = model._offsets(model._dims(B, Lv, Lt, Dv, Dt, False))
     names = {id(p): k for k, p in model.named_parameters()}
     flat = {names[id(p)]: g1[offs[i]: offs[i] + p.numel()] for i, p in enumerate(model._ordered_params())}
     rep = _grad_report(None, p2, lambda k: flat[k])
     worst_cos = min(rep.items(), key=lambda kv: kv[1][0])
     worst_ratio = max(rep.items(), key=lambda kv: abs(kv[1][1] - 1))
-    print(f"\n[bench path, train mode, B=256] {len(rep)} gradients; worst cosine {worst_cos[1][0]:.5f} ({worst_cos[0]}), "
-          f"worst norm ratio {worst_ratio[1][1]:.4f} ({worst_ratio[0]})")
-    bad = {k: v for k, v in rep.items() if v[0] < 0.99 or abs(v[1] - 1) > 0.03}
+    print(f"\n[{tag}: bench path, train mode, B={B} L_v={Lv}] pred_logits err {e:.2e}; relative loss errors "
+          + ", ".join(f"{k} {v:.1e}" for k, v in lerr.items())
+          + f"; {len(rep)} gradients; worst cosine {worst_cos[1][0]:.5f} ({worst_cos[0]}), worst norm ratio {worst_ratio[1][1]:.4f} ({worst_ratio[0]})")
+    assert len(rep) == 78
+    assert e < 4e-2, e
+    assert max(lerr.values()) < 3e-2, lerr
+    # floors: the measured level (round 2: worst cosine 0.9965, norm within 1.8 %) minus a small margin -- the noise is the plain-bf16
+    # 2818-wide input projection under dropout
+    bad = {k: v for k, v in rep.items() if v[0] < 0.995 or abs(v[1] - 1) > 0.025}
     assert not bad, sorted(bad.items())
+
+
+def test_bench_path_trainstep_dropout_replayed_through_oracle(dev):
+    """Config 2 at full size (B=256, L_v=75, L_t=32, d=1024, E=4): what `python bench.py` times.  (Under input dropout the native step's
+    packed stream keeps the valid clips, the three padded clips inside the conv heads' receptive field of a valid position -- each with
+    its own mask -- and the valid text tokens: exact for everything a loss can see, unlike round 1's shared-mask representative.)"""
+    _replay_bench_path(dev, "config2", 256, 75, 32, (201, 202))
+
+
+def test_config3_bench_path_replayed_through_oracle(dev):
+    """Config 3 (the 4M VLP pre-training shape, scripts/pretrain.sh:26-47) at production width: per-GPU shard B=256, L_v=128, L_t=32
+    (S=160: the 8-wave fused attention backward), d=1024, E=4, train mode p_in=0.5 / DropPath 0.1, packed="auto" loss-only stream,
+    Philox masks replayed through the oracle -- what `python bench.py --config 3` times."""
+    _replay_bench_path(dev, "config3", 256, 128, 32, (301, 302), compare_padded=False)
+
+
+def test_convergence_fixed_batch_matches_oracle_training(dev):
+    """200 native TrainStep steps (train mode: input dropout 0.5 + DropPath 0.1, clip 0.1, AdamW) on ONE fixed batch, against the oracle
+    trained with torch.optim.AdamW + clip_grad_norm_ on the same batch with the SAME per-step Philox masks (main/train_vlp_ddp.py:44-75).
+    bf16 operands vs fp32: the weighted total loss must follow the oracle's curve inside a stated band and end well below its start.
+    Width 256 / E=2 / B=32 so that 200 oracle steps take seconds; the production-width single-step parity is the replay tests above."""
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))          # (small tensors: more threads only add overhead; ~0.1 s per oracle step)
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                     input_dropout=0.5, dropout=0.0, droppath=0.1)
+    B, Lv, Lt, steps, lr = 32, 40, 12, 200, 2e-4
+    params = O.init_params(cfg, seed=901)
+    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=902, ragged=True)
+    wd = O.weight_dict(cfg)
+    keys = ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")
+    model, crit = build(cfg, params, dev, "auto", proj_precise="auto")
+    model.train()
+    model.set_seed(4242)
+    step = TrainStep(model, crit, lr=lr, weight_decay=1e-4, grad_clip=0.1, packed="auto")
+    batch = to_dev(inputs, dev)
+    batch["_lens_host"] = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+    tgd = to_dev(tg, dev)
+    dev_curve = torch.stack([step.step(batch, tgd) for _ in range(steps)]).cpu()
+    dev_total = sum(dev_curve[:, i] * wd[k] for i, k in enumerate(keys))
+    # oracle: same masks step by step
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    train_keys = [k for k in p2 if not k.startswith("txt_position_embed")]     # (unused parameters: no gradient in the reference either)
+    opt = torch.optim.AdamW([p2[k] for k in train_keys], lr=lr, weight_decay=1e-4)
+    ref_total = []
+    for it in range(steps):
+        seed = (4242 * 1000003 + it + 1) & 0xFFFFFFFFFFFFFFFF
+        rng = _philox_rng(seed, cfg, B, Lv, Lt, 0.5, 0.1)
+        opt.zero_grad(set_to_none=True)
+        out = O.forward(p2, cfg, inputs["src_txt"], inputs["src_txt_mask"], inputs["src_vid"], inputs["src_vid_mask"], rng=rng)
+        total = O.total_loss(O.criterion(out, tg, cfg), cfg)
+        total.backward()
+        torch.nn.utils.clip_grad_norm_([p2[k] for k in train_keys], 0.1)
+        opt.step()
+        ref_total.append(float(total))
+    ref_total = torch.tensor(ref_total)
+    rel = ((dev_total - ref_total).abs() / ref_total.abs().clamp(min=1.0))
+    sm = lambda x: torch.nn.functional.avg_pool1d(x[None, None], 10, 10)[0, 0]          # 10-step means: the curves, not the dropout noise
+    rel_sm = ((sm(dev_total) - sm(ref_total)).abs() / sm(ref_total).abs().clamp(min=1.0))
+    print(f"\n[convergence, 200 steps, fixed batch] total loss start {float(ref_total[0]):.3f} (oracle) / {float(dev_total[0]):.3f} (HIP); "
+          f"mean of last 10: {float(ref_total[-10:].mean()):.3f} / {float(dev_total[-10:].mean()):.3f}; per-step relative gap max {float(rel.max()):.3f} "
+          f"median {float(rel.median()):.4f}; 10-step-mean gap max {float(rel_sm.max()):.4f}; every 50th step: "
+          + ", ".join(f"{i}: {float(ref_total[i]):.3f}/{float(dev_total[i]):.3f}" for i in (0, 49, 99, 149, 199)))
+    assert float(rel[0]) < 2e-2                                     # identical weights and masks at step 1
+    assert float(rel_sm.max()) < 0.05 and float(rel.median()) < 0.02   # the band: 10-step means within 5 %, median step within 2 %
+    assert float(dev_total[-10:].mean()) < 0.75 * float(dev_total[:10].mean())   # and it does converge
+    assert float(ref_total[-10:].mean()) < 0.75 * float(ref_total[:10].mean())
 
 
 def test_eval_after_native_train_step_sees_new_weights(dev):
@@ -612,3 +699,94 @@ def test_drop_in_model_under_reference_ddp_wrapper(dev, tmp_path):
     a, b = r["ddp"], r["native"]
     assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())          # same kernels; fp32 atomic order only
     assert float((a @ b) / (a.norm() * b.norm())) > 0.99999
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the native data-parallel step itself (main/train_vlp_ddp.py:112,215,272-275): 2 ranks, gloo, both on cuda:0
+# ------------------------------------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    res = {}
+    # ---- (i) three real train-mode steps (dropout 0.5 / DropPath 0.1, clip, AdamW, overlapped bucketed exchange): the ranks start from
+    # DIFFERENT weights (the constructor must broadcast rank 0's), see different data and draw different masks; their flat parameter
+    # buffers must stay bit-identical
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                     input_dropout=0.5, dropout=0.0, droppath=0.1)
+    params = O.init_params(cfg, seed=91 + rank)
+    model, crit = build(cfg, params, dev, "auto", proj_precise="auto")
+    model.train()
+    model.set_seed(1000 + rank)
+    step = TrainStep(model, crit, lr=1e-3, grad_clip=0.1, overlap_comm=True, time_comm=True)
+    p_start = step.flat.clone()
+    for it in range(3):
+        inputs, tg = O.make_batch(cfg, 6, 30, 10, seed=500 + 10 * it + rank, ragged=True)
+        batch = to_dev(inputs, dev)
+        batch["_lens_host"] = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+        step.step(batch, to_dev(tg, dev))
+    torch.cuda.synchronize()
+    res["world"], res["overlap"], res["exposed"] = step.world, step.overlap, step.exposed_comm_ms()
+    res["flat"], res["start"], res["m"] = step.flat.cpu(), p_start.cpu(), step.m.cpu()
+    res["state_w"] = model.state_dict()["transformer.encoder.layers.0.linear1.weight"].cpu()      # (the parameters ARE views of the flat buffer)
+    # ---- (ii) rank-separable loss ("labels": a mean over valid clips, unragged shards): the exchanged gradient / world == the gradient
+    # of the concatenated batch on one device (autograd path, no exchange), in both wire dtypes and both exchange schedules
+    cfg2 = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                      input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params2 = O.init_params(cfg2, seed=95)
+    inputs, tg = O.make_batch(cfg2, 8, 30, 10, seed=96, ragged=False)
+    sl = slice(rank * 4, rank * 4 + 4)                                        # DistributedSampler-style shard (train_vlp_ddp.py:112)
+    ind = {k: v[sl].to(dev) for k, v in inputs.items()}
+    tgd = {k: v[sl].to(dev) for k, v in tg.items() if torch.is_tensor(v)}
+    for tag, kw in (("fp32", dict(overlap_comm=True)), ("fp32_flat", dict(overlap_comm=False)), ("bf16", dict(overlap_comm=True, grad_comm_dtype="bf16"))):
+        m2, c2 = build(cfg2, params2, dev, "bf16")
+        m2.eval()
+        c2.losses = ["labels"]
+        st2 = TrainStep(m2, c2, **kw)
+        st2.step(ind, tgd, optimize=False)
+        torch.cuda.synchronize()
+        offs = m2._offsets(m2._dims(4, 30, 10, 514, 512, False))
+        res["g_" + tag] = torch.cat([st2.grads[offs[i]: offs[i] + p.numel()] for i, p in enumerate(m2._ordered_params())]).double().cpu() / world
+    if rank == 0:
+        m3, c3 = build(cfg2, params2, dev, "bf16")
+        m3.eval()
+        c3.losses = ["labels"]
+        out = m3(**to_dev(inputs, dev))
+        ld = c3(out, to_dev({k: v for k, v in tg.items() if torch.is_tensor(v)}, dev))
+        (ld["loss_f"] * c3.weight_dict["loss_f"]).backward()
+        torch.cuda.synchronize()
+        res["g_full"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m3._ordered_params()]).double().cpu()
+    torch.save(res, out_path + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_native_trainstep_is_a_data_parallel_step(dev, tmp_path):
+    """VERDICT r2 missing #1: a 2-rank TrainStep IS a data-parallel step -- (i) flat parameters (and AdamW moments) bit-identical across
+    ranks after 3 train-mode steps from different initial weights / data / masks; (ii) for the rank-separable `labels` loss the exchanged
+    gradient equals the single-device gradient of the concatenated batch, with fp32 buckets (overlapped and flat) and with bf16 buckets
+    (within bf16 rounding of the wire format)."""
+    import torch.multiprocessing as mp
+    out_path = str(tmp_path / "dp.pt")
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_dp_worker, args=(2, port, out_path), nprocs=2, join=True)
+    r0, r1 = torch.load(out_path + ".0"), torch.load(out_path + ".1")
+    assert r0["world"] == 2 and r0["overlap"] and len(r0["exposed"]) == 3
+    assert torch.equal(r0["start"], r1["start"])                               # rank 1's own initial weights were replaced by rank 0's
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["m"], r1["m"])
+    assert not torch.equal(r0["flat"], r0["start"])                            # (and the steps did move them)
+    n = r0["state_w"].numel()
+    assert torch.equal(r0["state_w"], r1["state_w"]) and n > 0
+    full = r0["g_full"]
+    for tag, tol_max, tol_cos in (("fp32", 2e-3, 0.99999), ("fp32_flat", 2e-3, 0.99999), ("bf16", 1.2e-2, 0.9999)):
+        a0, a1 = r0["g_" + tag], r1["g_" + tag]
+        assert torch.equal(a0, a1), tag                                        # every rank holds the same reduced gradient
+        err = float((a0 - full).abs().max() / full.abs().max())
+        cos = float((a0 @ full) / (a0.norm() * full.norm()))
+        print(f"\n[2-rank TrainStep, {tag} buckets] reduced gradient vs concatenated-batch gradient: max err {err:.2e} of max |g|, cosine {cos:.7f}")
+        assert err <= tol_max and cos > tol_cos, (tag, err, cos)
+    print(f"[2-rank TrainStep] exposed communication per step (gloo through the host, both ranks on one GPU): {[round(x, 2) for x in r0['exposed']]} ms")

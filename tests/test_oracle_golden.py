@@ -248,3 +248,42 @@ def test_pipeline_oracle_matches_reference_collate(golden_dir):
                 assert np.array_equal(sp, z[f"tg/span_labels/{i}"])
         else:
             assert np.array_equal(v, z["tg/" + k]) and v.dtype == z["tg/" + k].dtype, k
+
+
+def test_nn_baseline_matches_oracle():
+    """oracle/nn_baseline.py (bench.py's CPU baseline, composed of the torch.nn modules the reference composes) loads the reference's
+    state_dict layout strictly and computes what the oracle computes: outputs, losses and every parameter gradient (eval mode)."""
+    from oracle.nn_baseline import NNBaseline
+    cfg = O.make_cfg(hidden_dim=64, nheads=2, dim_feedforward=96, enc_layers=2, v_feat_dim=34, t_feat_dim=24, max_q_l=16,
+                     input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=11)
+    inputs, tg = O.make_batch(cfg, 5, 14, 6, seed=12, ragged=True)
+    m = NNBaseline(cfg)
+    res = m.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m.eval()
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(p2, cfg, **inputs)
+    out = m(**inputs)
+    for k in ("pred_logits", "pred_spans", "saliency_scores", "vid_mem_proj", "txt_mem_proj"):
+        torch.testing.assert_close(out[k], ref[k], rtol=1e-5, atol=1e-6)
+    O.total_loss(O.criterion(ref, tg, cfg), cfg).backward()
+    O.total_loss(O.criterion(out, tg, cfg), cfg).backward()
+    named = dict(m.named_parameters())
+    n = 0
+    for k, p in p2.items():
+        if p.grad is None:
+            assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
+            continue
+        torch.testing.assert_close(named[k].grad, p.grad, rtol=2e-4, atol=1e-6)
+        n += 1
+    assert n == 12 * cfg.enc_layers + 30
+    # train mode: the dropouts are live (two calls differ) and DropPath scales whole samples
+    cfg_t = O.make_cfg(**{**vars(cfg), "input_dropout": 0.5, "droppath": 0.3})
+    mt = NNBaseline(cfg_t)
+    mt.load_state_dict(params, strict=True)
+    mt.train()
+    torch.manual_seed(0)
+    a = mt(**inputs)["pred_logits"]
+    b = mt(**inputs)["pred_logits"]
+    assert not torch.equal(a, b)

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -69,10 +70,33 @@ static void run(const char* buf, int ld, int ktiles, int reps, int share, int gr
          bytes / ms / 1e6 / grid);
 }
 
-int main() {
+// FETCH_SIZE calibration (tools/fetch_calib.sh): ONE launch per pattern over a known byte count, every byte read exactly once from a
+// buffer far larger than the Infinity Cache is hot with: the ratio known bytes / (FETCH_SIZE x 1024) is the correction factor of that pattern
+__global__ __launch_bounds__(256) void calib_linear_kernel(const u32x4* src, size_t n16, unsigned* sink) {
+  unsigned acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) { u32x4 v = src[i]; asm volatile("" :: "v"(v)); acc += 1; }
+  if (acc == 0xffffffffu) sink[0] = acc;
+}
+
+int main(int argc, char** argv) {
   const int ld = 2048, ktiles = 16, reps = 8;          // 1024 bf16 columns per row, K tiles of 64 columns
   char* buf; unsigned* sink;
   CK(hipMalloc(&buf, (size_t)256 * 256 * ld + 4096)); CK(hipMemset(buf, 1, (size_t)256 * 256 * ld + 4096)); CK(hipMalloc(&sink, 64));
+  if (argc > 1 && !strcmp(argv[1], "calib")) {
+    // three kernels, one launch each, 128 MiB each (the whole buffer, every byte once): (1) the NT GEMM's staging pattern via LDS-DMA (8 rows x
+    // 128 B per wave-instruction, rows 2 KB apart; 4 pieces per wave = 256 distinct rows per K tile), (2) the same addresses into registers,
+    // (3) a plain linear 16 B / lane stream (the guide's calibrated case: factor 2)
+    const size_t bytes = (size_t)256 * ktiles * 4 * 8 * 1024;
+    CK(hipFuncSetAttribute((const void*)stream_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 8 * 1024));
+    hipLaunchKernelGGL((stream_kernel<4, 2, true>), dim3(256), dim3(512), 2 * 4 * 8 * 1024, 0, buf, ld, ktiles, 1, 1, sink);
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL((stream_kernel<4, 2, false>), dim3(256), dim3(512), 0, 0, buf, ld, ktiles, 1, 1, sink);
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(calib_linear_kernel, dim3(2048), dim3(256), 0, 0, (const u32x4*)buf, bytes / 16, sink);
+    CK(hipDeviceSynchronize());
+    printf("calib: %zu bytes per kernel (stream_kernel<4,2,true>, stream_kernel<4,2,false>, calib_linear_kernel)\n", bytes);
+    return 0;
+  }
   for (int grid : {256, 64, 8}) {
     for (int share : {1, 4}) {
       run<8, 1, true>(buf, ld, ktiles, reps, share, grid, sink, "lds");

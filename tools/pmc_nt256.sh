@@ -22,13 +22,25 @@ def wsum(d, name):      # launch-count weighted mean over every nt256 instantiat
     return sum(v[name][0] * v[name][1] for v in d.values() if name in v) / max(n, 1), n
 p0, p1, p2 = parse(0), parse(1), parse(2)
 fetch, n = wsum(p0, "FETCH_SIZE"); gui, _ = wsum(p0, "GRBM_GUI_ACTIVE"); write, _ = wsum(p1, "WRITE_SIZE"); mfma, _ = wsum(p2, "SQ_VALU_MFMA_BUSY_CYCLES")
-fb, wb = fetch * 1024 * 2, write * 1024
-js = {"kernel": "gemm_nt256_kernel<*> (all instantiations, launch-weighted)",
+import sys
+sys.path.insert(0, R)
+from bench import kernel_src_sha
+factor, fsrc = 2.0, "guide: wide coalesced streaming reads are tallied at half their bytes (MI355X_MICROARCH.md, HBM section); uncalibrated for this pattern"
+for cal in (f"{R}/gpurun_out/fetch_calibration.json", f"{R}/profiles/r03_fetch_calibration.json"):
+    if os.path.exists(cal):
+        cj = json.load(open(cal))
+        pat = cj.get("patterns", {}).get("nt_staging_lds_dma", {})
+        if "factor" in pat:
+            factor, fsrc = pat["factor"], f"calibrated: tools/fetch_calib.sh, the kernel's own LDS-DMA staging pattern over a known byte count ({os.path.basename(cal)})"
+            break
+head = open(f"{R}/tools/.git_head").read().strip() if os.path.exists(f"{R}/tools/.git_head") else "unknown"
+fb, wb = fetch * 1024 * factor, write * 1024
+js = {"kernel_src_sha": kernel_src_sha(), "git_head": head, "fetch_factor": factor, "fetch_factor_source": fsrc, "kernel": "gemm_nt256_kernel<*> (all instantiations, launch-weighted)",
       "command": "tools/pmc_nt256.sh: rocprofv3 --pmc <pass> --kernel-include-regex gemm_nt256 -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-padded-compare --profile-steps 0  (three separate passes: FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE | SQ_*)",
       "launches_averaged": n, "per_instantiation": {k: {c: v[1] for c, v in d.items()} for k, d in {**p0}.items()},
       "FETCH_SIZE_KB_raw": round(fetch, 1), "WRITE_SIZE_KB_raw": round(write, 1),
       "fetch_bytes_corrected": int(fb), "write_bytes": int(wb), "traffic_bytes_per_launch": int(fb + wb),
-      "correction": "gfx950 rocprofv3 tallies the 128-B requests of wide coalesced reads at 64 B: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is; both in KiB",
+      "correction": "FETCH_SIZE (KiB) x fetch_factor; WRITE_SIZE (KiB) taken as is",
       "SQ_VALU_MFMA_BUSY_CYCLES": mfma, "GRBM_GUI_ACTIVE_sum_over_8_xcd": gui,
       "mfma_busy_frac": round(mfma / (gui / 8 * 1024), 3),
       "sq_wave_cycle_split": {k: round(wsum(p2, k)[0] / max(wsum(p2, "SQ_WAVE_CYCLES")[0], 1), 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")}}

@@ -11,12 +11,19 @@ LIB_PATH = os.environ.get("UVTG_LIB_PATH") or os.path.join(_HERE, "libuvtg.so") 
 
 class Dims(C.Structure):
     """struct uvtg_dims (include/uvtg.h)."""
-    _fields_ = [("B", C.c_int), ("Lv", C.c_int), ("Lt", C.c_int),
+    _fields_ = [("struct_size", C.c_int), ("B", C.c_int), ("Lv", C.c_int), ("Lt", C.c_int),
                 ("d", C.c_int), ("H", C.c_int), ("F", C.c_int), ("E", C.c_int),
                 ("Dv", C.c_int), ("Dt", C.c_int), ("n_proj", C.c_int),
                 ("precise", C.c_int), ("training", C.c_int), ("proj_precise", C.c_int),
                 ("p_in", C.c_float), ("p_attn", C.c_float), ("p_path", C.c_float),
                 ("seed", C.c_ulonglong), ("loss_only", C.c_int)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(Dims)
+
+
+ABI_VERSION = 200          # uvtg_version() this binding was written against
 
 
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -54,10 +61,13 @@ SIGNATURES = {
     "uvtg_debug_force_nt_tile": (_I, [_I]),
     "uvtg_debug_force_nt_bm": (_I, [_I]),
     "uvtg_debug_gemm_cus": (_I, [_I]),
+    "uvtg_set_reserved_cus": (_I, [_I]),
+    "uvtg_cast_f32": (_I, [_P, _P, _LL, _P]),
     "uvtg_debug_nt_tile_rows": (_I, [_I, _I, _I, _I, _I]),
     "uvtg_profile_start": (_I, []),
     "uvtg_profile_stop": (_I, [_P, _P, _P]),
     "uvtg_profile_event_floor_ms": (C.c_double, []),
+    "uvtg_profile_bytes": (_I, [_P]),
     "uvtg_profile_sections_start": (_I, []),
     "uvtg_profile_sections_stop": (_I, [_P, _P]),
     "uvtg_detr_criterion": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P,
@@ -89,6 +99,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.uvtg_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: uvtg_version() = {lib.uvtg_version()}, this binding expects {ABI_VERSION}; rebuild with "
+                           "`python -m univtg_amd.build --force`")
     _lib = lib
     return lib
 

@@ -33,6 +33,7 @@ struct Dm {
 
 int check_dims(const uvtg_dims* d) {
   if (!d) return -10;
+  if (d->struct_size != (int)sizeof(uvtg_dims)) return -18;     // caller built against another layout of the struct (uvtg_version)
   if (d->B <= 0 || d->Lv <= 0 || d->Lt <= 0 || d->E <= 0 || d->H <= 0) return -11;
   if (d->n_proj != 2) return -12;
   if (d->d % 32 || d->F % 8) return -13;
@@ -40,6 +41,9 @@ int check_dims(const uvtg_dims* d) {
   if (hd * d->H != d->d || (hd != 32 && hd != 64 && hd != 128)) return -14;
   if (d->precise && d->training) return -15;
   if (d->Dv <= 0 || d->Dt <= 0) return -16;
+  // (d % 32 == 0 and F % 8 == 0 make every weight MATRIX a multiple of 4 elements: the matrices the weight-gradient launches assign
+  // have no alignment padding behind them in the flat gradient buffer, so the clipping norm over the whole buffer sees no unwritten word)
+  if (((long long)d->d * d->Dv) % 4 || ((long long)d->d * d->Dt) % 4 || ((long long)d->F * d->d) % 4) return -13;
   return 0;
 }
 
@@ -319,7 +323,9 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // =================================================================================================
 // public: sizes / tables
 // =================================================================================================
-extern "C" int uvtg_version(void) { return 100; }
+// 100: round 1 ABI.  200: uvtg_dims gained struct_size (first field, validated) and loss_only; uvtg_decode_rank_nms / uvtg_postprocess_mr take
+// nms_thd as double; uvtg_debug_force_nt_wn / uvtg_set_dynamic_tiles removed ("ABI history").
+extern "C" int uvtg_version(void) { return 200; }
 
 extern "C" const char* uvtg_strerror(int code) {
   if (code == 0) return "ok";
@@ -340,6 +346,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -15: return "dims: precise mode is forward-only (training must be 0)";
     case -16: return "dims: feature dims must be positive";
     case -17: return "dims: too many encoder layers";
+    case -18: return "dims: struct_size does not match this library's uvtg_dims (caller built against another uvtg.h; see uvtg_version)";
     case -20: return "null pointer argument";
     case -21: return "force_nt_tile: tile must be 0, 128 or 256";
     case -22: return "backward: ready_events must hold enc_layers + 1 events (or n_events = 0)";
@@ -1031,6 +1038,10 @@ extern "C" int uvtg_wgrad_bf16_ws(const void* dY, const void* X, float* dW, floa
 extern "C" int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t st) {
   if (!src || !dst) return -20;
   return launch_cast_bf16(src, (bf16_t*)dst, n, (hipStream_t)st);
+}
+extern "C" int uvtg_cast_f32(const void* src, float* dst, long long n, uvtg_stream_t st) {
+  if (!src || !dst) return -20;
+  return launch_cast_f32((const bf16_t*)src, dst, n, (hipStream_t)st);
 }
 extern "C" int uvtg_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                   int rows, int D, uvtg_stream_t st) {

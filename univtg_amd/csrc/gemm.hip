@@ -1110,6 +1110,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
 
 void uvtg_prof_begin_launch(int family, double flops, hipStream_t s);
 void uvtg_prof_end_launch(int family, hipStream_t s);
+void uvtg_prof_add_bytes(int family, double bytes);
 
 static int check_nt(const GemmArgs& a, int elem) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
@@ -1150,7 +1151,26 @@ static bool nt256_ok(const GemmArgs& a) {
 static int g_num_cu = 0;
 static int g_cu_cap = 0;       // experiment knob: the persistent GEMM grids use at most this many CUs (0 = all)
 extern "C" int uvtg_debug_gemm_cus(int n) { g_cu_cap = n > 0 ? n : 0; return 0; }
-static int eff_cus() { return (g_cu_cap > 0 && g_cu_cap < g_num_cu) ? g_cu_cap : g_num_cu; }
+static int g_cu_reserved = 0;  // CUs left out of every persistent grid for the communication kernels of a data-parallel run
+static int eff_cus() {
+  int n = (g_cu_cap > 0 && g_cu_cap < g_num_cu) ? g_cu_cap : g_num_cu;
+  if (g_cu_reserved > 0) n = n - g_cu_reserved > 8 ? n - g_cu_reserved : 8;
+  return n;
+}
+static int ensure_num_cu() {
+  if (!g_num_cu) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipError_t e = hipGetDevice(&dev)) return (int)e;
+    if (hipError_t e = hipGetDeviceProperties(&pr, dev)) return (int)e;
+    g_num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+  }
+  return 0;
+}
+extern "C" int uvtg_set_reserved_cus(int k) {
+  g_cu_reserved = k > 0 ? k : 0;
+  if (ensure_num_cu()) return -1;
+  return eff_cus();
+}
 // relative time per output element of the persistent NT structure at the four tile heights
 #ifndef UVTG_NT_F4
 #define UVTG_NT_F5 1.02
@@ -1246,12 +1266,7 @@ static void nt_trace_launch(const GemmArgs& b, int tm, int grid, bool gather, bo
 }
 #endif
 static int launch_nt256(const GemmArgs& a, hipStream_t s) {
-  if (!g_num_cu) {
-    int dev = 0; hipDeviceProp_t pr;
-    if (hipError_t e = hipGetDevice(&dev)) return (int)e;
-    if (hipError_t e = hipGetDeviceProperties(&pr, dev)) return (int)e;
-    g_num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-  }
+  if (int e = ensure_num_cu()) return e;
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1 || b.o_rows || b.pos_map;
@@ -1273,6 +1288,13 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
   nt_trace_launch(b, best_tm, grid, gather, eop, s);
 #endif
   uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
+  {   // algorithmic bytes of the launch: both operands once, every output once, the epilogue operands once
+    const double mn = (double)b.M * b.N * b.groups;
+    double by = 2.0 * ((double)b.M * b.K + (double)b.N * b.K) * b.groups;
+    by += mn * ((b.outB ? 2 : 0) + (b.outF ? 4 : 0) + (b.outPre ? 2 : 0) + (b.outU ? 2 : 0) + (b.outUF ? 4 : 0));
+    by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0));
+    uvtg_prof_add_bytes(3, by);
+  }
   int rc;
   if (nt_order(best_tm) == 0)
     rc = best_tm == 5 ? launch_nt256_tm<5, 0>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
@@ -1307,7 +1329,8 @@ int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s) {
 static int g_tn_cus = 256;
 static void tn256_splits(int M, int total_tiles, int& splits, int& steps_per) {
   const int steps_total = cdiv(M, 64);
-  const int cus = (g_cu_cap > 0 && g_cu_cap < g_tn_cus) ? g_cu_cap : g_tn_cus;
+  int cus = (g_cu_cap > 0 && g_cu_cap < g_tn_cus) ? g_cu_cap : g_tn_cus;
+  if (g_cu_reserved > 0) cus = cus - g_cu_reserved > 8 ? cus - g_cu_reserved : 8;
   int want = cus / total_tiles;                        // tiles x splits ~ one unit per CU
   if (want < 1) want = 1;
   if (want > steps_total) want = steps_total;

@@ -96,6 +96,16 @@ __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, long long n) {
     for (long long j = i; j < n; j++) dst[j] = f2bf(src[j]);
   }
 }
+__global__ void cast_f32_kernel(const bf16_t* src, float* dst, long long n) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const u32x2 t = *(const u32x2*)(src + i);
+    const f32x4 v = {__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u), __uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
+    *(f32x4*)(dst + i) = v;
+  } else {
+    for (long long j = i; j < n; j++) dst[j] = bf2f(src[j]);
+  }
+}
 template <typename T> __device__ __forceinline__ T cvt(float v);
 template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float v) { return f2bf(v); }
@@ -940,6 +950,12 @@ int launch_sqsum(const float* x, long long n, float* sqsum, hipStream_t s) {
 int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, src, dst, n);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_cast_f32(const bf16_t* src, float* dst, long long n, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, src, dst, n);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -51,6 +51,7 @@ struct Prof {
   std::vector<hipEvent_t> ev[8];
   size_t used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double flops[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // algorithmic operand + output bytes of the family's launches (GEMM families)
   // section timing (its own pass: the per-launch events above would sit inside the sections)
   bool sec_on = false;
   std::vector<hipEvent_t> sev[4];
@@ -104,7 +105,7 @@ void uvtg_prof_end_launch(int family, hipStream_t s) {
   u += 2;
 }
 extern "C" int uvtg_profile_start(void) {
-  for (int f = 0; f < 8; f++) { g_prof.used[f] = 0; g_prof.flops[f] = 0; }
+  for (int f = 0; f < 8; f++) { g_prof.used[f] = 0; g_prof.flops[f] = 0; g_prof.bytes[f] = 0; }
   g_prof.on = true;
   return 0;
 }
@@ -138,6 +139,12 @@ extern "C" int uvtg_profile_stop(double* ms, double* flops, long long* launches)
   return 0;
 }
 extern "C" double uvtg_profile_event_floor_ms(void) { return g_prof.floor_ms; }
+void uvtg_prof_add_bytes(int family, double bytes) { if (g_prof.on) g_prof.bytes[family] += bytes; }
+extern "C" int uvtg_profile_bytes(double* bytes) {
+  if (!bytes) return -20;
+  for (int f = 0; f < 8; f++) bytes[f] = g_prof.bytes[f];
+  return 0;
+}
 
 // ---- section timing: one event pair around a whole section of uvtg_forward / uvtg_backward, on the launch stream ----
 // sections: 0 encoder forward (the E layers), 1 encoder backward (LayerNorm / dgrad / attention / weight gradients of the E layers),

@@ -185,6 +185,7 @@ int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv,
                     const float* dim_t, float* pos, unsigned char* kvalid, const int* skip /* [B*Lv], < 0: row not needed; may be NULL */, hipStream_t s);
 int launch_droppath_scales(float* scales, int n_layers2, int B, float p, unsigned long long seed, hipStream_t s);
 int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
+int launch_cast_f32(const bf16_t* src, float* dst, long long n, hipStream_t s);
 // zero the float ranges [off[i], off[i] + n[i]) of base (the gradients no weight-gradient launch assigns)
 constexpr int UVTG_MAX_ZERO_RANGES = 224;
 struct ZeroRanges { long long off[UVTG_MAX_ZERO_RANGES]; int n[UVTG_MAX_ZERO_RANGES]; int count; };

@@ -112,13 +112,13 @@ class _UniVTGFunction(torch.autograd.Function):
         Lt, Dt = src_txt.shape[1], src_txt.shape[2]
         dev = src_vid.device
         training = bool(need_grad)                     # decided by the caller: Function.forward runs under no_grad
-        if training and model.precision != "bf16":
-            raise RuntimeError("backward is implemented for precision='bf16'; the 'fp32x3' mode is inference-only")
+        if training and model.precision == "fp32x3":
+            raise RuntimeError("backward is implemented for the bf16 arithmetic (precision='auto' or 'bf16'); 'fp32x3' is inference-only")
         dims = model._dims(B, Lv, Lt, Dv, Dt, training)
         ptrs = model._param_ptrs(params)
         wcache = model._prepare(dims, ptrs, params)
         lens = None
-        if model.packed and model.precision == "bf16" and not model.return_memory:
+        if model.packed and not dims.precise and not model.return_memory:
             # packed (ragged) encoder stream: the valid lengths come back from the masks (one device->host sync; the reference's
             # own loop synchronises every step too, main/train_vlp_ddp.py:71-73)
             hl = torch.stack([src_vid_mask.sum(1), src_txt_mask.sum(1)]).to(torch.int32).cpu().reshape(-1).tolist()
@@ -169,7 +169,7 @@ class Model(nn.Module):
 
     def __init__(self, hidden_dim, nheads, dim_feedforward, enc_layers, txt_dim, vid_dim, input_dropout, dropout=0.1,
                  droppath=0.1, max_q_l=75, max_v_l=75, span_loss_type="l1", use_txt_pos=False, n_input_proj=2,
-                 precision="bf16", proj_precise="auto", packed=False):
+                 precision="auto", proj_precise="auto", packed=False):
         super().__init__()
         if span_loss_type != "l1":
             raise NotImplementedError("span_loss_type='ce' is not implemented by the reference forward either (univtg.py:137-138)")
@@ -177,8 +177,14 @@ class Model(nn.Module):
             raise NotImplementedError("--use_txt_pos is never set by the reference scripts and is not on the accelerated path")
         if n_input_proj != 2:
             raise NotImplementedError("only n_input_proj=2 (the value of every reference script) is implemented")
-        if precision not in ("bf16", "fp32x3"):
-            raise ValueError("precision must be 'bf16' or 'fp32x3'")
+        # precision: "auto" (default) = the arithmetic follows the call: fp32x3 (split-bf16 operands, fp32-class) for calls under
+        #                 torch.no_grad() -- the inference path of main/inference_mr.py:88-193, where north_star asks for span indices
+        #                 after NMS identical to the fp32 reference -- and bf16 MFMA operands when a backward will follow (training);
+        #            "bf16"   = bf16 operands for every call (fast inference, opt-in: post-NMS top-1 agrees with fp32 for ~98 % of the
+        #                 samples, the ordered top-10 list for ~85 %, tests/test_gpu_parity_full.py);
+        #            "fp32x3" = fp32-class arithmetic, inference only.
+        if precision not in ("auto", "bf16", "fp32x3"):
+            raise ValueError("precision must be 'auto', 'bf16' or 'fp32x3'")
         d = hidden_dim
         self.hidden_dim, self.nheads, self.dim_feedforward, self.enc_layers = d, nheads, dim_feedforward, enc_layers
         self.txt_dim, self.vid_dim = txt_dim, vid_dim
@@ -241,7 +247,8 @@ class Model(nn.Module):
         if training:
             self._step += 1
         return _lib.Dims(B=B, Lv=Lv, Lt=Lt, d=self.hidden_dim, H=self.nheads, F=self.dim_feedforward, E=self.enc_layers,
-                         Dv=Dv, Dt=Dt, n_proj=self.n_input_proj, precise=int(self.precision == "fp32x3"),
+                         Dv=Dv, Dt=Dt, n_proj=self.n_input_proj,
+                         precise=int(self.precision == "fp32x3" or (self.precision == "auto" and not training)),
                          training=int(training), proj_precise=int((not training) if self.proj_precise == "auto" else bool(self.proj_precise)),
                          p_in=self.input_dropout if self.training else 0.0,
                          p_attn=self.dropout if self.training else 0.0,
@@ -447,7 +454,7 @@ def build_model(args):
                   input_dropout=args.input_dropout, dropout=args.dropout, droppath=args.droppath,
                   max_q_l=args.max_q_l, max_v_l=getattr(args, "max_v_l", 75), span_loss_type=args.span_loss_type,
                   use_txt_pos=args.use_txt_pos, n_input_proj=args.n_input_proj,
-                  precision=getattr(args, "precision", "bf16"), proj_precise=getattr(args, "proj_precise", "auto"), packed=getattr(args, "packed", False))
+                  precision=getattr(args, "precision", "auto"), proj_precise=getattr(args, "proj_precise", "auto"), packed=getattr(args, "packed", False))
     if getattr(args, "pre_norm", False):
         raise NotImplementedError("--pre_norm crashes in the reference too (forward_pre is undefined, droppath.py:133)")
     matcher = build_matcher(args)

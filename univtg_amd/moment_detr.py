@@ -82,6 +82,13 @@ class SetCriterion(nn.Module):
             raise RuntimeError("univtg_amd SetCriterion runs on MI355X only (no CPU fallback)")
         if logits.shape[-1] != 2:
             raise ValueError("pred_logits must hold (foreground, background) logits")
+        # device LSAP limits (uvtg_hungarian: 32 targets x 256 queries per sample).  Beyond them the kernel writes n_match = -1 and the
+        # criterion would silently score the sample as all-background (HungarianMatcher.forward raises there): reject on the host,
+        # from sizes the host already holds -- no device sync.
+        sizes = [len(v["spans"]) for v in targets["span_labels"]]
+        if (sizes and max(sizes) > 32) or spans.shape[1] > 256:
+            raise RuntimeError(f"uvtg_hungarian: problem larger than the device LSAP limits (32 targets x 256 queries per sample); "
+                               f"got max targets {max(sizes) if sizes else 0}, queries {spans.shape[1]}")
         match = self.matcher.match_device(outputs, targets)
         none = torch.empty(0, device=logits.device)
         use_sal = top and "saliency" in self.losses and "saliency_pos_labels" in targets

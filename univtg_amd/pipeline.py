@@ -56,11 +56,17 @@ class _Staging:
         return slot
 
     @staticmethod
-    def release(slot):
-        """Call right after enqueueing the H2D copy that reads the slot's buffer (on the current stream)."""
-        if slot[1] is None:
-            slot[1] = torch.cuda.Event()
-        slot[1].record()
+    def release(slot, device=None):
+        """Call right after enqueueing the H2D copy that reads the slot's buffer: the event is recorded on the TARGET device's current
+        stream -- the stream the copy runs on (with cuda:0 current and an upload to cuda:1 the default record() would not cover it)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if slot[1] is None or getattr(slot[1], "_uvtg_dev", None) != dev.index:
+            with torch.cuda.device(dev):
+                slot[1] = torch.cuda.Event()
+            slot[1]._uvtg_dev = dev.index
+        slot[1].record(torch.cuda.current_stream(dev))
 
 
 _staging = _Staging()
@@ -72,7 +78,7 @@ def _upload(key, host_tensor_fn, numel, dtype, device):
     view = slot[0][:numel]
     host_tensor_fn(view)
     dev = view.to(device, non_blocking=True)
-    _staging.release(slot)
+    _staging.release(slot, device)
     return dev
 
 

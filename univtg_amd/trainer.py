@@ -39,9 +39,10 @@ def flatten_parameters(model: Model) -> torch.Tensor:
 
 class TrainStep:
     def __init__(self, model: Model, criterion: SetCriterion, lr=1e-4, weight_decay=1e-4, grad_clip=0.1,
-                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64, overlap_comm=True, packed="auto", loss_only=True):
-        if model.precision != "bf16":
-            raise RuntimeError("training uses precision='bf16'")
+                 betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=64, overlap_comm=True, packed="auto", loss_only=True,
+                 grad_comm_dtype="fp32", comm_cus=None, time_comm=False):
+        if model.precision == "fp32x3":
+            raise RuntimeError("training uses the bf16 arithmetic (precision='auto' or 'bf16'); 'fp32x3' is inference-only")
         self.lib = _lib.load()
         self.model, self.crit = model, criterion
         self.flat = getattr(model, "_flat", None)
@@ -66,6 +67,25 @@ class TrainStep:
         # overlap_comm="force" runs the bucketed side-stream exchange even at world size 1 (single-GPU test of the plumbing)
         self.overlap = bool(overlap_comm) and (self.world > 1 or overlap_comm == "force") and dev.type == "cuda"
         self._events = self._ev_arr = self._comm_stream = None
+        # gradient buckets on the wire ("bf16 or fp32"): "bf16" halves the bytes every xGMI link carries (174 -> 87 MB per rank
+        # and step); every range is rounded to bf16, SUM-reduced in bf16 and widened back (what DDP's bf16_compress_hook does)
+        if grad_comm_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_comm_dtype must be 'fp32' or 'bf16'")
+        self.grad_comm_dtype = grad_comm_dtype
+        self._grads_b = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=dev) if grad_comm_dtype == "bf16" else None
+        # CUs kept out of the persistent GEMM grids while a gradient exchange can be in flight (uvtg_set_reserved_cus): RCCL's kernels
+        # then never wait for a GEMM workgroup to retire.  Default: UVTG_COMM_CUS, else 0 (the communication kernels co-reside with the
+        # GEMM workgroups -- 13 KB of LDS and half the registers of a CU stay free beside a 320-row NT tile)
+        if comm_cus is None:
+            comm_cus = int(os.environ.get("UVTG_COMM_CUS", "0"))
+        self.comm_cus = int(comm_cus) if (self.world > 1 or overlap_comm == "force") else 0
+        if dev.type == "cuda":
+            self.gemm_cus = self.lib.uvtg_set_reserved_cus(self.comm_cus)
+        # time_comm: event pair (end of uvtg_backward on the compute stream, all ranges reduced) -> exposed_comm_ms(): the part of the
+        # exchange that backward did NOT hide
+        self.time_comm = bool(time_comm)
+        self._comm_ev = None
+        self._comm_ms = []
         wd = criterion.weight_dict
         self.go = torch.tensor([wd.get(k, 0.0) for k in LOSS_KEYS], dtype=torch.float32, device=dev)
         self.which = (1 if "spans" in criterion.losses else 0) | (2 if "labels" in criterion.losses else 0) | \
@@ -142,7 +162,18 @@ class TrainStep:
                               _ptr(self.g_vrow), _ptr(pos), _ptr(self.grads), _ptr(self.ws), st,
                               *self._event_args(dims), lens), "uvtg_backward")
         if self.world > 1 or self.overlap:
+            if self.time_comm:
+                if self._comm_ev is None:
+                    self._comm_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+                    self._comm_i = 0
+                if self._comm_i >= len(self._comm_ev):
+                    self.exposed_comm_ms()               # (drains the ring: one sync every 8 steps, only when timing is on)
+                e0, e1 = self._comm_ev[self._comm_i]
+                e0.record()
             self._exchange_gradients(dims)
+            if self.time_comm:
+                e1.record()
+                self._comm_i += 1
         if optimize:
             self.t += 1
             if self.world == 1 and not self.overlap and not os.environ.get("UVTG_PRENORM_OFF"):
@@ -240,18 +271,40 @@ class TrainStep:
             self._comm_stream = torch.cuda.Stream()
         return self._ev_arr, len(self._events)
 
+    def exposed_comm_ms(self):
+        """Per-step exposed communication times (ms) recorded since the last call (time_comm=True): from the end of uvtg_backward on the
+        compute stream to the moment every gradient range is reduced.  Synchronises."""
+        if self._comm_ev is not None:
+            torch.cuda.synchronize()
+            self._comm_ms += [a.elapsed_time(b) for a, b in self._comm_ev[: self._comm_i]]
+            self._comm_i = 0
+        out, self._comm_ms = self._comm_ms, []
+        return out
+
+    def _reduce_range(self, lo, hi):
+        """SUM all-reduce of grads[lo:hi] on the CURRENT stream, in the configured wire dtype."""
+        if hi <= lo:
+            return
+        if self._grads_b is None:
+            allreduce_flat_(self.grads[lo:hi], self.bucket, self.pg)
+            return
+        st = _stream()
+        gb = self._grads_b[lo:hi]
+        _lib.check(self.lib.uvtg_cast_bf16(_ptr(self.grads[lo:hi]), _ptr(gb), hi - lo, st), "uvtg_cast_bf16")
+        allreduce_flat_(gb, 2 * self.bucket, self.pg)        # (same bytes per collective as the fp32 buckets)
+        _lib.check(self.lib.uvtg_cast_f32(_ptr(gb), _ptr(self.grads[lo:hi]), hi - lo, st), "uvtg_cast_f32")
+
     def _exchange_gradients(self, dims):
         if not self.overlap:
-            allreduce_flat_(self.grads, self.bucket, self.pg)
+            self._reduce_range(0, self.grads.numel())
             return
         ranged, rest = self.bucket_ranges(dims)
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self._comm_stream):
             for ev, (lo, hi) in zip(self._events, ranged):
                 self._comm_stream.wait_event(ev)             # that range is final on the compute stream
-                allreduce_flat_(self.grads[lo:hi], self.bucket, self.pg)
+                self._reduce_range(lo, hi)
             self._comm_stream.wait_stream(main)              # end of backward: everything else is final
             for lo, hi in rest:
-                if hi > lo:
-                    allreduce_flat_(self.grads[lo:hi], self.bucket, self.pg)
+                self._reduce_range(lo, hi)
         main.wait_stream(self._comm_stream)                  # the optimizer step needs every reduced range
