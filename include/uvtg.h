@@ -163,6 +163,17 @@ int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int 
 long long uvtg_wgrad_scratch_floats(int M, int N, int K);
 int uvtg_wgrad_bf16_ws(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, float* scratch,
                        long long scratch_floats, uvtg_stream_t stream);
+/* `count` (<= 24) weight gradients over the SAME M reduction rows in ONE launch and without a reduce pass: dW[i][N_i,K_i] = dY[i][M,N_i]^T *
+ * X[i][M,K_i] (ASSIGNED), dbias[i][N_i] += colsum(dY[i]) (host arrays of device pointers; dbias or its entries may be NULL).  Every N_i, K_i
+ * a multiple of 256.  Whole 256 x 256 tiles per workgroup; the tiles that do not fill a last CU round are cut into <= 3 row ranges whose
+ * parts meet through write-through slabs and one ticket per tile (the last part to arrive folds the others).  slabs:
+ * uvtg_wgrad_multi_slab_floats(total tiles) floats, 16-byte aligned; tickets: >= total tiles unsigned, ZEROED by the caller before the call.
+ * -2: shapes / split this path does not take (use uvtg_wgrad_bf16_ws per gradient).  uvtg_backward runs the encoder's 5 E weight gradients
+ * through it when no per-layer readiness events are requested. */
+long long uvtg_wgrad_multi_slab_floats(int total_tiles);
+int uvtg_wgrad_bf16_multi(int count, const void* const* dY, const int* N, const void* const* X, const int* K, float* const* dW,
+                          float* const* dbias, int M, float* slabs, long long slab_floats, unsigned* tickets, int n_tickets,
+                          uvtg_stream_t stream);
 int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t stream);
 /* bf16 -> fp32 (exact).  With uvtg_cast_bf16: the optional bf16 gradient buckets of the data-parallel exchange. */
 int uvtg_cast_f32(const void* src, float* dst, long long n, uvtg_stream_t stream);
@@ -240,7 +251,10 @@ int uvtg_postprocess_mr(const float* pred_logits, const float* pred_spans, const
 /* ---- training-step shell: replaces clip_grad_norm_ + AdamW.step (main/train_vlp_ddp.py:66-68,
  * main/config.py:349-350) over ONE flat fp32 buffer laid out by uvtg_param_offsets.
  * g' = grads * grad_scale (1/world after an all-reduce-sum), clipped to global norm max_norm (<=0: off);
- * torch.optim.AdamW semantics (decoupled decay, bias correction with `step` starting at 1).  scratch: 2 floats. */
+ * torch.optim.AdamW semantics (decoupled decay, bias correction with `step` starting at 1).  scratch: UVTG_ADAMW_SCRATCH_FLOATS floats
+ * (per-block partial sums of the squared norm, folded in a fixed order: the clipping coefficient -- hence the update -- is bit-identical
+ * on every rank that holds the same reduced gradients, like the reference's clip_grad_norm_ on every DDP replica). */
+#define UVTG_ADAMW_SCRATCH_FLOATS 1024
 int uvtg_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float max_norm, float grad_scale, float* scratch, uvtg_stream_t stream);
@@ -282,6 +296,10 @@ int uvtg_debug_force_nt_bm(int bm);
 /* Host arithmetic only (no device needed): the tile height the persistent NT GEMM picks for an M x N launch of `groups` groups on `cus`
  * compute units, gather != 0 for launches with row gather / scatter / conv taps / row tables.  Returns 128, 192, 256 or 320. */
 int uvtg_debug_nt_tile_rows(int M, int N, int groups, int gather, int cus);
+/* Host arithmetic only: the launch plan of the persistent NT GEMM for an M x N x K launch -- out3 = {tile rows of the head (or only)
+ * launch, rows the head covers (0 = a single launch), tile rows of the tail launch}.  A launch whose last CU round would be sparsely
+ * filled is cut into whole rounds of tall tiles + a tail of short ones. */
+int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, int cus, int* out3);
 /* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
  * launches on different streams can run side by side. */
 int uvtg_debug_gemm_cus(int n);

@@ -81,6 +81,55 @@ def test_wgrad_tn256(dev, M, N, K):
     assert relerr(db, dy.double().sum(0)) < 3e-5
 
 
+@pytest.mark.parametrize("M,shapes", [
+    (20158, [(1024, 1024)] * 4 + [(2048, 1024)] + [(1024, 1024)] * 3 + [(2048, 1024)] + [(1024, 1024)] * 7 + [(2048, 1024), (1024, 1024), (1024, 1024)] + [(2048, 1024)]),   # the encoder's 20 gradients: 384 tiles = 256 whole + 128 in halves
+    (8200, [(1024, 1024)] * 5 + [(256, 1280)]),               # 85 tiles, fewer than CUs: every tile in 3 parts
+    (27392, [(1024, 1024)] * 16),                             # 256 tiles: whole tiles only
+    (4100, [(256, 256)] * 4 + [(3072, 1024)] * 2),            # 100 tiles in halves, ragged last 64-row step
+    (27392, [(1024, 1024)] * 18)])                            # 288 tiles = 256 whole + 32 that would need 8 parts: declined
+def test_wgrad_tn256_hybrid_multi(dev, M, shapes):
+    """gemm_tn256h_kernel (several weight gradients over the same rows, whole tiles + split tiles folded by the last arriver, NO reduce
+    pass) vs fp64.  Launched several times on CHANGING operands into NaN-filled outputs with fresh slabs: a stale slab line, a missed
+    ticket or an unwritten output element cannot hide."""
+    from univtg_amd import ops
+    g = torch.Generator().manual_seed(M + len(shapes))
+    for rep in range(3):
+        dys = [bf(torch.randn(M, n, generator=g) * (1 + rep)).to(dev) for n, k in shapes]
+        xs = [bf(torch.randn(M, k, generator=g)).to(dev) for n, k in shapes]
+        try:
+            dws, dbs = ops.wgrad_bf16_multi(dys, xs)
+        except RuntimeError as e:
+            assert "code -2" in str(e), e                       # declined: the launcher documents which splits it takes
+            assert len(shapes) == 18                           # (the one parametrisation whose remainder tiles would need 8 parts)
+            return
+        for i, (n, k) in enumerate(shapes):
+            ref = dys[i].double().t() @ xs[i].double()
+            assert relerr(dws[i], ref) < 3e-5, (rep, i, relerr(dws[i], ref))
+            assert relerr(dbs[i], dys[i].double().sum(0)) < 3e-5, (rep, i)
+
+
+def test_wgrad_tn256_hybrid_under_uneven_load(dev):
+    """The slab / ticket hand-off of the hybrid weight-gradient launch while another stream keeps part of the chip busy (uneven arrival of
+    the parts of a tile; cdna_hip_programming.md Guideline 16: hand-offs must be tested under uneven load, not on an idle chip)."""
+    from univtg_amd import ops
+    M = 20158
+    shapes = [(1024, 1024)] * 24
+    g = torch.Generator().manual_seed(7)
+    dys = [bf(torch.randn(M, n, generator=g)).to(dev) for n, k in shapes[:2]] * 12
+    xs = [bf(torch.randn(M, k, generator=g)).to(dev) for n, k in shapes[:2]] * 12
+    refs = [dys[i].double().t() @ xs[i].double() for i in range(2)]
+    side = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device=dev)
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep):
+                junk.mul_(1.0001)                                # HBM-bound traffic from another queue
+        dws, dbs = ops.wgrad_bf16_multi(dys, xs)
+        torch.cuda.synchronize()
+        for i in range(24):
+            assert relerr(dws[i], refs[i % 2]) < 3e-5, (rep, i)
+
+
 @pytest.mark.parametrize("rows,D", [(64, 1024), (37, 2818), (50, 512), (9, 514), (33, 64), (5, 2817)])
 def test_layernorm(dev, rows, D):
     from univtg_amd import ops

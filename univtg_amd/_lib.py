@@ -48,6 +48,8 @@ SIGNATURES = {
     "uvtg_wgrad_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uvtg_wgrad_scratch_floats": (_LL, [_I, _I, _I]),
     "uvtg_wgrad_bf16_ws": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _LL, _P]),
+    "uvtg_wgrad_multi_slab_floats": (_LL, [_I]),
+    "uvtg_wgrad_bf16_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _P, _LL, _P, _I, _P]),
     "uvtg_cast_bf16": (_I, [_P, _P, _LL, _P]),
     "uvtg_layernorm_fwd": (_I, [_P] * 6 + [_I, _I, _P]),
     "uvtg_layernorm_bwd": (_I, [_P] * 8 + [_I, _I, _P]),
@@ -64,6 +66,7 @@ SIGNATURES = {
     "uvtg_set_reserved_cus": (_I, [_I]),
     "uvtg_cast_f32": (_I, [_P, _P, _LL, _P]),
     "uvtg_debug_nt_tile_rows": (_I, [_I, _I, _I, _I, _I]),
+    "uvtg_debug_nt_plan": (_I, [_I, _I, _I, _I, _I, _I, _P]),
     "uvtg_profile_start": (_I, []),
     "uvtg_profile_stop": (_I, [_P, _P, _P]),
     "uvtg_profile_event_floor_ms": (C.c_double, []),

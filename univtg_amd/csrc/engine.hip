@@ -137,7 +137,11 @@ struct WSpace {
   // backward scratch
   float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2], *tn_scratch; long long tn_scratch_floats;
   float* gnorm2;       // sum of squares of the step's gradients, accumulated by uvtg_backward (uvtg_backward_gradnorm2)
-  bf16_t *dh2_pad, *dh1_pad, *dyB, *dyR, *dvmB, *gxb[2], *da, *dOb, *dqkv, *dyP[2], *dh1b[2];
+  bf16_t *dh2_pad, *dh1_pad, *dyR, *dvmB, *gxb[2], *dOb, *dyP[2], *dh1b[2];
+  // per-layer operands of the encoder's weight gradients (LayerNorm-2 / LayerNorm-1 input gradients, activation gradient, dqkv): kept
+  // until the end of the encoder backward so that the weight gradients of ALL layers can run as one launch without a reduce pass
+  bf16_t *dy2L[MAXE], *dy1L[MAXE], *daL[MAXE], *dqkvL[MAXE];
+  float* tnh_slabs; long long tnh_slab_floats; unsigned* tnh_tickets; int tnh_n_tickets;
   size_t bytes;
   WSpace(const Dm& m, void* base, float* x0) {
     Arena a(base);
@@ -206,7 +210,14 @@ struct WSpace {
       dvmB = a.take<bf16_t>((size_t)(m.Rp + 1) * d); gxb[0] = a.take<bf16_t>(M * d); gxb[1] = a.take<bf16_t>(M * d);     // (frame-row space on the loss-only stream)
       dyR = a.take<bf16_t>(M * d); delta = a.take<float>(B * m.c.H * m.S);
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
-      gnorm2 = a.take<float>(UVTG_SQSUM_FLOATS);
+      {   // clipping-norm slots, directly followed by the tickets of the hybrid weight-gradient launch: ONE memset zeroes both
+        const int dt = (int)((d + 255) / 256), ft = (int)((F + 255) / 256);
+        tnh_n_tickets = (int)E * (2 * dt * ft + 4 * dt * dt);
+        gnorm2 = a.take<float>(UVTG_SQSUM_FLOATS + (size_t)tnh_n_tickets);
+        tnh_tickets = (unsigned*)(gnorm2 + UVTG_SQSUM_FLOATS);
+        tnh_slab_floats = gemm_tn_multi_slab_floats(tnh_n_tickets, 320);
+        tnh_slabs = a.take<float>((size_t)tnh_slab_floats);
+      }
       {  // split-partial slabs of the 256-tile weight-gradient kernel: the largest requirement over the shapes backward launches
         long long need = 0;
         const int shapes[][3] = {{m.M, (int)d, (int)F}, {m.M, (int)F, (int)d}, {m.M, (int)d, (int)d}, {m.M, 2 * (int)d, (int)d}, {m.Rp, (int)d, (int)d}, {m.Rp, (int)d, 3 * (int)d},
@@ -216,14 +227,16 @@ struct WSpace {
         tn_scratch_floats = need; tn_scratch = a.take<float>((size_t)need);
       }
       dh2_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d); dh1_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d);
-      dyB = a.take<bf16_t>(M * d); da = a.take<bf16_t>(M * F); dOb = a.take<bf16_t>(M * d); dqkv = a.take<bf16_t>(M * 3 * d);
+      dOb = a.take<bf16_t>(M * d);
+      for (size_t l = 0; l < E; l++) { dy2L[l] = a.take<bf16_t>(M * d); dy1L[l] = a.take<bf16_t>(M * d); daL[l] = a.take<bf16_t>(M * F); dqkvL[l] = a.take<bf16_t>(M * 3 * d); }
       for (int i = 0; i < 2; i++) {
         const size_t R = i == 0 ? m.Mv : m.Mt, Kp = i == 0 ? m.Kpv : m.Kpt;
         dyP[i] = a.take<bf16_t>(R * d); dh1b[i] = a.take<bf16_t>(R * d);
         dA2[i] = a.take<float>(R * d); dA1[i] = a.take<float>(R * Kp);
       }
     } else {
-      dvm = gx[0] = gx[1] = dyF = delta = nullptr; dyR = dvmB = gxb[0] = gxb[1] = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dyB = da = dOb = dqkv = nullptr;
+      dvm = gx[0] = gx[1] = dyF = delta = nullptr; dyR = dvmB = gxb[0] = gxb[1] = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dOb = nullptr; gnorm2 = nullptr; tnh_slabs = nullptr; tnh_slab_floats = 0; tnh_tickets = nullptr; tnh_n_tickets = 0;
+      for (int l = 0; l < MAXE; l++) dy2L[l] = dy1L[l] = daL[l] = dqkvL[l] = nullptr;
       for (int i = 0; i < 2; i++) { dyP[i] = dh1b[i] = nullptr; dA2[i] = dA1[i] = nullptr; }
     }
     bytes = a.off + 256;
@@ -743,7 +756,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     TRY(launch_zero_ranges(grads, zr, s));
     zr_keep = zr;
   }
-  if (hipError_t e = hipMemsetAsync(ws.gnorm2, 0, UVTG_SQSUM_FLOATS * sizeof(float), s)) return (int)e;
+  if (hipError_t e = hipMemsetAsync(ws.gnorm2, 0, (UVTG_SQSUM_FLOATS + (size_t)ws.tnh_n_tickets) * sizeof(float), s)) return (int)e;   // (+ the hybrid launch's tickets)
   const int splits_M = 8, splits_v = 8;
   auto wgrad = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, int cs,
                    float* dbias, int q_off, int Mq, int splits) {
@@ -765,6 +778,31 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   auto tn_batch = [&](const GemmTNBatch& b) -> int {
     if (gemm_tn_batch_ok(b)) return launch_gemm_tn_batch(b, s);
     for (int i = 0; i < b.count; i++) TRY(launch_gemm_tn_bf16(b.g[i], s));      // small / odd shapes: one launch each
+    return 0;
+  };
+  // Encoder weight gradients.  Without per-layer readiness events (single rank: nobody waits for a layer's gradients) they are DEFERRED: every
+  // layer's operands stay in their own buffers and all 5 E gradients go out as ONE launch behind the encoder loop -- 384 tiles over the same
+  // rows at config 2, whole tiles per workgroup + half tiles for the remainder, no partial-slab reduce pass (gemm.hip, gemm_tn256h_kernel).
+  // With events (data-parallel overlap) each layer's two batches run in place, as before, and their gradients are final at the event.
+  static const bool defer_off = getenv("UVTG_TN_DEFER_OFF") != nullptr;
+  const bool defer = n_events == 0 && !defer_off;
+  GemmTNBatch deferred[2 * MAXE]; int n_deferred = 0;
+  auto tn_encoder = [&](const GemmTNBatch& b) -> int {
+    if (!defer) return tn_batch(b);
+    deferred[n_deferred++] = b;
+    return 0;
+  };
+  auto tn_flush = [&]() -> int {
+    if (!n_deferred) return 0;
+    GemmTNMulti mu; mu.count = 0; mu.slabs = ws.tnh_slabs; mu.slab_floats = ws.tnh_slab_floats; mu.tickets = ws.tnh_tickets; mu.n_tickets = ws.tnh_n_tickets;
+    bool fits = true;
+    for (int i = 0; i < n_deferred && fits; i++)
+      for (int j = 0; j < deferred[i].count; j++) {
+        if (mu.count >= UVTG_TNH_MAX_GROUPS) { fits = false; break; }
+        mu.g[mu.count++] = deferred[i].g[j];
+      }
+    if (fits && gemm_tn_multi_ok(mu)) return launch_gemm_tn_multi(mu, s);
+    for (int i = 0; i < n_deferred; i++) TRY(tn_batch(deferred[i]));            // shapes the hybrid launch does not take: the split + reduce path
     return 0;
   };
   // weight gradient of one Conv1d(k=3): dW[n][c][tap] = sum_rows dY[row][n] * X[row + tap - 1][c] over the zero-framed rows.
@@ -840,58 +878,60 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     const bool last = l == E - 1;
     const float* dp_attn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l) * B : nullptr;
     const float* dp_ffn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l + 1) * B : nullptr;
-    const bf16_t* dyRes = dp_ffn ? ws.dyR : ws.dyB;
+    bf16_t* const dy2 = ws.dy2L[l]; bf16_t* const dy1 = ws.dy1L[l]; bf16_t* const da = ws.daL[l]; bf16_t* const dqkv = ws.dqkvL[l];
+    const bf16_t* dyRes = dp_ffn ? ws.dyR : dy2;
     LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
     lb.gB = gin; lb.ldgB = d;
     if (last && packed) { lb.g2B = ws.g2p; lb.ldg2B = d; }
     else if (last) { lb.g2B = ws.dvmB; lb.ldg2B = d; lb.g2_S = S; lb.g2_Lv = Lv; }
     lb.xB = ws.y2b[l]; lb.ldxB = d; lb.mean = ws.mean2[l]; lb.rstd = ws.rstd2[l]; lb.gamma = P[m.lay(l, N2W)];
     lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
-    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S; lb.row_sample = row_sample;
+    lb.dxB = dy2; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S; lb.row_sample = row_sample;
     if (dp_ffn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
-    GemmArgs g = gemm_base(ws.dyB, d, w.w2T[l], d, M, F, d);          // d h = dy2 W2 ; da = dh * gelu'(a)
-    g.gradPre = ws.apre[l]; g.ldgp = F; g.actgrad = 2; g.outB = ws.da; g.ldoB = F;
+    GemmArgs g = gemm_base(dy2, d, w.w2T[l], d, M, F, d);             // d h = dy2 W2 ; da = dh * gelu'(a)
+    g.gradPre = ws.apre[l]; g.ldgp = F; g.actgrad = 2; g.outB = da; g.ldoB = F;
     TRY(launch_gemm_nt_bf16(g, s));
     {   // FFN weight gradients, one launch: dW2 = dy2^T h, dW1 = da^T x1
       GemmTNBatch tb; tb.count = 2;
-      tb.g[0] = tn_group(ws.dyB, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, G(m.lay(l, L2B)));
-      tb.g[1] = tn_group(ws.da, F, (const bf16_t*)ws.x1b[l], d, M, F, d, G(m.lay(l, L1W)), d, G(m.lay(l, L1B)));
-      TRY(tn_batch(tb));
+      tb.g[0] = tn_group(dy2, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, G(m.lay(l, L2B)));
+      tb.g[1] = tn_group(da, F, (const bf16_t*)ws.x1b[l], d, M, F, d, G(m.lay(l, L1W)), d, G(m.lay(l, L1B)));
+      TRY(tn_encoder(tb));
     }
-    g = gemm_base(ws.da, F, w.w1T[l], F, M, d, F);                     // dx1 = da W1 + dy2
+    g = gemm_base(da, F, w.w1T[l], F, M, d, F);                        // dx1 = da W1 + dy2
     g.residB = dyRes; g.ldrB = d; g.outB = ws.gxb[0]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
     memset(&lb, 0, sizeof(lb));
     lb.gB = ws.gxb[0]; lb.ldgB = d; lb.xB = ws.y1b[l]; lb.ldxB = d; lb.mean = ws.mean1[l]; lb.rstd = ws.rstd1[l];
     lb.gamma = P[m.lay(l, N1W)]; lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
-    lb.dxB = ws.dyB; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S; lb.row_sample = row_sample;
+    lb.dxB = dy1; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S; lb.row_sample = row_sample;
     if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
-    g = gemm_base(ws.dyB, d, w.woT[l], d, M, d, d);                    // dO = dy1 Wo
+    g = gemm_base(dy1, d, w.woT[l], d, M, d, d);                       // dO = dy1 Wo
     g.outB = ws.dOb; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
     if (packed) { at.seq_start = ws.pk.seq_start; at.seq_count = ws.pk.seq_count; at.row_sample = ws.pk.row_sample; at.total_rows = M; }
     at.B = B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = m.c.p_attn; at.seed = m.c.seed; at.layer = l;
-    at.dO = ws.dOb; at.lddo = d; at.delta = ws.delta; at.dqkv = ws.dqkv; at.lddqkv = 3 * d; at.qscale = 1.0f / sqrtf((float)m.hd);
+    at.dO = ws.dOb; at.lddo = d; at.delta = ws.delta; at.dqkv = dqkv; at.lddqkv = 3 * d; at.qscale = 1.0f / sqrtf((float)m.hd);
     TRY(launch_attn_bwd(at, s));
     {   // attention-block weight gradients, one launch: dWo = dy1^T o, dWq|dWk = dqk^T (x + pos), dWv = dv^T x
       GemmTNBatch tb; tb.count = 3;
-      tb.g[0] = tn_group(ws.dyB, d, (const bf16_t*)ws.o[l], d, M, d, d, G(m.lay(l, OPW)), d, G(m.lay(l, OPB)));
-      tb.g[1] = tn_group(ws.dqkv, 3 * d, ub_in, d, M, 2 * d, d, G(m.lay(l, IPW)), d, G(m.lay(l, IPB)));
-      tb.g[2] = tn_group(ws.dqkv + 2 * d, 3 * d, xb_in, d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, G(m.lay(l, IPB)) + 2 * d);
-      TRY(tn_batch(tb));
+      tb.g[0] = tn_group(dy1, d, (const bf16_t*)ws.o[l], d, M, d, d, G(m.lay(l, OPW)), d, G(m.lay(l, OPB)));
+      tb.g[1] = tn_group(dqkv, 3 * d, ub_in, d, M, 2 * d, d, G(m.lay(l, IPW)), d, G(m.lay(l, IPB)));
+      tb.g[2] = tn_group(dqkv + 2 * d, 3 * d, xb_in, d, M, d, d, G(m.lay(l, IPW)) + (size_t)2 * d * d, d, G(m.lay(l, IPB)) + 2 * d);
+      TRY(tn_encoder(tb));
     }
-    g = gemm_base(ws.dqkv, 3 * d, w.wqkvT[l], 3 * d, M, d, 3 * d);     // dx = dqkv Wqkv + dy1
-    g.residB = dp_attn ? ws.dyR : ws.dyB; g.ldrB = d; g.outB = ws.gxb[1]; g.ldoB = d;
+    g = gemm_base(dqkv, 3 * d, w.wqkvT[l], 3 * d, M, d, 3 * d);        // dx = dqkv Wqkv + dy1
+    g.residB = dp_attn ? ws.dyR : dy1; g.ldrB = d; g.outB = ws.gxb[1]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
     if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
   }
+  TRY(tn_flush());                               // the deferred weight gradients of all encoder layers, inside the encoder section
   uvtg_prof_section(1, 1, s);
   const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]
   // ---------------- saliency branch ----------------
@@ -1034,6 +1074,21 @@ extern "C" int uvtg_wgrad_bf16_ws(const void* dY, const void* X, float* dW, floa
   t.P = (const bf16_t*)dY; t.ldp = N; t.Q = (const bf16_t*)X; t.ldq = K; t.M = M; t.N = N; t.K = K; t.Mq = M;
   t.out = dW; t.ldo = K; t.col_stride = 1; t.dbias = dbias; t.splits = 8; t.scratch = scratch; t.scratch_floats = scratch_floats;
   return launch_gemm_tn_bf16(t, (hipStream_t)st);
+}
+extern "C" long long uvtg_wgrad_multi_slab_floats(int total_tiles) { return gemm_tn_multi_slab_floats(total_tiles, 320); }
+extern "C" int uvtg_wgrad_bf16_multi(int count, const void* const* dY, const int* N, const void* const* X, const int* K, float* const* dW,
+                                     float* const* dbias, int M, float* slabs, long long slab_floats, unsigned* tickets, int n_tickets,
+                                     uvtg_stream_t st) {
+  if (!dY || !N || !X || !K || !dW || !slabs || !tickets) return -20;
+  if (count < 1 || count > UVTG_TNH_MAX_GROUPS) return -11;
+  GemmTNMulti mu; mu.count = count; mu.slabs = slabs; mu.slab_floats = slab_floats; mu.tickets = tickets; mu.n_tickets = n_tickets;
+  for (int i = 0; i < count; i++) {
+    GemmTNArgs& t = mu.g[i]; memset(&t, 0, sizeof(t));
+    t.P = (const bf16_t*)dY[i]; t.ldp = N[i]; t.Q = (const bf16_t*)X[i]; t.ldq = K[i]; t.M = M; t.N = N[i]; t.K = K[i]; t.Mq = M;
+    t.out = dW[i]; t.ldo = K[i]; t.col_stride = 1; t.dbias = dbias ? dbias[i] : nullptr; t.splits = 8; t.assign = 1;
+  }
+  if (!gemm_tn_multi_ok(mu)) return -2;
+  return launch_gemm_tn_multi(mu, (hipStream_t)st);
 }
 extern "C" int uvtg_cast_bf16(const float* src, void* dst, long long n, uvtg_stream_t st) {
   if (!src || !dst) return -20;

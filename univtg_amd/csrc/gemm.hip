@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   __shared__ int s_tab[GATHER ? 3 : 1][RT]; // GATHER: the tile rows' entries of the output-row tables (o_rows, f_rows, pos_map)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
-  const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M - p.m_begin + BM - 1) / BM;
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
   const int nk = p.K / KB;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
     int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     gz = l / per_group; l -= gz * per_group;
-    m0 = (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
+    m0 = p.m_begin + (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
   };
   unsigned aofs[PA], bofs[PB];   // byte offsets of this lane's staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
   const char* Abase = (const char*)p.A;      // A operand of the tile being loaded (A2 for the column tiles from a2_n0 on)
@@ -1106,6 +1106,280 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn256h ("hybrid"): SEVERAL weight gradients over the same reduction rows in ONE launch with NO reduce pass.
+// The split-M kernel above pays for parallelism with partial slabs: a 1024 x 1024 gradient is 16 tiles, so its M rows are cut 8-16 ways to
+// fill 256 CUs, every unit writes a 256 KB fp32 slab and gemm_tn_reduce_kernel folds them (0.25 ms of the 7.5 ms training step, plus the
+// slab writes inside the units).  With the weight gradients of ALL encoder layers deferred to the end of the encoder backward there are
+// 384 tiles over the same rows: each workgroup takes WHOLE tiles (tile ids [0, full_tiles): results go straight to the gradient buffer)
+// and the `total_tiles - full_tiles` remaining tiles are cut into `nsplit` row ranges (2 at config 2) so that the last round fills the
+// chip too.  The parts of a split tile meet without a second kernel: every part stores its fp32 slab write-through (sc1), takes a ticket
+// (one device-scope atomic per part), and the part that draws the last ticket re-reads the other slabs behind ONE agent-scope acquire, adds
+// its own registers and writes the gradient (cdna_hip_programming.md Guideline 16, "splitk-seam": publish write-through, combine by the last
+// arriver; nothing spins, so no residency assumption).  A workgroup runs its split part FIRST: the parts of a tile then finish together.
+// Restrictions (the launcher falls back to the slab + reduce path otherwise): N, K multiples of 256, contiguous outputs, no conv taps.
+// ------------------------------------------------------------------------------------------------
+constexpr int TNH_SLAB = 65536 + 256;            // floats per part: the 256 x 256 partial tile + 256 bias-gradient partials
+struct TNHGroup { const bf16_t* P; const bf16_t* Q; float* out; float* dbias; int ldp, ldq, ldo, tiles_k, tile_base; unsigned bytes_p, bytes_q; };
+struct TNHPlan {
+  TNHGroup g[UVTG_TNH_MAX_GROUPS];
+  int count, M, steps_total, total_tiles, full_tiles, nsplit, steps_per;
+  float* slabs; unsigned* tickets; float* sqsum;
+};
+__global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
+  __shared__ unsigned s_ticket;
+  __shared__ float s_sq[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31, i16 = lane & 15, qd = (lane >> 4) & 1;
+  int l;
+  {
+    const int units = gridDim.x, q = units / 8, r = units % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)smem256;
+  const int mr = i16 >> 2;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int n = wm * 128 + i * 32 + 16 * qd + 4 * (i16 & 3);
+    aoff[i] = (8 * g + mr) * 512 + ((((n >> 3) ^ (mr << 2))) << 4) + (n & 7) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int k = wn * 64 + j * 32 + 16 * qd + 4 * (i16 & 3);
+    boff[j] = 32768 + (8 * g + mr) * 512 + ((((k >> 3) ^ (mr << 2))) << 4) + (k & 7) * 2;
+  }
+  const int n_split_tiles = plan.total_tiles - plan.full_tiles;
+  float sq_total = 0.f;
+  // unit list of this workgroup: its part of a split tile first, then whole tiles l, l + grid, ...
+  int tile_g = (l < n_split_tiles * plan.nsplit) ? plan.full_tiles + l / plan.nsplit : l;
+  int part = (l < n_split_tiles * plan.nsplit) ? l % plan.nsplit : -1;
+  if (part < 0 && tile_g >= plan.full_tiles) return;
+  while (true) {
+    int gi = 0;
+    while (gi + 1 < plan.count && tile_g >= plan.g[gi + 1].tile_base) gi++;
+    const TNHGroup p = plan.g[gi];
+    const int tile = tile_g - p.tile_base;
+    const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
+    const int n0 = tile_n * 256, k0 = tile_k * 256;
+    const int st0 = part < 0 ? 0 : part * plan.steps_per;
+    const int st1 = part < 0 ? plan.steps_total : min(plan.steps_total, st0 + plan.steps_per);
+    const i32x4 rp = tn_rsrc(p.P, p.bytes_p), rq = tn_rsrc(p.Q, p.bytes_q);
+    unsigned vp[4], vq[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int rr = (wave * 4 + i) * 2 + g;
+      const int cs = (l31 ^ ((rr & 3) << 2)) * 8;
+      vp[i] = (unsigned)(((st0 * 64 + rr) * p.ldp + n0 + cs) * 2);
+      vq[i] = (unsigned)(((st0 * 64 + rr) * p.ldq + k0 + cs) * 2);
+    }
+    const unsigned dp = (unsigned)(64 * p.ldp * 2), dq = (unsigned)(64 * p.ldq * 2);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.dbias && tile_k == 0 && wn == 0;
+    __syncthreads();                          // the previous unit's epilogue is done with the staging LDS
+    if (st0 < st1) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        tn_dma16(rp, vp[i], lds0 + (unsigned)(wave * 4096 + i * 1024));
+        tn_dma16(rq, vq[i], lds0 + (unsigned)(wave * 4096 + 32768 + i * 1024));
+        vp[i] += dp; vq[i] += dq;
+      }
+    }
+    auto main_loop = [&](auto with_bias) {
+      constexpr bool BIAS = decltype(with_bias)::value;
+      for (int st = st0; st < st1; st++) {
+        const int cur = (st - st0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned char* base = smem256 + cur * 65536;
+        const unsigned sb = lds0 + (unsigned)((cur ^ 1) * 65536 + wave * 4096);
+        s16x4 ta[2][4][2], tb[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ta[0][i][0] = lds_tr16((const bf16_t*)(base + aoff[i])); ta[0][i][1] = lds_tr16((const bf16_t*)(base + aoff[i] + 2048)); }
+#pragma unroll
+        for (int j = 0; j < 2; j++) { tb[0][j][0] = lds_tr16((const bf16_t*)(base + boff[j])); tb[0][j][1] = lds_tr16((const bf16_t*)(base + boff[j] + 2048)); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+          if (ks < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              ta[(ks + 1) & 1][i][0] = lds_tr16((const bf16_t*)(base + aoff[i] + (ks + 1) * 8192));
+              ta[(ks + 1) & 1][i][1] = lds_tr16((const bf16_t*)(base + aoff[i] + (ks + 1) * 8192 + 2048));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              tb[(ks + 1) & 1][j][0] = lds_tr16((const bf16_t*)(base + boff[j] + (ks + 1) * 8192));
+              tb[(ks + 1) & 1][j][1] = lds_tr16((const bf16_t*)(base + boff[j] + (ks + 1) * 8192 + 2048));
+            }
+          }
+          if (ks < 2) {
+#pragma unroll
+            for (int i = 2 * ks; i < 2 * ks + 2; i++) {
+              tn_dma16(rp, vp[i], sb + i * 1024);
+              tn_dma16(rq, vq[i], sb + 32768 + i * 1024);
+              vp[i] += dp; vq[i] += dq;
+            }
+          }
+          s16x8 a[4], b[2];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const s16x4 a0 = ta[ks & 1][i][0], a1 = ta[ks & 1][i][1];
+            a[i] = (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const s16x4 b0 = tb[ks & 1][j][0], b1 = tb[ks & 1][j][1];
+            b[j] = (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+            if constexpr (BIAS) {
+              const u32x2 h0 = __builtin_bit_cast(u32x2, ta[ks & 1][i][0]), h1 = __builtin_bit_cast(u32x2, ta[ks & 1][i][1]);
+              asm("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5"
+                  : "+v"(bsum[i]) : "s"(0x3f803f80u), "v"(h0[0]), "v"(h0[1]), "v"(h1[0]), "v"(h1[1]));
+            }
+          }
+        }
+        {
+          __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+          for (int ks = 0; ks < 3; ks++) {
+#pragma unroll
+            for (int n = 0; n < 3; n++) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+      }
+    };
+    if (do_bias) main_loop(std::true_type{}); else main_loop(std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces issued past the last step must not land in the epilogue's LDS slabs
+    __syncthreads();
+    // ---- epilogue ----  (buffer accesses: ONE per-lane byte offset + wave-uniform row offsets in SGPRs; with 64-bit row addresses
+    // the unrolled store sequence kept ~60 address registers alive through the K loop and spilled)
+    float* wbuf = (float*)smem256 + wave * 2048;             // [32][64] fp32, wave-private
+    const int c8 = (lane & 7) * 8;
+    const int tcol = wn * 64 + c8;
+    const unsigned vo_slab = (unsigned)(((lane >> 3) * 256 + tcol) * 4);
+    bool last = true;                                        // whole tile: this unit holds the final sums
+    if (part >= 0) {
+      // split part: publish the partial tile write-through, take a ticket; the last part of the tile to arrive folds the others into its own values
+      const int slab_id = (tile_g - plan.full_tiles) * plan.nsplit + part;
+      float* slab = plan.slabs + (size_t)slab_id * TNH_SLAB;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, TNH_SLAB * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            wbuf[((r & 3) + 8 * (r >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int row = q * 8 + (lane >> 3);
+          const u32x4 v0 = *(const u32x4*)(wbuf + row * 64 + c8), v1 = *(const u32x4*)(wbuf + row * 64 + c8 + 4);
+          const int so = (wm * 128 + i * 32 + q * 8) * 1024;              // bytes: tile rows are 256 floats
+          __builtin_amdgcn_raw_buffer_store_b128(v0, rs, vo_slab, so, 16);         // aux 16 = sc1: write-through
+          __builtin_amdgcn_raw_buffer_store_b128(v1, rs, vo_slab + 16, so, 16);
+        }
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+          if (g == 0) __hip_atomic_store(slab + 65536 + wm * 128 + i * 32 + l31, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
+      __syncthreads();                                        // ... before ONE lane takes the ticket
+      if (tid == 0) s_ticket = __hip_atomic_fetch_add(plan.tickets + (tile_g - plan.full_tiles), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      last = s_ticket == (unsigned)(plan.nsplit - 1);
+      if (last) {
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines of the other parts' slabs
+        __syncthreads();
+      }
+    }
+    if (last) {
+      float* out = p.out + (size_t)n0 * p.ldo + k0;
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7ffffff0, 0x00020000);
+      const unsigned vo_out = (unsigned)(((lane >> 3) * p.ldo + tcol) * 4);
+      const int row_bytes = p.ldo * 4;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            wbuf[((r & 3) + 8 * (r >> 2) + 4 * g) * 64 + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int row = q * 8 + (lane >> 3);
+          f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
+          const int trow0 = wm * 128 + i * 32 + q * 8;                     // wave-uniform
+          if (part >= 0) {
+            for (int o = 0; o < plan.nsplit; o++) {
+              if (o == part) continue;
+              const float* os = plan.slabs + (size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB;
+              const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)os, 0, TNH_SLAB * 4, 0x00020000);
+              const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab, trow0 * 1024, 0);
+              const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab + 16, trow0 * 1024, 0);
+              v0 += __builtin_bit_cast(f32x4, t0); v1 += __builtin_bit_cast(f32x4, t1);
+            }
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), ro, vo_out, trow0 * row_bytes, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), ro, vo_out + 16, trow0 * row_bytes, 0);
+          sq += (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]) + (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+        }
+      }
+      sq_total += sq;
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+          const int nn = wm * 128 + i * 32 + l31;
+          if (g == 0) {
+            if (part >= 0)
+              for (int o = 0; o < plan.nsplit; o++)
+                if (o != part) t += plan.slabs[(size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB + 65536 + nn];
+            p.dbias[n0 + nn] += t;                              // (one tile column block per bias entry: single writer)
+          }
+        }
+      }
+    }
+    // next unit
+    if (part >= 0) { part = -1; tile_g = l; }
+    else tile_g += gridDim.x;
+    if (tile_g >= plan.full_tiles) break;
+  }
+  if (plan.sqsum) {
+    sq_total = wave_sum(sq_total);
+    if (lane == 0) s_sq[wave] = sq_total;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; i++) t += s_sq[i];
+      if (t != 0.f) atomicAdd(plan.sqsum + 32 + (blockIdx.x & 63) * 32, t);
+    }
+  }
+}
+
 }  // namespace
 
 void uvtg_prof_begin_launch(int family, double flops, hipStream_t s);
@@ -1206,6 +1480,50 @@ extern "C" int uvtg_debug_nt_tile_rows(int M, int N, int groups, int gather, int
   if (M <= 0 || N <= 0 || groups <= 0 || cus <= 0) return -20;
   return 64 * nt256_pick_tm(M, N, groups, gather != 0, cus, 0);
 }
+// Launch plan of one persistent NT GEMM: either ONE launch at the height nt256_pick_tm chooses, or -- when that leaves a sparsely filled
+// last round -- a HEAD launch of whole CU rounds of tall tiles over rows [0, rows1) followed by a TAIL launch of short tiles over
+// [rows1, M).  A round costs the same whether 12 or 200 of its tiles exist (every tile runs its full K loop), so a 27392-row launch at
+// N = 1024 (all-ones masks: 344 tiles of 320 rows = 1.34 rounds, paid as 1.84) runs as 256 tiles of 320 rows + 216 tiles of 128 rows, and a
+// ragged batch whose packed row count lands just above 320 x 64 = 20480 pays a 128-row tail instead of a second 320-row round.
+// Same cost model as nt256_pick_tm (units: rows of a tile x per-height factor per round); the tail launch is charged its launch gap.
+struct NtPlan { int tm1, rows1, tm2; };      // rows1 == 0: single launch at tm1
+static double nt256_cost(int M, int N, int groups, int tm, int cus) {
+  static const double f[6] = {0, 0, UVTG_NT_F2, UVTG_NT_F3, UVTG_NT_F4, UVTG_NT_F5};
+  const long long tiles = (long long)cdiv(M, 64 * tm) * cdiv(N, 256) * groups;
+  const long long full = tiles / cus, rem = tiles % cus;
+  const double fill = (double)rem / cus;
+  const double rounds = (double)full + (rem ? 0.84 + 0.16 * (fill > 0.7 ? (fill - 0.7) / 0.3 : 0.0) : 0.0);
+  return rounds * (64.0 * tm) * f[tm];
+}
+static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, int force) {
+  static const bool split_off = getenv("UVTG_NT_SPLIT_OFF") != nullptr;      // experiment: single launches only
+  NtPlan pl{nt256_pick_tm(M, N, groups, gather, cus, force), 0, 0};
+  if (!pl.tm1 || split_off || force || cus < 1) return pl;
+  double best = nt256_cost(M, N, groups, pl.tm1, cus);
+  const double gap = 24.0 * 1024.0 / (K > 64 ? K : 64);          // ~3 us launch gap in units of one 320-row round at K = 1024 (~326 units ~ 40 us)
+  const int tn_g = cdiv(N, 256) * groups;
+  for (int tm1 = gather ? 4 : 5; tm1 >= 3; tm1--) {
+    const long long rt_total = cdiv(M, 64 * tm1);
+    const long long full_rounds = rt_total * tn_g / cus;
+    if (full_rounds < 1) continue;
+    const int rt1 = (int)(full_rounds * cus / tn_g);                // row tiles of the head: the most that fit into whole rounds
+    const long long rows1 = (long long)rt1 * 64 * tm1;
+    if (rt1 < 1 || rows1 >= M) continue;
+    const double head = nt256_cost((int)rows1, N, groups, tm1, cus);
+    for (int tm2 = 2; tm2 <= 4; tm2++) {
+      const double c = head + nt256_cost(M - (int)rows1, N, groups, tm2, cus) + gap;
+      if (c < best * 0.97) { best = c; pl = NtPlan{tm1, (int)rows1, tm2}; }      // (3 % margin: do not split for noise)
+    }
+  }
+  return pl;
+}
+// host arithmetic only (tests): out3 = {tile rows of the head (or only) launch, rows covered by the head (0 = single launch), tile rows of the tail}
+extern "C" int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, int cus, int* out3) {
+  if (M <= 0 || N <= 0 || K <= 0 || groups <= 0 || cus <= 0 || !out3) return -20;
+  const NtPlan pl = nt256_plan(M, N, K, groups, gather != 0, cus, 0);
+  out3[0] = 64 * pl.tm1; out3[1] = pl.rows1; out3[2] = 64 * pl.tm2;
+  return 0;
+}
 template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, bool eop, int epi, hipStream_t s) {
   constexpr int smem = TM == 5 ? 147456 : 131072;
   static bool attr = false;
@@ -1280,27 +1598,34 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
     else if (!b.outPre && !b.act && b.actgrad == 2 && eop && !b.residB && !b.rowscale) epi = 3;
   }
   if (!((epi_mask >> epi) & 1)) epi = 0;
-  const int best_tm = nt256_pick_tm(b.M, b.N, b.groups, gather, eff_cus(), g_force_bm);
-  if (!best_tm) return -21;
-  const long long tiles = (long long)cdiv(b.M, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
-  const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
+  const NtPlan plan = nt256_plan(b.M, b.N, b.K, b.groups, gather, eff_cus(), g_force_bm);
+  if (!plan.tm1) return -21;
+  const int M_all = b.M;
+  int rc = 0;
+  for (int part = 0; part < (plan.rows1 ? 2 : 1) && !rc; part++) {
+    const int best_tm = part == 0 ? plan.tm1 : plan.tm2;
+    b.m_begin = part == 0 ? 0 : plan.rows1;
+    b.M = (part == 0 && plan.rows1) ? plan.rows1 : M_all;
+    const int rows = b.M - b.m_begin;
+    const long long tiles = (long long)cdiv(rows, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
+    const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
 #ifdef UVTG_NT_TRACE
-  nt_trace_launch(b, best_tm, grid, gather, eop, s);
+    nt_trace_launch(b, best_tm, grid, gather, eop, s);
 #endif
-  uvtg_prof_begin_launch(3, 2.0 * b.M * b.N * b.K * b.groups, s);
-  {   // algorithmic bytes of the launch: both operands once, every output once, the epilogue operands once
-    const double mn = (double)b.M * b.N * b.groups;
-    double by = 2.0 * ((double)b.M * b.K + (double)b.N * b.K) * b.groups;
-    by += mn * ((b.outB ? 2 : 0) + (b.outF ? 4 : 0) + (b.outPre ? 2 : 0) + (b.outU ? 2 : 0) + (b.outUF ? 4 : 0));
-    by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0));
-    uvtg_prof_add_bytes(3, by);
+    uvtg_prof_begin_launch(3, 2.0 * rows * b.N * b.K * b.groups, s);
+    {   // algorithmic bytes of the launch: both operands once, every output once, the epilogue operands once
+      const double mn = (double)rows * b.N * b.groups;
+      double by = 2.0 * ((double)rows * b.K + (double)b.N * b.K) * b.groups;
+      by += mn * ((b.outB ? 2 : 0) + (b.outF ? 4 : 0) + (b.outPre ? 2 : 0) + (b.outU ? 2 : 0) + (b.outUF ? 4 : 0));
+      by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0));
+      uvtg_prof_add_bytes(3, by);
+    }
+    if (nt_order(best_tm) == 0)
+      rc = best_tm == 5 ? launch_nt256_tm<5, 0>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
+    else
+      rc = best_tm == 5 ? launch_nt256_tm<5, 1>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, epi, s));
+    uvtg_prof_end_launch(3, s);
   }
-  int rc;
-  if (nt_order(best_tm) == 0)
-    rc = best_tm == 5 ? launch_nt256_tm<5, 0>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
-  else
-    rc = best_tm == 5 ? launch_nt256_tm<5, 1>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, epi, s));
-  uvtg_prof_end_launch(3, s);
   if (rc) return rc;
   UVTG_CHECK_LAUNCH();
   return 0;
@@ -1414,6 +1739,89 @@ int launch_gemm_tn_batch(const GemmTNBatch& b, hipStream_t s) {
 #endif
   hipLaunchKernelGGL(gemm_tn256_kernel, dim3(pl.total_tiles * pl.splits), dim3(512), 131072, s, pl);
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mx + 255) / 256), b.count), dim3(256), 0, s, pl);
+  uvtg_prof_end_launch(2, s);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+// ---- hybrid (no reduce pass) launch of several weight gradients over the same rows -----------------------------------------
+static int g_tnh_max_split = -1;
+static void tnh_plan_counts(int M, int total_tiles, int cus, int& full_tiles, int& nsplit, int& steps_per) {
+  const int steps_total = cdiv(M, 64);
+  const int rem = total_tiles % cus;
+  full_tiles = total_tiles - rem;
+  nsplit = rem ? cus / rem : 0;
+  if (nsplit > steps_total / 8) nsplit = steps_total / 8;          // (a part needs a real reduction)
+  if (nsplit <= 1) { full_tiles = total_tiles; nsplit = 0; steps_per = steps_total; return; }
+  steps_per = cdiv(steps_total, nsplit);
+  nsplit = cdiv(steps_total, steps_per);                           // no empty part
+}
+static int tnh_cus() {
+  int cus = (g_cu_cap > 0 && g_cu_cap < g_tn_cus) ? g_cu_cap : g_tn_cus;
+  if (g_cu_reserved > 0) cus = cus - g_cu_reserved > 8 ? cus - g_cu_reserved : 8;
+  return cus;
+}
+static int tnh_total_tiles(const GemmTNMulti& b) {
+  int t = 0;
+  for (int i = 0; i < b.count; i++) t += cdiv(b.g[i].N, 256) * cdiv(b.g[i].K, 256);
+  return t;
+}
+long long gemm_tn_multi_slab_floats(int total_tiles, int cus_hint) {
+  // the split parts of a launch never outnumber its CUs (one part per workgroup), and a tile has <= 3 parts (gemm_tn_multi_ok)
+  const long long by_tiles = (long long)total_tiles * 3, by_cus = cus_hint > 0 ? cus_hint : 320;
+  return (by_tiles < by_cus ? by_tiles : by_cus) * TNH_SLAB;
+}
+bool gemm_tn_multi_ok(const GemmTNMulti& b) {
+  if (g_force_tile == 128 || b.count < 1 || b.count > UVTG_TNH_MAX_GROUPS || !b.slabs || !b.tickets) return false;
+  static const bool off = getenv("UVTG_TN_HYBRID_OFF") != nullptr;       // experiment: always the slab + reduce path
+  if (off) return false;
+  for (int i = 0; i < b.count; i++) {
+    const GemmTNArgs& a = b.g[i];
+    if (!tn256_group_ok(a) || a.M != b.g[0].M || a.ktap != 0 || a.col_stride != 1 || !a.assign || a.q_row_off != 0 || a.Mq != a.M) return false;
+    if (a.N % 256 || a.K % 256 || a.ldo % 4 || ((uintptr_t)a.out & 15)) return false;
+  }
+  if (((uintptr_t)b.slabs & 15)) return false;
+  const int tiles = tnh_total_tiles(b);
+  int full, nsplit, per;
+  tnh_plan_counts(b.g[0].M, tiles, tnh_cus(), full, nsplit, per);
+  if (g_tnh_max_split < 0) g_tnh_max_split = getenv("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(getenv("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
+  if (nsplit > g_tnh_max_split) return false;                       // the last arriver of a tile folds nsplit - 1 slabs alone: only short folds pay
+  if (full == 0 && nsplit == 0) return false;
+  if ((long long)(tiles - full) * nsplit * TNH_SLAB > b.slab_floats || tiles - full > b.n_tickets) return false;
+  return b.g[0].M >= 2048;
+}
+int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) g_tn_cus = pr.multiProcessorCount;
+    attr = true;
+  }
+  if (!gemm_tn_multi_ok(b)) return -2;
+  TNHPlan pl;
+  memset(&pl, 0, sizeof(pl));
+  pl.count = b.count; pl.M = b.g[0].M; pl.steps_total = cdiv(pl.M, 64);
+  int tiles = 0;
+  double flops = 0;
+  for (int i = 0; i < b.count; i++) {
+    const GemmTNArgs& a = b.g[i];
+    TNHGroup& g = pl.g[i];
+    g.P = a.P; g.Q = a.Q; g.out = a.out; g.dbias = a.dbias; g.ldp = a.ldp; g.ldq = a.ldq; g.ldo = a.ldo;
+    g.tiles_k = a.K / 256; g.tile_base = tiles;
+    g.bytes_p = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
+    g.bytes_q = (unsigned)((((long long)a.M - 1) * a.ldq + a.K) * 2);
+    tiles += (a.N / 256) * (a.K / 256);
+    flops += 2.0 * a.M * a.N * a.K;
+  }
+  pl.total_tiles = tiles;
+  const int cus = tnh_cus();
+  tnh_plan_counts(pl.M, tiles, cus, pl.full_tiles, pl.nsplit, pl.steps_per);
+  pl.slabs = b.slabs; pl.tickets = b.tickets; pl.sqsum = b.g[0].sqsum;
+  const int split_units = (tiles - pl.full_tiles) * pl.nsplit;
+  int grid = pl.full_tiles > split_units ? pl.full_tiles : split_units;
+  if (grid > cus) grid = cus;
+  uvtg_prof_begin_launch(2, flops, s);
+  hipLaunchKernelGGL(gemm_tn256h_kernel, dim3(grid), dim3(512), 131072, s, pl);
   uvtg_prof_end_launch(2, s);
   UVTG_CHECK_LAUNCH();
   return 0;

@@ -7,7 +7,11 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* out) {
+// Squared-norm partials, one per block, summed later in a FIXED order: every rank of a data-parallel run must derive the bit-identical
+// clipping coefficient from the bit-identical reduced gradients, or the replicas drift apart (an atomicAdd total depends on arrival order;
+// found by tests/test_gpu_parity_full.py::test_two_rank_native_trainstep_is_a_data_parallel_step)
+constexpr int SQN_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, long long n, float* out) {
   __shared__ float red[4];
   float acc = 0.f;
   const long long n4 = n / 4;
@@ -19,14 +23,26 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2s, float max_norm,
-                                                    float grad_scale, const float* sqn) {
+                                                    float grad_scale, const float* sqn, int n_partials) {
+  // squared norm: one value, or n_partials (a multiple of 256) per-block partials folded here in a fixed order -- every block, and every
+  // rank of a data-parallel run, computes the identical sum
+  float sq = *sqn;
+  if (n_partials > 0) {
+    __shared__ float red[4];
+    float t = 0.f;
+    for (int i = threadIdx.x; i < n_partials; i += 256) t += sqn[i];
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    sq = (red[0] + red[1]) + (red[2] + red[3]);
+  }
   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
-  const float total = sqrtf(*sqn) * grad_scale;
+  const float total = sqrtf(sq) * grad_scale;
   const float coef = grad_scale * (max_norm > 0.f ? fminf(1.f, max_norm / (total + 1e-6f)) : 1.f);
   const long long n4 = n / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -66,11 +82,10 @@ extern "C" int uvtg_adamw_clip_step(float* params, const float* grads, float* m,
   if (!params || !grads || !m || !v || !scratch) return -20;
   if (n <= 0 || n % 4 || step <= 0) return -11;
   hipStream_t s = (hipStream_t)stream;
-  if (hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float), s)) return (int)e;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(1024), dim3(256), 0, s, grads, n, scratch);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(SQN_BLOCKS), dim3(256), 0, s, grads, n, scratch);
   const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2s,
-                     max_norm, grad_scale, scratch);
+                     max_norm, grad_scale, scratch, SQN_BLOCKS);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -83,7 +98,7 @@ extern "C" int uvtg_adamw_clip_step_prenorm(float* params, const float* grads, f
   hipStream_t s = (hipStream_t)stream;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2s,
-                     max_norm, grad_scale, sqnorm_dev);
+                     max_norm, grad_scale, sqnorm_dev, 0);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -13,6 +13,9 @@ struct GemmArgs {
   const void* A2; int a2_n0;
   const void* B;      // bf16 / fp32 [N, ldb]
   int M, N, K, lda, ldb;
+  // row window of the persistent 256-wide kernel: tiles cover rows [m_begin, M) (set by its launcher when it cuts a launch into a whole
+  // number of CU rounds of tall tiles + a tail of short ones; all row addressing stays absolute).  0 everywhere else.
+  int m_begin;
   // A-row gather: arow(m) = (m / a_seg) * a_seg_stride + (m % a_seg) + a_off   (a_seg == 0: identity)
   // K is split in taps of `ktap` columns; tap t reads row arow(m) + t, columns k % ktap (3-tap conv).
   int a_seg, a_seg_stride, a_off, ktap;
@@ -71,6 +74,14 @@ struct GemmTNBatch { GemmTNArgs g[UVTG_TN_MAX_GROUPS]; int count; };
 bool gemm_tn_batch_ok(const GemmTNBatch& b);       // all groups eligible for the 256-tile kernel, same M, scratch large enough
 long long gemm_tn_batch_scratch_floats(const GemmTNBatch& b);
 int launch_gemm_tn_batch(const GemmTNBatch& b, hipStream_t s);
+// the same WITHOUT a reduce pass ("hybrid" plan, gemm.hip: gemm_tn256h_kernel): whole tiles per workgroup + the remainder cut into <= 3 row
+// ranges whose parts meet through write-through slabs and a ticket per tile.  Contiguous assigned outputs, N and K multiples of 256, no taps.
+// slabs: gemm_tn_multi_slab_floats(total 256 x 256 tiles) floats (16-byte aligned); tickets: one zeroed unsigned per tile.
+constexpr int UVTG_TNH_MAX_GROUPS = 24;
+struct GemmTNMulti { GemmTNArgs g[UVTG_TNH_MAX_GROUPS]; int count; float* slabs; long long slab_floats; unsigned* tickets; int n_tickets; };
+bool gemm_tn_multi_ok(const GemmTNMulti& b);
+long long gemm_tn_multi_slab_floats(int total_tiles, int cus_hint);
+int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s);
 bool gemm_tn_taps_ok(const GemmTNArgs& a);   // can this call (with ktap set) run as ONE launch?
 long long gemm_tn_scratch_floats(int M, int N, int K);   // scratch that makes every (M, N, K) eligible for the 256-tile kernel
 int launch_gemm_tn_bf16(const GemmTNArgs& a, hipStream_t s);

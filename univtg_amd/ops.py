@@ -72,6 +72,28 @@ def wgrad_bf16_ws(dy_bf16, x_bf16, with_bias=True):
     return dw, db
 
 
+def wgrad_bf16_multi(dys, xs, with_bias=True):
+    """Several weight gradients over the same rows in one launch, no reduce pass (uvtg_wgrad_bf16_multi).  dys[i] [M, N_i], xs[i] [M, K_i]
+    bf16-bit tensors; returns ([dW_i], [dbias_i])."""
+    lib = _lib.load()
+    _need_cuda(dys[0])
+    n = len(dys)
+    M = dys[0].shape[0]
+    dev = dys[0].device
+    Ns, Ks = [int(t.shape[1]) for t in dys], [int(t.shape[1]) for t in xs]
+    tiles = sum((a // 256) * (b // 256) for a, b in zip(Ns, Ks))
+    nf = lib.uvtg_wgrad_multi_slab_floats(tiles)
+    slabs = torch.empty(nf, device=dev)
+    tickets = torch.zeros(tiles, dtype=torch.int32, device=dev)
+    dws = [torch.full((a, b), float("nan"), device=dev) for a, b in zip(Ns, Ks)]       # assigned: every element must be written
+    dbs = [torch.zeros(a, device=dev) for a in Ns] if with_bias else None
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    iarr = lambda vs: (C.c_int * n)(*vs)
+    _lib.check(lib.uvtg_wgrad_bf16_multi(n, arr(dys), iarr(Ns), arr(xs), iarr(Ks), arr(dws), arr(dbs) if with_bias else None, M,
+                                         _ptr(slabs), nf, _ptr(tickets), tiles, _stream()), "uvtg_wgrad_bf16_multi")
+    return dws, dbs
+
+
 def layernorm_fwd(x, gamma, beta):
     _need_cuda(x)
     x = _f32c(x)

@@ -52,7 +52,7 @@ class TrainStep:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.grads = torch.zeros_like(self.flat)
-        self.scratch = torch.zeros(2, device=dev)
+        self.scratch = torch.zeros(1024, device=dev)          # UVTG_ADAMW_SCRATCH_FLOATS (include/uvtg.h)
         self.lr, self.wd, self.clip, self.betas, self.eps = lr, weight_decay, grad_clip, betas, eps
         self.t = 0
         self.pg = process_group
