@@ -133,7 +133,11 @@ int uvtg_criterion_fwd(int B, int Lv, int d, int which, float eos_coef,
                        const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,
                        const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
                        const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
-                       float* loss_ws, float* losses_out, uvtg_stream_t stream);
+                       float* loss_ws, float* losses_out,
+                       const float* cos_cached, const float* vnorm_cached, const float* qnorm_cached /* optional, all three or NULL:
+                       cosine(vid, txt) [B,Lv], |vid| [B,Lv], |txt| [B] from uvtg_forward_saliency_stats (same values the
+                       criterion would compute from vid / txt_mem itself; saves its pass over vid_mem_proj) */,
+                       uvtg_stream_t stream);
 /* go [5] (device): upstream gradient of each of the five losses.  Must follow the matching _fwd call.
  * Outputs: g_logits [B,Lv], g_spans [B,Lv,2], g_cos [B,Lv] (gradient wrt cosine(vid_mem_proj, txt_mem_proj), i.e.
  * wrt saliency_scores), g_vrow [B,d] (inter-video gradient wrt vid_mem_proj[b, pos_b, :]), g_txt [B,d].
@@ -147,7 +151,11 @@ int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coef,
                        const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
                        float* loss_ws, const float* losses_out, const float* go,
                        float* g_logits, float* g_spans, float* g_vid, float* g_txt, float* g_cos, float* g_vrow,
+                       const float* cos_cached, const float* vnorm_cached, const float* qnorm_cached /* as passed to _fwd */,
                        uvtg_stream_t stream);
+/* Where the saliency pass of the last uvtg_forward on `workspace` left cosine(vid_mem_proj, txt_mem_proj) [B,Lv], |vid_mem_proj| [B,Lv] and
+ * |txt_mem_proj| [B] (device addresses inside the workspace; valid until the next uvtg_forward on it). */
+int uvtg_forward_saliency_stats(const uvtg_dims* dm, void* workspace, const float** cosv, const float** vnorm, const float** qnorm);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels the engine launches) ----- */
 /* C[M,N] = A[M,K] * W[N,K]^T + bias (nn.Linear).  bf16: A,W bf16, C fp32.  f32x3: A,W fp32. act: 0/1 relu/2 gelu */

@@ -347,7 +347,8 @@ def test_convergence_fixed_batch_matches_oracle_training(dev):
           f"median {float(rel.median()):.4f}; 10-step-mean gap max {float(rel_sm.max()):.4f}; every 50th step: "
           + ", ".join(f"{i}: {float(ref_total[i]):.3f}/{float(dev_total[i]):.3f}" for i in (0, 49, 99, 149, 199)))
     assert float(rel[0]) < 2e-2                                     # identical weights and masks at step 1
-    assert float(rel_sm.max()) < 0.05 and float(rel.median()) < 0.02   # the band: 10-step means within 5 %, median step within 2 %
+    # the band (measured: 10-step means within 0.9-1.2 %, median step 0.3 %, worst single step 2.3-3.7 % -- dropout noise on bf16 weights)
+    assert float(rel_sm.max()) < 0.03 and float(rel.median()) < 0.01 and float(rel.max()) < 0.08
     assert float(dev_total[-10:].mean()) < 0.75 * float(dev_total[:10].mean())   # and it does converge
     assert float(ref_total[-10:].mean()) < 0.75 * float(ref_total[:10].mean())
 

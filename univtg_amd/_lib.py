@@ -41,8 +41,9 @@ SIGNATURES = {
     "uvtg_prepare_weights": (_I, [_DP, _P, _P, _P]),
     "uvtg_forward": (_I, [_DP, _P, _P] + [_P] * 5 + [_P] * 6 + [_P, _P] + [_P]),
     "uvtg_backward": (_I, [_DP, _P, _P] + [_P] * 4 + [_P] * 4 + [_P] * 5 + [_LL, _LL] + [_P, _P] + [_P, _P, _P] + [_P, _I] + [_P]),
-    "uvtg_criterion_fwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P]),
-    "uvtg_criterion_bwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P] + [_P] * 6 + [_P]),
+    "uvtg_criterion_fwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P] + [_P] * 3 + [_P]),
+    "uvtg_criterion_bwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P] + [_P] * 6 + [_P] * 3 + [_P]),
+    "uvtg_forward_saliency_stats": (_I, [_DP, _P, _P, _P, _P]),
     "uvtg_linear_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uvtg_linear_f32x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uvtg_wgrad_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

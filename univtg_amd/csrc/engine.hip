@@ -615,7 +615,7 @@ struct Fwd {
     return 0;
   }
 
-  int heads(float* pred_logits, float* pred_spans) {
+  int heads(float* pred_logits, float* pred_spans, HeadsFinalArgs& hf) {
     const int d = m.c.d, Lv = m.c.Lv, B = m.c.B;
     const size_t es = fast ? 2 : 4;
     const int* fs = halo ? ws.pk.fstart : nullptr;
@@ -645,11 +645,10 @@ struct Fwd {
     g.bias = w.bc1; g.act = 1;
     set_out(g, ws.h2_pad, 2 * d);
     TRY(run_gemm(g, !fast));
-    HeadsFinalArgs hf; memset(&hf, 0, sizeof(hf));
+    memset(&hf, 0, sizeof(hf));                      // (the last conv layer runs fused with the saliency pass: launch_heads_saliency_fwd)
     hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.precise = !fast; hf.fstart = fs; hf.kept = kc;
     hf.w_span = P[m.tail(SP2W)]; hf.b_span = P[m.tail(SP2B)]; hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)];
     hf.B = B; hf.Lv = Lv; hf.d = d; hf.pred_logits = pred_logits; hf.pred_spans = pred_spans;
-    TRY(launch_heads_final_fwd(hf, s));
     return 0;
   }
 };
@@ -702,9 +701,10 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   uvtg_prof_section(0, 0, s);
   for (int l = 0; l < m.c.E; l++) TRY(f.layer(l, memory));
   uvtg_prof_section(0, 1, s);
-  TRY(f.heads(pred_logits, pred_spans));
+  HeadsFinalArgs hf;
+  TRY(f.heads(pred_logits, pred_spans, hf));
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, txt_mem_proj, saliency);
-  TRY(launch_saliency_fwd(sa, s));
+  TRY(launch_heads_saliency_fwd(hf, sa, s));
   uvtg_prof_section(2, 1, s);
   return 0;
 }
@@ -840,11 +840,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   hf.dw_span = G(m.tail(SP2W)); hf.db_span = G(m.tail(SP2B)); hf.dw_cls = G(m.tail(CL2W)); hf.db_cls = G(m.tail(CL2B));
   hf.scratch = ws.tn_scratch; hf.scratch_floats = ws.tn_scratch_floats;
   TRY(launch_heads_final_bwd(hf, s));
-  for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 1 weight grads: 3 taps x 2 heads
-    float* dW = G(m.tail(hd_ == 0 ? SP1W : CL1W));
-    float* dBi = G(m.tail(hd_ == 0 ? SP1B : CL1B));
-    TRY(conv_wgrad(ws.dh2_pad + hd_ * d, 2 * d, (const bf16_t*)ws.h1_pad + hd_ * d, 2 * d, dW, dBi, Rf));
-  }
   {                                             // conv layer 1 dgrad (+ relu' of h1) -> dh1_pad
     GemmArgs g = gemm_base(ws.dh2_pad, 2 * d, w.wc1T, 3 * d, m.Mv, d, 3 * d);
     g.ktap = d; frame(g, true);
@@ -853,10 +848,24 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     g.outB = ws.dh1_pad; g.ldoB = 2 * d;
     TRY(launch_gemm_nt_bf16(g, s));
   }
-  for (int hd_ = 0; hd_ < 2; hd_++) {           // conv layer 0 weight grads
-    float* dW = G(m.tail(hd_ == 0 ? SP0W : CL0W));
-    float* dBi = G(m.tail(hd_ == 0 ? SP0B : CL0B));
-    TRY(conv_wgrad(ws.dh1_pad + hd_ * d, 2 * d, (const bf16_t*)ws.vm_pad, d, dW, dBi, Rf));
+  {   // weight gradients of the four d -> d convolutions (layer 1 and layer 0 of both heads): the same frame rows, ONE launch over 4 x 12
+      // tap tiles (5 row splits instead of 4 launches of 12 tiles x 21 splits each) + one reduce pass; their operands all exist by now
+    GemmTNBatch cb; cb.count = 0;
+    struct { const bf16_t* dY; int ldp; const bf16_t* X; int ldq; int w, b; } cw[4] = {
+      {ws.dh2_pad, 2 * d, (const bf16_t*)ws.h1_pad, 2 * d, SP1W, SP1B}, {ws.dh2_pad + d, 2 * d, (const bf16_t*)ws.h1_pad + d, 2 * d, CL1W, CL1B},
+      {ws.dh1_pad, 2 * d, (const bf16_t*)ws.vm_pad, d, SP0W, SP0B}, {ws.dh1_pad + d, 2 * d, (const bf16_t*)ws.vm_pad, d, CL0W, CL0B}};
+    bool all_ok = true;
+    for (auto& c : cw) {
+      GemmTNArgs t; memset(&t, 0, sizeof(t));
+      t.P = c.dY; t.ldp = c.ldp; t.Q = c.X; t.ldq = c.ldq; t.M = Rf; t.N = d; t.K = 3 * d; t.q_row_off = -1; t.Mq = Rf;
+      t.out = G(m.tail(c.w)); t.ldo = 3 * d; t.col_stride = 3; t.dbias = G(m.tail(c.b)); t.splits = splits_v; t.ktap = d; t.assign = 1; t.sqsum = ws.gnorm2;
+      t.scratch = ws.tn_scratch; t.scratch_floats = ws.tn_scratch_floats;
+      all_ok = all_ok && gemm_tn_taps_ok(t);
+      cb.g[cb.count++] = t;
+    }
+    static const bool cbatch_off = getenv("UVTG_TN_CONVBATCH_OFF") != nullptr;
+    if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) TRY(launch_gemm_tn_batch(cb, s));
+    else for (auto& c : cw) TRY(conv_wgrad(c.dY, c.ldp, c.X, c.ldq, G(m.tail(c.w)), G(m.tail(c.b)), Rf));
   }
   {                                             // conv layer 0 dgrad -> dvm (bf16; clip rows [B * Lv], or frame rows on the loss-only stream)
     GemmArgs g = gemm_base(ws.dh1_pad, 2 * d, w.wc0T, 6 * d, m.Mv, d, 6 * d);
@@ -952,9 +961,19 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     const bf16_t* a2b = pp ? ws.a2B[which] : (const bf16_t*)ws.a2[which];
     const bf16_t* a1b = pp ? ws.a1B[which] : (const bf16_t*)ws.a1[which];
     // (ws.dyP[which] = bf16(dx0 + saliency-branch gradients), packed per modality by launch_saliency_bwd)
-    TRY(wgrad(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, 1, G(m.tail(t1 + 3)), 0, R, splits_v));
-    hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + (which == 0 ? d : 0), G(m.tail(t1 + 3)), d);
-    UVTG_CHECK_LAUNCH();
+    // the two weight gradients of a modality reduce over the same rows: ONE launch (more tiles -> fewer row splits, one reduce pass) once
+    // the second one's operand (dh1b) exists; small / odd shapes keep the per-gradient launches
+    GemmTNBatch pb; pb.count = 2;
+    pb.g[0] = tn_group(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, G(m.tail(t1 + 3)));
+    pb.g[1] = tn_group(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, G(m.tail(t0 + 3)));
+    pb.g[0].splits = pb.g[1].splits = splits_v;
+    static const bool pbatch_off = getenv("UVTG_TN_PROJBATCH_OFF") != nullptr;
+    const bool proj_batch = !pbatch_off && R >= 2048 && gemm_tn_batch_ok(pb);
+    if (!proj_batch) {
+      TRY(wgrad(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, 1, G(m.tail(t1 + 3)), 0, R, splits_v));
+      hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + (which == 0 ? d : 0), G(m.tail(t1 + 3)), d);
+      UVTG_CHECK_LAUNCH();
+    }
     GemmArgs g = gemm_base(ws.dyP[which], d, which == 0 ? w.vp1T : w.tp1T, d, R, d, d);
     g.outF = ws.dA2[which]; g.ldoF = d;
     TRY(launch_gemm_nt_bf16(g, s));
@@ -965,7 +984,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     if (cv) lb.src_rows = ws.pk.vin_src;
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
-    TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
+    if (proj_batch) {
+      TRY(launch_gemm_tn_batch(pb, s));
+      hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + (which == 0 ? d : 0), G(m.tail(t1 + 3)), d);
+      UVTG_CHECK_LAUNCH();
+    } else {
+      TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
+    }
     g = gemm_base(ws.dh1b[which], d, which == 0 ? w.vp0T : w.tp0T, d, R, Kp, d);
     g.outF = ws.dA1[which]; g.ldoF = Kp;
     TRY(launch_gemm_nt_bf16(g, s));
@@ -991,6 +1016,17 @@ extern "C" const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* works
   return ws.gnorm2;
 }
 
+// device addresses of what the saliency pass of the last uvtg_forward on this workspace left behind: cosine(vid_mem_proj, txt_mem_proj)
+// [B, Lv], |vid_mem_proj| [B, Lv], |txt_mem_proj| [B] -- the criterion takes them instead of recomputing them from vid_mem_proj
+extern "C" int uvtg_forward_saliency_stats(const uvtg_dims* dm, void* workspace, const float** cosv, const float** vnorm, const float** qnorm) {
+  if (int e = check_dims(dm)) return e;
+  if (!workspace || !cosv || !vnorm || !qnorm) return -20;
+  Dm m(*dm);
+  WSpace ws(m, workspace, nullptr);
+  *cosv = ws.cosv; *vnorm = ws.vnorm; *qnorm = ws.qnorm;
+  return 0;
+}
+
 // =================================================================================================
 // criterion
 // =================================================================================================
@@ -998,8 +1034,9 @@ namespace {
 LossArgs loss_args(int B, int Lv, int d, int which, float eos_coef, const float* pred_logits, const float* pred_spans,
                    const float* vid, long long vid_sb, long long vid_st, const float* txt_mem, const float* timestamp,
                    const float* ts_mask, const float* ts_window, const float* span_nn, const float* sal, const long long* pos_idx,
-                   float* ws, float* losses) {
+                   float* ws, float* losses, const float* cos_c, const float* vnorm_c, const float* qnorm_c) {
   LossArgs a; memset(&a, 0, sizeof(a));
+  if (cos_c && vnorm_c && qnorm_c) { a.cos_c = cos_c; a.vnorm_c = vnorm_c; a.qnorm_c = qnorm_c; }
   a.B = B; a.Lv = Lv; a.d = d; a.pred_logits = pred_logits; a.pred_spans = pred_spans; a.vid = vid; a.vid_sb = vid_sb; a.vid_st = vid_st;
   a.txt = txt_mem; a.timestamp = timestamp; a.ts_mask = ts_mask; a.ts_window = ts_window; a.span_nn = span_nn; a.sal_tgt = sal;
   a.pos_idx = pos_idx; a.eos_coef = eos_coef; a.do_spans = which & 1; a.do_labels = (which >> 1) & 1; a.do_saliency = (which >> 2) & 1;
@@ -1012,12 +1049,13 @@ extern "C" int uvtg_criterion_fwd(int B, int Lv, int d, int which, float eos_coe
                                   const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,
                                   const float* timestamp, const float* timestamp_mask, const float* timestamp_window,
                                   const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
-                                  float* loss_ws, float* losses_out, uvtg_stream_t stream) {
+                                  float* loss_ws, float* losses_out, const float* cos_cached, const float* vnorm_cached,
+                                  const float* qnorm_cached, uvtg_stream_t stream) {
   if (B <= 0 || Lv <= 0 || d <= 0) return -11;
   if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !timestamp_window || !span_labels_nn || !loss_ws || !losses_out) return -20;
   if ((which & 4) && saliency_scores && pos_idx && (!vid || !txt_mem)) return -20;
   LossArgs a = loss_args(B, Lv, d, which, eos_coef, pred_logits, pred_spans, vid, vid_sb, vid_st, txt_mem, timestamp, timestamp_mask,
-                         timestamp_window, span_labels_nn, saliency_scores, pos_idx, loss_ws, losses_out);
+                         timestamp_window, span_labels_nn, saliency_scores, pos_idx, loss_ws, losses_out, cos_cached, vnorm_cached, qnorm_cached);
   return launch_losses_fwd(a, (hipStream_t)stream);
 }
 
@@ -1027,12 +1065,12 @@ extern "C" int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coe
                                   const float* span_labels_nn, const float* saliency_scores, const long long* pos_idx,
                                   float* loss_ws, const float* losses_out, const float* go,
                                   float* g_logits, float* g_spans, float* g_vid, float* g_txt, float* g_cos, float* g_vrow,
-                                  uvtg_stream_t stream) {
+                                  const float* cos_cached, const float* vnorm_cached, const float* qnorm_cached, uvtg_stream_t stream) {
   if (B <= 0 || Lv <= 0 || d <= 0) return -11;
   if (!pred_logits || !pred_spans || !timestamp || !timestamp_mask || !timestamp_window || !span_labels_nn || !loss_ws ||
       !losses_out || !go || !g_logits || !g_spans || !g_cos || !g_vrow || !g_txt) return -20;
   LossArgs a = loss_args(B, Lv, d, which, eos_coef, pred_logits, pred_spans, vid, vid_sb, vid_st, txt_mem, timestamp, timestamp_mask,
-                         timestamp_window, span_labels_nn, saliency_scores, pos_idx, loss_ws, (float*)losses_out);
+                         timestamp_window, span_labels_nn, saliency_scores, pos_idx, loss_ws, (float*)losses_out, cos_cached, vnorm_cached, qnorm_cached);
   a.go = go; a.g_logits = g_logits; a.g_spans = g_spans; a.g_vid = g_vid; a.g_txt = g_txt; a.g_cos = g_cos; a.g_vrow = g_vrow;
   hipStream_t s = (hipStream_t)stream;
   const bool sal = (which & 4) && saliency_scores && pos_idx;

@@ -12,7 +12,9 @@ constexpr float EPS = 1e-8f;          // sim_matrix / cosine_similarity eps
 
 struct WS {                            // carve-up of LossArgs::ws
   float *cosv, *vnorm, *qnorm, *sim, *lse_r, *lse_c, *zr, *zc, *cnt, *gz, *vpn, *dvh, *dqh, *acc;
-  __host__ __device__ WS(float* p, int B, int Lv, int d = 0) {
+  __host__ __device__ WS(const LossArgs& a) {
+    float* p = a.ws;
+    const int B = a.B, Lv = a.Lv, d = a.d;
     cosv = p; p += (size_t)B * Lv;
     vnorm = p; p += (size_t)B * Lv;
     gz = p; p += (size_t)B * Lv;
@@ -23,11 +25,13 @@ struct WS {                            // carve-up of LossArgs::ws
     zr = p; p += B;
     vpn = p; p += B;
     zc = p; p += Lv;
-    cnt = p; p += Lv;
-    p += (4 - ((size_t)(5 * B + 2 * Lv) & 3)) & 3;
+    p += (4 - ((size_t)(5 * B + Lv) & 3)) & 3;
     dvh = p; p += (size_t)B * d;
     dqh = p; p += (size_t)B * d;
-    acc = p; p += 8;
+    acc = p; p += 16;                    // 8 accumulators (+ 8 spare), directly followed by cnt: ONE memset zeroes both
+    cnt = p; p += Lv;
+    // per-clip cosine / norms the model forward already computed (uvtg_forward_saliency_stats): no stats pass over vid_mem_proj
+    if (a.cos_c) { cosv = (float*)a.cos_c; vnorm = (float*)a.vnorm_c; qnorm = (float*)a.qnorm_c; }
   }
 };
 
@@ -46,7 +50,7 @@ __device__ __forceinline__ float zval(const LossArgs& a, const WS& w, int b, int
 
 // per (b, t): |v|, cos(v, q_b);  per b: |q|
 __global__ __launch_bounds__(256) void loss_stats_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv, a.d);
+  const WS w(a);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.B * a.Lv) return;
@@ -64,18 +68,35 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(const LossArgs a) {
   }
 }
 
-// sim[i][j] = vhat_i . qhat_j  with v_i = vid[i, pos_i].  grid (B, ceil(B / 64)): block (i, jc) handles 64 text rows, each of
-// its 4 waves 16 of them, four at a time (independent 16-byte loads in flight; the kernel is pure L2 latency otherwise)
-__global__ __launch_bounds__(256) void loss_sim_kernel(const LossArgs a) {
-  extern __shared__ float sv[];
-  const WS w(a.ws, a.B, a.Lv, a.d);
-  const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ void giou_terms(float a0, float a1, float b0, float b1, float& I, float& U, float& H) {
+  I = fmaxf(fminf(a1, b1) - fmaxf(a0, b0), 0.f);
+  U = (a1 - a0) + (b1 - b0) - I;
+  H = fmaxf(fmaxf(a1, b1) - fminf(a0, b0), 0.f);
+}
+
+// ---- forward, two launches (round 3; were stats / sim / elem / lse / final = five) ----
+// launch 1, by block role: [0, sim blocks) the inter-video similarity rows (loss_sim_kernel's body); then the per-clip terms (SmoothL1, gIoU,
+// BCE and the counts, 256 clips per block, ws.acc[8] atomics: nwin, nval, ssum, lb, lg, lf); then the intra-video log-sum-exp tasks, one wave
+// each: row b (softmax over the clips of sample b -> zr[b], cnt[pos_b] += 1) and column t (softmax over the batch at clip t -> zc[t]).
+// None of these reads another block's output.  ws.acc and ws.cnt are zeroed by ONE memset in front of the launch.
+__device__ __forceinline__ void loss_sim_block(const LossArgs& a, const WS& w, int i, int jblock, float* sv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = (int)a.pos_idx[i];
   const float* v = vrow(a, i, p);
   const float vn = fmaxf(w.vnorm[i * a.Lv + p], EPS);
   for (int c = threadIdx.x; c < a.d; c += 256) sv[c] = v[c] / vn;
   __syncthreads();
-  const int jbase = blockIdx.y * 64 + wave * 16;
+  const int jbase = jblock * 64 + wave * 16;
   for (int j0 = jbase; j0 < min(a.B, jbase + 16); j0 += 4) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float* q[4];
@@ -104,108 +125,97 @@ __global__ __launch_bounds__(256) void loss_sim_kernel(const LossArgs a) {
     }
   }
 }
-
-__device__ __forceinline__ float block_sum(float v, float* red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float t = 0.f;
-  for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += red[i];
-  return t;
-}
-
-__device__ __forceinline__ void giou_terms(float a0, float a1, float b0, float b1, float& I, float& U, float& H) {
-  I = fmaxf(fminf(a1, b1) - fmaxf(a0, b0), 0.f);
-  U = (a1 - a0) + (b1 - b0) - I;
-  H = fmaxf(fmaxf(a1, b1) - fminf(a0, b0), 0.f);
-}
-
-// ---- forward scalars, in three small multi-block passes (was one 1024-thread block: ~220 us of pure latency) ----
-// ws.acc[8] (atomic accumulators): nwin, nval, ssum, lb, lg, lf
-__global__ __launch_bounds__(256) void loss_elem_kernel(const LossArgs a, float* acc) {
+__global__ __launch_bounds__(256) void loss_fwd1_kernel(const LossArgs a, int sim_blocks, int elem_blocks, int have_sal) {
+  extern __shared__ float sv[];
   __shared__ float red[4];
-  const WS w(a.ws, a.B, a.Lv, a.d);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = a.B * a.Lv;
-  float nwin = 0.f, nval = 0.f, ssum = 0.f, lb = 0.f, lg = 0.f, lf = 0.f;
-  if (i < n) {
-    const float win = a.ts_window[i], msk = a.ts_mask[i];
-    nwin = (win != 0.f); nval = (msk != 0.f);
-    if (a.sal_tgt) ssum = a.sal_tgt[i];
-    if (a.do_spans && win != 0.f) {
-      const float s0 = a.timestamp[2 * i] + a.pred_spans[2 * i], s1 = a.timestamp[2 * i + 1] + a.pred_spans[2 * i + 1];
-      const float g0 = a.span_nn[2 * i], g1 = a.span_nn[2 * i + 1];
-      const float d0 = fabsf(s0 - g0), d1 = fabsf(s1 - g1);
-      lb = win * ((d0 < 1.f ? 0.5f * d0 * d0 : d0 - 0.5f) + (d1 < 1.f ? 0.5f * d1 * d1 : d1 - 0.5f));
-      float I, U, H;
-      giou_terms(s0, s1, g0, g1, I, U, H);
-      lg = 1.f - (I / U - (H - U) / H);
-    }
-    if (a.do_labels && msk != 0.f) {
-      const float p = a.pred_logits[i], y = win != 0.f ? 1.f : 0.f, wt = win != 0.f ? 1.f : a.eos_coef;
-      lf = -wt * (y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
-    }
+  const WS w(a);
+  const int B = a.B, Lv = a.Lv, n = B * Lv;
+  int blk = blockIdx.x;
+  if (blk < sim_blocks) {
+    const int jb = (B + 63) / 64;
+    loss_sim_block(a, w, blk / jb, blk % jb, sv);
+    return;
   }
-  float vals[6] = {nwin, nval, ssum, lb, lg, lf};
+  blk -= sim_blocks;
+  if (blk < elem_blocks) {
+    const int i = blk * 256 + threadIdx.x;
+    float nwin = 0.f, nval = 0.f, ssum = 0.f, lb = 0.f, lg = 0.f, lf = 0.f;
+    if (i < n) {
+      const float win = a.ts_window[i], msk = a.ts_mask[i];
+      nwin = (win != 0.f); nval = (msk != 0.f);
+      if (a.sal_tgt) ssum = a.sal_tgt[i];
+      if (a.do_spans && win != 0.f) {
+        const float s0 = a.timestamp[2 * i] + a.pred_spans[2 * i], s1 = a.timestamp[2 * i + 1] + a.pred_spans[2 * i + 1];
+        const float g0 = a.span_nn[2 * i], g1 = a.span_nn[2 * i + 1];
+        const float d0 = fabsf(s0 - g0), d1 = fabsf(s1 - g1);
+        lb = win * ((d0 < 1.f ? 0.5f * d0 * d0 : d0 - 0.5f) + (d1 < 1.f ? 0.5f * d1 * d1 : d1 - 0.5f));
+        float I, U, H;
+        giou_terms(s0, s1, g0, g1, I, U, H);
+        lg = 1.f - (I / U - (H - U) / H);
+      }
+      if (a.do_labels && msk != 0.f) {
+        const float p = a.pred_logits[i], y = win != 0.f ? 1.f : 0.f, wt = win != 0.f ? 1.f : a.eos_coef;
+        lf = -wt * (y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+      }
+    }
+    float vals[6] = {nwin, nval, ssum, lb, lg, lf};
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const float t = block_sum(vals[k], red);
-    if (threadIdx.x == 0) atomicAdd(acc + k, t);
+    for (int k = 0; k < 6; k++) {
+      const float t = block_sum(vals[k], red);
+      if (threadIdx.x == 0) atomicAdd(w.acc + k, t);
+    }
+    return;
   }
-  if (i < a.Lv) w.cnt[i] = 0.f;       // (blocks 0.. cover Lv <= n)
-}
-
-// log-sum-exp rows / columns of the two NCE terms: one wave per task
-//   task < B          : inter-video row i and column i of sim / tau          -> lse_r[i], lse_c[i]
-//   task < 2B         : intra-video row b (softmax over the clips of sample b) -> zr[b], cnt[pos_b] += 1
-//   task < 2B + Lv    : intra-video column t (softmax over the batch at clip t) -> zc[t]
-__global__ __launch_bounds__(256) void loss_lse_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv, a.d);
+  blk -= elem_blocks;
+  if (!have_sal) return;
   const int lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int B = a.B, Lv = a.Lv;
+  const int task = blk * 4 + (threadIdx.x >> 6);
   if (task < B) {
-    const int i = task;
-    float mr = -INFINITY, mc = -INFINITY;
-    for (int j = lane; j < B; j += 64) { mr = fmaxf(mr, w.sim[i * B + j]); mc = fmaxf(mc, w.sim[j * B + i]); }
-    mr = wave_max(mr); mc = wave_max(mc);
-    float sr = 0.f, sc = 0.f;
-    for (int j = lane; j < B; j += 64) { sr += expf((w.sim[i * B + j] - mr) / TAU); sc += expf((w.sim[j * B + i] - mc) / TAU); }
-    sr = wave_sum(sr); sc = wave_sum(sc);
-    if (lane == 0) { w.lse_r[i] = mr / TAU + logf(sr); w.lse_c[i] = mc / TAU + logf(sc); }
-  } else if (task < 2 * B) {
-    const int b = task - B;
+    const int b = task;
     float m = -INFINITY;
     for (int t = lane; t < Lv; t += 64) m = fmaxf(m, zval(a, w, b, t));
     m = wave_max(m);
-    float s = 0.f;
-    for (int t = lane; t < Lv; t += 64) s += expf((zval(a, w, b, t) - m) / TAU);
-    s = wave_sum(s);
-    if (lane == 0) { w.zr[b] = m / TAU + logf(s); atomicAdd(&w.cnt[(int)a.pos_idx[b]], 1.f); }
-  } else if (task < 2 * B + Lv) {
-    const int t = task - 2 * B;
+    float sm = 0.f;
+    for (int t = lane; t < Lv; t += 64) sm += expf((zval(a, w, b, t) - m) / TAU);
+    sm = wave_sum(sm);
+    if (lane == 0) { w.zr[b] = m / TAU + logf(sm); atomicAdd(&w.cnt[(int)a.pos_idx[b]], 1.f); }
+  } else if (task < B + Lv) {
+    const int t = task - B;
     float m = -INFINITY;
     for (int b = lane; b < B; b += 64) m = fmaxf(m, zval(a, w, b, t));
     m = wave_max(m);
-    float s = 0.f;
-    for (int b = lane; b < B; b += 64) s += expf((zval(a, w, b, t) - m) / TAU);
-    s = wave_sum(s);
-    if (lane == 0) w.zc[t] = m / TAU + logf(s);
+    float sm = 0.f;
+    for (int b = lane; b < B; b += 64) sm += expf((zval(a, w, b, t) - m) / TAU);
+    sm = wave_sum(sm);
+    if (lane == 0) w.zc[t] = m / TAU + logf(sm);
   }
 }
 
-// one block: combine
-__global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, const float* acc, int have_sal) {
-  __shared__ float red[4];
-  const WS w(a.ws, a.B, a.Lv, a.d);
-  const int tid = threadIdx.x;
-  const float nwin = acc[0], nval = acc[1], ssum = acc[2];
+// launch 2, ONE 1024-thread block: the inter-video log-sum-exp rows and columns of sim / tau (thread per row, thread per column, online
+// softmax: one pass), then the five loss values.  (A last-arriver finalisation inside launch 1 would cost an agent-scope release + acquire per
+// block, ~3.5 us -- as much as this launch.)
+__global__ __launch_bounds__(1024) void loss_fwd2_kernel(const LossArgs a, int have_sal) {
+  __shared__ float red[16];
+  const WS w(a);
+  const int tid = threadIdx.x, B = a.B;
+  const float nwin = w.acc[0], nval = w.acc[1], ssum = w.acc[2];
   const bool sal_on = have_sal && ssum != 0.f;
+  if (sal_on) {
+    for (int task = tid; task < 2 * B; task += 1024) {
+      const bool col = task >= B;
+      const int i = col ? task - B : task;
+      float m = -INFINITY, sm = 0.f;
+      for (int j = 0; j < B; j++) {
+        const float x = (col ? w.sim[j * B + i] : w.sim[i * B + j]) / TAU;
+        if (x > m) { sm = sm * expf(m - x) + 1.f; m = x; } else sm += expf(x - m);
+      }
+      (col ? w.lse_c : w.lse_r)[i] = m + logf(sm);
+    }
+  }
+  __syncthreads();
   float inter = 0.f, intra = 0.f;
   if (sal_on) {
-    const int B = a.B;
-    for (int b = tid; b < B; b += blockDim.x) {
+    for (int b = tid; b < B; b += 1024) {
       const int p = (int)a.pos_idx[b];
       const float sd = w.sim[b * B + b] / TAU;
       inter += -(sd - w.lse_r[b]) - (sd - w.lse_c[b]);
@@ -213,12 +223,12 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, const
       intra += -(z - w.zr[b]) - (z - w.zc[p]);
     }
   }
-  inter = block_sum(inter, red) / (float)a.B;
-  intra = block_sum(intra, red) / (float)a.B;
+  inter = block_sum(inter, red) / (float)B;
+  intra = block_sum(intra, red) / (float)B;
   if (tid == 0) {
-    a.losses[0] = a.do_spans ? acc[3] / nwin : 0.f;
-    a.losses[1] = a.do_spans ? acc[4] / nwin : 0.f;
-    a.losses[2] = a.do_labels ? acc[5] / nval : 0.f;
+    a.losses[0] = a.do_spans ? w.acc[3] / nwin : 0.f;
+    a.losses[1] = a.do_spans ? w.acc[4] / nwin : 0.f;
+    a.losses[2] = a.do_labels ? w.acc[5] / nval : 0.f;
     a.losses[3] = sal_on ? inter : 0.f;
     a.losses[4] = sal_on ? intra : 0.f;
     a.losses[5] = sal_on ? 1.f : 0.f;
@@ -230,73 +240,69 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, const
 // ------------------------------------------------------------------------------------------------
 // gradients
 // ------------------------------------------------------------------------------------------------
-__global__ void loss_grad_small_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv, a.d);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = a.B * a.Lv;
+// launch 1 of the backward, by block role: [0, dvq blocks) the two small products dvh = dsim qhat, dqh = dsim^T vhat with
+// dsim[i][j] = go_inter / (B tau) (softmax_row + softmax_col - 2 delta) evaluated on the fly while the coefficients are staged (sim stays intact:
+// no separate dsim pass); then the per-clip gradients (spans, labels, d/d cosine), 256 clips per block.
+__device__ __forceinline__ float dsim_at(const LossArgs& a, const WS& w, int i, int j) {
+  const float sc = w.sim[i * a.B + j] / TAU, dl = (i == j) ? 1.f : 0.f;
+  return a.go[3] / ((float)a.B * TAU) * ((expf(sc - w.lse_r[i]) - dl) + (expf(sc - w.lse_c[j]) - dl));
+}
+__device__ __forceinline__ void loss_grad_clip(const LossArgs& a, const WS& w, int i) {
   const float nwin = a.losses[6], nval = a.losses[7];
   const bool sal_on = a.losses[5] != 0.f;
-  if (i < n) {
-    const int b = i / a.Lv, t = i % a.Lv;
-    const float win = a.ts_window[i], msk = a.ts_mask[i];
-    float gs0 = 0.f, gs1 = 0.f, gl = 0.f;
-    if (a.do_spans && win != 0.f) {
-      const float s0 = a.timestamp[2 * i] + a.pred_spans[2 * i], s1 = a.timestamp[2 * i + 1] + a.pred_spans[2 * i + 1];
-      const float g0 = a.span_nn[2 * i], g1 = a.span_nn[2 * i + 1];
-      const float e0 = s0 - g0, e1 = s1 - g1;
-      gs0 = a.go[0] * win * fminf(fmaxf(e0, -1.f), 1.f) / nwin;
-      gs1 = a.go[0] * win * fminf(fmaxf(e1, -1.f), 1.f) / nwin;
-      float I, U, H;
-      giou_terms(s0, s1, g0, g1, I, U, H);
-      const float dI0 = (I > 0.f && s0 > g0) ? -1.f : ((I > 0.f && s0 == g0) ? -0.5f : 0.f);
-      const float dI1 = (I > 0.f && s1 < g1) ? 1.f : ((I > 0.f && s1 == g1) ? 0.5f : 0.f);
-      const float dU0 = -1.f - dI0, dU1 = 1.f - dI1;
-      const float dH0 = (H > 0.f && s0 < g0) ? -1.f : ((H > 0.f && s0 == g0) ? -0.5f : 0.f);
-      const float dH1 = (H > 0.f && s1 > g1) ? 1.f : ((H > 0.f && s1 == g1) ? 0.5f : 0.f);
-      const float dg0 = (dI0 * U - I * dU0) / (U * U) + (dU0 * H - U * dH0) / (H * H);
-      const float dg1 = (dI1 * U - I * dU1) / (U * U) + (dU1 * H - U * dH1) / (H * H);
-      gs0 += -a.go[1] * dg0 / nwin;
-      gs1 += -a.go[1] * dg1 / nwin;
-    }
-    if (a.do_labels && msk != 0.f) {
-      const float p = a.pred_logits[i], y = win != 0.f ? 1.f : 0.f, wt = win != 0.f ? 1.f : a.eos_coef;
-      gl = a.go[2] * wt * (p - y) / fmaxf((1.f - p) * p, 1e-12f) / nval;
-    }
-    a.g_spans[2 * i] = gs0; a.g_spans[2 * i + 1] = gs1; a.g_logits[i] = gl;
-    float gz = 0.f;
-    if (sal_on) {
-      const int p = (int)a.pos_idx[b];
-      const float z = zval(a, w, b, t) / TAU;
-      const float dl = (t == p) ? 1.f : 0.f;
-      gz = a.go[4] / ((float)a.B * TAU) * ((expf(z - w.zr[b]) - dl) + (w.cnt[t] * expf(z - w.zc[t]) - dl));
-    }
-    a.g_cos[i] = gz;
+  const int b = i / a.Lv, t = i % a.Lv;
+  const float win = a.ts_window[i], msk = a.ts_mask[i];
+  float gs0 = 0.f, gs1 = 0.f, gl = 0.f;
+  if (a.do_spans && win != 0.f) {
+    const float s0 = a.timestamp[2 * i] + a.pred_spans[2 * i], s1 = a.timestamp[2 * i + 1] + a.pred_spans[2 * i + 1];
+    const float g0 = a.span_nn[2 * i], g1 = a.span_nn[2 * i + 1];
+    const float e0 = s0 - g0, e1 = s1 - g1;
+    gs0 = a.go[0] * win * fminf(fmaxf(e0, -1.f), 1.f) / nwin;
+    gs1 = a.go[0] * win * fminf(fmaxf(e1, -1.f), 1.f) / nwin;
+    float I, U, H;
+    giou_terms(s0, s1, g0, g1, I, U, H);
+    const float dI0 = (I > 0.f && s0 > g0) ? -1.f : ((I > 0.f && s0 == g0) ? -0.5f : 0.f);
+    const float dI1 = (I > 0.f && s1 < g1) ? 1.f : ((I > 0.f && s1 == g1) ? 0.5f : 0.f);
+    const float dU0 = -1.f - dI0, dU1 = 1.f - dI1;
+    const float dH0 = (H > 0.f && s0 < g0) ? -1.f : ((H > 0.f && s0 == g0) ? -0.5f : 0.f);
+    const float dH1 = (H > 0.f && s1 > g1) ? 1.f : ((H > 0.f && s1 == g1) ? 0.5f : 0.f);
+    const float dg0 = (dI0 * U - I * dU0) / (U * U) + (dU0 * H - U * dH0) / (H * H);
+    const float dg1 = (dI1 * U - I * dU1) / (U * U) + (dU1 * H - U * dH1) / (H * H);
+    gs0 += -a.go[1] * dg0 / nwin;
+    gs1 += -a.go[1] * dg1 / nwin;
   }
-}
-// dsim in place: sim[i][j] <- go_inter / (B tau) * (softmax_row + softmax_col - 2 delta)
-__global__ void loss_grad_sim_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv, a.d);
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.B * a.B) return;
-  const int i = idx / a.B, j = idx % a.B;
-  float g = 0.f;
-  if (a.losses[5] != 0.f) {
-    const float s = w.sim[idx] / TAU, dl = (i == j) ? 1.f : 0.f;
-    g = a.go[3] / ((float)a.B * TAU) * ((expf(s - w.lse_r[i]) - dl) + (expf(s - w.lse_c[j]) - dl));
+  if (a.do_labels && msk != 0.f) {
+    const float p = a.pred_logits[i], y = win != 0.f ? 1.f : 0.f, wt = win != 0.f ? 1.f : a.eos_coef;
+    gl = a.go[2] * wt * (p - y) / fmaxf((1.f - p) * p, 1e-12f) / nval;
   }
-  w.sim[idx] = g;
+  a.g_spans[2 * i] = gs0; a.g_spans[2 * i + 1] = gs1; a.g_logits[i] = gl;
+  float gz = 0.f;
+  if (sal_on) {
+    const int p = (int)a.pos_idx[b];
+    const float z = zval(a, w, b, t) / TAU;
+    const float dl = (t == p) ? 1.f : 0.f;
+    gz = a.go[4] / ((float)a.B * TAU) * ((expf(z - w.zr[b]) - dl) + (w.cnt[t] * expf(z - w.zc[t]) - dl));
+  }
+  a.g_cos[i] = gz;
 }
 
-// dvh[b][c] = sum_j dsim[b][j] qhat_j[c]   (blockIdx.y == 0),   dqh[b][c] = sum_i dsim[i][b] vhat_i[c]   (blockIdx.y == 1)
-// Block = 8 output rows x 256 columns (blockIdx.z): 64 column groups of 4 (16-byte loads) x 4 j-lanes that split the
+// dvh[b][c] = sum_j dsim[b][j] qhat_j[c]   (side 0),   dqh[b][c] = sum_i dsim[i][b] vhat_i[c]   (side 1)
+// dvq block = 8 output rows x 256 columns: 64 column groups of 4 (16-byte loads) x 4 j-lanes that split the
 // reduction; every source row loaded serves 8 outputs.
-__global__ __launch_bounds__(256) void loss_dvq_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv, a.d);
-  const int d = a.d, B = a.B, side = blockIdx.y;
-  if (a.losses[5] == 0.f) return;
+__global__ __launch_bounds__(256) void loss_bwd1_kernel(const LossArgs a, int dvq_blocks, int have_sal) {
+  const WS w(a);
+  const int d = a.d, B = a.B;
   __shared__ float coef[8][260];
   __shared__ float part[4][8][256];
-  const int b0 = blockIdx.x * 8, c0 = blockIdx.z * 256;
+  if ((int)blockIdx.x >= dvq_blocks) {
+    const int i = ((int)blockIdx.x - dvq_blocks) * 256 + threadIdx.x;
+    if (i < B * a.Lv) loss_grad_clip(a, w, i);
+    return;
+  }
+  if (!have_sal || a.losses[5] == 0.f) return;
+  const int nz = (d + 255) / 256;
+  const int bx = (int)blockIdx.x / (2 * nz), side = ((int)blockIdx.x / nz) & 1, bz = (int)blockIdx.x % nz;
+  const int b0 = bx * 8, c0 = bz * 256;
   const int cg = threadIdx.x & 63, jl = threadIdx.x >> 6;
   const int c = c0 + cg * 4;
   float acc[8][4];
@@ -309,8 +315,8 @@ __global__ __launch_bounds__(256) void loss_dvq_kernel(const LossArgs a) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < 8 * nj; idx += 256) {
       const int r = idx / nj, j = idx % nj, jj = j0 + j, bb = min(b0 + r, B - 1);
-      coef[r][j] = side == 0 ? w.sim[bb * B + jj] / fmaxf(w.qnorm[jj], EPS)
-                             : w.sim[jj * B + bb] / fmaxf(w.vnorm[jj * a.Lv + (int)a.pos_idx[jj]], EPS);
+      coef[r][j] = side == 0 ? dsim_at(a, w, bb, jj) / fmaxf(w.qnorm[jj], EPS)
+                             : dsim_at(a, w, jj, bb) / fmaxf(w.vnorm[jj * a.Lv + (int)a.pos_idx[jj]], EPS);
     }
     __syncthreads();
     if (c < d) {
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256) void loss_dvq_kernel(const LossArgs a) {
 // inter-video gradients in input space: g_vrow[b] = (dvh - vhat (vhat.dvh)) / |v_pos|, g_txt[b] = (dqh - qhat (qhat.dqh)) / |q|
 __global__ __launch_bounds__(256) void loss_grad_rows_kernel(const LossArgs a) {
   __shared__ float red[8];
-  const WS w(a.ws, a.B, a.Lv, a.d);
+  const WS w(a);
   const int b = blockIdx.x, d = a.d, tid = threadIdx.x;
   float* gv = a.g_vrow + (size_t)b * d;
   float* gt = a.g_txt + (size_t)b * d;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void loss_grad_rows_kernel(const LossArgs a) {
 // dense expansion for generic autograd callers:
 // g_vid[b, t, :] = gz * (qhat - cos vhat) / |v|  (+ g_vrow on the positive clip row)
 __global__ __launch_bounds__(256) void loss_expand_vid_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv, a.d);
+  const WS w(a);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.B * a.Lv) return;
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256) void loss_expand_vid_kernel(const LossArgs a) 
 }
 // g_txt[b, :] += sum_t gz (vhat_t - cos_t qhat) / |q|     (thread per column, loop over clips: no atomics)
 __global__ __launch_bounds__(256) void loss_expand_txt_kernel(const LossArgs a) {
-  const WS w(a.ws, a.B, a.Lv, a.d);
+  const WS w(a);
   const int b = blockIdx.x, d = a.d;
   if (a.losses[5] == 0.f) return;
   const float* q = a.txt + (size_t)b * d;
@@ -398,29 +404,27 @@ __global__ __launch_bounds__(256) void loss_expand_txt_kernel(const LossArgs a) 
 
 }  // namespace
 
-long long loss_ws_floats(int B, int Lv, int d) { return 3LL * B * Lv + (long long)B * B + 5LL * B + 2LL * Lv + 2LL * B * d + 64; }
+long long loss_ws_floats(int B, int Lv, int d) { return 3LL * B * Lv + (long long)B * B + 5LL * B + 2LL * Lv + 2LL * B * d + 96; }
 
 int launch_losses_fwd(const LossArgs& a, hipStream_t s) {
   const int n = a.B * a.Lv;
-  if (a.do_saliency && a.sal_tgt && a.pos_idx) {
-    hipLaunchKernelGGL(loss_stats_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_sim_kernel, dim3(a.B, cdiv(a.B, 64)), dim3(256), a.d * sizeof(float), s, a);
-  }
-  const WS w(a.ws, a.B, a.Lv, a.d);
   const bool have_sal = a.do_saliency && a.sal_tgt && a.pos_idx;
-  hipMemsetAsync(w.acc, 0, 8 * sizeof(float), s);
-  hipLaunchKernelGGL(loss_elem_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, w.acc);
-  if (have_sal) hipLaunchKernelGGL(loss_lse_kernel, dim3(cdiv(2 * a.B + a.Lv, 4)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a, w.acc, have_sal ? 1 : 0);
+  const WS w(a);
+  if (hipError_t e = hipMemsetAsync(w.acc, 0, (16 + (size_t)a.Lv) * sizeof(float), s)) return (int)e;      // accumulators + cnt
+  if (have_sal && !a.cos_c) hipLaunchKernelGGL(loss_stats_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);
+  const int sim_blocks = have_sal ? a.B * cdiv(a.B, 64) : 0, elem_blocks = cdiv(n, 256), lse_blocks = have_sal ? cdiv(a.B + a.Lv, 4) : 0;
+  hipLaunchKernelGGL(loss_fwd1_kernel, dim3(sim_blocks + elem_blocks + lse_blocks), dim3(256), a.d * sizeof(float), s, a, sim_blocks, elem_blocks,
+                     have_sal ? 1 : 0);
+  hipLaunchKernelGGL(loss_fwd2_kernel, dim3(1), dim3(1024), 0, s, a, have_sal ? 1 : 0);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
 int launch_losses_bwd(const LossArgs& a, hipStream_t s) {
   const int n = a.B * a.Lv;
-  hipLaunchKernelGGL(loss_grad_small_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a);
-  if (a.do_saliency && a.sal_tgt && a.pos_idx) {
-    hipLaunchKernelGGL(loss_grad_sim_kernel, dim3(cdiv(a.B * a.B, 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_dvq_kernel, dim3(cdiv(a.B, 8), 2, cdiv(a.d, 256)), dim3(256), 0, s, a);
+  const bool have_sal = a.do_saliency && a.sal_tgt && a.pos_idx;
+  const int dvq_blocks = have_sal ? cdiv(a.B, 8) * 2 * cdiv(a.d, 256) : 0;
+  hipLaunchKernelGGL(loss_bwd1_kernel, dim3(dvq_blocks + cdiv(n, 256)), dim3(256), 0, s, a, dvq_blocks, have_sal ? 1 : 0);
+  if (have_sal) {
     hipLaunchKernelGGL(loss_grad_rows_kernel, dim3(a.B), dim3(256), 0, s, a);
     if (a.g_vid) {     // dense mode: full gradients wrt vid_mem_proj / txt_mem_proj
       hipLaunchKernelGGL(loss_expand_vid_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a);

@@ -4,6 +4,7 @@
 // with sigmoid / sign (model/univtg.py:129-136,375-382), weighted text pooling + cosine saliency
 // (model/univtg.py:36-49,143-147) and their backward passes.
 #include "uvtg_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -704,6 +705,106 @@ __global__ __launch_bounds__(256) void saliency_cos_kernel(const SaliencyArgs a)
   }
 }
 
+// ---------------- the fused per-clip head pass (north_star: "(saliency, fg-prob, span offsets) in one pass") ----------------
+// ONE launch for everything behind the second conv layer: one 1024-thread block per sample pools its text tokens (weighted softmax pooling,
+// model/univtg.py:36-49) and then walks its clips, one wave per clip: the last Conv1d(k = 3) tap sums of both heads + sigmoid / sign
+// (model/univtg.py:129-136) AND cosine(vid_mem_proj, txt_mem_proj) + log-mask (model/univtg.py:143-147) -- pred_logits, pred_spans and
+// saliency_scores of a clip leave together.  Replaces heads_final_fwd + saliency_pool + saliency_cos (three launches, 88 us at config 2);
+// used when the batch gives every CU a block (B >= 128), else the per-clip grids above keep the chip full (L_v = 1200, B = 32).
+template <typename T>
+__global__ __launch_bounds__(1024) void heads_saliency_fwd_kernel(const HeadsFinalArgs h, const SaliencyArgs a) {
+  extern __shared__ float sm[];                 // [Lt] logits / alpha | [d] pooled | [16] scratch
+  float* s_alpha = sm;
+  float* s_pool = sm + a.Lt;
+  float* s_red = s_pool + a.d;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
+  const float* xt = a.x0 + ((size_t)b * a.S + a.Lv) * d;      // text rows
+  for (int t = wave; t < a.Lt; t += 16) {
+    float acc = 0.f;
+    for (int c = lane; c < d; c += 64) acc += xt[(size_t)t * d + c] * a.w_pool[c];
+    acc = wave_sum(acc);
+    if (lane == 0) s_alpha[t] = acc + (1.0f - a.txt_mask[b * a.Lt + t]) * (-1e30f);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float mx = -INFINITY;
+    for (int t = lane; t < a.Lt; t += 64) mx = fmaxf(mx, s_alpha[t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < a.Lt; t += 64) sum += expf(s_alpha[t] - mx);
+    sum = wave_sum(sum);
+    for (int t = lane; t < a.Lt; t += 64) {
+      const float al = expf(s_alpha[t] - mx) / sum;
+      s_alpha[t] = al;
+      if (a.alpha) a.alpha[b * a.Lt + t] = al;
+    }
+  }
+  __syncthreads();
+  float nsq = 0.f;
+  for (int c = tid; c < d; c += 1024) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < a.Lt; t++) acc += s_alpha[t] * xt[(size_t)t * d + c];
+    a.pooled[(size_t)b * d + c] = acc;
+    s_pool[c] = acc;
+    nsq += acc * acc;
+  }
+  nsq = wave_sum(nsq);
+  if (lane == 0) s_red[wave] = nsq;
+  __syncthreads();
+  float qn = 0.f;
+  for (int i = 0; i < 16; i++) qn += s_red[i];
+  qn = sqrtf(qn);
+  if (tid == 0 && a.qnorm) a.qnorm[b] = qn;
+  // ---- the clips of this sample, one wave each ----
+  const int fs = h.fstart ? h.fstart[b] : b * (h.Lv + 2);
+  const int kept = h.kept ? h.kept[b] : h.Lv;
+  const T* h2 = (const T*)h.h2;
+  for (int t = wave; t < a.Lv; t += 16) {
+    const int row = b * a.Lv + t;
+    // cosine saliency (lane owns 4 consecutive fp32 channels per pass)
+    const float* v = a.x0 + ((size_t)b * a.S + t) * d;
+    float dot = 0.f, vs = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 x = *(const f32x4*)(v + c), y = *(const f32x4*)(s_pool + c);
+      dot += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+      vs += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+    // last conv layer of both heads (lane owns 8 consecutive channels per pass); clips without a frame row (loss-only stream): constants
+    float z0 = 0.f, z1 = 0.f, zc = 0.f;
+    const bool framed = t < kept;
+    if (framed) {
+      for (int c = lane * 8; c < d; c += 512) {
+        float w0[24], w1[24], wc[24];
+        ldw24(h.w_span + (size_t)c * 3, w0); ldw24(h.w_span + ((size_t)d + c) * 3, w1); ldw24(h.w_cls + (size_t)c * 3, wc);
+#pragma unroll
+        for (int tap = 0; tap < 3; tap++) {
+          const T* hr = h2 + (size_t)(fs + t + tap) * h.ldh;
+          float hs[8], hc[8];
+          ld8<T>(hr + c, hs); ld8<T>(hr + d + c, hc);
+#pragma unroll
+          for (int e = 0; e < 8; e++) { z0 += hs[e] * w0[e * 3 + tap]; z1 += hs[e] * w1[e * 3 + tap]; zc += hc[e] * wc[e * 3 + tap]; }
+        }
+      }
+    }
+    dot = wave_sum(dot); vs = wave_sum(vs); z0 = wave_sum(z0); z1 = wave_sum(z1); zc = wave_sum(zc);
+    if (lane == 0) {
+      const float vn = sqrtf(vs);
+      const float cs = dot / (fmaxf(vn, 1e-8f) * fmaxf(qn, 1e-8f));
+      if (a.vnorm) a.vnorm[row] = vn;
+      if (a.cosv) a.cosv[row] = cs;
+      a.sal[row] = cs + (a.vid_mask[row] != 0.f ? 0.f : UVTG_LOG_TINY);
+      if (framed) {
+        h.pred_spans[(size_t)row * 2 + 0] = -1.0f / (1.0f + expf(-(z0 + h.b_span[0])));
+        h.pred_spans[(size_t)row * 2 + 1] = 1.0f / (1.0f + expf(-(z1 + h.b_span[1])));
+        h.pred_logits[row] = 1.0f / (1.0f + expf(-(zc + h.b_cls[0])));
+      } else {
+        h.pred_spans[(size_t)row * 2] = -0.5f; h.pred_spans[(size_t)row * 2 + 1] = 0.5f; h.pred_logits[row] = 0.5f;
+      }
+    }
+  }
+}
+
 // backward.  Everything that flows into the pre-encoder tokens x0 from saliency / vid_mem_proj / txt_mem_proj is added
 // to the encoder's gradient dx0 while the rows are re-packed per modality in bf16 for the input-projection backward
 // (three passes: dq per sample and column; softmax gradient per sample; then one wave per token row).
@@ -1048,6 +1149,19 @@ int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s) {
 int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(saliency_pool_kernel, dim3(a.B), dim3(1024), (a.Lt + 16) * sizeof(float), s, a);
   hipLaunchKernelGGL(saliency_cos_kernel, dim3(cdiv(a.B * a.Lv, 4)), dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+// heads' last layer + activations + text pooling + cosine saliency: ONE launch when every CU gets a sample, else the three per-stage launches
+int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hipStream_t s) {
+  static const bool off = getenv("UVTG_HEADFUSE_OFF") != nullptr;      // experiment: always the separate launches
+  const size_t sh = ((size_t)a.Lt + a.d + 16) * sizeof(float);
+  if (off || a.B < 128 || sh > 60 * 1024 || (a.d % 8)) {
+    if (int e = launch_heads_final_fwd(h, s)) return e;
+    return launch_saliency_fwd(a, s);
+  }
+  if (h.precise) hipLaunchKernelGGL(heads_saliency_fwd_kernel<float>, dim3(a.B), dim3(1024), sh, s, h, a);
+  else hipLaunchKernelGGL(heads_saliency_fwd_kernel<bf16_t>, dim3(a.B), dim3(1024), sh, s, h, a);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -266,6 +266,7 @@ struct SaliencyArgs {             // weighted text pooling + cosine saliency (mo
   float* dw_pool;                 // [d] atomically accumulated
 };
 int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s);
+int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hipStream_t s);   // heads_final_fwd + saliency_fwd, fused when B >= 128
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
@@ -285,6 +286,9 @@ struct LossArgs {
   const long long* pos_idx;   // [B] or null  (saliency_pos_labels[:, 0])
   float eos_coef;
   int do_spans, do_labels, do_saliency;
+  // optional (all three or none): per-clip cosine(vid_mem_proj, txt_mem_proj) [B, Lv], |vid_mem_proj| [B, Lv], |txt_mem_proj| [B] as the model
+  // forward's saliency pass already computed them (uvtg_forward_saliency_stats) -- saves the criterion's own pass over vid_mem_proj
+  const float* cos_c; const float* vnorm_c; const float* qnorm_c;
   float* ws;                  // workspace, uvtg_loss_ws_floats(B, Lv) floats
   float* losses;              // [8]: loss_b, loss_g, loss_f, loss_s_inter, loss_s_intra, active, Nwin, Nvalid
   // backward

@@ -334,7 +334,7 @@ class _CriterionFunction(torch.autograd.Function):
         losses = torch.empty(8, device=pl.device)
         _lib.check(lib.uvtg_criterion_fwd(B, Lv, d, which, eos_coef, _ptr(pl), _ptr(ps), _ptr(vid), vid.stride(0), vid.stride(1),
                                           _ptr(tx), _ptr(timestamp), _ptr(ts_mask), _ptr(ts_window), _ptr(span_nn), _ptr(sal),
-                                          _ptr(pos_idx), _ptr(ws), _ptr(losses), _stream()), "uvtg_criterion_fwd")
+                                          _ptr(pos_idx), _ptr(ws), _ptr(losses), None, None, None, _stream()), "uvtg_criterion_fwd")
         ctx.which, ctx.eos, ctx.ws = which, eos_coef, ws
         ctx.shapes = (pred_logits.shape, pred_spans.shape, txt.shape)
         ctx.save_for_backward(pl, ps, vid, tx, timestamp, ts_mask, ts_window, span_nn, sal, pos_idx, losses)
@@ -352,7 +352,7 @@ class _CriterionFunction(torch.autograd.Function):
         _lib.check(lib.uvtg_criterion_bwd(B, Lv, d, ctx.which, ctx.eos, _ptr(pl), _ptr(ps), _ptr(vid), vid.stride(0), vid.stride(1),
                                           _ptr(tx), _ptr(timestamp), _ptr(ts_mask), _ptr(ts_window), _ptr(span_nn), _ptr(sal),
                                           _ptr(pos_idx), _ptr(ctx.ws), _ptr(losses), _ptr(go), _ptr(g_l), _ptr(g_s), _ptr(g_v),
-                                          _ptr(g_t), _ptr(g_c), _ptr(g_r), _stream()), "uvtg_criterion_bwd")
+                                          _ptr(g_t), _ptr(g_c), _ptr(g_r), None, None, None, _stream()), "uvtg_criterion_bwd")
         sl, ss, st = ctx.shapes
         return (None, None, g_l.view(sl), g_s.view(ss), g_v, g_t.view(st)) + (None,) * 6
 

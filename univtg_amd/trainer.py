@@ -153,9 +153,13 @@ class TrainStep:
                      _ptr(self.x0), S * d, d, _ptr(self.txt_mem), _ptr(tg["timestamp"]), _ptr(tg["timestamp_mask"]),
                      _ptr(tg["timestamp_window"]), _ptr(tg["span_labels_nn"]), _ptr(sal), _ptr(pos), _ptr(self.loss_ws),
                      _ptr(self.losses))
-        chk(lib.uvtg_criterion_fwd(*crit_args, st), "uvtg_criterion_fwd")
+        # cosine / norms of the saliency branch: the forward's saliency pass left them in the workspace (no second pass over vid_mem_proj)
+        stats = (C.c_void_p(), C.c_void_p(), C.c_void_p())
+        chk(lib.uvtg_forward_saliency_stats(C.byref(dims), _ptr(self.ws), C.byref(stats[0]), C.byref(stats[1]), C.byref(stats[2])),
+            "uvtg_forward_saliency_stats")
+        chk(lib.uvtg_criterion_fwd(*crit_args, *stats, st), "uvtg_criterion_fwd")
         chk(lib.uvtg_criterion_bwd(*crit_args, _ptr(self.go), _ptr(self.g_logits), _ptr(self.g_spans), None,
-                                   _ptr(self.g_txt), _ptr(self.g_cos), _ptr(self.g_vrow), st), "uvtg_criterion_bwd")
+                                   _ptr(self.g_txt), _ptr(self.g_cos), _ptr(self.g_vrow), *stats, st), "uvtg_criterion_bwd")
         chk(lib.uvtg_backward(C.byref(dims), self.ptrs, _ptr(self.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                               _ptr(src_vid_mask), _ptr(self.x0), _ptr(self.pred_logits), _ptr(self.pred_spans), _ptr(self.txt_mem),
                               _ptr(self.g_logits), _ptr(self.g_spans), _ptr(self.g_cos), _ptr(self.g_txt), None, 0, 0,
