@@ -191,46 +191,58 @@ __global__ __launch_bounds__(256) void loss_fwd1_kernel(const LossArgs a, int si
   }
 }
 
-// launch 2, ONE 1024-thread block: the inter-video log-sum-exp rows and columns of sim / tau (thread per row, thread per column, online
-// softmax: one pass), then the five loss values.  (A last-arriver finalisation inside launch 1 would cost an agent-scope release + acquire per
-// block, ~3.5 us -- as much as this launch.)
-__global__ __launch_bounds__(1024) void loss_fwd2_kernel(const LossArgs a, int have_sal) {
-  __shared__ float red[16];
+// launch 2: one wave per sample i -- the inter-video log-sum-exp of row i and of column i of sim / tau (lanes stride the row / column:
+// coalesced, independent loads), the sample's inter- and intra-video NCE terms added into ws.acc[6] / [7]; the block that draws the last
+// ticket (ws.acc[8], zeroed with the accumulators) writes the five loss values behind one agent-scope acquire.  (First version: ONE
+// 1024-thread block with a thread per row / column -- 94 us of dependent strided loads, measured; the per-block release + acquire here costs
+// ~3.5 us and runs concurrently across the blocks.)
+__global__ __launch_bounds__(256) void loss_fwd2_kernel(const LossArgs a, int have_sal) {
+  __shared__ float red[4];
+  __shared__ unsigned s_ticket;
   const WS w(a);
-  const int tid = threadIdx.x, B = a.B;
-  const float nwin = w.acc[0], nval = w.acc[1], ssum = w.acc[2];
+  const int tid = threadIdx.x, lane = tid & 63, B = a.B;
+  const float ssum = w.acc[2];
   const bool sal_on = have_sal && ssum != 0.f;
-  if (sal_on) {
-    for (int task = tid; task < 2 * B; task += 1024) {
-      const bool col = task >= B;
-      const int i = col ? task - B : task;
-      float m = -INFINITY, sm = 0.f;
-      for (int j = 0; j < B; j++) {
-        const float x = (col ? w.sim[j * B + i] : w.sim[i * B + j]) / TAU;
-        if (x > m) { sm = sm * expf(m - x) + 1.f; m = x; } else sm += expf(x - m);
-      }
-      (col ? w.lse_c : w.lse_r)[i] = m + logf(sm);
+  const int i = blockIdx.x * 4 + (tid >> 6);
+  float inter = 0.f, intra = 0.f;
+  if (sal_on && i < B) {
+    float mr = -INFINITY, mc = -INFINITY;
+    for (int j = lane; j < B; j += 64) { mr = fmaxf(mr, w.sim[i * B + j]); mc = fmaxf(mc, w.sim[j * B + i]); }
+    mr = wave_max(mr); mc = wave_max(mc);
+    float sr = 0.f, sc = 0.f;
+    for (int j = lane; j < B; j += 64) { sr += expf((w.sim[i * B + j] - mr) / TAU); sc += expf((w.sim[j * B + i] - mc) / TAU); }
+    sr = wave_sum(sr); sc = wave_sum(sc);
+    if (lane == 0) {
+      const float lr = mr / TAU + logf(sr), lc = mc / TAU + logf(sc);
+      w.lse_r[i] = lr; w.lse_c[i] = lc;
+      const int p = (int)a.pos_idx[i];
+      const float sd = w.sim[i * B + i] / TAU;
+      inter = -(sd - lr) - (sd - lc);
+      const float z = zval(a, w, i, p) / TAU;
+      intra = -(z - w.zr[i]) - (z - w.zc[p]);
     }
+  }
+  inter = block_sum(inter, red);
+  intra = block_sum(intra, red);
+  if (tid == 0) {
+    if (sal_on) { atomicAdd(w.acc + 6, inter); atomicAdd(w.acc + 7, intra); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_ticket = __hip_atomic_fetch_add((unsigned*)(w.acc + 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  float inter = 0.f, intra = 0.f;
-  if (sal_on) {
-    for (int b = tid; b < B; b += 1024) {
-      const int p = (int)a.pos_idx[b];
-      const float sd = w.sim[b * B + b] / TAU;
-      inter += -(sd - w.lse_r[b]) - (sd - w.lse_c[b]);
-      const float z = zval(a, w, b, p) / TAU;
-      intra += -(z - w.zr[b]) - (z - w.zc[p]);
-    }
-  }
-  inter = block_sum(inter, red) / (float)B;
-  intra = block_sum(intra, red) / (float)B;
+  if (s_ticket != gridDim.x - 1) return;
   if (tid == 0) {
-    a.losses[0] = a.do_spans ? w.acc[3] / nwin : 0.f;
-    a.losses[1] = a.do_spans ? w.acc[4] / nwin : 0.f;
-    a.losses[2] = a.do_labels ? w.acc[5] / nval : 0.f;
-    a.losses[3] = sal_on ? inter : 0.f;
-    a.losses[4] = sal_on ? intra : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = __hip_atomic_load(w.acc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float nwin = v[0], nval = v[1];
+    a.losses[0] = a.do_spans ? v[3] / nwin : 0.f;
+    a.losses[1] = a.do_spans ? v[4] / nwin : 0.f;
+    a.losses[2] = a.do_labels ? v[5] / nval : 0.f;
+    a.losses[3] = sal_on ? v[6] / (float)B : 0.f;
+    a.losses[4] = sal_on ? v[7] / (float)B : 0.f;
     a.losses[5] = sal_on ? 1.f : 0.f;
     a.losses[6] = nwin;
     a.losses[7] = nval;
@@ -415,7 +427,7 @@ int launch_losses_fwd(const LossArgs& a, hipStream_t s) {
   const int sim_blocks = have_sal ? a.B * cdiv(a.B, 64) : 0, elem_blocks = cdiv(n, 256), lse_blocks = have_sal ? cdiv(a.B + a.Lv, 4) : 0;
   hipLaunchKernelGGL(loss_fwd1_kernel, dim3(sim_blocks + elem_blocks + lse_blocks), dim3(256), a.d * sizeof(float), s, a, sim_blocks, elem_blocks,
                      have_sal ? 1 : 0);
-  hipLaunchKernelGGL(loss_fwd2_kernel, dim3(1), dim3(1024), 0, s, a, have_sal ? 1 : 0);
+  hipLaunchKernelGGL(loss_fwd2_kernel, dim3(have_sal ? cdiv(a.B, 4) : 1), dim3(256), 0, s, a, have_sal ? 1 : 0);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

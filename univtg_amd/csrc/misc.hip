@@ -706,22 +706,29 @@ __global__ __launch_bounds__(256) void saliency_cos_kernel(const SaliencyArgs a)
 }
 
 // ---------------- the fused per-clip head pass (north_star: "(saliency, fg-prob, span offsets) in one pass") ----------------
-// ONE launch for everything behind the second conv layer: one 1024-thread block per sample pools its text tokens (weighted softmax pooling,
-// model/univtg.py:36-49) and then walks its clips, one wave per clip: the last Conv1d(k = 3) tap sums of both heads + sigmoid / sign
-// (model/univtg.py:129-136) AND cosine(vid_mem_proj, txt_mem_proj) + log-mask (model/univtg.py:143-147) -- pred_logits, pred_spans and
-// saliency_scores of a clip leave together.  Replaces heads_final_fwd + saliency_pool + saliency_cos (three launches, 88 us at config 2);
-// used when the batch gives every CU a block (B >= 128), else the per-clip grids above keep the chip full (L_v = 1200, B = 32).
-template <typename T>
-__global__ __launch_bounds__(1024) void heads_saliency_fwd_kernel(const HeadsFinalArgs h, const SaliencyArgs a) {
+// ONE launch for everything behind the second conv layer: one 512-thread block per sample pools its text tokens (weighted softmax pooling,
+// model/univtg.py:36-49) and then walks its clips: the last Conv1d(k = 3) tap sums of both heads + sigmoid / sign (model/univtg.py:129-136)
+// AND cosine(vid_mem_proj, txt_mem_proj) + log-mask (model/univtg.py:143-147) -- pred_logits, pred_spans and saliency_scores of a clip leave
+// together.  Replaces heads_final_fwd + saliency_pool + saliency_cos (three launches, 88 us at config 2).
+// Each wave owns a CONTIGUOUS run of clips and every lane the same 8 channels per pass for all of them, so that (1) the lane's 72 tap weights
+// per pass are fetched ONCE into registers (the per-clip kernel re-reads 288 B per lane and clip: 700 MB of L1/L2 traffic at config 2 against
+// 66 MB of hidden rows) and (2) the three hidden rows of a clip slide: one new row per clip.  (A first version -- 16 waves, weights re-read
+// per clip -- took 93 us: no faster than the three launches.)  Used when the batch gives every CU a block (B >= 128) in bf16 mode; else the
+// per-clip grids keep the chip full (L_v = 1200, B = 32).
+template <int NPASS>     // d = 512 * NPASS
+__global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFinalArgs h, const SaliencyArgs a) {
   extern __shared__ float sm[];                 // [Lt] logits / alpha | [d] pooled | [16] scratch
   float* s_alpha = sm;
   float* s_pool = sm + a.Lt;
   float* s_red = s_pool + a.d;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
   const float* xt = a.x0 + ((size_t)b * a.S + a.Lv) * d;      // text rows
-  for (int t = wave; t < a.Lt; t += 16) {
+  for (int t = wave; t < a.Lt; t += 8) {
     float acc = 0.f;
-    for (int c = lane; c < d; c += 64) acc += xt[(size_t)t * d + c] * a.w_pool[c];
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 x = *(const f32x4*)(xt + (size_t)t * d + c), wv = *(const f32x4*)(a.w_pool + c);
+      acc += x[0] * wv[0] + x[1] * wv[1] + x[2] * wv[2] + x[3] * wv[3];
+    }
     acc = wave_sum(acc);
     if (lane == 0) s_alpha[t] = acc + (1.0f - a.txt_mask[b * a.Lt + t]) * (-1e30f);
   }
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(1024) void heads_saliency_fwd_kernel(const HeadsFin
   }
   __syncthreads();
   float nsq = 0.f;
-  for (int c = tid; c < d; c += 1024) {
+  for (int c = tid; c < d; c += 512) {
     float acc = 0.f;
 #pragma unroll 8
     for (int t = 0; t < a.Lt; t++) acc += s_alpha[t] * xt[(size_t)t * d + c];
@@ -753,15 +760,34 @@ __global__ __launch_bounds__(1024) void heads_saliency_fwd_kernel(const HeadsFin
   if (lane == 0) s_red[wave] = nsq;
   __syncthreads();
   float qn = 0.f;
-  for (int i = 0; i < 16; i++) qn += s_red[i];
+  for (int i = 0; i < 8; i++) qn += s_red[i];
   qn = sqrtf(qn);
   if (tid == 0 && a.qnorm) a.qnorm[b] = qn;
-  // ---- the clips of this sample, one wave each ----
+  // ---- the clips of this sample: wave w owns clips [t0, t1) ----
   const int fs = h.fstart ? h.fstart[b] : b * (h.Lv + 2);
   const int kept = h.kept ? h.kept[b] : h.Lv;
-  const T* h2 = (const T*)h.h2;
-  for (int t = wave; t < a.Lv; t += 16) {
+  const bf16_t* h2 = (const bf16_t*)h.h2;
+  const int per = (a.Lv + 7) / 8, t0 = wave * per, t1 = min(a.Lv, t0 + per);
+  float w0[NPASS][24], w1[NPASS][24], wc[NPASS][24];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ps++) {
+    const int c = lane * 8 + 512 * ps;
+    ldw24(h.w_span + (size_t)c * 3, w0[ps]); ldw24(h.w_span + ((size_t)d + c) * 3, w1[ps]); ldw24(h.w_cls + (size_t)c * 3, wc[ps]);
+  }
+  // hidden rows fs + t - 1 + 1 .. : rows[k] = frame row fs + t + k (k = 0, 1, 2 are the clip's three taps), raw bf16 (span half | class half)
+  u32x4 rs[3][NPASS], rc[3][NPASS];
+  auto load_row = [&](int fr, u32x4 (&os)[NPASS], u32x4 (&oc)[NPASS]) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++) {
+      const bf16_t* hr = h2 + (size_t)fr * h.ldh + lane * 8 + 512 * ps;
+      os[ps] = *(const u32x4*)hr; oc[ps] = *(const u32x4*)(hr + d);
+    }
+  };
+  if (t0 < t1 && t0 < kept) { load_row(fs + t0, rs[0], rc[0]); load_row(fs + t0 + 1, rs[1], rc[1]); }
+  for (int t = t0; t < t1; t++) {
     const int row = b * a.Lv + t;
+    const bool framed = t < kept;
+    if (framed) load_row(fs + t + 2, rs[2], rc[2]);
     // cosine saliency (lane owns 4 consecutive fp32 channels per pass)
     const float* v = a.x0 + ((size_t)b * a.S + t) * d;
     float dot = 0.f, vs = 0.f;
@@ -770,22 +796,22 @@ __global__ __launch_bounds__(1024) void heads_saliency_fwd_kernel(const HeadsFin
       dot += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
       vs += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
     }
-    // last conv layer of both heads (lane owns 8 consecutive channels per pass); clips without a frame row (loss-only stream): constants
     float z0 = 0.f, z1 = 0.f, zc = 0.f;
-    const bool framed = t < kept;
     if (framed) {
-      for (int c = lane * 8; c < d; c += 512) {
-        float w0[24], w1[24], wc[24];
-        ldw24(h.w_span + (size_t)c * 3, w0); ldw24(h.w_span + ((size_t)d + c) * 3, w1); ldw24(h.w_cls + (size_t)c * 3, wc);
 #pragma unroll
-        for (int tap = 0; tap < 3; tap++) {
-          const T* hr = h2 + (size_t)(fs + t + tap) * h.ldh;
-          float hs[8], hc[8];
-          ld8<T>(hr + c, hs); ld8<T>(hr + d + c, hc);
+      for (int ps = 0; ps < NPASS; ps++)
 #pragma unroll
-          for (int e = 0; e < 8; e++) { z0 += hs[e] * w0[e * 3 + tap]; z1 += hs[e] * w1[e * 3 + tap]; zc += hc[e] * wc[e * 3 + tap]; }
-        }
-      }
+        for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float s_lo = __uint_as_float(rs[tap][ps][e] << 16), s_hi = __uint_as_float(rs[tap][ps][e] & 0xffff0000u);
+            const float c_lo = __uint_as_float(rc[tap][ps][e] << 16), c_hi = __uint_as_float(rc[tap][ps][e] & 0xffff0000u);
+            z0 += s_lo * w0[ps][(2 * e) * 3 + tap] + s_hi * w0[ps][(2 * e + 1) * 3 + tap];
+            z1 += s_lo * w1[ps][(2 * e) * 3 + tap] + s_hi * w1[ps][(2 * e + 1) * 3 + tap];
+            zc += c_lo * wc[ps][(2 * e) * 3 + tap] + c_hi * wc[ps][(2 * e + 1) * 3 + tap];
+          }
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) { rs[0][ps] = rs[1][ps]; rc[0][ps] = rc[1][ps]; rs[1][ps] = rs[2][ps]; rc[1][ps] = rc[2][ps]; }
     }
     dot = wave_sum(dot); vs = wave_sum(vs); z0 = wave_sum(z0); z1 = wave_sum(z1); zc = wave_sum(zc);
     if (lane == 0) {
@@ -1156,12 +1182,12 @@ int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
 int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hipStream_t s) {
   static const bool off = getenv("UVTG_HEADFUSE_OFF") != nullptr;      // experiment: always the separate launches
   const size_t sh = ((size_t)a.Lt + a.d + 16) * sizeof(float);
-  if (off || a.B < 128 || sh > 60 * 1024 || (a.d % 8)) {
+  if (off || h.precise || a.B < 128 || (a.d != 512 && a.d != 1024) || sh > 60 * 1024) {
     if (int e = launch_heads_final_fwd(h, s)) return e;
     return launch_saliency_fwd(a, s);
   }
-  if (h.precise) hipLaunchKernelGGL(heads_saliency_fwd_kernel<float>, dim3(a.B), dim3(1024), sh, s, h, a);
-  else hipLaunchKernelGGL(heads_saliency_fwd_kernel<bf16_t>, dim3(a.B), dim3(1024), sh, s, h, a);
+  if (a.d == 1024) hipLaunchKernelGGL(heads_saliency_fwd_kernel<2>, dim3(a.B), dim3(512), sh, s, h, a);
+  else hipLaunchKernelGGL(heads_saliency_fwd_kernel<1>, dim3(a.B), dim3(512), sh, s, h, a);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
