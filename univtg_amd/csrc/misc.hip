@@ -813,7 +813,7 @@ __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFina
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) { rs[0][ps] = rs[1][ps]; rc[0][ps] = rc[1][ps]; rs[1][ps] = rs[2][ps]; rc[1][ps] = rc[2][ps]; }
     }
-    dot = wave_sum(dot); vs = wave_sum(vs); z0 = wave_sum(z0); z1 = wave_sum(z1); zc = wave_sum(zc);
+    dot = wave_sum_dpp(dot); vs = wave_sum_dpp(vs); z0 = wave_sum_dpp(z0); z1 = wave_sum_dpp(z1); zc = wave_sum_dpp(zc);      // (DPP: no LDS crossbar round trips)
     if (lane == 0) {
       const float vn = sqrtf(vs);
       const float cs = dot / (fmaxf(vn, 1e-8f) * fmaxf(qn, 1e-8f));

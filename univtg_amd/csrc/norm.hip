@@ -365,21 +365,6 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512, (NV * VEC <= 16) ? UVTG_
     }
   }
 }
-// wave64 sum without the LDS crossbar: four DPP steps inside each row of 16 lanes, then the four row sums through SGPRs
-// (6 dependent ds_bpermute round trips per __shfl_xor reduction otherwise -- the row loop below is a latency chain)
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);    // row_half_mirror
-  v += dpp_mov<0x140>(v);    // row_mirror
-  const int b = __float_as_int(v);      // (the builtin is typed int: a float argument would be converted by VALUE)
-  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
-         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
-}
-
 // The encoder's LayerNorm backward (bf16 streams, D <= 1024, no dropout / ReLU mask): same math as ln_bwd_kernel, built for the
 // HBM rate -- 164 MB per launch at config 2 (x, g in; dx scaled + unscaled out).
 //  * the next row's x / g (/ g2) are fetched, still PACKED (4 registers per 16 bytes), before the current row's math;
