@@ -258,9 +258,9 @@ int zero_frame(void* p, int B, int Lv, int row_bytes, hipStream_t s, const int* 
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-__global__ void concat2_kernel(const float* a, const float* b, float* dst, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { dst[i] = a[i]; dst[n + i] = b[i]; }
+__global__ void concat2_kernel(const float* a, const float* b, float* dst, const float* a2, const float* b2, float* dst2, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;       // two concatenations per launch (the merged conv biases of both conv layers)
+  if (i < n) { dst[i] = a[i]; dst[n + i] = b[i]; dst2[i] = a2[i]; dst2[n + i] = b2[i]; }
 }
 // gather token rows (b*S + off + t) of a fp32 [B*S, d] tensor into a compact bf16 [B*L, d] one
 __global__ void gather_rows_bf16_kernel(const float* src, int S, int off, int L, int d, bf16_t* dst, long long n4) {
@@ -276,6 +276,10 @@ __global__ void gather_rows_bf16_kernel(const float* src, int S, int off, int L,
 __global__ void add_vec_kernel(float* dst, const float* src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] += src[i];
+}
+__global__ void add_vec2_kernel(float* dst_a, const float* src_a, float* dst_b, const float* src_b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { dst_a[i] += src_a[i]; dst_b[i] += src_b[i]; }
 }
 
 #define TRY(x) do { int e__ = (x); if (e__) return e__; } while (0)
@@ -449,8 +453,7 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     TRY(launch_conv_w_fwd(P[m.tail(SP1W)], d, d, nullptr, w.wc1F, 3 * d, s));
     TRY(launch_conv_w_fwd(P[m.tail(CL1W)], d, d, nullptr, w.wc1F + cw, 3 * d, s));
   }
-  hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP0B)], P[m.tail(CL0B)], w.bc0, d);
-  hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP1B)], P[m.tail(CL1B)], w.bc1, d);
+  hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP0B)], P[m.tail(CL0B)], w.bc0, P[m.tail(SP1B)], P[m.tail(CL1B)], w.bc1, d);
   UVTG_CHECK_LAUNCH();
   if (tr) {
     // dgrad operands: conv0 merged [d, 3 * 2d] (taps flipped), conv1 per head [d, 3d]
@@ -464,8 +467,7 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     TRY(launch_cast_pad_f32(P[m.tail(VP0W)], d, m.c.Dv, w.vp0F, m.Kpv, s));
     TRY(launch_cast_pad_f32(P[m.tail(TP0W)], d, m.c.Dt, w.tp0F, m.Kpt, s));
   } else {
-    TRY(launch_cast_pad_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0B, m.Kpv, s));
-    TRY(launch_cast_pad_bf16(P[m.tail(TP0W)], d, m.c.Dt, w.tp0B, m.Kpt, s));
+    TRY(launch_cast_pad2_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0B, m.Kpv, P[m.tail(TP0W)], d, m.c.Dt, w.tp0B, m.Kpt, s));
     if (!tr) {
       cast(P[m.tail(VP1W)], w.vp1B, (long long)d * d);
       cast(P[m.tail(TP1W)], w.tp1B, (long long)d * d);
@@ -620,7 +622,7 @@ struct Fwd {
     const size_t es = fast ? 2 : 4;
     const int* fs = halo ? ws.pk.fstart : nullptr;
     const int* kc = halo ? ws.pk.kept : nullptr;
-    TRY(zero_frame(ws.vm_pad, B, Lv, (int)(d * es), s, fs, kc));
+    if (!packed) TRY(zero_frame(ws.vm_pad, B, Lv, (int)(d * es), s, fs, kc));      // (packed stream: unpack_vm wrote the frame's zero rows)
     if (!halo) {
       TRY(zero_frame(ws.h1_pad, B, Lv, (int)(2 * d * es), s));
       TRY(zero_frame(ws.h2_pad, B, Lv, (int)(2 * d * es), s));
@@ -693,8 +695,11 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
                            ws.pk, s));
   }
   uvtg_prof_section(2, 0, s);
-  TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, f.packed ? ws.pk.vin_of : nullptr, s));
-  if (f.tr && m.c.p_path > 0.f) TRY(launch_droppath_scales(ws.dps, 2 * m.c.E, m.c.B, m.c.p_path, m.c.seed, s));
+  {
+    const bool dp = f.tr && m.c.p_path > 0.f;       // (the DropPath factors of the step are drawn by the same launch)
+    TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, f.packed ? ws.pk.vin_of : nullptr, s,
+                        dp ? ws.dps : nullptr, 2 * m.c.E * m.c.B, m.c.p_path, m.c.seed));
+  }
   TRY(f.project(0, src_vid, x0));
   if (f.packed && f.Rv < m.Mv) TRY(launch_fill_dropped_rows(x0, ws.pk, pmode == PACK_FULL, m.c.B, m.S, m.c.Lv, m.c.d, s));
   TRY(f.project(1, src_txt, x0));
@@ -753,10 +758,10 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       if (zr.count >= UVTG_MAX_ZERO_RANGES) return -17;
       zr.off[zr.count] = off[i]; zr.n[zr.count] = (int)(off[i + 1] - off[i]); zr.count++;
     }
-    TRY(launch_zero_ranges(grads, zr, s));
+    // (the same launch zeroes the clipping-norm slots and the hybrid weight-gradient launch's tickets: was a memset)
+    TRY(launch_zero_ranges(grads, zr, s, ws.gnorm2, UVTG_SQSUM_FLOATS + ws.tnh_n_tickets));
     zr_keep = zr;
   }
-  if (hipError_t e = hipMemsetAsync(ws.gnorm2, 0, (UVTG_SQSUM_FLOATS + (size_t)ws.tnh_n_tickets) * sizeof(float), s)) return (int)e;   // (+ the hybrid launch's tickets)
   const int splits_M = 8, splits_v = 8;
   auto wgrad = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, int rows, int N, int K, float* out, int ldo, int cs,
                    float* dbias, int q_off, int Mq, int splits) {
@@ -830,8 +835,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       if (scatter_out) { g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1; }
     }
   };
-  TRY(zero_frame(ws.dh2_pad, B, Lv, 2 * d * 2, s, fs, kc));
-  if (!halo) TRY(zero_frame(ws.dh1_pad, B, Lv, 2 * d * 2, s));
+  if (!halo) TRY(zero_frame(ws.dh1_pad, B, Lv, 2 * d * 2, s));      // (dh2_pad's frame rows are zeroed by heads_final_bwd_dh itself)
   HeadsFinalArgs hf; memset(&hf, 0, sizeof(hf));
   hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.w_span = P[m.tail(SP2W)]; hf.b_span = P[m.tail(SP2B)];
   hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)]; hf.B = B; hf.Lv = Lv; hf.d = d; hf.fstart = fs; hf.kept = kc;
@@ -971,8 +975,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     const bool proj_batch = !pbatch_off && R >= 2048 && gemm_tn_batch_ok(pb);
     if (!proj_batch) {
       TRY(wgrad(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, 1, G(m.tail(t1 + 3)), 0, R, splits_v));
-      hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + (which == 0 ? d : 0), G(m.tail(t1 + 3)), d);
-      UVTG_CHECK_LAUNCH();
     }
     GemmArgs g = gemm_base(ws.dyP[which], d, which == 0 ? w.vp1T : w.tp1T, d, R, d, d);
     g.outF = ws.dA2[which]; g.ldoF = d;
@@ -986,8 +988,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     TRY(launch_ln_bwd(lb, s));
     if (proj_batch) {
       TRY(launch_gemm_tn_batch(pb, s));
-      hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + (which == 0 ? d : 0), G(m.tail(t1 + 3)), d);
-      UVTG_CHECK_LAUNCH();
     } else {
       TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
     }
@@ -1002,6 +1002,9 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
   }
+  // token-type rows: row 1 (video) / row 0 (text) receive the bias gradient of their modality's second projection (univtg.py:114-115), one launch
+  hipLaunchKernelGGL(add_vec2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + d, G(m.tail(VP1B)), G(m.tail(TOK)), G(m.tail(TP1B)), d);
+  UVTG_CHECK_LAUNCH();
   TRY(launch_sqsum_ranges(grads, zr_keep, ws.gnorm2, s));      // the gradients no weight-gradient launch assigned
   uvtg_prof_section(3, 1, s);
   return 0;

@@ -10,10 +10,21 @@ namespace {
 
 // ---------------- position table + key validity ----------------
 // skip (optional, [B*Lv]): rows with skip[row] < 0 have no packed row and nobody reads their table entry (pk.vin_of)
+// dps (optional): the n_dp = 2 E B DropPath factors of the step, drawn by the first blocks of this launch (was its own 5 us launch)
 __global__ void seq_prep_kernel(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
-                                const float* dim_t, float* pos, unsigned char* kvalid, const int* skip) {
+                                const float* dim_t, float* pos, unsigned char* kvalid, const int* skip,
+                                float* dps, int n_dp, float p_path, unsigned long long seed) {
   const int row = blockIdx.x;             // (b, t) over B*Lv
   const int b = row / Lv, t = row % Lv;
+  if (dps) {
+    const int i = row * blockDim.x + threadIdx.x;
+    if (i < n_dp) {
+      unsigned r[4];
+      philox4(seed, (unsigned long long)i, UVTG_RNG_PATH, r);
+      const float keep = 1.0f - p_path;
+      dps[i] = floorf(keep + u01(r[0])) / keep;     // drop_path(): mask = floor(keep + U[0,1)), x / keep * mask
+    }
+  }
   if (t == 0) {
     const int S = Lv + Lt;
     for (int s = threadIdx.x; s < S; s += blockDim.x)
@@ -60,7 +71,11 @@ __global__ void droppath_kernel(float* scales, int n, int B, float p, unsigned l
   scales[i] = floorf(keep + u01(r[0])) / keep;     // drop_path(): mask = floor(keep + U[0,1)), x / keep * mask
 }
 
-__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const ZeroRanges r) {
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const ZeroRanges r, float* extra, int n_extra) {
+  if ((int)blockIdx.x == r.count) {       // one more block: a second buffer (the clipping-norm slots + tickets of uvtg_backward; was a memset)
+    for (int i = threadIdx.x; i < n_extra; i += 256) extra[i] = 0.f;
+    return;
+  }
   float* p = base + r.off[blockIdx.x];
   for (int i = threadIdx.x; i < r.n[blockIdx.x]; i += 256) p[i] = 0.f;
 }
@@ -117,6 +132,17 @@ __global__ void cast_pad_kernel(const float* src, int rows, int cols, T* dst, in
   if (i >= (long long)rows * ld) return;
   const int r = (int)(i / ld), c = (int)(i % ld);
   dst[i] = cvt<T>(c < cols ? src[(size_t)r * cols + c] : 0.f);
+}
+// two zero-padded casts in one launch (blockIdx.y picks): the bf16 first-projection operands of both modalities
+__global__ void cast_pad2_bf16_kernel(const float* src0, int rows0, int cols0, bf16_t* dst0, int ld0,
+                                      const float* src1, int rows1, int cols1, bf16_t* dst1, int ld1) {
+  const bool second = blockIdx.y != 0;
+  const float* src = second ? src1 : src0; bf16_t* dst = second ? dst1 : dst0;
+  const int rows = second ? rows1 : rows0, cols = second ? cols1 : cols0, ld = second ? ld1 : ld0;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * ld) return;
+  const int r = (int)(i / ld), c = (int)(i % ld);
+  dst[i] = f2bf(c < cols ? src[(size_t)r * cols + c] : 0.f);
 }
 // dst[c][r] = src[r][c]  (bf16), 32x32 LDS tile
 __global__ void transpose_bf16_kernel(const float* src, int rows, int cols, bf16_t* dst, int ld) {
@@ -370,10 +396,15 @@ __global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, co
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, s) over B * Lv
   if (row >= B * Lv) return;
   const int b = row / Lv, s = row % Lv;
+  const u32x4 z = {0, 0, 0, 0};                 // dropped padded clips (beyond the conv halo): zero rows
+  {   // the two zero rows that frame the sample (the k = 3 convolution's padding): written here instead of by a zero_frame launch
+    const int fs0 = fstart ? fstart[b] : b * (Lv + 2), nk = kept ? kept[b] : Lv;
+    if (s == 0) for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + (size_t)fs0 * d + c) = z;
+    if (s == nk - 1) for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + (size_t)(fs0 + nk + 1) * d + c) = z;
+  }
   if (kept && s >= kept[b]) return;                         // ragged frames: a dropped clip has no frame row
   const int pk = pad2pack[b * S + s];
   const size_t src = (size_t)(pk < 0 ? 0 : pk) * d, dst = (size_t)((fstart ? fstart[b] : b * (Lv + 2)) + s + 1) * d;
-  const u32x4 z = {0, 0, 0, 0};                 // dropped padded clips (beyond the conv halo): zero rows
   for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + dst + c) = pk < 0 ? z : *(const u32x4*)(packed + src + c);
 }
 // conv-head gradient wrt the clip rows (padded layout) -> packed rows: valid clips copy, the representative gets the SUM over the
@@ -476,8 +507,14 @@ __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFina
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, u)
   if (row >= a.B * a.Lv) return;
   const int b = row / a.Lv, u = row % a.Lv, d = a.d;
-  if (a.kept && u >= a.kept[b]) return;
   const int fs = a.fstart ? a.fstart[b] : b * (a.Lv + 2);
+  {   // the two zero rows framing the sample's gradient rows (was a zero_frame launch)
+    const int nk = a.kept ? a.kept[b] : a.Lv;
+    const u32x4 z = {0, 0, 0, 0};
+    if (u == 0) for (int c = lane * 8; c < 2 * d; c += 512) *(u32x4*)(a.dh2 + (size_t)fs * a.lddh + c) = z;
+    if (u == nk - 1) for (int c = lane * 8; c < 2 * d; c += 512) *(u32x4*)(a.dh2 + (size_t)(fs + nk + 1) * a.lddh + c) = z;
+  }
+  if (a.kept && u >= a.kept[b]) return;
   const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(fs + u + 1) * a.ldh;
   bf16_t* out = a.dh2 + (size_t)(fs + u + 1) * a.lddh;
   constexpr int NPP = NP > 0 ? NP : 1;
@@ -1045,8 +1082,13 @@ int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S,
   return 0;
 }
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
-                    const float* dim_t, float* pos, unsigned char* kvalid, const int* skip, hipStream_t s) {
-  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, skip);
+                    const float* dim_t, float* pos, unsigned char* kvalid, const int* skip, hipStream_t s,
+                    float* dps, int n_dp, float p_path, unsigned long long seed) {
+  if (dps && (long long)B * Lv * 256 < n_dp) {        // (never at real shapes: the grid has B * Lv blocks of 256 threads)
+    if (int e = launch_droppath_scales(dps, n_dp / B, B, p_path, seed, s)) return e;
+    dps = nullptr;
+  }
+  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, skip, dps, n_dp, p_path, seed);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -1055,9 +1097,9 @@ int launch_droppath_scales(float* scales, int n, int B, float p, unsigned long l
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s) {
-  if (r.count <= 0) return 0;
-  hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count), dim3(256), 0, s, base, r);
+int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* extra, int n_extra) {
+  if (r.count <= 0 && !extra) return 0;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count + (extra ? 1 : 0)), dim3(256), 0, s, base, r, extra, n_extra);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -1095,6 +1137,13 @@ int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld
 int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s) {
   const long long n = (long long)rows * ld;
   hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst, ld);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_cast_pad2_bf16(const float* src0, int rows0, int cols0, bf16_t* dst0, int ld0, const float* src1, int rows1, int cols1, bf16_t* dst1, int ld1,
+                          hipStream_t s) {
+  const long long n0 = (long long)rows0 * ld0, n1 = (long long)rows1 * ld1, n = n0 > n1 ? n0 : n1;
+  hipLaunchKernelGGL(cast_pad2_bf16_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, s, src0, rows0, cols0, dst0, ld0, src1, rows1, cols1, dst1, ld1);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

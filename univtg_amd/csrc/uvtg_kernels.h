@@ -193,19 +193,22 @@ int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S,
 
 int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask, hipStream_t s);
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
-                    const float* dim_t, float* pos, unsigned char* kvalid, const int* skip /* [B*Lv], < 0: row not needed; may be NULL */, hipStream_t s);
+                    const float* dim_t, float* pos, unsigned char* kvalid, const int* skip /* [B*Lv], < 0: row not needed; may be NULL */, hipStream_t s,
+                    float* dps = nullptr, int n_dp = 0, float p_path = 0.f, unsigned long long seed = 0 /* optional: also draw the DropPath factors */);
 int launch_droppath_scales(float* scales, int n_layers2, int B, float p, unsigned long long seed, hipStream_t s);
 int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
 int launch_cast_f32(const bf16_t* src, float* dst, long long n, hipStream_t s);
 // zero the float ranges [off[i], off[i] + n[i]) of base (the gradients no weight-gradient launch assigns)
 constexpr int UVTG_MAX_ZERO_RANGES = 224;
 struct ZeroRanges { long long off[UVTG_MAX_ZERO_RANGES]; int n[UVTG_MAX_ZERO_RANGES]; int count; };
-int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s);
+int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* extra = nullptr, int n_extra = 0);   // extra: one more float buffer zeroed by the same launch
 constexpr int UVTG_SQSUM_FLOATS = 32 + 64 * 32;
 int launch_sqsum_ranges(const float* base, const ZeroRanges& r, float* sqsum, hipStream_t s);     // sqsum[0] += sum of squares over the ranges + the 64 slots
 int launch_sqsum(const float* x, long long n, float* sqsum, hipStream_t s);
 int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s);
 int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);
+int launch_cast_pad2_bf16(const float* src0, int rows0, int cols0, bf16_t* dst0, int ld0, const float* src1, int rows1, int cols1, bf16_t* dst1, int ld1,
+                          hipStream_t s);
 int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);  // dst[c][r]
 // batched forms for the per-step operand-cache rebuild: all casts / transposes / conv re-layouts of a step in one launch each
 constexpr int UVTG_MAX_PREP_OPS = 80;
