@@ -87,7 +87,7 @@ def test_wgrad_tn256(dev, M, N, K):
     (27392, [(1024, 1024)] * 16),                             # 256 tiles: whole tiles only
     (4100, [(256, 256)] * 4 + [(3072, 1024)] * 2),            # 100 tiles in halves, ragged last 64-row step
     (27392, [(1024, 1024)] * 18),                             # 288 tiles of 428 steps on 256 pieces of 482
-    (15700, [(1024, 1024), (1024, 2824), (520, 264)])])       # ragged N and K (the input projections' shapes): bounds-checked element stores
+    (15700, [(1024, 1024)] * 4 + [(1024, 2824), (520, 264)])])   # ragged N and K (the input projections' shapes): bounds-checked element stores
 def test_wgrad_tn256_hybrid_multi(dev, M, shapes):
     """gemm_tn256h_kernel (several weight gradients in one stream-K launch: whole tiles + cut tiles folded by the last arriver, NO reduce
     pass) vs fp64.  Launched several times on CHANGING operands into NaN-filled outputs with fresh slabs: a stale slab line, a missed

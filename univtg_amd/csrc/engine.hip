@@ -883,7 +883,9 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       cb.g[cb.count++] = t;
     }
     static const bool cbatch_off = getenv("UVTG_TN_CONVBATCH_OFF") != nullptr;
-    static const bool tail_off = getenv("UVTG_TN_TAILDEFER_OFF") != nullptr;     // experiment: conv / projection gradients in place (slab + reduce)
+    // conv / projection gradients through the reduce-free stream-K launch: measured SLOWER than their batched slab + reduce launches (groups with
+    // different row counts never walk their rows in step, taps store 4 bytes at a time): opt-in experiment (UVTG_TN_TAILDEFER=1)
+    static const bool tail_off = getenv("UVTG_TN_TAILDEFER") == nullptr;
     if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) { if (tail_off || !tn_tail(cb)) TRY(launch_gemm_tn_batch(cb, s)); }
     else for (auto& c : cw) TRY(conv_wgrad(c.dY, c.ldp, c.X, c.ldq, G(m.tail(c.w)), G(m.tail(c.b)), Rf));
   }
@@ -1003,7 +1005,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
     if (proj_batch) {
-      static const bool tail_off2 = getenv("UVTG_TN_TAILDEFER_OFF") != nullptr;
+      static const bool tail_off2 = getenv("UVTG_TN_TAILDEFER") == nullptr;
       if (tail_off2 || !tn_tail(pb)) TRY(launch_gemm_tn_batch(pb, s));
     } else {
       TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));

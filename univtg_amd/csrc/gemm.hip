@@ -1161,12 +1161,24 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
   int gs = l * per;                                            // next global step of this workgroup's piece
   const int ge = min(plan.total_steps, gs + per);
   if (gs >= ge) return;
+  // Segment order: the CUT tiles of the piece first (its head and / or tail), then the whole tiles.  With equal tiles every workgroup then
+  // walks its whole tiles from row 0 in step with its neighbours, and the tiles of a gradient -- which share their dY / X row panels through
+  // the XCD's L2 -- touch the same rows at the same time.  (In plain piece order half the workgroups start 158 steps into a tile: the panels
+  // of a row window were fetched twice, and the encoder launch took 1.28 instead of 0.89 ms.)
+  const int gs_begin = gs;
   int gi = 0;
+  for (int pass = 0; pass < 2; pass++) {
+  gs = gs_begin; gi = 0;
   while (gi + 1 < plan.count && gs >= plan.g[gi + 1].step_base) gi++;
   while (gs < ge) {
     const TNHGroup p = plan.g[gi];
     const int rel = gs - p.step_base, tile = rel / p.steps, st0 = rel - tile * p.steps;
     const int st1 = min(p.steps, st0 + (ge - gs));
+    if ((st0 == 0 && st1 == p.steps) != (pass == 1)) {      // pass 0: cut tiles only; pass 1: whole tiles only
+      gs += st1 - st0;
+      while (gi + 1 < plan.count && gs >= plan.g[gi + 1].step_base) gi++;
+      continue;
+    }
     const int tile_n = tile / p.tiles_k, tile_k = tile - tile_n * p.tiles_k;
     const int n0 = tile_n * 256, k0 = tile_k * 256;
     const int q_tap = p.ktap > 0 ? k0 / p.ktap : 0, kq0 = k0 - q_tap * (p.ktap > 0 ? p.ktap : 0);   // conv tap of this k tile
@@ -1384,6 +1396,7 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
     // next segment of this workgroup's piece
     gs += st1 - st0;
     while (gi + 1 < plan.count && gs >= plan.g[gi + 1].step_base) gi++;
+  }
   }
   if (plan.sqsum) {
     sq_total = wave_sum(sq_total);
