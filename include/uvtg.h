@@ -171,15 +171,13 @@ int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int 
 long long uvtg_wgrad_scratch_floats(int M, int N, int K);
 int uvtg_wgrad_bf16_ws(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, float* scratch,
                        long long scratch_floats, uvtg_stream_t stream);
-/* `count` (<= 24) weight gradients over the same M reduction rows in ONE launch and without a reduce pass: dW[i][N_i,K_i] = dY[i][M,N_i]^T *
- * X[i][M,K_i] (ASSIGNED), dbias[i][N_i] += colsum(dY[i]) (host arrays of device pointers; dbias or its entries may be NULL); N_i, K_i
- * multiples of 8.  Stream-K: the 256 x 256 tiles of all gradients are laid end to end as one sequence of 64-row steps, every workgroup takes
- * an equally long piece; a tile inside one piece goes straight to dW, a tile cut by a piece boundary has 2-4 parts that meet through
- * write-through slabs and one ticket per tile (the last part to arrive folds the others).  slabs: uvtg_wgrad_multi_slab_floats() floats,
- * 16-byte aligned; tickets: >= total tiles unsigned, ZEROED by the caller before the call.  -2: a plan this path does not take (a tile
- * would be cut into more than 4 parts, M < 1024: use uvtg_wgrad_bf16_ws per gradient).  uvtg_backward runs the encoder's 5 E weight
- * gradients through it -- and the conv-head / input-projection ones (conv taps, ragged K) in a second launch -- when no per-layer readiness
- * events are requested. */
+/* `count` (<= 24) weight gradients over the SAME M reduction rows in ONE launch and without a reduce pass: dW[i][N_i,K_i] = dY[i][M,N_i]^T *
+ * X[i][M,K_i] (ASSIGNED), dbias[i][N_i] += colsum(dY[i]) (host arrays of device pointers; dbias or its entries may be NULL).  Every N_i, K_i
+ * a multiple of 256.  Whole 256 x 256 tiles per workgroup; the tiles that do not fill a last CU round are cut into <= 3 row ranges whose
+ * parts meet through write-through slabs and one ticket per tile (the last part to arrive folds the others).  slabs:
+ * uvtg_wgrad_multi_slab_floats(total tiles) floats, 16-byte aligned; tickets: >= total tiles unsigned, ZEROED by the caller before the call.
+ * -2: shapes / split this path does not take (use uvtg_wgrad_bf16_ws per gradient).  uvtg_backward runs the encoder's 5 E weight gradients
+ * through it when no per-layer readiness events are requested. */
 long long uvtg_wgrad_multi_slab_floats(int total_tiles);
 int uvtg_wgrad_bf16_multi(int count, const void* const* dY, const int* N, const void* const* X, const int* K, float* const* dW,
                           float* const* dbias, int M, float* slabs, long long slab_floats, unsigned* tickets, int n_tickets,

@@ -212,9 +212,7 @@ struct WSpace {
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
       {   // clipping-norm slots, directly followed by the tickets of the hybrid weight-gradient launch: ONE memset zeroes both
         const int dt = (int)((d + 255) / 256), ft = (int)((F + 255) / 256);
-        // one ticket per 256 x 256 tile: the encoder's launch (E x (2 d F + 4 d d)) and, in its own range behind it, the launch of the conv-head
-        // and input-projection gradients (4 x d x 3d, 2 x d x d, d x Dv, d x Dt)
-        tnh_n_tickets = (int)E * (2 * dt * ft + 4 * dt * dt) + 4 * dt * 3 * dt + 2 * dt * dt + dt * ((m.c.Dv + 255) / 256 + (m.c.Dt + 255) / 256);
+        tnh_n_tickets = (int)E * (2 * dt * ft + 4 * dt * dt);
         gnorm2 = a.take<float>(UVTG_SQSUM_FLOATS + (size_t)tnh_n_tickets);
         tnh_tickets = (unsigned*)(gnorm2 + UVTG_SQSUM_FLOATS);
         tnh_slab_floats = gemm_tn_multi_slab_floats(tnh_n_tickets, 320);
@@ -793,38 +791,29 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // With events (data-parallel overlap) each layer's two batches run in place, as before, and their gradients are final at the event.
   static const bool defer_off = getenv("UVTG_TN_DEFER_OFF") != nullptr;
   const bool defer = n_events == 0 && !defer_off;
-  // (a second deferred list -- the conv-head and input-projection gradients -- goes out as one more stream-K launch at the end of backward)
-  GemmTNBatch deferred[2 * MAXE], deferred_tail[4]; int n_deferred = 0, n_deferred_tail = 0;
-  const int enc_tickets = (int)E * (2 * ((d + 255) / 256) * ((F + 255) / 256) + 4 * ((d + 255) / 256) * ((d + 255) / 256));
+  GemmTNBatch deferred[2 * MAXE]; int n_deferred = 0;
   auto tn_encoder = [&](const GemmTNBatch& b) -> int {
     if (!defer) return tn_batch(b);
     deferred[n_deferred++] = b;
     return 0;
   };
-  auto tn_tail = [&](const GemmTNBatch& b) -> int {        // conv / projection batches: returns 1 when deferred
-    if (!defer || n_deferred_tail >= 4) return 0;
-    deferred_tail[n_deferred_tail++] = b;
-    return 1;
-  };
-  auto tn_flush_list = [&](GemmTNBatch* list, int n, unsigned* tickets, int n_tickets) -> int {
-    if (!n) return 0;
-    GemmTNMulti mu; mu.count = 0; mu.slabs = ws.tnh_slabs; mu.slab_floats = ws.tnh_slab_floats; mu.tickets = tickets; mu.n_tickets = n_tickets;
+  auto tn_flush = [&]() -> int {
+    if (!n_deferred) return 0;
+    GemmTNMulti mu; mu.count = 0; mu.slabs = ws.tnh_slabs; mu.slab_floats = ws.tnh_slab_floats; mu.tickets = ws.tnh_tickets; mu.n_tickets = ws.tnh_n_tickets;
     bool fits = true;
-    for (int i = 0; i < n && fits; i++)
-      for (int j = 0; j < list[i].count; j++) {
+    for (int i = 0; i < n_deferred && fits; i++)
+      for (int j = 0; j < deferred[i].count; j++) {
         if (mu.count >= UVTG_TNH_MAX_GROUPS) { fits = false; break; }
-        mu.g[mu.count++] = list[i].g[j];
+        mu.g[mu.count++] = deferred[i].g[j];
       }
     if (fits && gemm_tn_multi_ok(mu)) return launch_gemm_tn_multi(mu, s);
-    for (int i = 0; i < n; i++) TRY(tn_batch(list[i]));                         // shapes the stream-K launch does not take: the split + reduce path
+    for (int i = 0; i < n_deferred; i++) TRY(tn_batch(deferred[i]));            // shapes the hybrid launch does not take: the split + reduce path
     return 0;
   };
-  auto tn_flush = [&]() -> int { const int e = tn_flush_list(deferred, n_deferred, ws.tnh_tickets, enc_tickets); n_deferred = 0; return e; };
-  auto tn_flush_tail = [&]() -> int {
-    const int e = tn_flush_list(deferred_tail, n_deferred_tail, ws.tnh_tickets + enc_tickets, ws.tnh_n_tickets - enc_tickets);
-    n_deferred_tail = 0;
-    return e;
-  };
+  // (The conv-head and input-projection gradients stay on the batched slab + reduce launches.  A stream-K generalisation of the hybrid kernel
+  // -- tiles of all groups end to end, equal pieces per workgroup, conv taps and ragged K in its epilogue -- was built and measured in round 3:
+  // correct, and SLOWER on both launches (encoder 1.27 vs 0.89 ms, tail 0.71 vs 0.61 ms): cutting every third tile breaks up the sets of tiles
+  // that share a dY / X row panel through one XCD's L2 at the same time, which the whole-groups-first plan keeps together.)
   // weight gradient of one Conv1d(k=3): dW[n][c][tap] = sum_rows dY[row][n] * X[row + tap - 1][c] over the zero-framed rows.
   // One launch over K = 3 d (the k tiles pick their tap's row offset) when the 256-tile kernel takes it, else one per tap.
   auto conv_wgrad = [&](const bf16_t* dY, int ldp, const bf16_t* X, int ldq, float* dW, float* dBi, int rows) -> int {
@@ -883,10 +872,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       cb.g[cb.count++] = t;
     }
     static const bool cbatch_off = getenv("UVTG_TN_CONVBATCH_OFF") != nullptr;
-    // conv / projection gradients through the reduce-free stream-K launch: measured SLOWER than their batched slab + reduce launches (groups with
-    // different row counts never walk their rows in step, taps store 4 bytes at a time): opt-in experiment (UVTG_TN_TAILDEFER=1)
-    static const bool tail_off = getenv("UVTG_TN_TAILDEFER") == nullptr;
-    if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) { if (tail_off || !tn_tail(cb)) TRY(launch_gemm_tn_batch(cb, s)); }
+    if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) TRY(launch_gemm_tn_batch(cb, s));
     else for (auto& c : cw) TRY(conv_wgrad(c.dY, c.ldp, c.X, c.ldq, G(m.tail(c.w)), G(m.tail(c.b)), Rf));
   }
   {                                             // conv layer 0 dgrad -> dvm (bf16; clip rows [B * Lv], or frame rows on the loss-only stream)
@@ -1005,8 +991,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
     if (proj_batch) {
-      static const bool tail_off2 = getenv("UVTG_TN_TAILDEFER") == nullptr;
-      if (tail_off2 || !tn_tail(pb)) TRY(launch_gemm_tn_batch(pb, s));
+      TRY(launch_gemm_tn_batch(pb, s));
     } else {
       TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
     }
@@ -1021,7 +1006,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
     TRY(launch_ln_bwd(lb, s));
   }
-  TRY(tn_flush_tail());                          // conv-head + input-projection weight gradients: one stream-K launch (single-rank steps)
   // token-type rows: row 1 (video) / row 0 (text) receive the bias gradient of their modality's second projection (univtg.py:114-115), one launch
   hipLaunchKernelGGL(add_vec2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + d, G(m.tail(VP1B)), G(m.tail(TOK)), G(m.tail(TP1B)), d);
   UVTG_CHECK_LAUNCH();

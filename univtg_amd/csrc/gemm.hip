@@ -1108,30 +1108,31 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
 
 
 // ------------------------------------------------------------------------------------------------
-// gemm_tn256h: SEVERAL weight gradients in ONE launch with NO reduce pass (round 3).
+// gemm_tn256h ("hybrid"): SEVERAL weight gradients over the same reduction rows in ONE launch with NO reduce pass.
 // The split-M kernel above pays for parallelism with partial slabs: a 1024 x 1024 gradient is 16 tiles, so its M rows are cut 8-16 ways to
-// fill 256 CUs, every unit writes a 256 KB fp32 slab and gemm_tn_reduce_kernel folds them (0.25 ms of the round-2 training step, plus the slab
-// writes inside the units).  Here the 256 x 256 tiles of ALL groups of a launch are laid end to end as one sequence of 64-row K steps
-// (stream-K: a tile of a group with M rows is ceil(M / 64) steps) and every workgroup takes one contiguous, equally long piece of it.  A tile
-// that lies inside one piece is finished by that workgroup (results straight to the gradient buffer, bias gradient and squared norm included);
-// a tile cut by a piece boundary has 2 (rarely 3-4) parts that meet without a second kernel: every part stores its fp32 partial tile
-// write-through (sc1), every storing wave drains vmcnt(0), one lane takes a ticket (device-scope atomic), and the part that draws the LAST
-// ticket re-reads the other parts' slabs behind ONE agent-scope acquire, adds its own registers and writes the gradient
-// (cdna_hip_programming.md Guideline 16, "splitk-seam": publish write-through, combine by the last arriver; nothing spins, so no residency
-// assumption).  At config 2 the encoder's 20 gradients are 384 tiles of 316 steps on 256 workgroups: one whole tile + one half per workgroup.
-// Groups may differ in rows, shape, conv taps (Q row offset per tap tile, stride-3 outputs) and ragged N / K (bounds-checked element stores).
+// fill 256 CUs, every unit writes a 256 KB fp32 slab and gemm_tn_reduce_kernel folds them (0.25 ms of the 7.5 ms training step, plus the
+// slab writes inside the units).  With the weight gradients of ALL encoder layers deferred to the end of the encoder backward there are
+// 384 tiles over the same rows: each workgroup takes WHOLE tiles (tile ids [0, full_tiles): results go straight to the gradient buffer)
+// and the `total_tiles - full_tiles` remaining tiles are cut into `nsplit` row ranges (2 at config 2) so that the last round fills the
+// chip too.  The parts of a split tile meet without a second kernel: every part stores its fp32 slab write-through (sc1), takes a ticket
+// (one device-scope atomic per part), and the part that draws the last ticket re-reads the other slabs behind ONE agent-scope acquire, adds
+// its own registers and writes the gradient (cdna_hip_programming.md Guideline 16, "splitk-seam": publish write-through, combine by the last
+// arriver; nothing spins, so no residency assumption).  A workgroup runs its split part FIRST: the parts of a tile then finish together.
+// Restrictions (the launcher falls back to the slab + reduce path otherwise): N, K multiples of 256, contiguous outputs, no conv taps.
 // ------------------------------------------------------------------------------------------------
 constexpr int TNH_SLAB = 65536 + 256;            // floats per part: the 256 x 256 partial tile + 256 bias-gradient partials
-struct TNHGroup {
-  const bf16_t* P; const bf16_t* Q; float* out; float* dbias;
-  int ldp, ldq, ldo, tiles_k, tile_base, steps, step_base, N, K, q_row_off, ktap, col_stride;
-  unsigned bytes_p, bytes_q;
-};
+struct TNHGroup { const bf16_t* P; const bf16_t* Q; float* out; float* dbias; int ldp, ldq, ldo, tiles_k, tile_base; unsigned bytes_p, bytes_q; };
 struct TNHPlan {
   TNHGroup g[UVTG_TNH_MAX_GROUPS];
-  int count, total_steps, per;                   // workgroup l owns global steps [l * per, (l + 1) * per)
+  int count, M, steps_total, total_tiles, full_tiles, nsplit, steps_per;
   float* slabs; unsigned* tickets; float* sqsum;
 };
+// PF: L2 touch-ahead.  The operand panels of a step come from HBM (2 GB of activations and gradients per launch: nothing stays in a cache), and
+// the staging DMA runs ONE step (~1.9 us) ahead -- about one loaded HBM round trip, so part of every miss is exposed (the stream-K experiment
+// showed how sensitive the K loop is: with the L2 sharing of the row panels broken it ran 40 % slower).  With PF every thread touches ONE
+// 128-byte line of the rows the DMA will fetch `PF` steps later (64 rows x 2 panels x 4 lines = 512 lines = one per thread; a discarded dword
+// load, issued LAST in the step so that the step's waits can be vmcnt(1)): the HBM latency is paid by the touch, the DMA hits L2.
+template <int PF>
 __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   __shared__ unsigned s_ticket;
@@ -1156,32 +1157,21 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
     const int k = wn * 64 + j * 32 + 16 * qd + 4 * (i16 & 3);
     boff[j] = 32768 + (8 * g + mr) * 512 + ((((k >> 3) ^ (mr << 2))) << 4) + (k & 7) * 2;
   }
+  const int n_split_tiles = plan.total_tiles - plan.full_tiles;
   float sq_total = 0.f;
-  const int per = plan.per;
-  int gs = l * per;                                            // next global step of this workgroup's piece
-  const int ge = min(plan.total_steps, gs + per);
-  if (gs >= ge) return;
-  // Segment order: the CUT tiles of the piece first (its head and / or tail), then the whole tiles.  With equal tiles every workgroup then
-  // walks its whole tiles from row 0 in step with its neighbours, and the tiles of a gradient -- which share their dY / X row panels through
-  // the XCD's L2 -- touch the same rows at the same time.  (In plain piece order half the workgroups start 158 steps into a tile: the panels
-  // of a row window were fetched twice, and the encoder launch took 1.28 instead of 0.89 ms.)
-  const int gs_begin = gs;
-  int gi = 0;
-  for (int pass = 0; pass < 2; pass++) {
-  gs = gs_begin; gi = 0;
-  while (gi + 1 < plan.count && gs >= plan.g[gi + 1].step_base) gi++;
-  while (gs < ge) {
+  // unit list of this workgroup: its part of a split tile first, then whole tiles l, l + grid, ...
+  int tile_g = (l < n_split_tiles * plan.nsplit) ? plan.full_tiles + l / plan.nsplit : l;
+  int part = (l < n_split_tiles * plan.nsplit) ? l % plan.nsplit : -1;
+  if (part < 0 && tile_g >= plan.full_tiles) return;
+  while (true) {
+    int gi = 0;
+    while (gi + 1 < plan.count && tile_g >= plan.g[gi + 1].tile_base) gi++;
     const TNHGroup p = plan.g[gi];
-    const int rel = gs - p.step_base, tile = rel / p.steps, st0 = rel - tile * p.steps;
-    const int st1 = min(p.steps, st0 + (ge - gs));
-    if ((st0 == 0 && st1 == p.steps) != (pass == 1)) {      // pass 0: cut tiles only; pass 1: whole tiles only
-      gs += st1 - st0;
-      while (gi + 1 < plan.count && gs >= plan.g[gi + 1].step_base) gi++;
-      continue;
-    }
-    const int tile_n = tile / p.tiles_k, tile_k = tile - tile_n * p.tiles_k;
+    const int tile = tile_g - p.tile_base;
+    const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * 256, k0 = tile_k * 256;
-    const int q_tap = p.ktap > 0 ? k0 / p.ktap : 0, kq0 = k0 - q_tap * (p.ktap > 0 ? p.ktap : 0);   // conv tap of this k tile
+    const int st0 = part < 0 ? 0 : part * plan.steps_per;
+    const int st1 = part < 0 ? plan.steps_total : min(plan.steps_total, st0 + plan.steps_per);
     const i32x4 rp = tn_rsrc(p.P, p.bytes_p), rq = tn_rsrc(p.Q, p.bytes_q);
     unsigned vp[4], vq[4];
 #pragma unroll
@@ -1189,9 +1179,15 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
       const int rr = (wave * 4 + i) * 2 + g;
       const int cs = (l31 ^ ((rr & 3) << 2)) * 8;
       vp[i] = (unsigned)(((st0 * 64 + rr) * p.ldp + n0 + cs) * 2);
-      vq[i] = (unsigned)(((st0 * 64 + rr + p.q_row_off + q_tap) * p.ldq + kq0 + cs) * 2);   // negative rows wrap to out-of-range: zeros
+      vq[i] = (unsigned)(((st0 * 64 + rr) * p.ldq + k0 + cs) * 2);
     }
     const unsigned dp = (unsigned)(64 * p.ldp * 2), dq = (unsigned)(64 * p.ldq * 2);
+    // touch-ahead: waves 0-3 walk the P panel, waves 4-7 the Q panel; thread = (row of the step, 128-byte line of the 512-byte row segment)
+    const int pf_q = wave >> 2;
+    const i32x4 rpf = pf_q ? rq : rp;
+    unsigned vpf = (unsigned)((((st0 + PF) * 64 + ((tid & 255) >> 2)) * (pf_q ? p.ldq : p.ldp) + (pf_q ? k0 : n0)) * 2 + (tid & 3) * 128);
+    const unsigned dpf = pf_q ? dq : dp;
+    unsigned junk = 0;
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -1201,18 +1197,26 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.dbias && tile_k == 0 && wn == 0;
-    __syncthreads();                          // the previous segment's epilogue is done with the staging LDS
+    __syncthreads();                          // the previous unit's epilogue is done with the staging LDS
+    if (st0 < st1) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      tn_dma16(rp, vp[i], lds0 + (unsigned)(wave * 4096 + i * 1024));
-      tn_dma16(rq, vq[i], lds0 + (unsigned)(wave * 4096 + 32768 + i * 1024));
-      vp[i] += dp; vq[i] += dq;
+      for (int i = 0; i < 4; i++) {
+        tn_dma16(rp, vp[i], lds0 + (unsigned)(wave * 4096 + i * 1024));
+        tn_dma16(rq, vq[i], lds0 + (unsigned)(wave * 4096 + 32768 + i * 1024));
+        vp[i] += dp; vq[i] += dq;
+      }
+      if constexpr (PF > 0) {      // the lines of steps st0 + 1 .. st0 + PF - 1 (iteration st touches step st + PF); the youngest VMEM op is a touch from here on
+#pragma unroll
+        for (int k = 1; k < PF; k++)
+          asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(junk) : "v"(vpf - (unsigned)(PF - k) * dpf), "s"(rpf) : "memory");
+      }
     }
     auto main_loop = [&](auto with_bias) {
       constexpr bool BIAS = decltype(with_bias)::value;
       for (int st = st0; st < st1; st++) {
         const int cur = (st - st0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PF > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // every DMA piece of this step landed; the youngest touch may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const unsigned char* base = smem256 + cur * 65536;
         const unsigned sb = lds0 + (unsigned)((cur ^ 1) * 65536 + wave * 4096);
@@ -1241,6 +1245,12 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
               tn_dma16(rp, vp[i], sb + i * 1024);
               tn_dma16(rq, vq[i], sb + 32768 + i * 1024);
               vp[i] += dp; vq[i] += dq;
+            }
+          }
+          if constexpr (PF > 0) {
+            if (ks == 2) {           // behind the step's last DMA piece: the next step's wait is vmcnt(1)
+              asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(junk) : "v"(vpf), "s"(rpf) : "memory");
+              vpf += dpf;
             }
           }
           s16x8 a[4], b[2];
@@ -1282,6 +1292,7 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
     };
     if (do_bias) main_loop(std::true_type{}); else main_loop(std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces issued past the last step must not land in the epilogue's LDS slabs
+    asm volatile("" :: "v"(junk));
     __syncthreads();
     // ---- epilogue ----  (buffer accesses: ONE per-lane byte offset + wave-uniform row offsets in SGPRs; with 64-bit row addresses
     // the unrolled store sequence kept ~60 address registers alive through the K loop and spilled)
@@ -1289,15 +1300,11 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
     const int c8 = (lane & 7) * 8;
     const int tcol = wn * 64 + c8;
     const unsigned vo_slab = (unsigned)(((lane >> 3) * 256 + tcol) * 4);
-    const bool whole = st0 == 0 && st1 == p.steps;
-    const int gtile = p.tile_base + tile;
-    // the workgroups whose pieces overlap this tile: w_lo .. w_hi (this one included); a part's slab is 2 w + 1 when the tile STARTS in
-    // w's piece (w == w_lo), 2 w when it continues from the previous workgroup
-    const int tstart = p.step_base + tile * p.steps;
-    const int w_lo = tstart / per, w_hi = (tstart + p.steps - 1) / per;
-    bool last = true;                                        // whole tile: this segment holds the final sums
-    if (!whole) {
-      float* slab = plan.slabs + (size_t)(2 * l + (l == w_lo ? 1 : 0)) * TNH_SLAB;
+    bool last = true;                                        // whole tile: this unit holds the final sums
+    if (part >= 0) {
+      // split part: publish the partial tile write-through, take a ticket; the last part of the tile to arrive folds the others into its own values
+      const int slab_id = (tile_g - plan.full_tiles) * plan.nsplit + part;
+      float* slab = plan.slabs + (size_t)slab_id * TNH_SLAB;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, TNH_SLAB * 4, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -1324,19 +1331,18 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
       __syncthreads();                                        // ... before ONE lane takes the ticket
-      if (tid == 0) s_ticket = __hip_atomic_fetch_add(plan.tickets + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) s_ticket = __hip_atomic_fetch_add(plan.tickets + (tile_g - plan.full_tiles), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      last = s_ticket == (unsigned)(w_hi - w_lo);
+      last = s_ticket == (unsigned)(plan.nsplit - 1);
       if (last) {
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines of the other parts' slabs
         __syncthreads();
       }
     }
     if (last) {
-      const bool vec = p.col_stride == 1 && p.ktap == 0 && (p.ldo & 3) == 0 && n0 + 256 <= p.N && k0 + 256 <= p.K;   // aligned, fully inside
-      float* out = p.out + (size_t)n0 * p.ldo + (size_t)kq0 * p.col_stride + q_tap;
+      float* out = p.out + (size_t)n0 * p.ldo + k0;
       const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7ffffff0, 0x00020000);
-      const unsigned vo_out = (unsigned)(((lane >> 3) * p.ldo + tcol * p.col_stride) * 4);
+      const unsigned vo_out = (unsigned)(((lane >> 3) * p.ldo + tcol) * 4);
       const int row_bytes = p.ldo * 4;
       float sq = 0.f;
 #pragma unroll
@@ -1351,31 +1357,19 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
           const int row = q * 8 + (lane >> 3);
           f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
           const int trow0 = wm * 128 + i * 32 + q * 8;                     // wave-uniform
-          if (!whole) {
-            for (int o = w_lo; o <= w_hi; o++) {
-              if (o == l) continue;
-              const float* os = plan.slabs + (size_t)(2 * o + (o == w_lo ? 1 : 0)) * TNH_SLAB;
+          if (part >= 0) {
+            for (int o = 0; o < plan.nsplit; o++) {
+              if (o == part) continue;
+              const float* os = plan.slabs + (size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB;
               const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)os, 0, TNH_SLAB * 4, 0x00020000);
               const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab, trow0 * 1024, 0);
               const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab + 16, trow0 * 1024, 0);
               v0 += __builtin_bit_cast(f32x4, t0); v1 += __builtin_bit_cast(f32x4, t1);
             }
           }
-          if (vec) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), ro, vo_out, trow0 * row_bytes, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), ro, vo_out + 16, trow0 * row_bytes, 0);
-            sq += (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]) + (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-          } else if (n0 + trow0 + (lane >> 3) < p.N) {
-            // conv taps (elements 3 floats apart), ragged N / K or unaligned rows: bounds-checked element stores
-            const float ve[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const int klim = (p.ktap > 0 ? p.ktap : p.K) - kq0 - tcol;      // columns of this lane's run that exist
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-              if (e < klim) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[e]), ro, vo_out + (unsigned)(e * p.col_stride * 4), trow0 * row_bytes, 0);
-                sq += ve[e] * ve[e];
-              }
-          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), ro, vo_out, trow0 * row_bytes, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), ro, vo_out + 16, trow0 * row_bytes, 0);
+          sq += (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]) + (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
         }
       }
       sq_total += sq;
@@ -1385,18 +1379,18 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
           float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
           const int nn = wm * 128 + i * 32 + l31;
           if (g == 0) {
-            if (!whole)
-              for (int o = w_lo; o <= w_hi; o++)
-                if (o != l) t += plan.slabs[(size_t)(2 * o + (o == w_lo ? 1 : 0)) * TNH_SLAB + 65536 + nn];
-            if (n0 + nn < p.N) p.dbias[n0 + nn] += t;          // (one tile column block per bias entry: single writer)
+            if (part >= 0)
+              for (int o = 0; o < plan.nsplit; o++)
+                if (o != part) t += plan.slabs[(size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB + 65536 + nn];
+            p.dbias[n0 + nn] += t;                              // (one tile column block per bias entry: single writer)
           }
         }
       }
     }
-    // next segment of this workgroup's piece
-    gs += st1 - st0;
-    while (gi + 1 < plan.count && gs >= plan.g[gi + 1].step_base) gi++;
-  }
+    // next unit
+    if (part >= 0) { part = -1; tile_g = l; }
+    else tile_g += gridDim.x;
+    if (tile_g >= plan.full_tiles) break;
   }
   if (plan.sqsum) {
     sq_total = wave_sum(sq_total);
@@ -1786,54 +1780,32 @@ int launch_gemm_tn_batch(const GemmTNBatch& b, hipStream_t s) {
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-// ---- stream-K launch (no reduce pass) of several weight gradients -----------------------------------------------------------
-static int g_tnh_max_parts = -1;
+// ---- hybrid (no reduce pass) launch of several weight gradients over the same rows -----------------------------------------
+static int g_tnh_max_split = -1;
+static void tnh_plan_counts(int M, int total_tiles, int cus, int& full_tiles, int& nsplit, int& steps_per) {
+  const int steps_total = cdiv(M, 64);
+  const int rem = total_tiles % cus;
+  full_tiles = total_tiles - rem;
+  nsplit = rem ? cus / rem : 0;
+  if (nsplit > steps_total / 8) nsplit = steps_total / 8;          // (a part needs a real reduction)
+  if (nsplit <= 1) { full_tiles = total_tiles; nsplit = 0; steps_per = steps_total; return; }
+  steps_per = cdiv(steps_total, nsplit);
+  nsplit = cdiv(steps_total, steps_per);                           // no empty part
+}
 static int tnh_cus() {
   int cus = (g_cu_cap > 0 && g_cu_cap < g_tn_cus) ? g_cu_cap : g_tn_cus;
   if (g_cu_reserved > 0) cus = cus - g_cu_reserved > 8 ? cus - g_cu_reserved : 8;
   return cus;
 }
-// fills the plan (without pointers when pl.slabs stays null); returns the largest number of parts a tile is cut into, 0 when nothing to do
-static int tnh_fill_plan(const GemmTNMulti& b, TNHPlan& pl, int& grid, int& tiles_out) {
-  memset(&pl, 0, sizeof(pl));
-  pl.count = b.count;
-  int tiles = 0; long long steps = 0;
-  for (int i = 0; i < b.count; i++) {
-    const GemmTNArgs& a = b.g[i];
-    TNHGroup& g = pl.g[i];
-    g.P = a.P; g.Q = a.Q; g.out = a.out; g.dbias = a.dbias; g.ldp = a.ldp; g.ldq = a.ldq; g.ldo = a.ldo;
-    g.N = a.N; g.K = a.K; g.q_row_off = a.q_row_off; g.ktap = a.ktap; g.col_stride = a.col_stride;
-    g.tiles_k = cdiv(a.K, 256); g.tile_base = tiles; g.steps = cdiv(a.M, 64); g.step_base = (int)steps;
-    g.bytes_p = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
-    const int kq = a.ktap > 0 ? a.ktap : a.K;
-    const int kcols = a.ldq < (kq + 7) / 8 * 8 ? a.ldq : (kq + 7) / 8 * 8;
-    g.bytes_q = (unsigned)((((long long)a.Mq - 1) * a.ldq + kcols) * 2);
-    const int nt = cdiv(a.N, 256) * g.tiles_k;
-    tiles += nt; steps += (long long)nt * g.steps;
-  }
-  tiles_out = tiles;
-  if (steps <= 0 || steps >= (1LL << 31)) return 0;
-  pl.total_steps = (int)steps;
-  const int cus = tnh_cus();
-  grid = steps < cus ? (int)steps : cus;
-  pl.per = (int)((steps + grid - 1) / grid);
-  grid = (int)((steps + pl.per - 1) / pl.per);               // no empty piece
-  int max_parts = 1;
-  for (int i = 0; i < b.count; i++) {                         // (uniform tiles per group: the worst cut of a group is reached within its first `per` offsets)
-    const TNHGroup& g = pl.g[i];
-    const int nt = cdiv(g.N, 256) * g.tiles_k;
-    for (int t = 0; t < nt; t++) {
-      const long long t0 = (long long)g.step_base + (long long)t * g.steps;
-      const int parts = (int)((t0 + g.steps - 1) / pl.per - t0 / pl.per) + 1;
-      if (parts > max_parts) max_parts = parts;
-    }
-  }
-  return max_parts;
+static int tnh_total_tiles(const GemmTNMulti& b) {
+  int t = 0;
+  for (int i = 0; i < b.count; i++) t += cdiv(b.g[i].N, 256) * cdiv(b.g[i].K, 256);
+  return t;
 }
 long long gemm_tn_multi_slab_floats(int total_tiles, int cus_hint) {
-  // every workgroup publishes at most two partial tiles (the first and the last segment of its piece)
-  (void)total_tiles;
-  return 2LL * (cus_hint > 0 ? cus_hint : 320) * TNH_SLAB;
+  // the split parts of a launch never outnumber its CUs (one part per workgroup), and a tile has <= 3 parts (gemm_tn_multi_ok)
+  const long long by_tiles = (long long)total_tiles * 3, by_cus = cus_hint > 0 ? cus_hint : 320;
+  return (by_tiles < by_cus ? by_tiles : by_cus) * TNH_SLAB;
 }
 bool gemm_tn_multi_ok(const GemmTNMulti& b) {
   if (g_force_tile == 128 || b.count < 1 || b.count > UVTG_TNH_MAX_GROUPS || !b.slabs || !b.tickets) return false;
@@ -1841,33 +1813,57 @@ bool gemm_tn_multi_ok(const GemmTNMulti& b) {
   if (off) return false;
   for (int i = 0; i < b.count; i++) {
     const GemmTNArgs& a = b.g[i];
-    if (!tn256_group_ok(a) || !a.assign || a.M < 1024) return false;
-    if (a.ktap == 0 && a.col_stride != 1) return false;
-    if (a.ktap > 0 && a.col_stride * a.ktap != a.K) return false;        // taps: out[n][c][tap], K = taps x ktap, ktap a multiple of 256
+    if (!tn256_group_ok(a) || a.M != b.g[0].M || a.ktap != 0 || a.col_stride != 1 || !a.assign || a.q_row_off != 0 || a.Mq != a.M) return false;
+    if (a.N % 256 || a.K % 256 || a.ldo % 4 || ((uintptr_t)a.out & 15)) return false;
   }
   if (((uintptr_t)b.slabs & 15)) return false;
-  TNHPlan pl; int grid = 0, tiles = 0;
-  const int parts = tnh_fill_plan(b, pl, grid, tiles);
-  if (g_tnh_max_parts < 0) g_tnh_max_parts = getenv("UVTG_TN_HYBRID_MAXPARTS") ? atoi(getenv("UVTG_TN_HYBRID_MAXPARTS")) : 4;
-  if (parts < 1 || parts > g_tnh_max_parts) return false;             // the last arriver of a tile folds parts - 1 slabs alone: only short folds pay
-  return 2LL * grid * TNH_SLAB <= b.slab_floats && tiles <= b.n_tickets;
+  const int tiles = tnh_total_tiles(b);
+  int full, nsplit, per;
+  tnh_plan_counts(b.g[0].M, tiles, tnh_cus(), full, nsplit, per);
+  if (g_tnh_max_split < 0) g_tnh_max_split = getenv("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(getenv("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
+  if (nsplit > g_tnh_max_split) return false;                       // the last arriver of a tile folds nsplit - 1 slabs alone: only short folds pay
+  if (full == 0 && nsplit == 0) return false;
+  if ((long long)(tiles - full) * nsplit * TNH_SLAB > b.slab_floats || tiles - full > b.n_tickets) return false;
+  return b.g[0].M >= 2048;
 }
 int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
     int dev = 0; hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) g_tn_cus = pr.multiProcessorCount;
     attr = true;
   }
   if (!gemm_tn_multi_ok(b)) return -2;
-  TNHPlan pl; int grid = 0, tiles = 0;
-  tnh_fill_plan(b, pl, grid, tiles);
-  pl.slabs = b.slabs; pl.tickets = b.tickets; pl.sqsum = b.g[0].sqsum;
+  TNHPlan pl;
+  memset(&pl, 0, sizeof(pl));
+  pl.count = b.count; pl.M = b.g[0].M; pl.steps_total = cdiv(pl.M, 64);
+  int tiles = 0;
   double flops = 0;
-  for (int i = 0; i < b.count; i++) flops += 2.0 * b.g[i].M * b.g[i].N * b.g[i].K;
+  for (int i = 0; i < b.count; i++) {
+    const GemmTNArgs& a = b.g[i];
+    TNHGroup& g = pl.g[i];
+    g.P = a.P; g.Q = a.Q; g.out = a.out; g.dbias = a.dbias; g.ldp = a.ldp; g.ldq = a.ldq; g.ldo = a.ldo;
+    g.tiles_k = a.K / 256; g.tile_base = tiles;
+    g.bytes_p = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
+    g.bytes_q = (unsigned)((((long long)a.M - 1) * a.ldq + a.K) * 2);
+    tiles += (a.N / 256) * (a.K / 256);
+    flops += 2.0 * a.M * a.N * a.K;
+  }
+  pl.total_tiles = tiles;
+  const int cus = tnh_cus();
+  tnh_plan_counts(pl.M, tiles, cus, pl.full_tiles, pl.nsplit, pl.steps_per);
+  pl.slabs = b.slabs; pl.tickets = b.tickets; pl.sqsum = b.g[0].sqsum;
+  const int split_units = (tiles - pl.full_tiles) * pl.nsplit;
+  int grid = pl.full_tiles > split_units ? pl.full_tiles : split_units;
+  if (grid > cus) grid = cus;
   uvtg_prof_begin_launch(2, flops, s);
-  hipLaunchKernelGGL(gemm_tn256h_kernel, dim3(grid), dim3(512), 131072, s, pl);
+  static const int pf = getenv("UVTG_TN_TOUCH") ? atoi(getenv("UVTG_TN_TOUCH")) : 0;      // L2 touch-ahead distance in steps (0 = off, 2, 3)
+  if (pf == 2) hipLaunchKernelGGL(gemm_tn256h_kernel<2>, dim3(grid), dim3(512), 131072, s, pl);
+  else if (pf == 3) hipLaunchKernelGGL(gemm_tn256h_kernel<3>, dim3(grid), dim3(512), 131072, s, pl);
+  else hipLaunchKernelGGL(gemm_tn256h_kernel<0>, dim3(grid), dim3(512), 131072, s, pl);
   uvtg_prof_end_launch(2, s);
   UVTG_CHECK_LAUNCH();
   return 0;

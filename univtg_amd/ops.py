@@ -81,7 +81,7 @@ def wgrad_bf16_multi(dys, xs, with_bias=True):
     M = dys[0].shape[0]
     dev = dys[0].device
     Ns, Ks = [int(t.shape[1]) for t in dys], [int(t.shape[1]) for t in xs]
-    tiles = sum(-(-a // 256) * -(-b // 256) for a, b in zip(Ns, Ks))
+    tiles = sum((a // 256) * (b // 256) for a, b in zip(Ns, Ks))
     nf = lib.uvtg_wgrad_multi_slab_floats(tiles)
     slabs = torch.empty(nf, device=dev)
     tickets = torch.zeros(tiles, dtype=torch.int32, device=dev)
