@@ -1127,12 +1127,9 @@ struct TNHPlan {
   int count, M, steps_total, total_tiles, full_tiles, nsplit, steps_per;
   float* slabs; unsigned* tickets; float* sqsum;
 };
-// PF: L2 touch-ahead.  The operand panels of a step come from HBM (2 GB of activations and gradients per launch: nothing stays in a cache), and
-// the staging DMA runs ONE step (~1.9 us) ahead -- about one loaded HBM round trip, so part of every miss is exposed (the stream-K experiment
-// showed how sensitive the K loop is: with the L2 sharing of the row panels broken it ran 40 % slower).  With PF every thread touches ONE
-// 128-byte line of the rows the DMA will fetch `PF` steps later (64 rows x 2 panels x 4 lines = 512 lines = one per thread; a discarded dword
-// load, issued LAST in the step so that the step's waits can be vmcnt(1)): the HBM latency is paid by the touch, the DMA hits L2.
-template <int PF>
+// (Measured and dropped, round 3: an L2 "touch-ahead" -- every thread loads one 128-byte line of the rows the staging DMA will fetch 2 or 3
+// steps later, the step's waits relaxed to vmcnt(1) -- made the launch 4 % SLOWER: the one-step-ahead DMA already covers the HBM round trip;
+// what the K loop is sensitive to is how many workgroups share a row panel through an XCD's L2 at the same time, see engine.hip.)
 __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   __shared__ unsigned s_ticket;
@@ -1182,12 +1179,6 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
       vq[i] = (unsigned)(((st0 * 64 + rr) * p.ldq + k0 + cs) * 2);
     }
     const unsigned dp = (unsigned)(64 * p.ldp * 2), dq = (unsigned)(64 * p.ldq * 2);
-    // touch-ahead: waves 0-3 walk the P panel, waves 4-7 the Q panel; thread = (row of the step, 128-byte line of the 512-byte row segment)
-    const int pf_q = wave >> 2;
-    const i32x4 rpf = pf_q ? rq : rp;
-    unsigned vpf = (unsigned)((((st0 + PF) * 64 + ((tid & 255) >> 2)) * (pf_q ? p.ldq : p.ldp) + (pf_q ? k0 : n0)) * 2 + (tid & 3) * 128);
-    const unsigned dpf = pf_q ? dq : dp;
-    unsigned junk = 0;
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -1205,18 +1196,12 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
         tn_dma16(rq, vq[i], lds0 + (unsigned)(wave * 4096 + 32768 + i * 1024));
         vp[i] += dp; vq[i] += dq;
       }
-      if constexpr (PF > 0) {      // the lines of steps st0 + 1 .. st0 + PF - 1 (iteration st touches step st + PF); the youngest VMEM op is a touch from here on
-#pragma unroll
-        for (int k = 1; k < PF; k++)
-          asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(junk) : "v"(vpf - (unsigned)(PF - k) * dpf), "s"(rpf) : "memory");
-      }
     }
     auto main_loop = [&](auto with_bias) {
       constexpr bool BIAS = decltype(with_bias)::value;
       for (int st = st0; st < st1; st++) {
         const int cur = (st - st0) & 1;
-        if constexpr (PF > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // every DMA piece of this step landed; the youngest touch may fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const unsigned char* base = smem256 + cur * 65536;
         const unsigned sb = lds0 + (unsigned)((cur ^ 1) * 65536 + wave * 4096);
@@ -1245,12 +1230,6 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
               tn_dma16(rp, vp[i], sb + i * 1024);
               tn_dma16(rq, vq[i], sb + 32768 + i * 1024);
               vp[i] += dp; vq[i] += dq;
-            }
-          }
-          if constexpr (PF > 0) {
-            if (ks == 2) {           // behind the step's last DMA piece: the next step's wait is vmcnt(1)
-              asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(junk) : "v"(vpf), "s"(rpf) : "memory");
-              vpf += dpf;
             }
           }
           s16x8 a[4], b[2];
@@ -1292,7 +1271,6 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
     };
     if (do_bias) main_loop(std::true_type{}); else main_loop(std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces issued past the last step must not land in the epilogue's LDS slabs
-    asm volatile("" :: "v"(junk));
     __syncthreads();
     // ---- epilogue ----  (buffer accesses: ONE per-lane byte offset + wave-uniform row offsets in SGPRs; with 64-bit row addresses
     // the unrolled store sequence kept ~60 address registers alive through the K loop and spilled)
@@ -1829,9 +1807,7 @@ bool gemm_tn_multi_ok(const GemmTNMulti& b) {
 int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)) return (int)e;
     int dev = 0; hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) g_tn_cus = pr.multiProcessorCount;
     attr = true;
@@ -1860,10 +1836,7 @@ int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s) {
   int grid = pl.full_tiles > split_units ? pl.full_tiles : split_units;
   if (grid > cus) grid = cus;
   uvtg_prof_begin_launch(2, flops, s);
-  static const int pf = getenv("UVTG_TN_TOUCH") ? atoi(getenv("UVTG_TN_TOUCH")) : 0;      // L2 touch-ahead distance in steps (0 = off, 2, 3)
-  if (pf == 2) hipLaunchKernelGGL(gemm_tn256h_kernel<2>, dim3(grid), dim3(512), 131072, s, pl);
-  else if (pf == 3) hipLaunchKernelGGL(gemm_tn256h_kernel<3>, dim3(grid), dim3(512), 131072, s, pl);
-  else hipLaunchKernelGGL(gemm_tn256h_kernel<0>, dim3(grid), dim3(512), 131072, s, pl);
+  hipLaunchKernelGGL(gemm_tn256h_kernel, dim3(grid), dim3(512), 131072, s, pl);
   uvtg_prof_end_launch(2, s);
   UVTG_CHECK_LAUNCH();
   return 0;

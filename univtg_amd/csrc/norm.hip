@@ -5,6 +5,7 @@
 // (model/transformer_encoder_droppath.py:116) and the zero-framed copy of the video rows that the
 // Conv1d heads read (model/univtg.py:127-130).
 #include "uvtg_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -591,6 +592,81 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwdArgs a) {
     }
   }
 }
+// Round 3: the same with ONE WAVE per row.  The block-per-row kernel above pays two block-wide reductions (four barriers) per row on a
+// load -> reduce -> reduce -> draw -> store latency chain: 90 us for the 268 MB of the video features at config 2 (3 TB/s).  Here a lane owns
+// whole column quads c4 = lane + 64 k (two 8-byte loads each: the rows are only 8-byte aligned), the two row sums are DPP wave sums (no LDS, no
+// barrier), and the dropout draw is one Philox call per owned quad -- the same (row, column) -> mask mapping as everywhere else
+// (counter = row * ceil(D / 4) + c / 4, word c % 4).  NQ = quads per lane (12 covers D <= 3072).
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a) {
+  const int lane = threadIdx.x & 63, D = a.D, D4 = (D + 3) >> 2;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int lrow = a.src_rows ? a.src_rows[row] : row;
+  const float* xr = a.x + (size_t)(a.gather_x ? lrow : row) * a.ldx;
+  float v[NQ][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const int c = (lane + 64 * k) * 4;
+    v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
+    if (c + 1 < D) { const f32x2 t = *(const f32x2*)(xr + c); v[k][0] = t[0]; v[k][1] = t[1]; }
+    if (c + 3 < D) { const f32x2 t = *(const f32x2*)(xr + c + 2); v[k][2] = t[0]; v[k][3] = t[1]; }
+    sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  const float mean = wave_sum_dpp(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const int c = (lane + 64 * k) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (c + e < D) { const float t = v[k][e] - mean; sq += t * t; }
+  }
+  const float rstd = rsqrtf(wave_sum_dpp(sq) / (float)D + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
+  }
+  const float inv = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const int c4 = lane + 64 * k, c = c4 * 4;
+    if (c >= a.Dpad && c >= D) continue;
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      float ks[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f) {
+        unsigned r[4];
+        philox4(a.seed, (unsigned long long)lrow * (unsigned long long)D4 + (unsigned long long)c4, a.stream_id, r);
+#pragma unroll
+        for (int e = 0; e < 4; e++) ks[e] = (u01(r[e]) >= a.p_drop) ? inv : 0.0f;
+      }
+      if (c + 3 < D) {
+        const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) y[e] = ((v[k][e] - mean) * rstd * gm[e] + bt[e]) * ks[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (c + e < D) y[e] = ((v[k][e] - mean) * rstd * a.gamma[c + e] + a.beta[c + e]) * ks[e];
+      }
+    }
+    // (columns [D, Dpad) are written as zeros: the GEMM operand is zero-padded to whole K tiles)
+    if (a.yF2) {
+      float* o = a.yF2 + (size_t)row * a.ldyF2 + c;
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (c + e < (a.Dpad > D ? a.Dpad : D)) o[e] = y[e];
+    }
+    if (a.yB) {
+      bf16_t* o = a.yB + (size_t)row * a.ldyB + c;
+      if (c + 3 < (a.Dpad > D ? a.Dpad : D)) { u32x2 t; t[0] = pack_bf2(y[0], y[1]); t[1] = pack_bf2(y[2], y[3]); *(u32x2*)o = t; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) if (c + e < (a.Dpad > D ? a.Dpad : D)) o[e] = f2bf(y[e]);
+      }
+    }
+  }
+}
 // dgamma / dbeta only (the feature LayerNorm has no upstream: dx is never needed), i.e. a pure column reduction over the rows:
 // thread = 2 columns, block = 512 columns x a slice of rows, per-block partials folded by ln_bwd_reduce_kernel.
 __global__ __launch_bounds__(256) void ln_dgb_wide_kernel(const LnBwdArgs a, int rows_per_block) {
@@ -711,7 +787,12 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
                       al(a.pos, a.D, 4, 8);
   const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.yB, a.ldyB, 2, 16) && al(a.yU, a.ldyU, 2, 16) && al(a.yP, a.ldyP, 2, 16);
   if (a.D > 2048 && a.D <= 3072 && a.D % 2 == 0 && align8 && a.x && !a.yF && !a.pos && !a.pos_row && !a.yU && !a.yUF && !a.yP && !a.yPF) {
-    hipLaunchKernelGGL((ln_fwd_wide_kernel<6>), dim3(min(a.rows, 4096)), dim3(256), 0, s, a);     // block per row (see the kernel)
+    static const bool wave_off = getenv("UVTG_LN_WIDE_WAVE_OFF") != nullptr;     // experiment: the block-per-row kernel
+    const int dmax = a.Dpad > a.D ? a.Dpad : a.D;
+    if (!wave_off && dmax <= 3072 && (a.ldx % 2 == 0) && (!a.yB || a.ldyB % 4 == 0) && (!a.yF2 || a.ldyF2 % 4 == 0) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16))
+      hipLaunchKernelGGL((ln_fwd_wide_wave_kernel<12>), dim3(cdiv(a.rows, 4)), dim3(256), 0, s, a);     // wave per row
+    else
+      hipLaunchKernelGGL((ln_fwd_wide_kernel<6>), dim3(min(a.rows, 4096)), dim3(256), 0, s, a);         // block per row (see the kernel)
     UVTG_CHECK_LAUNCH();
     return 0;
   }
