@@ -43,6 +43,37 @@ __device__ __forceinline__ s16x8 pack8_lo(const float* v) {   // residual after 
 }
 __device__ __forceinline__ s16x8 cat4(s16x4 a, s16x4 b) { return (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
+// The backward kernels evaluate p = exp(s - lse) as exp2(s * log2(e) - lse * log2(e)): one v_fma + one v_exp per element.  A query row
+// beyond the sequence gets the "lse" ROW_OFF (exp2 underflows to an exact 0), a padded / absent key the bias -ROW_OFF: no per-element
+// compare, branch or LDS look-up is left in the softmax sections (round 3: the per-element `sL[ql]` / `sD[ql]` / `sValid[kl]` reads were 32
+// dependent LDS round trips per query block, each behind its own s_waitcnt -- more time than the block's 32 MFMAs).
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float ROW_OFF = 1e30f;
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// [rows][HD] bf16 tile that is read both by rows (ds_read_b128: one row per lane) and transposed (ds_read_b64_tr_b16: a 32-lane group
+// covers 4 rows x 64 bytes).  Padded rows (HD + 8 elements = 4 banks of skew per row) keep the row reads conflict-free but put the four
+// rows of a transposing read on overlapping banks (4-way).  SWZ (HD = 128 only: 16 chunks of 16 bytes = one 256-byte bank row per tile
+// row): chunk c of row r is stored at chunk c ^ (4 (r & 3) + ((r >> 2) & 3)) -- the 16 rows of a ds_read_b128 lane group land on 16
+// different chunks, and the 4 rows of a transposing read on 4 different 64-byte quarters (tools/lds_conflict_probe.hip).
+template <int HD, bool SWZ> struct TileRT {
+  static_assert(!SWZ || HD == 128, "the chunk swizzle assumes 16 chunks per row");
+  static constexpr int STR = SWZ ? HD : HD + 8;
+  __device__ static __forceinline__ int off(int r, int col) {
+    if constexpr (SWZ) return r * HD + ((((col >> 3) ^ (((r & 3) << 2) | ((r >> 2) & 3)))) << 3) + (col & 7);
+    else return r * STR + col;
+  }
+  // offset of (r, col + dcol) from base = off(r, col) when dcol is a multiple of 16 elements that only sets bits col has clear (head-dim
+  // blocks / k-steps): the chunk permutation is an XOR, so the step is an XOR of the offset (one VALU op instead of one register per step)
+  __device__ static __forceinline__ int step(int base, int dcol) {
+    if constexpr (SWZ) return base ^ dcol; else return base + dcol;
+  }
+  // offset of (r + 8, col) from off(r, col) for r % 16 < 8, and of (r + 4, col) for r % 8 < 4: bits 2..3 of the row are bits 0..1 of the
+  // permutation, so the row step flips one chunk bit
+  __device__ static __forceinline__ int rows8(int base) { if constexpr (SWZ) return (base ^ 16) + 8 * STR; else return base + 8 * STR; }
+  __device__ static __forceinline__ int rows4(int base) { if constexpr (SWZ) return (base ^ 8) + 4 * STR; else return base + 4 * STR; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -310,15 +341,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 //  Splitting it into a dV pass and a dK pass (208 / 256 registers, two workgroups per CU, 40 instead of 32 MFMAs per query block and
 //  Q / dO streamed twice) measured SLOWER: 2117 vs 1847 us for the whole backward at B=32, S=1232.)
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, bool DROP, bool SWZ>
 __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnArgs a) {
-  constexpr int QSTR = HD + 8;
-  constexpr bool VREG = true;          // (head_dim 128 needs ~280 registers with K and V resident: one workgroup per CU there, no spill)
-  __shared__ __attribute__((aligned(16))) bf16_t sQ[2][32 * QSTR];
-  __shared__ __attribute__((aligned(16))) bf16_t sO[2][32 * QSTR];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[VREG ? 8 : 128 * HD];
-  __shared__ float sL[2][32], sD[2][32];
-  using KS = KSwz<HD>;
+  using QT = TileRT<HD, SWZ>;
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[2][32 * QT::STR];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[2][32 * QT::STR];
+  __shared__ __attribute__((aligned(16))) float sL[2][32], sD[2][32];     // lse * log2(e) (ROW_OFF beyond S), delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
@@ -331,16 +359,16 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
   const bool kin = key < S;
   const bool kok = kin && a.kvalid[rowbase + min(key, S - 1)];
   // this lane's K / V row as MFMA B fragments: k-step ks covers head-dim columns 16 ks + 8 g .. + 7
-  s16x8 kf[HD / 16], vf[VREG ? HD / 16 : 1];
+  s16x8 kf[HD / 16], vf[HD / 16];
   {
     const bf16_t* base = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) {
       const u32x4 z = {0, 0, 0, 0};
       const u32x4 kv = kin ? *(const u32x4*)(base + d + 16 * ks) : z;
+      const u32x4 vv = kin ? *(const u32x4*)(base + 2 * d + 16 * ks) : z;
       kf[ks] = __builtin_bit_cast(s16x8, kv);
-      if constexpr (VREG) { const u32x4 vv = kin ? *(const u32x4*)(base + 2 * d + 16 * ks) : z; vf[ks] = __builtin_bit_cast(s16x8, vv); }
-      else *(u32x4*)(&sV[KS::off(wave * 32 + l31, 2 * ks + g)]) = kin ? *(const u32x4*)(base + 2 * d + 16 * ks) : z;   // wave-private rows
+      vf[ks] = __builtin_bit_cast(s16x8, vv);
     }
   }
   f32x16 dk[HD / 32], dv[HD / 32];
@@ -348,7 +376,7 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
   for (int i = 0; i < HD / 32; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-  const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
+  [[maybe_unused]] const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
 
   constexpr int NPT = (32 * CH + 255) / 256;         // staging pieces per thread per operand
   u32x4 pq[NPT], po[NPT];
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
       const int q = tid + 256 * i, r = q / CH, c = q % CH;
-      const int qi = min(qb * 32 + r, S - 1);          // clamped rows are loaded, masked in the math (qi < S)
+      const int qi = min(qb * 32 + r, S - 1);          // clamped rows are loaded; their probabilities are exact zeros (ROW_OFF)
       const bool on = q < 32 * CH;
       const u32x4 z = {0, 0, 0, 0};
       pq[i] = on ? *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8) : z;
@@ -365,10 +393,16 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     }
     if (tid < 32) {
       const int qi = min(qb * 32 + tid, S - 1);
-      pl = a.lse[((size_t)b * a.H + h) * a.S + qi];
+      const float l = a.lse[((size_t)b * a.H + h) * a.S + qi];
+      pl = (qb * 32 + tid < S) ? l * LOG2E : ROW_OFF;
       pdl = a.delta[((size_t)b * a.H + h) * a.S + qi];
     }
   };
+  // LDS offsets of this lane's fragments inside a tile (loop invariants; with SWZ the chunk index is lane dependent, so they cannot be
+  // instruction immediates)
+  const int qoff = QT::off(l31, 8 * g);                                        // + k-step: QT::step(qoff, 16 ks)
+  const int toff0 = QT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));      // + head-dim block: QT::step(toff, 32 blk); + 16 rows for the
+  const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
   const int nqb = (S + 31) / 32;
   prefetch(0);
   for (int qb = 0; qb < nqb; qb++) {
@@ -378,8 +412,8 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
       const int q = tid + 256 * i;
       if (q < 32 * CH) {
         const int r = q / CH, c = q % CH;
-        *(u32x4*)(&sQ[buf][r * QSTR + c * 8]) = pq[i];
-        *(u32x4*)(&sO[buf][r * QSTR + c * 8]) = po[i];
+        *(u32x4*)(&sQ[buf][QT::off(r, c * 8)]) = pq[i];
+        *(u32x4*)(&sO[buf][QT::off(r, c * 8)]) = po[i];
       }
     }
     if (tid < 32) { sL[buf][tid] = pl; sD[buf][tid] = pdl; }
@@ -387,38 +421,45 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     if (qb + 1 < nqb) prefetch(qb + 1);
     const bf16_t* bq = sQ[buf];
     const bf16_t* bo = sO[buf];
+    // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
+    f32x4 Lq[4], Dq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
     // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
     f32x16 sc, dp;
 #pragma unroll
     for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) {
-      const s16x8 qf = *(const s16x8*)(&bq[l31 * QSTR + 16 * ks + 8 * g]);
-      const s16x8 of = *(const s16x8*)(&bo[l31 * QSTR + 16 * ks + 8 * g]);
+      const s16x8 qf = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]);
+      const s16x8 of = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]);
       sc = mfma32(qf, kf[ks], sc);
-      if constexpr (VREG) dp = mfma32(of, vf[ks], dp);
-      else dp = mfma32(of, *(const s16x8*)(&sV[KS::off(wave * 32 + l31, 2 * ks + g)]), dp);
+      dp = mfma32(of, vf[ks], dp);
     }
     float pd[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const int ql = (r & 3) + 8 * (r >> 2) + 4 * g, qi = qb * 32 + ql;
-      float p = (kok && qi < S) ? __expf(sc[r] - sL[buf][ql]) : 0.f;
-      float ksc = 1.f;
-      if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
-      pd[r] = p * ksc;
-      ds[r] = p * (dp[r] * ksc - sD[buf][ql]);
+      float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));
+      p = kok ? p : 0.f;
+      if constexpr (DROP) {
+        const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
+        pd[r] = p * ksc;
+        ds[r] = p * (dp[r] * ksc - Dq[r >> 2][r & 3]);
+      } else {
+        pd[r] = p;
+        ds[r] = p * (dp[r] - Dq[r >> 2][r & 3]);
+      }
     }
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
       const s16x8 pb = pack8(&pd[8 * hf]);
       const s16x8 db = pack8(&ds[8 * hf]);
-      const int qr = 16 * hf + 4 * g + (i16 >> 2);
 #pragma unroll
       for (int blk = 0; blk < HD / 32; blk++) {
-        const int col = blk * 32 + 16 * qd + 4 * (i16 & 3);
-        const s16x8 ot = cat4(lds_tr16(&bo[qr * QSTR + col]), lds_tr16(&bo[(qr + 8) * QSTR + col]));
-        const s16x8 qt = cat4(lds_tr16(&bq[qr * QSTR + col]), lds_tr16(&bq[(qr + 8) * QSTR + col]));
+        const int o0 = QT::step(toff0, 32 * blk) + 16 * hf * QT::STR, o1 = QT::step(toff1, 32 * blk) + 16 * hf * QT::STR;
+        const s16x8 ot = cat4(lds_tr16(&bo[o0]), lds_tr16(&bo[o1]));
+        const s16x8 qt = cat4(lds_tr16(&bq[o0]), lds_tr16(&bq[o1]));
         dv[blk] = mfma32(ot, pb, dv[blk]);
         dk[blk] = mfma32(qt, db, dk[blk]);
       }
@@ -443,12 +484,13 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
 // ------------------------------------------------------------------------------------------------
 // backward: dQ   (one wave = 32 queries, loops over 64-key tiles)
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, bool DROP, bool SWZ>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
-  constexpr int KSTR = HD + 8;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * KSTR];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * KSTR];
-  __shared__ unsigned char sValid[64];
+  using KT = TileRT<HD, SWZ>;
+  constexpr int VSTR = HD + 8;                       // V is read by rows only
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * KT::STR];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * VSTR];
+  __shared__ __attribute__((aligned(16))) float sBias[64];     // 0 on a real key, -ROW_OFF on padding and beyond S
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
@@ -463,61 +505,65 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     qf[ks] = *(const s16x8*)(qkv + (rowbase + qrow) * a.ldqkv + h * HD + 16 * ks + 8 * g);
     of[ks] = *(const s16x8*)(a.dO + (rowbase + qrow) * a.lddo + h * HD + 16 * ks + 8 * g);
   }
-  const float lse = a.lse[((size_t)b * a.H + h) * a.S + qrow];
+  const float L2 = a.lse[((size_t)b * a.H + h) * a.S + qrow] * LOG2E;
   const float dl = a.delta[((size_t)b * a.H + h) * a.S + qrow];
   f32x16 dq[HD / 32];
 #pragma unroll
   for (int i = 0; i < HD / 32; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
-  const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
+  [[maybe_unused]] const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
   constexpr int CH = HD / 8;
+  // this lane's fragment offsets inside the K / V tiles (rows 0..31; + 32 rows for kb = 1, + 16 for hf = 1: the same chunk permutation)
+  const int koff = KT::off(l31, 8 * g), voff = l31 * VSTR + 8 * g;
+  const int toff0 = KT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3)), toff1 = KT::rows8(toff0);
   const int ntiles = (S + 63) / 64;
   for (int kt = 0; kt < ntiles; kt++) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < (64 * CH) / 256; i++) {
       const int q = tid + 256 * i, r = q / CH, c = q % CH;
-      const int key = kt * 64 + r;
-      u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-      if (key < S) {
-        const bf16_t* base = qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
-        kv = *(const u32x4*)(base + d);
-        vv = *(const u32x4*)(base + 2 * d);
-      }
-      *(u32x4*)(&sK[r * KSTR + c * 8]) = kv;
-      *(u32x4*)(&sV[r * KSTR + c * 8]) = vv;
+      const int key = min(kt * 64 + r, S - 1);         // rows beyond S: clamped duplicates, their dS is an exact zero (bias)
+      const bf16_t* base = qkv + (rowbase + key) * a.ldqkv + h * HD + c * 8;
+      const u32x4 kv = *(const u32x4*)(base + d);
+      const u32x4 vv = *(const u32x4*)(base + 2 * d);
+      *(u32x4*)(&sK[KT::off(r, c * 8)]) = kv;
+      *(u32x4*)(&sV[r * VSTR + c * 8]) = vv;
     }
-    if (tid < 64) { const int key = kt * 64 + tid; sValid[tid] = (key < S) ? a.kvalid[rowbase + key] : 0; }
+    if (tid < 64) { const int key = kt * 64 + tid; sBias[tid] = (key < S && a.kvalid[rowbase + key]) ? 0.f : -ROW_OFF; }
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
+      f32x4 bq[4];                                     // bias of this lane's 16 accumulator registers: keys kb*32 + 8 j + 4 g + (0..3)
+#pragma unroll
+      for (int j = 0; j < 4; j++) bq[j] = *(const f32x4*)(&sBias[kb * 32 + 8 * j + 4 * g]);
       f32x16 sc, dp;
 #pragma unroll
       for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ks++) {
-        const int o = (kb * 32 + l31) * KSTR + 16 * ks + 8 * g;
-        sc = mfma32(*(const s16x8*)(&sK[o]), qf[ks], sc);
-        dp = mfma32(*(const s16x8*)(&sV[o]), of[ks], dp);
+        sc = mfma32(*(const s16x8*)(&sK[KT::step(koff, 16 * ks) + kb * 32 * KT::STR]), qf[ks], sc);
+        dp = mfma32(*(const s16x8*)(&sV[voff + 16 * ks + kb * 32 * VSTR]), of[ks], dp);
       }
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float p = sValid[kl] ? __expf(sc[r] - lse) : 0.f;
-        float ksc = 1.f;
-        if (a.p_drop > 0.f) ksc = keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, kt * 64 + kl, a.S, a.p_drop);
-        ds[r] = p * (dp[r] * ksc - dl);
+        const float p = exp2_raw(fmaf(sc[r], LOG2E, bq[r >> 2][r & 3] - L2));
+        if constexpr (DROP) {
+          const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, kt * 64 + kl, a.S, a.p_drop);
+          ds[r] = p * (dp[r] * ksc - dl);
+        } else {
+          ds[r] = p * (dp[r] - dl);
+        }
       }
 #pragma unroll
       for (int hf = 0; hf < 2; hf++) {
         const s16x8 db = pack8(&ds[8 * hf]);
-        const int kr = kb * 32 + 16 * hf + 4 * g + (i16 >> 2);
 #pragma unroll
         for (int blk = 0; blk < HD / 32; blk++) {
-          const int col = blk * 32 + 16 * qd + 4 * (i16 & 3);
-          const s16x8 kt_ = cat4(lds_tr16(&sK[kr * KSTR + col]), lds_tr16(&sK[(kr + 8) * KSTR + col]));
+          const int rowo = (kb * 32 + 16 * hf) * KT::STR;
+          const s16x8 kt_ = cat4(lds_tr16(&sK[KT::step(toff0, 32 * blk) + rowo]), lds_tr16(&sK[KT::step(toff1, 32 * blk) + rowo]));
           dq[blk] = mfma32(kt_, db, dq[blk]);
         }
       }
@@ -550,17 +596,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 // NW = 4: up to 128 keys, two workgroups per CU.  NW = 8 (128 < S <= 256, e.g. the pretraining shape L_v = 128 + 32 text tokens): 256 keys,
 // 8 waves, one workgroup per CU (the same two waves per SIMD); the dQ^T tile of a query block is summed over two key halves by two
 // wave groups and folded through an fp32 LDS slab.
-template <int HD, int NW>
+template <int HD, int NW, bool SWZ>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kernel(const AttnArgs a) {
   constexpr int KROWS = 32 * NW, T = 64 * NW;
-  constexpr int KSTR = HD + 8, QSTR = HD + 8, DSTR = KROWS + 8, CH = HD / 8;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[KROWS * KSTR];
+  constexpr int DQSTR = HD + 8, CH = HD / 8;
+  using KT = TileRT<HD, SWZ>;           // K, Q, dO tiles: read by rows and transposed
+  __shared__ __attribute__((aligned(16))) bf16_t sK[KROWS * KT::STR];
   __shared__ float sPart[NW == 8 ? 4 * 16 * 64 : 1];     // NW = 8: dQ^T partials of the upper key half, [hd tile][acc register][lane]
-  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * QSTR];
-  __shared__ __attribute__((aligned(16))) bf16_t sO[32 * QSTR];
-  __shared__ __attribute__((aligned(16))) bf16_t sDS[32 * DSTR];
-  __shared__ __attribute__((aligned(16))) bf16_t sDQ[32 * QSTR];   // dQ rows of the previous query block, stored out coalesced
-  __shared__ float sL[32], sD[32];
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * KT::STR];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[32 * KT::STR];
+  // dS of the query block as [key][32 queries] (64-byte rows), 8-byte unit u (4 queries) of key k stored at unit u ^ ((k >> 1) & 7): each
+  // lane (= key) stores the two packed halves of its dK operand as they are (4 x ds_write_b64, 16 consecutive keys on 16 different bank
+  // pairs) and the dQ pass fetches its B fragments with the transposing read (4 keys x 64 bytes per 32-lane group = all 64 banks).  The
+  // [query][key] image it replaces took 16 two-byte stores per lane and block.
+  __shared__ __attribute__((aligned(16))) bf16_t sDS[KROWS * 32];
+  __shared__ __attribute__((aligned(16))) bf16_t sDQ[32 * DQSTR];   // dQ rows of the previous query block, stored out coalesced
+  __shared__ __attribute__((aligned(16))) float sL[32], sD[32];     // lse * log2(e) (ROW_OFF beyond S), delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
@@ -581,14 +632,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
   auto prefetch = [&](int qb) {
     if (tid < 32) {
       const int qi = min(qb * 32 + tid, S - 1);
-      pl = a.lse[((size_t)b * a.H + h) * a.S + qi];
+      const float l = a.lse[((size_t)b * a.H + h) * a.S + qi];
+      pl = (qb * 32 + tid < S) ? l * LOG2E : ROW_OFF;
       pdl = a.delta[((size_t)b * a.H + h) * a.S + qi];
     }
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int q = tid + T * i, r = q / CH, c = q % CH, qi = qb * 32 + r;
-      pq[i] = (u32x4){0, 0, 0, 0}; po[i] = (u32x4){0, 0, 0, 0};
-      if (q < 32 * CH && qi < S) {
+      const int q = tid + T * i, r = q / CH, c = q % CH, qi = min(qb * 32 + r, S - 1);   // clamped rows: exact-zero probabilities (ROW_OFF)
+      if (q < 32 * CH) {
         pq[i] = *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8);
         po[i] = *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8);
       }
@@ -596,21 +647,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
   };
   const int nqb = (S + 31) / 32;
   prefetch(0);                                       // first query block's rows are in flight while K is staged
-  // K (all keys) -> LDS, zero rows beyond S
+  // K (all keys) -> LDS; rows beyond S are clamped duplicates (kok masks them)
 #pragma unroll
   for (int i = 0; i < (KROWS * CH) / T; i++) {
     const int q = tid + T * i, r = q / CH, c = q % CH;
-    u32x4 kv = {0, 0, 0, 0};
-    if (r < S) kv = *(const u32x4*)(qkv + (rowbase + r) * a.ldqkv + d + h * HD + c * 8);
-    *(u32x4*)(&sK[r * KSTR + c * 8]) = kv;
+    *(u32x4*)(&sK[KT::off(r, c * 8)]) = *(const u32x4*)(qkv + (rowbase + min(r, S - 1)) * a.ldqkv + d + h * HD + c * 8);
   }
+  // loop-invariant LDS offsets of this lane's fragments
+  // (few bases: the kernel sits at the 256-register line, everything else is derived where it is used)
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int qoff = KT::off(l31, 8 * g);                                         // Q / dO row l31, + k-step: KT::step(., 16 ks); the K row of
+                                                                                // this lane's key is 32 wave rows further (same permutation)
+  const int toff0 = KT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));       // transposed Q / dO fragments; + 16 rows (hf), + head-dim block
+  const int tile_hd = wave_s & 3, khalf = wave_s >> 2;
+  const int ktoff0 = KT::off(8 * g + (i16 >> 2), tile_hd * 32 + 16 * qd + 4 * (i16 & 3)) + khalf * 128 * KT::STR;     // dQ pass: K^T fragments,
+                                                                                                                      // + 16 kk rows
+  const int dsw = key * 32 + (((key >> 1) & 7) << 2);                           // dS store: unit u of this key at dsw ^ (u << 2)
+  // dS fetch (dQ pass): keys 16 kk + 8 g + 4 t + (i16 >> 2); t = 1: four rows further, unit index ^ 2
+  const int dsr0 = (khalf * 128 + 8 * g + (i16 >> 2)) * 32 + (((4 * qd + (i16 & 3)) ^ ((4 * g + (i16 >> 3)) & 7)) << 2);
   // the dQ^T fragments hold (head dim, query): 8 bytes per lane at a 6 KB stride.  Each wave drops its tile into sDQ instead and
   // the whole block writes the 32 rows out 16 bytes per lane, 16 lanes per contiguous 256-byte row, one query block later.
   auto flush_dq = [&](int qbp) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int q = tid + T * i, r = q / CH, c = q % CH, qi = qbp * 32 + r;
-      if (q < 32 * CH && qi < S) *(u32x4*)(a.dqkv + (rowbase + qi) * a.lddqkv + h * HD + c * 8) = *(const u32x4*)(&sDQ[r * QSTR + c * 8]);
+      if (q < 32 * CH && qi < S) *(u32x4*)(a.dqkv + (rowbase + qi) * a.lddqkv + h * HD + c * 8) = *(const u32x4*)(&sDQ[r * DQSTR + c * 8]);
     }
   };
   for (int qb = 0; qb < nqb; qb++) {
@@ -619,10 +680,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int q = tid + T * i, r = q / CH, c = q % CH;
-      if (q < 32 * CH) { *(u32x4*)(&sQ[r * QSTR + c * 8]) = pq[i]; *(u32x4*)(&sO[r * QSTR + c * 8]) = po[i]; }
+      if (q < 32 * CH) { *(u32x4*)(&sQ[KT::off(r, c * 8)]) = pq[i]; *(u32x4*)(&sO[KT::off(r, c * 8)]) = po[i]; }
     }
-    if (tid < 32) { sL[tid] = pl; sD[tid] = pdl; }   // rows beyond S: clamped duplicates, masked by qi < S below
-    if (qb + 1 < nqb) prefetch(qb + 1);
+    if (tid < 32) { sL[tid] = pl; sD[tid] = pdl; }
     // V fragments are re-fetched (L2 hits) per query block instead of living in 32 registers across the whole loop:
     // with the 128 dK / dV accumulators that keeps the kernel at two workgroups per CU without spilling
     // (hoisting these loads above the first barrier measured 11 % slower)
@@ -630,37 +690,50 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) vf[ks] = *(const s16x8*)(vrow + 16 * ks);
     __syncthreads();
+    // (the swizzled fragment offsets are XORs of these bases: behind an opaque move they are recomputed where they are used instead of
+    //  being hoisted out of the loop into ~30 registers the kernel does not have)
+    int qo = qoff, t0 = toff0, kt0 = ktoff0;
+    if constexpr (SWZ) asm volatile("" : "+v"(qo), "+v"(t0), "+v"(kt0));
+    const int ko = qo + wave_s * 32 * KT::STR, t1 = KT::rows8(t0), kt1 = KT::rows4(kt0);
     // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
     f32x16 sc, dp;
 #pragma unroll
     for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) {
-      const s16x8 qf = *(const s16x8*)(&sQ[l31 * QSTR + 16 * ks + 8 * g]);
-      const s16x8 of = *(const s16x8*)(&sO[l31 * QSTR + 16 * ks + 8 * g]);
-      const s16x8 kf = *(const s16x8*)(&sK[key * KSTR + 16 * ks + 8 * g]);
+      const s16x8 qf = *(const s16x8*)(&sQ[KT::step(qo, 16 * ks)]);
+      const s16x8 of = *(const s16x8*)(&sO[KT::step(qo, 16 * ks)]);
+      const s16x8 kf = *(const s16x8*)(&sK[KT::step(ko, 16 * ks)]);
       sc = mfma32(qf, kf, sc);
       dp = mfma32(of, vf[ks], dp);
     }
+    // the next query block's rows are requested HERE, when the 32 registers of the V fragments are dead (the kernel sits at the 256-register
+    // line: requested before the MFMAs, the compiler parks them in scratch -- behind a vmcnt(0) that exposes the whole load latency)
+    if (qb + 1 < nqb) prefetch(qb + 1);
+    // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
+    f32x4 Lq[4], Dq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[8 * j + 4 * g]); }
     float pd[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const int ql = (r & 3) + 8 * (r >> 2) + 4 * g, qi = qb * 32 + ql;
-      float p = (kok && qi < S) ? __expf(sc[r] - sL[ql]) : 0.f;
+      float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));
+      p = kok ? p : 0.f;
       pd[r] = p;
-      ds[r] = p * (dp[r] - sD[ql]);
-      sDS[ql * DSTR + key] = f2bf(ds[r]);
+      ds[r] = p * (dp[r] - Dq[r >> 2][r & 3]);
     }
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
       const s16x8 pb = pack8(&pd[8 * hf]);
       const s16x8 db = pack8(&ds[8 * hf]);
-      const int qr = 16 * hf + 4 * g + (i16 >> 2);
+      // db = dS of queries 16 hf + 4 g + (0..3) | 16 hf + 8 + 4 g + (0..3): units 4 hf + g and 4 hf + 2 + g of this key's row
+      *(s16x4*)(&sDS[dsw ^ ((4 * hf + g) << 2)]) = (s16x4){db[0], db[1], db[2], db[3]};
+      *(s16x4*)(&sDS[dsw ^ ((4 * hf + 2 + g) << 2)]) = (s16x4){db[4], db[5], db[6], db[7]};
 #pragma unroll
       for (int blk = 0; blk < HD / 32; blk++) {
-        const int col = blk * 32 + 16 * qd + 4 * (i16 & 3);
-        const s16x8 ot = cat4(lds_tr16(&sO[qr * QSTR + col]), lds_tr16(&sO[(qr + 8) * QSTR + col]));
-        const s16x8 qt = cat4(lds_tr16(&sQ[qr * QSTR + col]), lds_tr16(&sQ[(qr + 8) * QSTR + col]));
+        const int o0 = KT::step(t0, 32 * blk) + 16 * hf * KT::STR, o1 = KT::step(t1, 32 * blk) + 16 * hf * KT::STR;
+        const s16x8 ot = cat4(lds_tr16(&sO[o0]), lds_tr16(&sO[o1]));
+        const s16x8 qt = cat4(lds_tr16(&sQ[o0]), lds_tr16(&sQ[o1]));
         dv[blk] = mfma32(ot, pb, dv[blk]);
         dk[blk] = mfma32(qt, db, dk[blk]);
       }
@@ -669,18 +742,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
     // dQ^T tile (head dims 32 t .. +31) x (32 queries) = sum over the keys of K^T dS^T: wave w takes tile t = w % 4 over the keys
     // 128 (w / 4) .. + 127; with 8 waves the upper half's partial goes through sPart and the lower half's waves finish the tile
     {
-      const int tile_hd = wave & 3, khalf = wave >> 2;
       const bool dq_on = tile_hd * 32 < HD;
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; r++) dq[r] = 0.f;
       if (dq_on) {
-        const int col = tile_hd * 32 + 16 * qd + 4 * (i16 & 3);
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) {
-          const int kr = khalf * 128 + 16 * kk + 8 * g + (i16 >> 2);
-          const s16x8 kt_ = cat4(lds_tr16(&sK[kr * KSTR + col]), lds_tr16(&sK[(kr + 4) * KSTR + col]));
-          const s16x8 db = *(const s16x8*)(&sDS[l31 * DSTR + khalf * 128 + 16 * kk + 8 * g]);
+          const s16x8 kt_ = cat4(lds_tr16(&sK[kt0 + 16 * kk * KT::STR]), lds_tr16(&sK[kt1 + 16 * kk * KT::STR]));
+          const s16x8 db = cat4(lds_tr16(&sDS[dsr0 + 16 * kk * 32]), lds_tr16(&sDS[(dsr0 ^ 8) + 4 * 32 + 16 * kk * 32]));
           dq = mfma32(kt_, db, dq);
         }
       }
@@ -702,15 +772,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
           u32x2 t;
           t[0] = pack_bf2(dq[4 * rq] * a.qscale, dq[4 * rq + 1] * a.qscale);
           t[1] = pack_bf2(dq[4 * rq + 2] * a.qscale, dq[4 * rq + 3] * a.qscale);
-          *(u32x2*)(&sDQ[l31 * QSTR + c]) = t;
+          *(u32x2*)(&sDQ[l31 * DQSTR + c]) = t;
         }
       }
     }
   }
   __syncthreads();                                   // last dQ tiles are in sDQ; nobody reads sK any more
   flush_dq(nqb - 1);
-  // dK, dV: same transposition through a wave-private slab in the dead K tile (32 keys x HD, padded rows)
-  bf16_t* slab = sK + wave * 32 * KSTR;
+  // dK, dV: same transposition through a wave-private slab in the dead K tile (32 keys x HD, the K tile's own row layout)
+  bf16_t* slab = sK + wave * 32 * KT::STR;
 #pragma unroll
   for (int which = 0; which < 2; which++) {
 #pragma unroll
@@ -721,13 +791,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
         u32x2 t;
         if (which == 0) { t[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); t[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]); }
         else { t[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); t[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]); }
-        *(u32x2*)(slab + l31 * KSTR + c) = t;
+        *(u32x2*)(slab + KT::off(l31, c)) = t;
       }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < (32 * CH) / 64; i++) {
       const int idx = lane + 64 * i, r = idx / CH, c = idx % CH, kk = wave * 32 + r;
-      const u32x4 v = *(const u32x4*)(slab + r * KSTR + c * 8);
+      const u32x4 v = *(const u32x4*)(slab + KT::off(r, c * 8));
       if (kk < S) *(u32x4*)(a.dqkv + (rowbase + kk) * a.lddqkv + (which + 1) * d + h * HD + c * 8) = v;
     }
     __builtin_amdgcn_wave_barrier();
@@ -763,10 +833,12 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
   UVTG_CHECK_LAUNCH();
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
+  static const bool swz_off = getenv("UVTG_ATTN_SWZ_OFF") != nullptr;       // experiment: padded rows instead of the chunk swizzle (head_dim 128)
+  const bool swz = a.hd == 128 && !swz_off;
   if (a.S <= 128 && a.p_drop <= 0.f) {   // whole (sample, head) problem in one workgroup: one pass over q, k, v, dO
-    if (a.hd == 128) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4>), grid, blk, 0, s, a);
-    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 4>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 4>), grid, blk, 0, s, a);
+    if (a.hd == 128) { if (swz) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, true>), grid, blk, 0, s, a); else hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false>), grid, blk, 0, s, a); }
+    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 4, false>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 4, false>), grid, blk, 0, s, a);
     uvtg_prof_end_launch(5, s);
     UVTG_CHECK_LAUNCH();
     return 0;
@@ -774,19 +846,22 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   static const bool fused8_off = getenv("UVTG_ATTN_FUSED8_OFF") != nullptr;      // experiment: the split kernels for 128 < S <= 256
   if (a.S <= 256 && a.p_drop <= 0.f && !fused8_off) {   // the same with 8 waves / 256 keys (one workgroup per CU)
     const dim3 g8(1, a.H, a.B), b8(512);
-    if (a.hd == 128) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 8>), g8, b8, 0, s, a);
-    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 8>), g8, b8, 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 8>), g8, b8, 0, s, a);
+    if (a.hd == 128) { if (swz) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 8, true>), g8, b8, 0, s, a); else hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 8, false>), g8, b8, 0, s, a); }
+    else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 8, false>), g8, b8, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 8, false>), g8, b8, 0, s, a);
     uvtg_prof_end_launch(5, s);
     UVTG_CHECK_LAUNCH();
     return 0;
   }
-#define BWD(HD_)                                                                                  \
-  if (a.hd == HD_) {                                                                              \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_>), grid, blk, 0, s, a);                          \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_>), grid, blk, 0, s, a);                            \
+#define BWD(HD_, DROP_, SWZ_)                                                                     \
+  {                                                                                               \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);             \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);               \
   }
-  BWD(32) BWD(64) BWD(128)
+  const bool drop = a.p_drop > 0.f;
+  if (a.hd == 128) { if (drop) { if (swz) BWD(128, true, true) else BWD(128, true, false) } else { if (swz) BWD(128, false, true) else BWD(128, false, false) } }
+  else if (a.hd == 64) { if (drop) BWD(64, true, false) else BWD(64, false, false) }
+  else { if (drop) BWD(32, true, false) else BWD(32, false, false) }
 #undef BWD
   uvtg_prof_end_launch(5, s);
   UVTG_CHECK_LAUNCH();
