@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NP = PRECISE ? 2 : 1;
   __shared__ __attribute__((aligned(16))) bf16_t sK[NP][64 * HD];
   __shared__ __attribute__((aligned(16))) bf16_t sV[NP][64 * VSTR];
-  __shared__ unsigned char sValid[64];
+  __shared__ __attribute__((aligned(16))) float sBias[64];     // 0 on a real key, NEG_BIG on padding and beyond S (added in the log2 domain)
   using KS = KSwz<HD>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         *(u32x4*)(&sK[0][KS::off(r, c)]) = pk[i];
         *(u32x4*)(&sV[0][r * VSTR + c * 8]) = pvv[i];
       }
-      if (tid < 64) sValid[tid] = pval;
+      if (tid < 64) sBias[tid] = pval ? 0.f : NEG_BIG;
       if (kt + 1 < ntiles) fetch(kt + 1);
     } else {
       constexpr int PC = HD / 4;                       // float4 pieces per row
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
       }
     }
     if constexpr (PRECISE) {
-      if (tid < 64) { const int key = kt * 64 + tid; sValid[tid] = (key < S) ? a.kvalid[rowbase + key] : 0; }
+      if (tid < 64) { const int key = kt * 64 + tid; sBias[tid] = (key < S && a.kvalid[rowbase + key]) ? 0.f : NEG_BIG; }
     }
     __syncthreads();
 
@@ -192,26 +192,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         sc[kb] = mfma32(kf, qh[ks], sc[kb]);
       }
     }
+    // online softmax in the log2 domain: t = s log2(e) + bias (one v_fma per element; the running maximum m_run is a log2-domain value too)
     float mx = NEG_BIG;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        sc[kb][r] = sValid[kl] ? sc[kb][r] : NEG_BIG;
-        mx = fmaxf(mx, sc[kb][r]);
+      for (int j = 0; j < 4; j++) {
+        const f32x4 bk = *(const f32x4*)(&sBias[kb * 32 + 8 * j + 4 * g]);      // keys kb*32 + 8 j + 4 g + (0..3) = registers 4 j .. 4 j + 3
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          sc[kb][4 * j + e] = fmaf(sc[kb][4 * j + e], LOG2E, bk[e]);
+          mx = fmaxf(mx, sc[kb][4 * j + e]);
+        }
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = exp2_raw(m_run - m_new);
+    const float m_use = fmaxf(m_new, -1e20f);          // nothing but padding so far: t - m_use stays at -1e30, p = 0 (not exp2(0))
     float rs = 0.f;
     float pv[2][16];
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float p = sValid[kl] ? __expf(sc[kb][r] - m_new) : 0.f;
+        const float p = exp2_raw(sc[kb][r] - m_use);
         rs += p;
         pv[kb][r] = p;
       }
@@ -227,10 +231,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
           pv[kb][r] *= keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, key, a.S, a.p_drop);
         }
     }
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {     // (the running maximum settles after the first tiles: HD/2 multiplies saved per tile)
 #pragma unroll
-    for (int i = 0; i < HD / 32; i++)
+      for (int i = 0; i < HD / 32; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) oacc[i][r] *= alpha;
+        for (int r = 0; r < 16; r++) oacc[i][r] *= alpha;
+    }
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (q_raw < S && a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run + __logf(l_run);
+    if (q_raw < S && a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run * 0.6931471805599453f + __logf(l_run);
   } else if (q_raw < S) {
     const float inv = 1.0f / l_run;
 #pragma unroll
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
           *(f32x4*)((float*)a.o + off) = t;
         }
       }
-    if (a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run + __logf(l_run);
+    if (a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run * 0.6931471805599453f + __logf(l_run);
   }
 }
 
@@ -341,8 +347,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 //  Splitting it into a dV pass and a dK pass (208 / 256 registers, two workgroups per CU, 40 instead of 32 MFMAs per query block and
 //  Q / dO streamed twice) measured SLOWER: 2117 vs 1847 us for the whole backward at B=32, S=1232.)
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool DROP, bool SWZ>
-__global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+// VRES: the V fragments stay in registers for the whole kernel.  Without it they are re-fetched (L2 hits) per query block, like the fused
+// kernel does: at head_dim 128 that is what brings the kernel under 256 registers = two workgroups per CU.
+template <int HD, bool DROP, bool SWZ, bool VRES>
+__global__ __launch_bounds__(256, (HD < 128 || !VRES) ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   using QT = TileRT<HD, SWZ>;
   __shared__ __attribute__((aligned(16))) bf16_t sQ[2][32 * QT::STR];
   __shared__ __attribute__((aligned(16))) bf16_t sO[2][32 * QT::STR];
@@ -359,17 +367,13 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
   const bool kin = key < S;
   const bool kok = kin && a.kvalid[rowbase + min(key, S - 1)];
   // this lane's K / V row as MFMA B fragments: k-step ks covers head-dim columns 16 ks + 8 g .. + 7
-  s16x8 kf[HD / 16], vf[HD / 16];
-  {
-    const bf16_t* base = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
+  // (keys beyond S: clamped duplicates -- their probabilities are exact zeros (kok) and their rows are not stored)
+  s16x8 kf[HD / 16], vres[VRES ? HD / 16 : 1];
+  const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
 #pragma unroll
-    for (int ks = 0; ks < HD / 16; ks++) {
-      const u32x4 z = {0, 0, 0, 0};
-      const u32x4 kv = kin ? *(const u32x4*)(base + d + 16 * ks) : z;
-      const u32x4 vv = kin ? *(const u32x4*)(base + 2 * d + 16 * ks) : z;
-      kf[ks] = __builtin_bit_cast(s16x8, kv);
-      vf[ks] = __builtin_bit_cast(s16x8, vv);
-    }
+  for (int ks = 0; ks < HD / 16; ks++) {
+    kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
+    if constexpr (VRES) vres[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
   }
   f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
@@ -417,14 +421,15 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
       }
     }
     if (tid < 32) { sL[buf][tid] = pl; sD[buf][tid] = pdl; }
+    s16x8 vf[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ks++) {
+      if constexpr (VRES) vf[ks] = vres[ks]; else vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+    }
     __syncthreads();          // (the other buffer's last readers passed the previous iteration's barrier)
-    if (qb + 1 < nqb) prefetch(qb + 1);
+    if constexpr (VRES) { if (qb + 1 < nqb) prefetch(qb + 1); }
     const bf16_t* bq = sQ[buf];
     const bf16_t* bo = sO[buf];
-    // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
-    f32x4 Lq[4], Dq[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
     // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
     f32x16 sc, dp;
 #pragma unroll
@@ -436,6 +441,12 @@ __global__ __launch_bounds__(256, HD < 128 ? 2 : 1) void attn_bwd_dkdv_kernel(co
       sc = mfma32(qf, kf[ks], sc);
       dp = mfma32(of, vf[ks], dp);
     }
+    // (two workgroups per CU: the next block's rows are requested when the V fragments are dead, see the fused kernel)
+    if constexpr (!VRES) { if (qb + 1 < nqb) prefetch(qb + 1); }
+    // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
+    f32x4 Lq[4], Dq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
     float pd[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -853,9 +864,11 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     UVTG_CHECK_LAUNCH();
     return 0;
   }
+  static const bool vres_off = getenv("UVTG_ATTN_DKDV_NOVRES") != nullptr;   // experiment: V fragments re-fetched per query block (two workgroups per CU at head_dim 128)
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);             \
+    if (HD_ < 128 || !vres_off) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_, true>), grid, blk, 0, s, a);   \
+    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_, false>), grid, blk, 0, s, a); \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);               \
   }
   const bool drop = a.p_drop > 0.f;
