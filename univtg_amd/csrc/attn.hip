@@ -347,14 +347,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 //  Splitting it into a dV pass and a dK pass (208 / 256 registers, two workgroups per CU, 40 instead of 32 MFMAs per query block and
 //  Q / dO streamed twice) measured SLOWER: 2117 vs 1847 us for the whole backward at B=32, S=1232.)
 // ------------------------------------------------------------------------------------------------
-// VRES: the V fragments stay in registers for the whole kernel.  Without it they are re-fetched (L2 hits) per query block, like the fused
-// kernel does: at head_dim 128 that is what brings the kernel under 256 registers = two workgroups per CU.
-template <int HD, bool DROP, bool SWZ, bool VRES>
-__global__ __launch_bounds__(256, (HD < 128 || !VRES) ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnArgs a) {
+// (head_dim 128: ~330 registers, one workgroup per CU.  Re-fetching the V fragments per query block -- what keeps the fused kernel at 256 --
+//  measured 30 % SLOWER here: 39 query blocks x 2560 workgroups x 32 KB = 3.2 GB of L2 reads per launch, and the kernel spilled.)
+template <int HD, bool DROP, bool SWZ>
+__global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   using QT = TileRT<HD, SWZ>;
-  __shared__ __attribute__((aligned(16))) bf16_t sQ[2][32 * QT::STR];
-  __shared__ __attribute__((aligned(16))) bf16_t sO[2][32 * QT::STR];
-  __shared__ __attribute__((aligned(16))) float sL[2][32], sD[2][32];     // lse * log2(e) (ROW_OFF beyond S), delta
+  // Software pipeline over the query blocks (round 3): iteration qb computes S / dP and the softmax section of block qb AND the dV / dK
+  // products of block qb - 1 -- two independent instruction streams in one basic block, so that the 16 MFMAs of the older block run under
+  // the exp2 / pack VALU work of the newer one (at head_dim 128 this kernel is alone on its SIMD: nothing else hides them).  Three tile
+  // buffers, one barrier per iteration: the buffer written at the top of iteration qb was last read in iteration qb - 2.
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[3][32 * QT::STR];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[3][32 * QT::STR];
+  __shared__ __attribute__((aligned(16))) float sL[3][32], sD[3][32];     // lse * log2(e) (ROW_OFF beyond S), delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
@@ -368,12 +372,14 @@ __global__ __launch_bounds__(256, (HD < 128 || !VRES) ? 2 : 1) void attn_bwd_dkd
   const bool kok = kin && a.kvalid[rowbase + min(key, S - 1)];
   // this lane's K / V row as MFMA B fragments: k-step ks covers head-dim columns 16 ks + 8 g .. + 7
   // (keys beyond S: clamped duplicates -- their probabilities are exact zeros (kok) and their rows are not stored)
-  s16x8 kf[HD / 16], vres[VRES ? HD / 16 : 1];
-  const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
+  s16x8 kf[HD / 16], vf[HD / 16];
+  {
+    const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
 #pragma unroll
-  for (int ks = 0; ks < HD / 16; ks++) {
-    kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
-    if constexpr (VRES) vres[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+    for (int ks = 0; ks < HD / 16; ks++) {
+      kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
+      vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+    }
   }
   f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
@@ -402,15 +408,7 @@ __global__ __launch_bounds__(256, (HD < 128 || !VRES) ? 2 : 1) void attn_bwd_dkd
       pdl = a.delta[((size_t)b * a.H + h) * a.S + qi];
     }
   };
-  // LDS offsets of this lane's fragments inside a tile (loop invariants; with SWZ the chunk index is lane dependent, so they cannot be
-  // instruction immediates)
-  const int qoff = QT::off(l31, 8 * g);                                        // + k-step: QT::step(qoff, 16 ks)
-  const int toff0 = QT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));      // + head-dim block: QT::step(toff, 32 blk); + 16 rows for the
-  const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
-  const int nqb = (S + 31) / 32;
-  prefetch(0);
-  for (int qb = 0; qb < nqb; qb++) {
-    const int buf = qb & 1;
+  auto stage = [&](int buf) {                         // the prefetched rows -> tile buffer `buf`
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
       const int q = tid + 256 * i;
@@ -421,30 +419,36 @@ __global__ __launch_bounds__(256, (HD < 128 || !VRES) ? 2 : 1) void attn_bwd_dkd
       }
     }
     if (tid < 32) { sL[buf][tid] = pl; sD[buf][tid] = pdl; }
-    s16x8 vf[HD / 16];
-#pragma unroll
-    for (int ks = 0; ks < HD / 16; ks++) {
-      if constexpr (VRES) vf[ks] = vres[ks]; else vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
-    }
-    __syncthreads();          // (the other buffer's last readers passed the previous iteration's barrier)
-    if constexpr (VRES) { if (qb + 1 < nqb) prefetch(qb + 1); }
+  };
+  // LDS offsets of this lane's fragments inside a tile (with SWZ the chunk index is lane dependent: steps are XORs, not immediates)
+  const int qoff = QT::off(l31, 8 * g);                                        // + k-step: QT::step(qoff, 16 ks)
+  const int toff0 = QT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));      // + head-dim block: QT::step(toff, 32 blk); + 16 rows for the
+  const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
+  // S = Q K^T, dP = dO V^T of the block in buffer `buf`: reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key.  The row fragments are fetched
+  // AHEAD k-steps in front of their MFMAs, in fenced steps (left alone the compiler keeps ONE fragment pair in flight and every MFMA waits
+  // out an LDS round trip); `extra(ks)` issues further LDS reads behind the MFMAs of k-step ks (the caller's fragments for what follows)
+  auto scores = [&](int buf, f32x16& sc, f32x16& dp, auto&& extra) {
     const bf16_t* bq = sQ[buf];
     const bf16_t* bo = sO[buf];
-    // S = Q K^T, dP = dO V^T : reg r <-> query (r&3)+8(r>>2)+4g, lane <-> key
-    f32x16 sc, dp;
+    constexpr int KS = HD / 16, AHEAD = KS < 4 ? KS : 4;
+    s16x8 qf[KS], of[KS];
 #pragma unroll
     for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < HD / 16; ks++) {
-      const s16x8 qf = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]);
-      const s16x8 of = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]);
-      sc = mfma32(qf, kf[ks], sc);
-      dp = mfma32(of, vf[ks], dp);
+    for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      sc = mfma32(qf[ks], kf[ks], sc);
+      dp = mfma32(of[ks], vf[ks], dp);
+      if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
+      extra(ks);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // (two workgroups per CU: the next block's rows are requested when the V fragments are dead, see the fused kernel)
-    if constexpr (!VRES) { if (qb + 1 < nqb) prefetch(qb + 1); }
-    // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
-    f32x4 Lq[4], Dq[4];
+  };
+  // P (after dropout) and dS of the block, packed as the B operands of the dV / dK products: [hf] = queries 16 hf .. 16 hf + 15
+  auto softmax = [&](int qb, int buf, const f32x16& sc, const f32x16& dp, s16x8 (&pb)[2], s16x8 (&db)[2]) {
+    f32x4 Lq[4], Dq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
 #pragma unroll
     for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
     float pd[16], ds[16];
@@ -463,19 +467,106 @@ __global__ __launch_bounds__(256, (HD < 128 || !VRES) ? 2 : 1) void attn_bwd_dkd
       }
     }
 #pragma unroll
-    for (int hf = 0; hf < 2; hf++) {
-      const s16x8 pb = pack8(&pd[8 * hf]);
-      const s16x8 db = pack8(&ds[8 * hf]);
+    for (int hf = 0; hf < 2; hf++) { pb[hf] = pack8(&pd[8 * hf]); db[hf] = pack8(&ds[8 * hf]); }
+  };
+  // dV^T += dO^T P, dK^T += Q^T dS of the block in buffer `buf`
+  auto products = [&](int buf, const s16x8 (&pb)[2], const s16x8 (&db)[2]) {
+    const bf16_t* bq = sQ[buf];
+    const bf16_t* bo = sO[buf];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++)
 #pragma unroll
       for (int blk = 0; blk < HD / 32; blk++) {
         const int o0 = QT::step(toff0, 32 * blk) + 16 * hf * QT::STR, o1 = QT::step(toff1, 32 * blk) + 16 * hf * QT::STR;
         const s16x8 ot = cat4(lds_tr16(&bo[o0]), lds_tr16(&bo[o1]));
         const s16x8 qt = cat4(lds_tr16(&bq[o0]), lds_tr16(&bq[o1]));
-        dv[blk] = mfma32(ot, pb, dv[blk]);
-        dk[blk] = mfma32(qt, db, dk[blk]);
+        dv[blk] = mfma32(ot, pb[hf], dv[blk]);
+        dk[blk] = mfma32(qt, db[hf], dk[blk]);
       }
-    }
+  };
+  const int nqb = (S + 31) / 32;
+  s16x8 pb[2], db[2];
+  prefetch(0);
+  stage(0);
+  __syncthreads();
+  if (1 < nqb) prefetch(1);
+  {
+    f32x16 sc, dp;
+    scores(0, sc, dp, [](int) {});
+    softmax(0, 0, sc, dp, pb, db);
   }
+  int bc = 1, bp = 0;                                  // tile buffers of the current / the previous block
+  for (int qb = 1; qb < nqb; qb++) {
+    stage(bc);
+    __syncthreads();          // (buffer bc was last read two iterations ago; every wave passed the barrier in between)
+    if (qb + 1 < nqb) prefetch(qb + 1);
+    // The older block's 16 product MFMAs go out two at a time, each pair followed by the softmax arithmetic of two score elements of the
+    // newer block (~12 VALU operations: they issue while the pair runs), fenced so that the order survives the scheduler -- left alone it
+    // issues all 32 MFMAs first and the ~190 VALU operations behind them, and with in-order issue nothing overlaps.  The transposed
+    // fragments of a pair are fetched two pairs ahead; the first two pairs' ride under the score MFMAs.
+    const bf16_t* pq_ = sQ[bp];
+    const bf16_t* po_ = sO[bp];
+    auto frag = [&](int step, s16x8& ot, s16x8& qt) {       // step = (HD / 32) hf + blk
+      const int hf = step / (HD / 32), blk = step % (HD / 32);
+      const int o0 = QT::step(toff0, 32 * blk) + 16 * hf * QT::STR, o1 = QT::step(toff1, 32 * blk) + 16 * hf * QT::STR;
+      ot = cat4(lds_tr16(&po_[o0]), lds_tr16(&po_[o1]));
+      qt = cat4(lds_tr16(&pq_[o0]), lds_tr16(&pq_[o1]));
+    };
+    constexpr int NSTEP = 2 * (HD / 32), EPS = 16 / NSTEP;   // product steps (pairs of MFMAs), score elements per step
+    s16x8 fo[2], fq[2];
+    f32x4 Lq[4], Dq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
+    f32x16 sc, dp;
+    constexpr int KS = HD / 16;
+    scores(bc, sc, dp, [&](int ks) {      // behind the last four k-steps (no row fragments left to fetch): the first two product steps' fragments, the statistics
+      if (ks == KS - 4 || KS < 4 && ks == 0) frag(0, fo[0], fq[0]);
+      if (ks == KS - 3 || KS < 4 && ks == 0) frag(1, fo[1], fq[1]);
+      if (ks == KS - 2 || KS < 4 && ks == KS - 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) Lq[j] = *(const f32x4*)(&sL[bc][8 * j + 4 * g]);
+      }
+      if (ks == KS - 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) Dq[j] = *(const f32x4*)(&sD[bc][8 * j + 4 * g]);
+      }
+    });
+    unsigned pw[8], dw[8];                                   // the newer block's P / dS, packed pair by pair as they are produced
+#pragma unroll
+    for (int step = 0; step < NSTEP; step++) {
+      const int hf = step / (HD / 32), blk = step % (HD / 32);
+      dv[blk] = mfma32(fo[step & 1], pb[hf], dv[blk]);
+      dk[blk] = mfma32(fq[step & 1], db[hf], dk[blk]);
+      if (step + 2 < NSTEP) frag(step + 2, fo[step & 1], fq[step & 1]);
+#pragma unroll
+      for (int e = 0; e < EPS; e += 2) {
+        float pd[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int r = step * EPS + e + u;
+          float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));
+          p = kok ? p : 0.f;
+          if constexpr (DROP) {
+            const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
+            pd[u] = p * ksc;
+            ds[u] = p * (dp[r] * ksc - Dq[r >> 2][r & 3]);
+          } else {
+            pd[u] = p;
+            ds[u] = p * (dp[r] - Dq[r >> 2][r & 3]);
+          }
+        }
+        pw[(step * EPS + e) / 2] = pack_bf2(pd[0], pd[1]);
+        dw[(step * EPS + e) / 2] = pack_bf2(ds[0], ds[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      pb[hf] = __builtin_bit_cast(s16x8, (u32x4){pw[4 * hf], pw[4 * hf + 1], pw[4 * hf + 2], pw[4 * hf + 3]});
+      db[hf] = __builtin_bit_cast(s16x8, (u32x4){dw[4 * hf], dw[4 * hf + 1], dw[4 * hf + 2], dw[4 * hf + 3]});
+    }
+    bp = bc; bc = bc == 2 ? 0 : bc + 1;
+  }
+  products(bp, pb, db);
   if (kin) {
 #pragma unroll
     for (int blk = 0; blk < HD / 32; blk++)
@@ -847,7 +938,10 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   static const bool swz_off = getenv("UVTG_ATTN_SWZ_OFF") != nullptr;       // experiment: padded rows instead of the chunk swizzle (head_dim 128)
   const bool swz = a.hd == 128 && !swz_off;
   if (a.S <= 128 && a.p_drop <= 0.f) {   // whole (sample, head) problem in one workgroup: one pass over q, k, v, dO
-    if (a.hd == 128) { if (swz) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, true>), grid, blk, 0, s, a); else hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false>), grid, blk, 0, s, a); }
+    // (4-wave kernel: padded rows -- 0.370 vs 0.390 ms per step at config 2: three or four query blocks per workgroup, the XORs and the 16 bytes
+    //  of scratch cost more than the transposing reads gain; the 8-wave kernel and the split kernels gain 5 - 8 % from the swizzle)
+    static const bool swz4_on = getenv("UVTG_ATTN_SWZ4_ON") != nullptr;
+    if (a.hd == 128) { if (swz && swz4_on) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, true>), grid, blk, 0, s, a); else hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false>), grid, blk, 0, s, a); }
     else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 4, false>), grid, blk, 0, s, a);
     else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 4, false>), grid, blk, 0, s, a);
     uvtg_prof_end_launch(5, s);
@@ -864,11 +958,9 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     UVTG_CHECK_LAUNCH();
     return 0;
   }
-  static const bool vres_off = getenv("UVTG_ATTN_DKDV_NOVRES") != nullptr;   // experiment: V fragments re-fetched per query block (two workgroups per CU at head_dim 128)
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
-    if (HD_ < 128 || !vres_off) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_, true>), grid, blk, 0, s, a);   \
-    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_, false>), grid, blk, 0, s, a); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);             \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);               \
   }
   const bool drop = a.p_drop > 0.f;
