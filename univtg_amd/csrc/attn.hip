@@ -21,6 +21,18 @@ template <int HD> struct KSwz {      // swizzle for [rows][HD] bf16 tiles read w
   __device__ static __forceinline__ int off(int r, int chunk) { return r * HD + ((chunk ^ ((r / RPB) % CPR)) * 8); }
 };
 
+// XCD-aware decode of the 1-D grids of the tiled kernels.  Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  All
+// `nblk` 128-row blocks of one (sample, head) stream the SAME K / V rows (forward, dQ) or Q / dO rows (dK / dV): with the (block, head, sample)
+// grid their ids were consecutive, i.e. one block per XCD, and every XCD pulled every head's rows into its own L2 (8 x the traffic, S = 1232:
+// 1.3 GB per launch).  Here XCD x takes a contiguous range of the block list, so that the blocks of a head run on ONE XCD, back to back.
+__device__ __forceinline__ void attn_block_id(int nblk, int H, int& blk, int& h, int& b) {
+  const int total = gridDim.x, q = total / 8, r = total % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  blk = v % nblk;
+  const int bh = v / nblk;
+  h = bh % H; b = bh / H;
+}
+
 // Counter = position in the PADDED [B, H, S, S] probability tensor (S = a.S also on the packed stream, whose in-sample row order under
 // dropout is the padded layout's): padded and packed executions draw identical masks.
 __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned stream, int bh, int q, int k, int S, float p) {
@@ -89,9 +101,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   using KS = KSwz<HD>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S;
-  if ((int)blockIdx.x * 128 >= S) return;
-  const int q_raw = blockIdx.x * 128 + wave * 32 + l31;
+  int qblk, h, b;
+  attn_block_id((a.S + 127) / 128, a.H, qblk, h, b);
+  const int S = a.seq_count ? a.seq_count[b] : a.S;
+  if (qblk * 128 >= S) return;
+  const int q_raw = qblk * 128 + wave * 32 + l31;
   const int qrow = min(q_raw, S - 1);
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
 
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < (32 * CPR) / 64; i++) {
         const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR;
-        const int q = blockIdx.x * 128 + wave * 32 + row;
+        const int q = qblk * 128 + wave * 32 + row;
         const u32x4 v = *(const u32x4*)(slab + row * OSTR + ch * 8);
         if (q < S) *(u32x4*)((bf16_t*)a.o + (rowbase + q) * a.ldo + h * HD + pass * (HD / 2) + ch * 8) = v;
       }
@@ -361,10 +375,12 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
   __shared__ __attribute__((aligned(16))) float sL[3][32], sD[3][32];     // lse * log2(e) (ROW_OFF beyond S), delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
-  if ((int)blockIdx.x * 128 >= S) return;
+  int kblk, h, b;
+  attn_block_id((a.S + 127) / 128, a.H, kblk, h, b);
+  const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  if (kblk * 128 >= S) return;
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
-  const int key0 = blockIdx.x * 128;
+  const int key0 = kblk * 128;
   const bf16_t* qkv = (const bf16_t*)a.qkv;
   constexpr int CH = HD / 8;
   const int key = key0 + wave * 32 + l31;            // this lane's key (lane <-> key in S, dP tiles)
@@ -595,10 +611,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sBias[64];     // 0 on a real key, -ROW_OFF on padding and beyond S
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int b = blockIdx.z, h = blockIdx.y, S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
-  if ((int)blockIdx.x * 128 >= S) return;
+  int qblk, h, b;
+  attn_block_id((a.S + 127) / 128, a.H, qblk, h, b);
+  const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  if (qblk * 128 >= S) return;
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
-  const int q_raw = blockIdx.x * 128 + wave * 32 + l31;
+  const int q_raw = qblk * 128 + wave * 32 + l31;
   const int qrow = min(q_raw, S - 1);
   const bf16_t* qkv = (const bf16_t*)a.qkv;
   s16x8 qf[HD / 16], of[HD / 16];
@@ -913,7 +931,7 @@ void uvtg_prof_end_launch(int family, hipStream_t s);
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
   if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
-  dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
+  dim3 grid(cdiv(a.S, 128) * a.H * a.B), blk(256);      // decoded by attn_block_id
   uvtg_prof_begin_launch(4, 4.0 * a.B * a.H * (double)a.S * a.S * a.hd, s);
 #define FWD(HD_)                                                                                  \
   if (a.hd == HD_) {                                                                              \
@@ -958,10 +976,11 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     UVTG_CHECK_LAUNCH();
     return 0;
   }
+  const dim3 grid1(cdiv(a.S, 128) * a.H * a.B);          // decoded by attn_block_id
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);             \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid, blk, 0, s, a);               \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);            \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);              \
   }
   const bool drop = a.p_drop > 0.f;
   if (a.hd == 128) { if (drop) { if (swz) BWD(128, true, true) else BWD(128, true, false) } else { if (swz) BWD(128, false, true) else BWD(128, false, false) } }
