@@ -417,14 +417,13 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
       pq[i] = on ? *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8) : z;
       po[i] = on ? *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8) : z;
     }
-    if (tid < 32) {
+    if (tid < 32) {          // (raw values: anything computed from them HERE would wait out the whole load latency right behind the request)
       const int qi = min(qb * 32 + tid, S - 1);
-      const float l = a.lse[((size_t)b * a.H + h) * a.S + qi];
-      pl = (qb * 32 + tid < S) ? l * LOG2E : ROW_OFF;
+      pl = a.lse[((size_t)b * a.H + h) * a.S + qi];
       pdl = a.delta[((size_t)b * a.H + h) * a.S + qi];
     }
   };
-  auto stage = [&](int buf) {                         // the prefetched rows -> tile buffer `buf`
+  auto stage = [&](int buf, int qb) {                 // the prefetched rows of block qb -> tile buffer `buf`
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
       const int q = tid + 256 * i;
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
         *(u32x4*)(&sO[buf][QT::off(r, c * 8)]) = po[i];
       }
     }
-    if (tid < 32) { sL[buf][tid] = pl; sD[buf][tid] = pdl; }
+    if (tid < 32) { sL[buf][tid] = (qb * 32 + tid < S) ? pl * LOG2E : ROW_OFF; sD[buf][tid] = pdl; }
   };
   // LDS offsets of this lane's fragments inside a tile (with SWZ the chunk index is lane dependent: steps are XORs, not immediates)
   const int qoff = QT::off(l31, 8 * g);                                        // + k-step: QT::step(qoff, 16 ks)
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
   const int nqb = (S + 31) / 32;
   s16x8 pb[2], db[2];
   prefetch(0);
-  stage(0);
+  stage(0, 0);
   __syncthreads();
   if (1 < nqb) prefetch(1);
   {
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
   }
   int bc = 1, bp = 0;                                  // tile buffers of the current / the previous block
   for (int qb = 1; qb < nqb; qb++) {
-    stage(bc);
+    stage(bc, qb);
     __syncthreads();          // (buffer bc was last read two iterations ago; every wave passed the barrier in between)
     if (qb + 1 < nqb) prefetch(qb + 1);
     // The older block's 16 product MFMAs go out two at a time, each pair followed by the softmax arithmetic of two score elements of the
@@ -750,10 +749,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
   u32x4 pq[NP], po[NP];
   float pl = 0.f, pdl = 0.f;                         // lse / delta of query qb*32 + tid (tid < 32), fetched with the block's rows
   auto prefetch = [&](int qb) {
-    if (tid < 32) {
+    if (tid < 32) {          // (raw values: anything computed from them HERE would wait out the whole load latency right behind the request)
       const int qi = min(qb * 32 + tid, S - 1);
-      const float l = a.lse[((size_t)b * a.H + h) * a.S + qi];
-      pl = (qb * 32 + tid < S) ? l * LOG2E : ROW_OFF;
+      pl = a.lse[((size_t)b * a.H + h) * a.S + qi];
       pdl = a.delta[((size_t)b * a.H + h) * a.S + qi];
     }
 #pragma unroll
@@ -802,7 +800,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
       const int q = tid + T * i, r = q / CH, c = q % CH;
       if (q < 32 * CH) { *(u32x4*)(&sQ[KT::off(r, c * 8)]) = pq[i]; *(u32x4*)(&sO[KT::off(r, c * 8)]) = po[i]; }
     }
-    if (tid < 32) { sL[tid] = pl; sD[tid] = pdl; }
+    if (tid < 32) { sL[tid] = (qb * 32 + tid < S) ? pl * LOG2E : ROW_OFF; sD[tid] = pdl; }
     // V fragments are re-fetched (L2 hits) per query block instead of living in 32 registers across the whole loop:
     // with the 128 dK / dV accumulators that keeps the kernel at two workgroups per CU without spilling
     // (hoisting these loads above the first barrier measured 11 % slower)
