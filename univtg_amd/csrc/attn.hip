@@ -363,7 +363,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // (head_dim 128: ~330 registers, one workgroup per CU.  Re-fetching the V fragments per query block -- what keeps the fused kernel at 256 --
 //  measured 30 % SLOWER here: 39 query blocks x 2560 workgroups x 32 KB = 3.2 GB of L2 reads per launch, and the kernel spilled.)
-template <int HD, bool DROP, bool SWZ>
+// ABL (measurement builds only, -DUVTG_ATTN_ABLATE; results are garbage): 1 = no product MFMAs / transposing reads, 2 = no softmax arithmetic,
+// 3 = no staging / prefetch after the first block, 4 = no barrier in the loop, 5 = no score MFMAs / row reads
+template <int HD, bool DROP, bool SWZ, int ABL = 0>
 __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnArgs a) {
   using QT = TileRT<HD, SWZ>;
   // Software pipeline over the query blocks (round 3): iteration qb computes S / dP and the softmax section of block qb AND the dV / dK
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
   const bool kin = key < S;
   const bool kok = kin && a.kvalid[rowbase + min(key, S - 1)];
   // this lane's K / V row as MFMA B fragments: k-step ks covers head-dim columns 16 ks + 8 g .. + 7
-  // (keys beyond S: clamped duplicates -- their probabilities are exact zeros (kok) and their rows are not stored)
+  // (keys beyond S: clamped duplicates whose rows are not stored)
   s16x8 kf[HD / 16], vf[HD / 16];
   {
     const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
@@ -449,14 +451,18 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
     s16x8 qf[KS], of[KS];
 #pragma unroll
     for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
+    if constexpr (ABL != 5) {
 #pragma unroll
-    for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+      for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      sc = mfma32(qf[ks], kf[ks], sc);
-      dp = mfma32(of[ks], vf[ks], dp);
-      if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
+      if constexpr (ABL != 5) {
+        sc = mfma32(qf[ks], kf[ks], sc);
+        dp = mfma32(of[ks], vf[ks], dp);
+      }
+      if (ABL != 5 && ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
       extra(ks);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -469,8 +475,7 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
     float pd[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));
-      p = kok ? p : 0.f;
+      const float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));      // (padded keys: see the stores at the end)
       if constexpr (DROP) {
         const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
@@ -512,9 +517,9 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
   }
   int bc = 1, bp = 0;                                  // tile buffers of the current / the previous block
   for (int qb = 1; qb < nqb; qb++) {
-    stage(bc, qb);
-    __syncthreads();          // (buffer bc was last read two iterations ago; every wave passed the barrier in between)
-    if (qb + 1 < nqb) prefetch(qb + 1);
+    if constexpr (ABL != 3) stage(bc, qb);
+    if constexpr (ABL != 4) __syncthreads();          // (buffer bc was last read two iterations ago; every wave passed the barrier in between)
+    if constexpr (ABL != 3) { if (qb + 1 < nqb) prefetch(qb + 1); }
     // The older block's 16 product MFMAs go out two at a time, each pair followed by the softmax arithmetic of two score elements of the
     // newer block (~12 VALU operations: they issue while the pair runs), fenced so that the order survives the scheduler -- left alone it
     // issues all 32 MFMAs first and the ~190 VALU operations behind them, and with in-order issue nothing overlaps.  The transposed
@@ -533,8 +538,8 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
     f32x16 sc, dp;
     constexpr int KS = HD / 16;
     scores(bc, sc, dp, [&](int ks) {      // behind the last four k-steps (no row fragments left to fetch): the first two product steps' fragments, the statistics
-      if (ks == KS - 4 || KS < 4 && ks == 0) frag(0, fo[0], fq[0]);
-      if (ks == KS - 3 || KS < 4 && ks == 0) frag(1, fo[1], fq[1]);
+      if (ABL != 1 && (ks == KS - 4 || KS < 4 && ks == 0)) frag(0, fo[0], fq[0]);
+      if (ABL != 1 && (ks == KS - 3 || KS < 4 && ks == 0)) frag(1, fo[1], fq[1]);
       if (ks == KS - 2 || KS < 4 && ks == KS - 1) {
 #pragma unroll
         for (int j = 0; j < 4; j++) Lq[j] = *(const f32x4*)(&sL[bc][8 * j + 4 * g]);
@@ -548,17 +553,19 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
 #pragma unroll
     for (int step = 0; step < NSTEP; step++) {
       const int hf = step / (HD / 32), blk = step % (HD / 32);
-      dv[blk] = mfma32(fo[step & 1], pb[hf], dv[blk]);
-      dk[blk] = mfma32(fq[step & 1], db[hf], dk[blk]);
-      if (step + 2 < NSTEP) frag(step + 2, fo[step & 1], fq[step & 1]);
+      if constexpr (ABL != 1) {
+        dv[blk] = mfma32(fo[step & 1], pb[hf], dv[blk]);
+        dk[blk] = mfma32(fq[step & 1], db[hf], dk[blk]);
+        if (step + 2 < NSTEP) frag(step + 2, fo[step & 1], fq[step & 1]);
+      }
 #pragma unroll
       for (int e = 0; e < EPS; e += 2) {
         float pd[2], ds[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
           const int r = step * EPS + e + u;
-          float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));
-          p = kok ? p : 0.f;
+          if constexpr (ABL == 2) { pd[u] = sc[r]; ds[u] = dp[r]; continue; }
+          const float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));
           if constexpr (DROP) {
             const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
             const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
@@ -582,7 +589,10 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
     bp = bc; bc = bc == 2 ? 0 : bc + 1;
   }
   products(bp, pb, db);
+  // A lane's key contributes to nobody's sums but its own dK / dV row: the key-padding mask is applied HERE (a padded key's row is zero)
+  // instead of as a select per probability in the loop
   if (kin) {
+    const u32x2 z = {0u, 0u};
 #pragma unroll
     for (int blk = 0; blk < HD / 32; blk++)
 #pragma unroll
@@ -591,9 +601,9 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
         bf16_t* base = a.dqkv + (rowbase + key) * a.lddqkv + h * HD + c;
         u32x2 t;
         t[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); t[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]);
-        *(u32x2*)(base + d) = t;
+        *(u32x2*)(base + d) = kok ? t : z;
         t[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); t[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]);
-        *(u32x2*)(base + 2 * d) = t;
+        *(u32x2*)(base + 2 * d) = kok ? t : z;
       }
   }
 }
@@ -688,6 +698,148 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
       }
     }
   }
+  if (q_raw < S) {
+#pragma unroll
+    for (int blk = 0; blk < HD / 32; blk++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const int c = blk * 32 + 8 * rq + 4 * g;
+        u32x2 t;
+        t[0] = pack_bf2(dq[blk][4 * rq] * a.qscale, dq[blk][4 * rq + 1] * a.qscale);
+        t[1] = pack_bf2(dq[blk][4 * rq + 2] * a.qscale, dq[blk][4 * rq + 3] * a.qscale);
+        *(u32x2*)(a.dqkv + (rowbase + q_raw) * a.lddqkv + h * HD + c) = t;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dQ at head_dim 128 with the K / V tiles delivered by LDS-DMA (round 3).  The kernel above loads a tile into registers, stores it
+// to LDS and synchronises twice per tile with the load latency in the open (PMC: 46 % of its wave cycles wait on a counter; 254 registers
+// leave no room for a register prefetch).  Here the 64-key tile kt + 1 is requested straight into the OTHER half of a double buffer while
+// tile kt is multiplied: `buffer_load ... lds` (16 bytes per lane, 1 KB = 4 swizzled tile rows per wave-instruction, the chunk permutation
+// applied on the SOURCE address), no registers, one barrier per tile.  The requests are issued from inline asm: hipcc answers every transposing
+// LDS read that follows an LDS-DMA it knows of with `s_waitcnt vmcnt(0)` (gemm.hip, weight-gradient kernel), which would put the latency back.
+// ------------------------------------------------------------------------------------------------
+typedef int __attribute__((ext_vector_type(4))) i32x4_t;
+__device__ __forceinline__ void attn_dma16(i32x4_t rsrc, unsigned voff, unsigned lds_dst) {      // (M0 is the compiler's: saved and restored)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const AttnArgs a, unsigned qkv_bytes) {
+  constexpr int HD = 128;
+  using KT = TileRT<HD, true>;
+  __shared__ __attribute__((aligned(1024))) bf16_t sKV[2][2][64 * HD];      // [buffer][K | V][64 keys x 128], swizzled 256-byte rows
+  __shared__ __attribute__((aligned(16))) float sBias[2][64];               // 0 on a real key, -ROW_OFF on padding and beyond S
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  int qblk, h, b;
+  attn_block_id((a.S + 127) / 128, a.H, qblk, h, b);
+  const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  if (qblk * 128 >= S) return;
+  const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
+  const int q_raw = qblk * 128 + wave * 32 + l31;
+  const int qrow = min(q_raw, S - 1);
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  // buffer resource over the whole qkv matrix (wave-uniform)
+  i32x4_t rsrc;
+  {
+    const unsigned long long pa = (unsigned long long)(uintptr_t)qkv;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pa);
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu));
+    rsrc[2] = __builtin_amdgcn_readfirstlane((int)qkv_bytes);
+    rsrc[3] = 0x00020000;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)&sKV[0][0][0];
+  // this lane's share of a tile: pieces 4 wave .. 4 wave + 3 of K and of V (a piece = 4 tile rows = 1 KB); lane l supplies physical chunk
+  // l & 15 of row 4 p + (l >> 4), i.e. the logical chunk (l & 15) ^ (4 (l >> 4) + (p & 3))
+  auto request = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int p = wave * 4 + i, row = 4 * p + (lane >> 4);
+      const int chunk = (lane & 15) ^ (((lane >> 4) << 2) | (p & 3));
+      const int key = min(kt * 64 + row, S - 1);          // rows beyond S: clamped duplicates, their dS is an exact zero (bias)
+      const unsigned src = (unsigned)(((rowbase + key) * (size_t)a.ldqkv + (size_t)h * HD + (size_t)chunk * 8) * 2);
+      attn_dma16(rsrc, src + (unsigned)d * 2u, lds0 + (unsigned)((buf * 2 + 0) * 64 * HD * 2 + p * 1024));
+      attn_dma16(rsrc, src + (unsigned)d * 4u, lds0 + (unsigned)((buf * 2 + 1) * 64 * HD * 2 + p * 1024));
+    }
+  };
+  auto bias_of = [&](int kt) -> float {                  // tid < 64
+    const int key = kt * 64 + tid;
+    return (key < S && a.kvalid[rowbase + min(key, S - 1)]) ? 0.f : -ROW_OFF;
+  };
+  const int ntiles = (S + 63) / 64;
+  request(0, 0);
+  float nbias = tid < 64 ? bias_of(0) : 0.f;
+  s16x8 qf[HD / 16], of[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ks++) {
+    qf[ks] = *(const s16x8*)(qkv + (rowbase + qrow) * a.ldqkv + h * HD + 16 * ks + 8 * g);
+    of[ks] = *(const s16x8*)(a.dO + (rowbase + qrow) * a.lddo + h * HD + 16 * ks + 8 * g);
+  }
+  const float L2 = a.lse[((size_t)b * a.H + h) * a.S + qrow] * LOG2E;
+  const float dl = a.delta[((size_t)b * a.H + h) * a.S + qrow];
+  f32x16 dq[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
+  [[maybe_unused]] const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
+  // this lane's fragment offsets inside a tile (rows 0..31; + 32 rows for kb = 1, + 16 for hf = 1: the same chunk permutation)
+  const int koff = KT::off(l31, 8 * g);
+  const int toff0 = KT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3)), toff1 = KT::rows8(toff0);
+  if (tid < 64) sBias[0][tid] = nbias;
+  for (int kt = 0; kt < ntiles; kt++) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed (and everything older)
+    __syncthreads();                                     // ... everybody's; and everybody is done with the other buffer (tile kt - 1)
+    if (kt + 1 < ntiles) {
+      request(kt + 1, buf ^ 1);
+      if (tid < 64) nbias = bias_of(kt + 1);
+    }
+    const bf16_t* sK = sKV[buf][0];
+    const bf16_t* sV = sKV[buf][1];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      f32x4 bq[4];                                     // bias of this lane's 16 accumulator registers: keys kb*32 + 8 j + 4 g + (0..3)
+#pragma unroll
+      for (int j = 0; j < 4; j++) bq[j] = *(const f32x4*)(&sBias[buf][kb * 32 + 8 * j + 4 * g]);
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++) {
+        const int o = KT::step(koff, 16 * ks) + kb * 32 * KT::STR;
+        sc = mfma32(*(const s16x8*)(&sK[o]), qf[ks], sc);
+        dp = mfma32(*(const s16x8*)(&sV[o]), of[ks], dp);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float p = exp2_raw(fmaf(sc[r], LOG2E, bq[r >> 2][r & 3] - L2));
+        if constexpr (DROP) {
+          const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, q_raw, kt * 64 + kl, a.S, a.p_drop);
+          ds[r] = p * (dp[r] * ksc - dl);
+        } else {
+          ds[r] = p * (dp[r] - dl);
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const s16x8 db = pack8(&ds[8 * hf]);
+#pragma unroll
+        for (int blk = 0; blk < HD / 32; blk++) {
+          const int rowo = (kb * 32 + 16 * hf) * KT::STR;
+          const s16x8 kt_ = cat4(lds_tr16(&sK[KT::step(toff0, 32 * blk) + rowo]), lds_tr16(&sK[KT::step(toff1, 32 * blk) + rowo]));
+          dq[blk] = mfma32(kt_, db, dq[blk]);
+        }
+      }
+    }
+    if (kt + 1 < ntiles && tid < 64) sBias[buf ^ 1][tid] = nbias;     // (visible behind the next barrier; its last readers passed this one)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
   if (q_raw < S) {
 #pragma unroll
     for (int blk = 0; blk < HD / 32; blk++)
@@ -975,10 +1127,34 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     return 0;
   }
   const dim3 grid1(cdiv(a.S, 128) * a.H * a.B);          // decoded by attn_block_id
+  // dQ by LDS-DMA (head_dim 128): the buffer descriptor addresses the qkv matrix with 32-bit byte offsets
+  static const bool dq_dma_off = getenv("UVTG_ATTN_DQ_DMA_OFF") != nullptr;
+  const unsigned long long qkv_bytes = (unsigned long long)rows * a.ldqkv * 2ull;
+  const bool dq_dma = !dq_dma_off && qkv_bytes < (1ull << 32);
+#ifdef UVTG_ATTN_ABLATE
+  {
+    static const int abl = getenv("UVTG_ATTN_ABL") ? atoi(getenv("UVTG_ATTN_ABL")) : 0;
+    if (a.hd == 128 && swz && a.p_drop <= 0.f && abl > 0) {
+      switch (abl) {
+        case 1: hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, true, 1>), grid1, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, true, 2>), grid1, blk, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, true, 3>), grid1, blk, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, true, 4>), grid1, blk, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, true, 5>), grid1, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, true, 0>), grid1, blk, 0, s, a); break;     // 6: the whole kernel, alone
+      }
+      uvtg_prof_end_launch(5, s);
+      UVTG_CHECK_LAUNCH();
+      return 0;          // (dK / dV only: the ablation runs time this kernel alone)
+    }
+  }
+#endif
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);            \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);              \
+    if (HD_ == 128 && dq_dma) {                                                                   \
+      hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DROP_>), grid1, blk, 0, s, a, (unsigned)qkv_bytes); \
+    } else hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);       \
   }
   const bool drop = a.p_drop > 0.f;
   if (a.hd == 128) { if (drop) { if (swz) BWD(128, true, true) else BWD(128, true, false) } else { if (swz) BWD(128, false, true) else BWD(128, false, false) } }
