@@ -17,5 +17,5 @@ cp $OUT/pmc_nt256.json $OUT/${TAG}_pmc_nt256.json; for i in 0 1 2; do cp $OUT/pm
 tail -24 $OUT/${TAG}_pmc_nt256.log | head -12
 ( timeout 400 python bench.py --mode infer 2>/dev/null | tail -1 ) > $OUT/${TAG}_bench_infer.json; cut -c1-200 $OUT/${TAG}_bench_infer.json
 for c in 3 5 4; do ( timeout 150 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 ) > $OUT/${TAG}_bench_config$c.json; cut -c1-120 $OUT/${TAG}_bench_config$c.json; done
-bash tools/prof.sh ${TAG}c2 26 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-steps 0 --no-padded-compare > /dev/null 2>&1
-bash tools/prof.sh ${TAG}c4 26 python $R/bench.py --config 4 --steps 20 --warmup 3 --no-cpu-baseline --profile-steps 0 --no-padded-compare > /dev/null 2>&1
+timeout 400 bash tools/prof.sh ${TAG}c2 26 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-steps 0 --no-padded-compare > /dev/null 2>&1
+timeout 400 bash tools/prof.sh ${TAG}c4 26 python $R/bench.py --config 4 --steps 20 --warmup 3 --no-cpu-baseline --profile-steps 0 --no-padded-compare > /dev/null 2>&1
