@@ -955,7 +955,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
     if (tid < 32) { sL[tid] = (qb * 32 + tid < S) ? pl * LOG2E : ROW_OFF; sD[tid] = pdl; }
     // V fragments are re-fetched (L2 hits) per query block instead of living in 32 registers across the whole loop:
     // with the 128 dK / dV accumulators that keeps the kernel at two workgroups per CU without spilling
-    // (hoisting these loads above the first barrier measured 11 % slower)
+    // (hoisting these loads above the first barrier measured 11 % slower in round 2; fully resident -- loaded once in front of the loop -- the
+    //  compiler parks 25 dwords in scratch and the backward takes 0.59 instead of 0.38 ms per step: profiles/r03_ab_fused_attn_v_resident.txt)
     s16x8 vf[HD / 16];
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) vf[ks] = *(const s16x8*)(vrow + 16 * ks);
