@@ -1,5 +1,5 @@
 #!/bin/bash
-# visit T: fused attention backward with the V fragments resident (100 B of scratch) against the per-block re-fetch
+# visit T: fused attention backward variants (V fragments resident | requested at the top of the iteration) against the committed build
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
 BASE=$R/univtg_amd/libuvtg_base.so
