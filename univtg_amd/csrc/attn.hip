@@ -867,7 +867,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const AttnArgs 
 // NW = 4: up to 128 keys, two workgroups per CU.  NW = 8 (128 < S <= 256, e.g. the pretraining shape L_v = 128 + 32 text tokens): 256 keys,
 // 8 waves, one workgroup per CU (the same two waves per SIMD); the dQ^T tile of a query block is summed over two key halves by two
 // wave groups and folded through an fp32 LDS slab.
-template <int HD, int NW, bool SWZ>
+// ABL (measurement builds only, -DUVTG_ATTN_ABLATE; results are garbage): 1 = no dQ pass, 2 = no product MFMAs / transposing reads, 3 = no score
+// MFMAs / row reads, 4 = no softmax arithmetic, 5 = no V re-fetch, 6 = no Q / dO prefetch + staging after the first block, 7 = no dK / dV epilogue
+template <int HD, int NW, bool SWZ, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kernel(const AttnArgs a) {
   constexpr int KROWS = 32 * NW, T = 64 * NW;
   constexpr int DQSTR = HD + 8, CH = HD / 8;
@@ -947,10 +949,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
   for (int qb = 0; qb < nqb; qb++) {
     __syncthreads();                                 // previous block's readers of sQ / sO / sDS are done, its dQ tiles are in sDQ
     if (qb > 0) flush_dq(qb - 1);
+    if (ABL != 6 || qb == 0) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int q = tid + T * i, r = q / CH, c = q % CH;
       if (q < 32 * CH) { *(u32x4*)(&sQ[KT::off(r, c * 8)]) = pq[i]; *(u32x4*)(&sO[KT::off(r, c * 8)]) = po[i]; }
+    }
     }
     if (tid < 32) { sL[tid] = (qb * 32 + tid < S) ? pl * LOG2E : ROW_OFF; sD[tid] = pdl; }
     // V fragments are re-fetched (L2 hits) per query block instead of living in 32 registers across the whole loop:
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
     //  compiler parks 25 dwords in scratch and the backward takes 0.59 instead of 0.38 ms per step: profiles/r03_ab_fused_attn_v_resident.txt)
     s16x8 vf[HD / 16];
 #pragma unroll
-    for (int ks = 0; ks < HD / 16; ks++) vf[ks] = *(const s16x8*)(vrow + 16 * ks);
+    for (int ks = 0; ks < HD / 16; ks++) { if constexpr (ABL == 5) vf[ks] = (s16x8){1, 2, 3, 4, 5, 6, 7, 8}; else vf[ks] = *(const s16x8*)(vrow + 16 * ks); }
     __syncthreads();
     // (the swizzled fragment offsets are XORs of these bases: behind an opaque move they are recomputed where they are used instead of
     //  being hoisted out of the loop into ~30 registers the kernel does not have)
@@ -972,6 +976,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
     for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ks++) {
+      if constexpr (ABL == 3) { sc[ks] += __builtin_bit_cast(float, (int)vf[ks][0]); continue; }
       const s16x8 qf = *(const s16x8*)(&sQ[KT::step(qo, 16 * ks)]);
       const s16x8 of = *(const s16x8*)(&sO[KT::step(qo, 16 * ks)]);
       const s16x8 kf = *(const s16x8*)(&sK[KT::step(ko, 16 * ks)]);
@@ -980,7 +985,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
     }
     // the next query block's rows are requested HERE, when the 32 registers of the V fragments are dead (the kernel sits at the 256-register
     // line: requested before the MFMAs, the compiler parks them in scratch -- behind a vmcnt(0) that exposes the whole load latency)
-    if (qb + 1 < nqb) prefetch(qb + 1);
+    if (ABL != 6 && qb + 1 < nqb) prefetch(qb + 1);
     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
     f32x4 Lq[4], Dq[4];
 #pragma unroll
@@ -988,6 +993,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
     float pd[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
+      if constexpr (ABL == 4) { pd[r] = sc[r] * 1e-3f; ds[r] = dp[r] * 1e-3f; continue; }
       float p = exp2_raw(fmaf(sc[r], LOG2E, -Lq[r >> 2][r & 3]));
       p = kok ? p : 0.f;
       pd[r] = p;
@@ -1003,6 +1009,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
 #pragma unroll
       for (int blk = 0; blk < HD / 32; blk++) {
         const int o0 = KT::step(t0, 32 * blk) + 16 * hf * KT::STR, o1 = KT::step(t1, 32 * blk) + 16 * hf * KT::STR;
+        if constexpr (ABL == 2) { dv[blk][0] += __builtin_bit_cast(float, (int)pb[0]); dk[blk][0] += __builtin_bit_cast(float, (int)db[0]); continue; }
         const s16x8 ot = cat4(lds_tr16(&sO[o0]), lds_tr16(&sO[o1]));
         const s16x8 qt = cat4(lds_tr16(&sQ[o0]), lds_tr16(&sQ[o1]));
         dv[blk] = mfma32(ot, pb, dv[blk]);
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; r++) dq[r] = 0.f;
-      if (dq_on) {
+      if (dq_on && ABL != 1) {
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) {
           const s16x8 kt_ = cat4(lds_tr16(&sK[kt0 + 16 * kk * KT::STR]), lds_tr16(&sK[kt1 + 16 * kk * KT::STR]));
@@ -1050,6 +1057,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
   }
   __syncthreads();                                   // last dQ tiles are in sDQ; nobody reads sK any more
   flush_dq(nqb - 1);
+  if constexpr (ABL == 7) { if (dk[0][0] + dv[0][0] == 12345.f) a.dqkv[0] = 1; return; }
   // dK, dV: same transposition through a wave-private slab in the dead K tile (32 keys x HD, the K tile's own row layout)
   bf16_t* slab = sK + wave * 32 * KT::STR;
 #pragma unroll
@@ -1106,6 +1114,25 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
   static const bool swz_off = getenv("UVTG_ATTN_SWZ_OFF") != nullptr;       // experiment: padded rows instead of the chunk swizzle (head_dim 128)
   const bool swz = a.hd == 128 && !swz_off;
+#ifdef UVTG_ATTN_ABLATE
+  {
+    static const int fabl = getenv("UVTG_ATTN_FABL") ? atoi(getenv("UVTG_ATTN_FABL")) : 0;
+    if (fabl > 0 && a.S <= 128 && a.hd == 128 && a.p_drop <= 0.f) {
+      switch (fabl) {
+        case 1: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 1>), grid, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 2>), grid, blk, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 3>), grid, blk, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 4>), grid, blk, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 5>), grid, blk, 0, s, a); break;
+        case 6: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 6>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 7>), grid, blk, 0, s, a); break;
+      }
+      uvtg_prof_end_launch(5, s);
+      UVTG_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+#endif
   if (a.S <= 128 && a.p_drop <= 0.f) {   // whole (sample, head) problem in one workgroup: one pass over q, k, v, dO
     // (4-wave kernel: padded rows -- 0.370 vs 0.390 ms per step at config 2: three or four query blocks per workgroup, the XORs and the 16 bytes
     //  of scratch cost more than the transposing reads gain; the 8-wave kernel and the split kernels gain 5 - 8 % from the swizzle)
