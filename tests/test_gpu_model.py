@@ -688,7 +688,7 @@ def test_pipeline_collate_upload_matches_reference(dev, golden_dir):
     assert np.array_equal(mi16["src_vid_mask"].cpu().numpy(), z["in/src_vid_mask"])
 
 
-@pytest.mark.parametrize("case", ["tiny_golden", "production_width"])
+@pytest.mark.parametrize("case", ["tiny_golden", "production_width", "long_sequence"])
 def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
     """Train-mode parity: input dropout (p=0.5), attention dropout and DropPath all on.  The kernels' counter-based masks are
     regenerated on the host (tests/philox_ref.py), handed to the CPU oracle as explicit Bernoulli masks, and outputs, losses and
@@ -699,10 +699,16 @@ def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
     if case == "tiny_golden":
         meta, _, params, inputs, tg, *_ = load_case(golden_dir, "tiny_eval_ragged")
         cfg = O.make_cfg(**{**meta["cfg"], "input_dropout": 0.5, "dropout": 0.1, "droppath": 0.25})
-    else:       # d=1024, D_v=2818: the wide-row LayerNorm kernels and their lane-pair Philox sharing
+    elif case == "production_width":       # d=1024, D_v=2818: the wide-row LayerNorm kernels and their lane-pair Philox sharing
         cfg = O.make_cfg(input_dropout=0.5, dropout=0.1, droppath=0.25, enc_layers=1)
         params = O.init_params(cfg, seed=11)
         inputs, tg = O.make_batch(cfg, 4, 12, 5, seed=12, ragged=True)
+    else:       # S = 300 + 12 > 256 at head_dim 128: the tiled attention kernels' DROPOUT instantiations over many query / key blocks (the
+                # pipelined dK/dV loop, the LDS-DMA dQ kernel; attention dropout never reaches the fused S <= 256 kernels)
+        cfg = O.make_cfg(hidden_dim=256, nheads=2, dim_feedforward=256, v_feat_dim=514, max_v_l=300, input_dropout=0.5, dropout=0.1, droppath=0.25,
+                         enc_layers=2)
+        params = O.init_params(cfg, seed=13)
+        inputs, tg = O.make_batch(cfg, 2, 300, 12, seed=14, ragged=True)
     model, crit = build(cfg, params, dev, "bf16")
     model.train()
     model.set_seed(20240917)
