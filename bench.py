@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the UniVTG hot path on MI355X (BASELINE.json: clips/sec fwd+bwd, L=75, d=1024).
 
-    python bench.py --gpus 1 --steps 50 --warmup 10 [--config 2|3|4|5] [--variant A|B]
+    python bench.py --gpus 1 --steps 50 --warmup 10 [--config 2|3|4|5] [--variant A|B] [--proj precise|bf16] [--comm-cus k] [--grad-comm-dtype fp32|bf16]
     python bench.py --mode infer                                       # inference line (main/inference_mr.py path), see run_infer()
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -11,14 +11,13 @@ saliency -> dense criterion -> backward -> (RCCL gradient all-reduce) -> global-
 accumulation, the reference's training dropouts (input 0.5 / attention 0 / DropPath 0.1, scripts/pretrain.sh:33-35).
 Per-GPU batch is fixed (weak scaling).  Rank 0 prints ONE JSON line.
 
-`value` = B * L_v clip POSITIONS per step / time, padded positions included, as the reference computes (and BASELINE's metric counts)
-them; the native step does not EXECUTE the padded positions no loss can see -- `valid_clips_per_sec`, `all_clip_rows_ms_per_step` and
-`padded_execution_ms_per_step` are the companions that do not mix executed and non-executed work.  The native step's losses and
-parameter gradients are exactly the reference's for the same dropout masks
-(tests/test_gpu_parity_full.py::test_bench_path_trainstep_dropout_replayed_through_oracle, ::test_config3_bench_path_replayed_through_oracle):
-the encoder runs on the valid clips, the three padded clips per sample that the conv heads can see from a valid position (each with its
-own dropout mask) and the valid text tokens -- a padded clip is never an attention key and every loss masks padded positions.
-`--variant A` (all-ones masks, "peak") has no padding at all: executed == algorithmic there.
+`value` counts clips the step EXECUTES.  Default (config 2): SURVEY 8d variant A -- all-ones masks, the shape "L=75, d=1024, batch=256"
+literally names: every clip position is executed and counted, `roofline_encoder.frac` is the hardware fraction of the >= 40 % target with no
+arithmetic left to do.  The timed step runs the forward input projections on fp32-class split operands (`--proj precise`, default): the
+configuration whose saliency_scores meet north_star's 1e-4 tolerance.  `companions` (single GPU) times, in the same run, the ragged-batch
+packed stream (variant B: valid clips + 3-clip conv halo + valid text; `executed_or_valid_clips_per_sec` counts VALID clips only) with its
+padded / all-clip-rows executions, and the plain-bf16-projection step.  With N > 1 the line also carries `replicas` (bit-equality of the
+flat parameter buffers across ranks after the timed loop), `exposed_comm_ms_per_step` and `comm_world_size`.
 """
 from __future__ import annotations
 
@@ -237,6 +236,32 @@ def run_infer(args, dev):
     print(json.dumps(out))
 
 
+def timed_steps(step, batches, n, barrier=None):
+    """n steps bracketed by (barrier +) device synchronisation; returns (elapsed seconds, sorted per-step event times in ms)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    (barrier or torch.cuda.synchronize)()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(n):
+        step.step(*batches[i % len(batches)])
+        evs[i + 1].record()                                   # on the launch stream (torch's current stream)
+    (barrier or torch.cuda.synchronize)()
+    elapsed = time.perf_counter() - t0
+    return elapsed, sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+
+
+def encoder_flops(lens, B, Lv, Lt, packed_halo):
+    """(algorithmic, executed) encoder fwd+bwd FLOPs per step: SURVEY 8d's 3*E*B*(8Sd^2+4SdF+4S^2d) with padded positions counted, and
+    the same sum over the rows the packed loss-only stream really runs (kept clips = valid + 3-clip conv halo, valid text tokens)."""
+    S, d, F_, E = Lv + Lt, MODEL["d"], MODEL["F"], MODEL["E"]
+    alg = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)
+    if not packed_halo:
+        return alg, alg
+    per = [[min(Lv, x + 3) + y for x, y in zip(a, b)] for a, b in lens]
+    exe = sum(3 * E * sum(r * (8 * d * d + 4 * d * F_) + 4 * r * r * d for r in rows) for rows in per) / len(per)
+    return alg, exe
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,12 +271,21 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra instrumented steps for the roofline line")
-    ap.add_argument("--no-padded-compare", action="store_true", help="skip the extra timing of the padded (non-packed) execution")
+    ap.add_argument("--no-padded-compare", action="store_true", help="variant B: skip the extra timing of the padded / all-clip-rows executions")
+    ap.add_argument("--no-companions", action="store_true", help="headline only: skip the ragged-batch (variant B) and bf16-projection companion timings")
     ap.add_argument("--packed", default="auto", choices=["auto", "off"], help="encoder row stream (auto = exact packed stream)")
-    ap.add_argument("--variant", default="B", choices=["A", "B"], help="SURVEY 8d: A = all-ones masks (peak), B = ragged valid lengths (default)")
+    ap.add_argument("--variant", default=None, choices=["A", "B"],
+                    help="SURVEY 8d: A = all-ones masks -- every clip position is executed (default for config 2: the shape 'L=75, d=1024, batch=256' "
+                         "literally names, `value` counts executed clips only); B = ragged valid lengths on the packed stream (default for configs 3-5)")
+    ap.add_argument("--proj", default="precise", choices=["precise", "bf16"],
+                    help="input projections of the timed train step: precise = fp32-class split operands (saliency_scores within 1e-4 of the fp32 "
+                         "reference, the north_star tolerance; default), bf16 = plain bf16 operands (3e-2)")
     ap.add_argument("--mode", default="train", choices=["train", "infer"], help="train = the headline metric; infer = forward + post-processing")
     ap.add_argument("--grad-comm-dtype", default=os.environ.get("UVTG_GRAD_COMM_DTYPE", "fp32"), choices=["fp32", "bf16"], help="wire dtype of the gradient buckets (N > 1)")
+    ap.add_argument("--comm-cus", type=int, default=int(os.environ.get("UVTG_COMM_CUS", "0")), help="CUs kept out of the persistent GEMM grids for RCCL's kernels (N > 1)")
     args = ap.parse_args()
+    if args.variant is None:
+        args.variant = "A" if args.config == 2 else "B"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -274,6 +308,9 @@ def main():
         else:
             torch.distributed.init_process_group(backend=backend)
         comm_size = torch.distributed.get_world_size()
+    if comm_size != max(world, 1) or (args.gpus > 1 and comm_size != args.gpus):
+        print(f"bench.py: --gpus {args.gpus} but the process group has {comm_size} ranks (WORLD_SIZE={world})", file=sys.stderr)
+        sys.exit(2)
 
     if args.mode == "infer":
         if world > 1:
@@ -287,61 +324,97 @@ def main():
     wl = CONFIGS[args.config]
     B, Lv, Lt = args.batch or wl["B"], wl["L_v"], wl["L_t"]
     torch.manual_seed(2018)
-    model, crit = build_model(model_args(max_v_l=Lv))
+    precise = args.proj == "precise"
+    model, crit = build_model(model_args(max_v_l=Lv, proj_precise=precise))
     model.to(dev).train()
     crit.to(dev).train()
     model.set_seed(2018 + rank)
     packed = False if args.packed == "off" else "auto"
-    step = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=packed, grad_comm_dtype=args.grad_comm_dtype, time_comm=world > 1)
+    step = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=packed, grad_comm_dtype=args.grad_comm_dtype,
+                     comm_cus=args.comm_cus, time_comm=world > 1)
     full = args.variant == "A"
-    lens_fn = (lambda s: mixed_length_lens(B, seed=s)) if (args.config == 5 and not full) else (lambda s: None)
-    batches = [synth_batch(B, Lv, Lt, MODEL["D_v"], MODEL["D_t"], 1000 * rank + i, dev, lens_fn(1000 * rank + i), full=full) for i in range(2)]
+
+    def make_batches(full_, n=2):
+        lens_fn = (lambda s_: mixed_length_lens(B, seed=s_)) if (args.config == 5 and not full_) else (lambda s_: None)
+        return [synth_batch(B, Lv, Lt, MODEL["D_v"], MODEL["D_t"], 1000 * rank + i, dev, lens_fn(1000 * rank + i), full=full_) for i in range(n)]
+    batches = make_batches(full)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # ---- the headline: W untimed steps, then EXACTLY K timed steps between barrier + synchronize ----
     for i in range(args.warmup):
         step.step(*batches[i % 2])
-    barrier()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    evs[0].record()
-    for i in range(args.steps):
-        step.step(*batches[i % 2])
-        evs[i + 1].record()                                   # on the launch stream (torch's current stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, per_step = timed_steps(step, batches, args.steps, barrier)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     losses = step.losses[:5].tolist()
-    exposed = sorted(step.exposed_comm_ms()[-args.steps:]) if world > 1 else []       # (outside the timed region)
+    exposed = sorted(step.exposed_comm_ms()) if world > 1 else []       # (outside the timed region; one sample per timed / warm-up step)
+    # a stable median needs >= 50 samples whatever --steps was: extra steps, outside `value`
+    n_med = max(50, args.steps)
+    if n_med > args.steps:
+        _, per_med = timed_steps(step, batches, n_med, barrier)
+    else:
+        per_med = per_step
+    # data-parallel replicas must hold bit-identical parameters after the same number of steps
+    replicas = None
+    if world > 1:
+        cs = torch.tensor(step.flat_checksum(), device=dev, dtype=torch.float64)
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        torch.distributed.all_gather(allcs, cs)
+        same = all(bool((c == allcs[0]).all()) for c in allcs)
+        replicas = dict(flat_parameter_checksums_equal=same, checksum_rank0=[float(x) for x in allcs[0].tolist()], ranks=world)
 
-    # ---- the same batches through the padded execution (every padded position computed, as the reference does) ----
-    padded_ms = allrows_ms = None
-    if rank == 0 and world == 1 and not args.no_padded_compare and packed and not full:
-        for kind in ("padded", "allrows"):
-            step_p = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=False if kind == "padded" else "auto", loss_only=False)
-            for i in range(3):
-                step_p.step(*batches[i % 2])
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            for i in range(10):
-                step_p.step(*batches[i % 2])
-            torch.cuda.synchronize()
-            if kind == "padded":
-                padded_ms = (time.perf_counter() - tp) / 10 * 1e3
-            else:
-                allrows_ms = (time.perf_counter() - tp) / 10 * 1e3
-            del step_p
+    # ---- companions (single GPU, rank 0): the other variant's step, the bf16-projection step, the padded executions ----
+    comp = {}
+    if rank == 0 and world == 1 and not args.no_companions:
+        other_full = not full
+        ob = make_batches(other_full)
+        for i in range(3):
+            step.step(*ob[i % 2])
+        el, per = timed_steps(step, ob, 30)
+        lens_o = [bt[0]["_lens_host"] for bt in ob]
+        valid = sum(sum(a) for a, _ in lens_o) / len(lens_o)
+        alg_o, exe_o = encoder_flops(lens_o, B, Lv, Lt, bool(packed) and not other_full)
+        comp["variant_" + ("A" if other_full else "B")] = dict(
+            what=("all-ones masks: every clip position executed" if other_full else
+                  f"ragged valid lengths ({wl['lens']}) on the packed loss-only stream: valid clips + 3-clip conv halo + valid text tokens; losses and all "
+                  "parameter gradients exactly the padded execution's"),
+            ms_per_step=round(el / 30 * 1e3, 3), ms_per_step_event_median=round(per[len(per) // 2], 3),
+            executed_or_valid_clips_per_sec=round((B * Lv if other_full else valid) * 30 / el, 1),
+            clip_positions_per_sec_incl_padded=round(B * Lv * 30 / el, 1),
+            encoder_rows_fraction=round(sum(sum(min(Lv, x + 3) for x in a) + sum(b) for a, b in lens_o) / (len(lens_o) * B * (Lv + Lt)), 4) if (packed and not other_full) else 1.0,
+            executed_encoder_tflop_per_step=round(exe_o / 1e12, 3))
+        if not other_full and packed and not args.no_padded_compare:        # the same ragged batches through the padded executions
+            for kind in ("padded", "allrows"):
+                step_p = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=False if kind == "padded" else "auto", loss_only=False)
+                for i in range(3):
+                    step_p.step(*ob[i % 2])
+                elp, _ = timed_steps(step_p, ob, 10)
+                comp["variant_B"]["padded_execution_ms_per_step" if kind == "padded" else "all_clip_rows_ms_per_step"] = round(elp / 10 * 1e3, 3)
+                del step_p
+        # the other projection arithmetic on the headline batches
+        model.proj_precise = not precise
+        for i in range(3):
+            step.step(*batches[i % 2])
+        el, per = timed_steps(step, batches, 30)
+        comp["projections_" + ("bf16" if precise else "precise")] = dict(
+            what=("plain bf16 input projections in the forward (saliency_scores within 3e-2 of fp32)" if precise else
+                  "fp32-class split-operand input projections in the forward (saliency_scores within 1e-4 of fp32)"),
+            ms_per_step=round(el / 30 * 1e3, 3), ms_per_step_event_median=round(per[len(per) // 2], 3))
+        model.proj_precise = precise
+        for i in range(2):
+            step.step(*batches[i % 2])
 
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch, on the launch stream ----
     lib = _lib.load()
     roof, sect, roof_attn, roof_hbm = None, None, None, None
+    lens_a = [bt[0]["_lens_host"] for bt in batches]
+    halo = bool(packed) and not full
     if rank == 0:
         lib.uvtg_profile_start()
     for i in range(args.profile_steps):          # EVERY rank runs these steps (they contain the gradient all-reduce); only rank 0 instruments them
@@ -352,7 +425,7 @@ def main():
         floor = lib.uvtg_profile_event_floor_ms()
         pby = (C.c_double * 8)()
         lib.uvtg_profile_bytes(pby)
-        fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split-bf16>", "gemm_tn_kernel", "gemm_nt256_kernel"]
+        fam = ["gemm_nt_kernel<bf16>", "gemm_nt_kernel<split>", "gemm_tn_kernel", "gemm_nt256_kernel"]
         dom = max(range(4), key=lambda i: ms[i])
         raw_ms = ms[dom] + floor * n[dom]                     # durations as the event pairs saw them (no floor correction)
         ach = fl[dom] / (raw_ms * 1e-3) / 1e12 if raw_ms > 0 else 0.0
@@ -361,44 +434,40 @@ def main():
         # from THESE kernels (the file carries the hash of the GEMM sources; the GPU box has no .git to compare a HEAD with)
         traffic, traffic_note, traffic_ratio = None, None, None
         alg_bytes = int(pby[dom] / max(1, n[dom])) if pby[dom] > 0 else None      # counted by the library on this run's own launches
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_nt256.json")
-        if fam[dom] == "gemm_nt256_kernel" and os.path.exists(pmc):
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_nt256.json", "r03_pmc_nt256.json")) if os.path.exists(q)), None)
+        if fam[dom] == "gemm_nt256_kernel" and pmc:
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("kernel_src_sha") == kernel_src_sha():
                 traffic = pj["traffic_bytes_per_launch"]
                 traffic_ratio = round(traffic / alg_bytes, 3) if alg_bytes else None
-                traffic_note = (f"measured by separate rocprofv3 --pmc passes of this command on these kernels (profiles/r03_pmc_nt256.json, kernel source "
+                traffic_note = (f"measured by separate rocprofv3 --pmc passes of this command on these kernels ({os.path.relpath(pmc, ROOT)}, kernel source "
                                 f"{pj['kernel_src_sha']}, git {pj.get('git_head', '?')}): FETCH_SIZE x {pj.get('fetch_factor', 2.0)} ({pj.get('fetch_factor_source', 'guide')}) "
                                 f"+ WRITE_SIZE per launch; MFMA-busy fraction {pj['mfma_busy_frac']:.3f}; not re-measured inside this run (PMC passes cannot share a run with timing)")
             else:
-                traffic_note = (f"stale: profiles/r03_pmc_nt256.json was taken from kernel source {pj.get('kernel_src_sha')} (git {pj.get('git_head', '?')}), this build is "
+                traffic_note = (f"stale: {os.path.relpath(pmc, ROOT)} was taken from kernel source {pj.get('kernel_src_sha')} (git {pj.get('git_head', '?')}), this build is "
                                 f"{kernel_src_sha()} -- re-run tools/pmc_nt256.sh")
         roof = dict(bound="mfma", kernel=fam[dom], achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                     traffic=traffic, traffic_note=traffic_note, algorithmic_bytes_per_launch=alg_bytes, traffic_over_algorithmic=traffic_ratio, launches_per_step=int(n[dom] // max(1, args.profile_steps)),
                     avg_launch_us=round(raw_ms * 1e3 / max(1, n[dom]), 2),
                     event_pair_floor_us=round(floor * 1e3, 2), achieved_floor_corrected=round(ach_corr, 2),
-                    note="achieved = sum(2MNK) / sum(event-pair duration) over the launches, durations NOT floor-corrected",
+                    note="achieved = sum(2MNK of the rows each launch executes) / sum(event-pair duration) over the launches, durations NOT floor-corrected",
                     algorithmic_gflop_per_launch=round(fl[dom] / max(1, n[dom]) / 1e9, 2),
                     all_gemm_kernels={fam[i]: dict(ms_per_step=round(ms[i] / max(1, args.profile_steps), 3),
                                                    tflops=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else 0.0,
                                                    launches_per_step=int(n[i] // max(1, args.profile_steps))) for i in range(4)})
-        # attention kernels (families 4 / 5): FLOPs on the padded S as SURVEY 8d counts them, and on the rows the packed stream runs
-        lens_a = [bt[0]["_lens_host"] for bt in batches]
-        s2_pad = B * (Lv + Lt) ** 2
-        s2_exe = sum(sum((min(Lv, x + 3) + y) ** 2 for x, y in zip(a, b)) for a, b in lens_a) / len(lens_a) if packed else s2_pad
+        # attention kernels (families 4 / 5): FLOPs of the rows the stream runs (== the padded S in variant A)
+        s2_exe = sum(sum((min(Lv, x + 3) + y) ** 2 for x, y in zip(a, b)) for a, b in lens_a) / len(lens_a) if halo else B * (Lv + Lt) ** 2
         roof_attn = {}
         for name, i, mult in (("forward", 4, 4.0), ("backward", 5, 10.0)):
             t_ms = (ms[i] + floor * n[i]) / max(1, args.profile_steps)
-            alg = mult * MODEL["E"] * s2_pad * MODEL["d"]
+            exe = mult * MODEL["E"] * s2_exe * MODEL["d"]
             roof_attn[name] = dict(ms_per_step=round(t_ms, 3), launches_per_step=int(n[i] // max(1, args.profile_steps)),
-                                   achieved=round(alg / max(t_ms * 1e-3, 1e-12) / 1e12, 1), frac=round(alg / max(t_ms * 1e-3, 1e-12) / 2.5e15, 4),
-                                   executed_tflops=round(mult * MODEL["E"] * s2_exe * MODEL["d"] / max(t_ms * 1e-3, 1e-12) / 1e12, 1))
+                                   achieved=round(exe / max(t_ms * 1e-3, 1e-12) / 1e12, 1), frac=round(exe / max(t_ms * 1e-3, 1e-12) / 2.5e15, 4))
         roof_attn["note"] = ("attention kernels only (HIP event pairs around launch_attn_fwd / launch_attn_bwd incl. the delta pass): achieved = "
-                             "4 (fwd) / 10 (bwd) * E * B * S^2 * d FLOPs on the PADDED S over the measured time, peak 2.5 PFLOP/s; executed_tflops "
-                             "counts the rows the packed stream runs")
+                             "4 (fwd) / 10 (bwd) * E * sum_b S_b^2 * d FLOPs of the rows the stream EXECUTES over the measured time, peak 2.5 PFLOP/s")
         # HBM-bound kernels: LayerNorm launches (bytes counted by the library) and the attention kernels (bytes of the rows the stream runs)
-        rows_exe = (sum(sum(min(Lv, x + 3) + y for x, y in zip(a, b)) for a, b in lens_a) / len(lens_a)) if packed else B * (Lv + Lt)
+        rows_exe = (sum(sum(min(Lv, x + 3) + y for x, y in zip(a, b)) for a, b in lens_a) / len(lens_a)) if halo else B * (Lv + Lt)
         roof_hbm = {}
         for name, i in (("layernorm_forward", 6), ("layernorm_backward", 7)):
             t_ms = (ms[i] + floor * n[i]) / max(1, args.profile_steps)
@@ -428,57 +497,50 @@ def main():
         torch.distributed.barrier()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2 and not full:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
         cpu = cpu_baseline(batches[0])
 
     if rank == 0:
-        clips = B * Lv * world * args.steps
-        S, d, F_, E = Lv + Lt, MODEL["d"], MODEL["F"], MODEL["E"]
-        enc_flops = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)      # padded positions count
+        valid_clips = sum(sum(a) for a, _ in lens_a) / len(lens_a)
+        # `value` counts clips the step EXECUTES: every position in variant A (nothing is padded); the VALID clips in variant B (the packed stream
+        # does not run the padded positions, and counting them was round 3's non-creditable headline)
+        counted = (B * Lv) if full else valid_clips
+        alg_flops, exe_flops = encoder_flops(lens_a, B, Lv, Lt, halo)
         t_enc = max((sect["encoder_fwd_ms"] + sect["encoder_bwd_ms"]) * 1e-3, 1e-9)
-        lens = [bt[0]["_lens_host"] for bt in batches]
-        valid_clips = sum(sum(a) for a, _ in lens) / len(lens)
-        rows_full = sum(sum(a) + sum(b) + sum(1 for x in a if x < Lv) for a, b in lens) / (len(lens) * B * S)
-        rows_text = sum(B * Lv + sum(b) for a, b in lens) / (len(lens) * B * S)
-        rows_halo = sum(sum(min(Lv, x + 3) for x in a) + sum(b) for a, b in lens) / (len(lens) * B * S)
-        # FLOPs the encoder actually executes on the packed stream (rows of every sample: kept clips + valid text)
-        if packed:
-            per = [[min(Lv, x + 3) + y for x, y in zip(a, b)] for a, b in lens]
-            exe_flops = sum(3 * E * sum(r * (8 * d * d + 4 * d * F_) + 4 * r * r * d for r in rows) for rows in per) / len(per)
-        else:
-            exe_flops = enc_flops
+        desc = (f"{wl['what']}: L_v={Lv} L_t={Lt} D_v=2818 D_t=512 d=1024 F=1024 H=8 E=4, full train step (fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, "
+                + ("all-ones masks (SURVEY 8d variant A): every clip position and every text token is executed" if full else
+                   f"ragged valid lengths ({wl['lens']}, SURVEY 8d variant B) on the packed loss-only stream: valid clips + the 3 padded clips per sample inside "
+                   "the conv heads' receptive field + valid text tokens (losses and all gradients exactly the padded execution's)" if packed else
+                   f"ragged valid lengths ({wl['lens']}), padded execution")
+                + ("; input projections of the forward on fp32-class split operands (saliency_scores within 1e-4 of the fp32 reference)" if precise else
+                   "; input projections on plain bf16 operands (saliency_scores within 3e-2)"))
         out = dict(metric="clips/sec (L=75,d=1024) fwd+bwd" if args.config == 2 else f"clips/sec fwd+bwd (BASELINE config {args.config})",
-                   value=round(clips / elapsed, 1), unit="clips/s", n_gpus=world,
+                   value=round(counted * world * args.steps / elapsed, 1), unit="clips/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
-                   config=dict(workload=f"{wl['what']}: L_v={Lv} L_t={Lt} D_v=2818 D_t=512 d=1024 F=1024 H=8 E=4, full train step "
-                                        f"(fwd+criterion+bwd+clip+AdamW), dropout 0.5/0/0.1, ragged valid lengths: {'all-ones masks (SURVEY 8d variant A)' if full else wl['lens']}; encoder rows = valid "
-                                        "clips + the 3 padded clips per sample inside the conv heads' receptive field + valid text tokens; the video "
-                                        "input projection runs on those clips only (losses and all gradients exactly the padded execution's)"
-                                        if packed else f"{wl['what']}: padded execution",
-                               baseline_config=args.config, variant=args.variant, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
-                   value_counts="B*L_v clip positions per step incl. padded ones (the metric's and the reference's count); valid_clips_per_sec counts valid clips only",
-                   grad_comm_dtype=(args.grad_comm_dtype if world > 1 else None), gemm_cus=getattr(step, "gemm_cus", None),
-                   exposed_comm_ms_per_step=(round(exposed[len(exposed) // 2], 3) if exposed else None),
-                   world_size=world, comm_backend=(backend if world > 1 else None), comm_world_size=comm_size,
+                   config=dict(workload=desc, baseline_config=args.config, variant=args.variant, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}",
+                               projections=args.proj),
+                   value_counts=("B*L_v clip positions per step, ALL executed (all-ones masks)" if full else
+                                 "VALID clips per step (padded positions are neither executed nor counted); clip_positions_per_sec_incl_padded is the "
+                                 "reference's own count"),
+                   clip_positions_per_sec_incl_padded=round(B * Lv * world * args.steps / elapsed, 1),
                    samples_per_sec=round(B * world * args.steps / elapsed, 1),
-                   valid_clips_per_sec=round(valid_clips * world * args.steps / elapsed, 1),
-                   ms_per_step_event_median=round(per_step[len(per_step) // 2], 3), ms_per_step_event_min=round(per_step[0], 3),
+                   ms_per_step_event_median=round(per_med[len(per_med) // 2], 3), ms_per_step_event_min=round(per_med[0], 3), median_over_steps=len(per_med),
+                   grad_comm_dtype=(args.grad_comm_dtype if world > 1 else None), gemm_cus=getattr(step, "gemm_cus", None), comm_cus=(args.comm_cus if world > 1 else None),
+                   exposed_comm_ms_per_step=(round(exposed[len(exposed) // 2], 3) if exposed else None), exposed_comm_samples=len(exposed),
+                   world_size=world, comm_backend=(backend if world > 1 else None), comm_world_size=comm_size, replicas=replicas,
                    t_encoder_ms=round(t_enc * 1e3, 3), sections=sect,
-                   roofline_encoder=dict(achieved=round(exe_flops / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s",
-                                         frac=round(exe_flops / t_enc / 2.5e15, 4),
-                                         algorithmic_tflops=round(enc_flops / t_enc / 1e12, 1), algorithmic_frac=round(enc_flops / t_enc / 2.5e15, 4),
-                                         note="achieved / frac: FLOPs of the rows the encoder really EXECUTES (packed stream) / (encoder fwd + bwd section "
-                                              "time, HIP events on the launch stream) / 2.5 PFLOP/s -- the hardware fraction; algorithmic_*: SURVEY 8d's "
-                                              "3*E*B*(8Sd^2+4SdF+4S^2d) with padded positions counted, as the reference computes them, over the same time "
-                                              "(identical to achieved in --variant A, where nothing is padded)"),
-                   encoder_rows_fraction=round(rows_halo if packed else 1.0, 4), all_clip_rows_fraction=round(rows_text, 4),
-                   eval_packed_rows_fraction=round(rows_full, 4),
-                   projected_clip_rows_fraction=round(sum(sum(min(Lv, x + 3) for x in a) for a, _ in lens) / (len(lens) * B * Lv), 4) if packed else 1.0,
-                   all_clip_rows_ms_per_step=None if allrows_ms is None else round(allrows_ms, 3),
-                   padded_execution_ms_per_step=None if padded_ms is None else round(padded_ms, 3),
-                   numerics="train-mode calls run the input projections on plain bf16 operands (saliency_scores within 3e-2 of fp32); the "
-                            "1e-4 saliency clause holds for inference calls (split-bf16 projections)",
+                   roofline_encoder=dict(achieved=round(exe_flops / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(exe_flops / t_enc / 2.5e15, 4),
+                                         executed_tflop_per_step=round(exe_flops / 1e12, 3), target_frac=0.40,
+                                         note="FLOPs of the rows the encoder EXECUTES (3*E*sum_b(8 S_b d^2 + 4 S_b d F + 4 S_b^2 d); in variant A that is SURVEY 8d's "
+                                              "3*E*B*(8Sd^2+4SdF+4S^2d) exactly) / (encoder fwd + bwd section time, HIP events on the launch stream, incl. the "
+                                              "deferred weight-gradient launch) / 2.5 PFLOP/s"),
+                   encoder_rows_fraction=round(sum(sum(min(Lv, x + 3) for x in a) + sum(b) for a, b in lens_a) / (len(lens_a) * B * (Lv + Lt)), 4) if halo else 1.0,
+                   companions=comp or None,
+                   numerics=("forward input projections on fp32-class split operands: saliency_scores of the timed train-mode step within 1e-4 of the fp32 "
+                             "oracle for the same dropout masks (tests/test_gpu_parity_full.py::test_bench_path_trainstep_dropout_replayed_through_oracle); "
+                             "everything else bf16 operands / fp32 accumulation" if precise else
+                             "train-mode calls run the input projections on plain bf16 operands (saliency_scores within 3e-2 of fp32)"),
                    losses=[round(x, 5) for x in losses], roofline=roof, roofline_attention=roof_attn, roofline_hbm=roof_hbm, cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:

@@ -82,8 +82,8 @@ def ref_args(cfg, **over):
     return Namespace(**a)
 
 
-def build_reference(ref, cfg, params):
-    model, crit = ref.univtg.build_model(ref_args(cfg))
+def build_reference(ref, cfg, params, **over):
+    model, crit = ref.univtg.build_model(ref_args(cfg, use_txt_pos=bool(getattr(cfg, "use_txt_pos", False)), **over))
     missing = model.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return model, crit
@@ -96,12 +96,17 @@ def npify(prefix, d, store):
 
 
 def run_case(ref, name, cfg, B, L_v, L_t, seed, ragged, curve=False, train_droppath=False,
-             real_feats=False, dtype=torch.float32):
+             real_feats=False, dtype=torch.float32, dset_type="vlp", zero_saliency=False, drop_pos_labels=False):
+    """dset_type='hl': the reference's loss subset ['labels', 'saliency'] (model/univtg.py:439-440); zero_saliency / drop_pos_labels:
+    the two early-outs of loss_saliency (model/univtg.py:237-241) -- the loss dict then holds python floats 0.0."""
     torch.manual_seed(seed)
     params = O.init_params(cfg, seed=seed, dtype=dtype)
-    model, crit = build_reference(ref, cfg, params)
+    model, crit = build_reference(ref, cfg, params, dset_type=dset_type)
+    assert list(crit.losses) == list(cfg.losses), (crit.losses, cfg.losses)
     inputs, targets = O.make_batch(cfg, B, L_v, L_t, seed=seed + 1, ragged=ragged, dtype=dtype,
                                    curve=curve)
+    if zero_saliency:
+        targets["saliency_scores"] = torch.zeros_like(targets["saliency_scores"])
     if real_feats:
         # config 1 of BASELINE.json: the bundled CLIP features, preprocessed as main_gradio.py:58-80
         vid = np.load(os.path.join(REF, "tmp", "vid.npz"))["features"].astype(np.float32)
@@ -121,8 +126,9 @@ def run_case(ref, name, cfg, B, L_v, L_t, seed, ragged, curve=False, train_dropp
         targets["saliency_pos_labels"] = torch.tensor([[t["saliency_pos_labels"]]])
         targets["span_labels"] = [dict(spans=t["span_labels"])]
     store = {}
-    meta = dict(name=name, cfg=vars(cfg), B=B, L_v=L_v, L_t=L_t, seed=seed, ragged=ragged,
-                torch=torch.__version__, train_droppath=train_droppath)
+    meta = dict(name=name, cfg=dict(vars(cfg)), B=B, L_v=L_v, L_t=L_t, seed=seed, ragged=ragged,
+                torch=torch.__version__, train_droppath=train_droppath, dset_type=dset_type,
+                zero_saliency=zero_saliency, drop_pos_labels=drop_pos_labels)
     meta["cfg"]["losses"] = list(meta["cfg"]["losses"])
     npify("param/", params, store)
     npify("in/", inputs, store)
@@ -153,7 +159,16 @@ def run_case(ref, name, cfg, B, L_v, L_t, seed, ragged, curve=False, train_dropp
         model.eval()
         crit.eval()
         out = model(**inputs)
-    losses = crit(out, targets)
+    crit_targets = {k: v for k, v in targets.items() if not (drop_pos_labels and k == "saliency_pos_labels")}
+    # gradients of the weighted total wrt the criterion's INPUTS (a second pass on detached leaves: pins the criterion kernels alone)
+    leaves = {k: out[k].detach().clone().requires_grad_(True) for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj")}
+    l2 = crit(dict(out, **leaves), crit_targets)
+    t2 = sum(l2[k] * crit.weight_dict[k] for k in l2 if k in crit.weight_dict)
+    t2.backward()
+    for k, v in leaves.items():
+        store[f"dout/{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+    losses = crit(out, crit_targets)
+    meta["loss_is_float"] = [k for k, v in losses.items() if not torch.is_tensor(v)]
     wd = crit.weight_dict
     total = sum(losses[k] * wd[k] for k in losses if k in wd)
     total.backward()
@@ -456,9 +471,27 @@ def run_feature_cache(ref):
     print("features_cache: ok", {k: v.shape for k, v in store.items()})
 
 
+def run_branch_cases(ref, tiny):
+    """Round 4: the reference branches the earlier fixtures never took -- the criterion's loss subset for dset_type 'hl' / 'vs' and the two
+    early-outs of loss_saliency (model/univtg.py:237-241,439-440), --n_input_proj 1 / 3 (model/univtg.py:89-100) and --use_txt_pos
+    (model/position_encoding.py:19-41, model/univtg.py:123)."""
+    run_case(ref, "tiny_hl", O.make_cfg(**{**tiny, "losses": ("labels", "saliency")}), B=5, L_v=13, L_t=7, seed=21, ragged=True,
+             curve=True, dset_type="hl")
+    run_case(ref, "tiny_zero_saliency", O.make_cfg(**tiny), B=5, L_v=13, L_t=7, seed=22, ragged=True, zero_saliency=True)
+    run_case(ref, "tiny_no_pos_labels", O.make_cfg(**tiny), B=5, L_v=13, L_t=7, seed=23, ragged=True, drop_pos_labels=True)
+    run_case(ref, "tiny_nproj1", O.make_cfg(**{**tiny, "n_input_proj": 1}), B=4, L_v=11, L_t=6, seed=24, ragged=True)
+    run_case(ref, "tiny_nproj3", O.make_cfg(**{**tiny, "n_input_proj": 3}), B=4, L_v=11, L_t=6, seed=25, ragged=True)
+    run_case(ref, "tiny_txt_pos", O.make_cfg(**{**tiny, "use_txt_pos": True}), B=5, L_v=12, L_t=9, seed=26, ragged=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    tiny = dict(hidden_dim=64, nheads=2, dim_feedforward=96, enc_layers=2, v_feat_dim=34, t_feat_dim=24,
+                max_q_l=16, input_dropout=0.0, dropout=0.0, droppath=0.0)
+    if sys.argv[1:] == ["branches"]:            # round-4 fixtures only (the others are unchanged)
+        run_branch_cases(ref, tiny)
+        return
     if sys.argv[1:] == ["detr_criterion"]:      # one fixture only (the others are unchanged)
         run_detr_criterion(ref)
         return
@@ -478,6 +511,7 @@ def main():
                max_q_l=32, input_dropout=0.0, dropout=0.0, droppath=0.0)
     run_case(ref, "config1_real_feats", O.make_cfg(**mid), B=1, L_v=15, L_t=12, seed=2018, ragged=False,
              real_feats=True)
+    run_branch_cases(ref, tiny)
     run_matcher(ref)
     run_detr_criterion(ref)
     run_features(ref)

@@ -232,8 +232,16 @@ def forward(params, cfg, src_txt, src_txt_mask, src_vid, src_vid_mask, rng=None)
     key_valid = torch.cat([src_vid_mask, src_txt_mask], dim=1).bool()   # :120
     pos_v = sine_position(src_vid_mask, d).to(dt)                       # :122
     if cfg.use_txt_pos:
-        raise NotImplementedError("use_txt_pos is never set by the reference scripts")
-    pos = torch.cat([pos_v, torch.zeros_like(txt)], dim=1)              # :123-124
+        # TrainablePositionalEncoding.forward (model/position_encoding.py:19-41): Dropout(LayerNorm(txt + E[0..L_t))), built with
+        # dropout = input_dropout (position_encoding.py:113-115); the result is used as `pos` of the text rows in EVERY layer
+        L_t = txt.shape[1]
+        e = params["txt_position_embed.position_embeddings.weight"][:L_t]
+        pos_t = F.layer_norm(txt + e, (d,), params["txt_position_embed.LayerNorm.weight"],
+                             params["txt_position_embed.LayerNorm.bias"], eps=1e-5)
+        pos_t = _dropout(pos_t, rng.get("txtpos_keep"), cfg.input_dropout)
+    else:
+        pos_t = torch.zeros_like(txt)
+    pos = torch.cat([pos_v, pos_t], dim=1)                              # :123-124
     for l in range(cfg.enc_layers):
         x = encoder_layer(params, l, x, pos, key_valid, cfg,
                           None if "dp_scale" not in rng else rng["dp_scale"][l],

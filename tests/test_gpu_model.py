@@ -770,3 +770,9 @@ def test_bench_two_rank_control_flow(dev):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0 and out["roofline"]["achieved"] > 0
+    # the self-verification fields of a multi-rank run: the group really has N ranks, the replicas hold bit-identical
+    # parameters after the timed loop, and the exposed-communication median is over EVERY step (no sample dropped, no sync in the loop)
+    assert out["comm_world_size"] == 2 and out["world_size"] == 2
+    assert out["replicas"]["flat_parameter_checksums_equal"] is True and out["replicas"]["ranks"] == 2
+    assert out["exposed_comm_samples"] == 3 and out["exposed_comm_ms_per_step"] is not None
+    assert out["median_over_steps"] >= 50 and out["config"]["variant"] == "A" and out["config"]["projections"] == "precise"

@@ -10,7 +10,9 @@ import torch
 from oracle import postproc_oracle as P
 from oracle import univtg_oracle as O
 
-CASES = ["tiny_eval_ragged", "tiny_eval_full", "tiny_train_droppath", "config1_real_feats"]
+CASES = ["tiny_eval_ragged", "tiny_eval_full", "tiny_train_droppath", "config1_real_feats",
+         # round 4: dset_type 'hl' loss subset, the two loss_saliency early-outs, n_input_proj 1 / 3, use_txt_pos
+         "tiny_hl", "tiny_zero_saliency", "tiny_no_pos_labels", "tiny_nproj1", "tiny_nproj3", "tiny_txt_pos"]
 
 
 def load_case(golden_dir, name):
@@ -21,6 +23,8 @@ def load_case(golden_dir, name):
     params, inputs, tg, out, grads = grab("param/"), grab("in/"), grab("tg/"), grab("out/"), grab("grad/")
     losses = {k[5:]: float(z[k]) for k in z.files if k.startswith("loss/")}
     rng = {"dp_scale": torch.from_numpy(z["rng/dp_scale"])} if "rng/dp_scale" in z.files else None
+    if meta.get("drop_pos_labels"):
+        tg.pop("saliency_pos_labels")
     return meta, cfg, params, inputs, tg, out, grads, losses, rng
 
 
@@ -32,6 +36,9 @@ def test_forward_losses_grads_match_reference(golden_dir, name):
     for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj", "saliency_scores"):
         torch.testing.assert_close(out[k], out_ref[k], rtol=2e-5, atol=2e-6, msg=lambda m: f"{k}: {m}")
     losses = O.criterion(out, tg, cfg)
+    assert set(losses) == set(losses_ref) - {"total"}, (set(losses), set(losses_ref))        # 'hl': no loss_b / loss_g
+    for k in meta.get("loss_is_float", []):                 # the early-outs hand out python floats 0.0 (model/univtg.py:237-241)
+        assert not torch.is_tensor(losses[k]) and losses[k] == 0.0 and losses_ref[k] == 0.0
     for k, v in losses.items():
         assert abs(float(v.detach() if torch.is_tensor(v) else v) - losses_ref[k]) <= 2e-5 * max(1.0, abs(losses_ref[k])), (k, float(v), losses_ref[k])
     total = O.total_loss(losses, cfg)

@@ -1411,33 +1411,6 @@ static int g_force_tile = 0;   // 0: automatic, 128 / 256: force that NT tile si
 static int g_force_bm = 0;     // 0: automatic, 128 / 192 / 256: force the tile height of the 256-wide persistent kernel
 extern "C" int uvtg_debug_force_nt_bm(int bm) { if (bm != 0 && bm != 128 && bm != 192 && bm != 256 && bm != 320) return -21; g_force_bm = bm; return 0; }
 extern "C" int uvtg_debug_force_nt_tile(int tile) { if (tile != 0 && tile != 128 && tile != 256) return -21; g_force_tile = tile; return 0; }
-static bool nt256_ok(const GemmArgs& a) {
-  if (g_force_tile == 128) return false;
-  if (a.K % 64 || a.ktap % 64 || a.lda % 8 || a.ldb % 8 || a.N % 8) return false;
-  if (a.ldoF % 8 || a.ldoB % 8 || a.ldoU % 8 || a.ldr % 8 || a.ldrB % 8 || a.ldgp % 8 || a.ldpre_out % 8 || a.ldpos % 8 || a.colscale_n % 8) return false;
-  if (a.gA % 8 || a.gB % 8 || a.gBias % 4 || a.gOut % 8 || a.gPre % 8) return false;
-  const int groups = a.groups > 0 ? a.groups : 1;
-  if (g_force_tile != 256) {  // pick the structure that wastes less of the chip: the persistent 256-wide kernel at ITS best tile height (whole or
-    // partly filled CU rounds, nt256_cost) vs rounds of 512 register-staged 128 x 128 tiles (two per CU = the output area of one 128 x 256 tile,
-    // at 620 / 950 of the persistent kernel's in-loop rate).  (Round 2 compared 256-row tiles only: the 8192-row text GEMMs -- 128 tiles of
-    // 256 rows, half a round -- went to the 128-tile kernel at 443 TF/s although 256 tiles of 128 rows fill exactly one round.)
-    const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128) * groups;
-    const double c128 = (double)((t128 + 511) / 512) * 128.0 * (950.0 / 620.0);
-    const bool gather_ = a.a_seg || a.o_seg || a.a_off || a.o_off || a.ktap != a.K || groups != 1 || a.o_rows || a.pos_map;
-    const int cus = g_num_cu > 0 ? g_num_cu : 256;
-    double c256 = 1e30;
-    for (int tm = gather_ ? 4 : 5; tm >= 2; tm--) { const double c = nt256_cost(a.M, a.N, groups, tm, cus); if (c < c256) c256 = c; }
-    static const bool old_choice = getenv("UVTG_NT_OLD_128_CHOICE") != nullptr;
-    if (old_choice) {
-      const long long t256 = (long long)cdiv(a.M, 256) * cdiv(a.N, 256) * groups;
-      const double e256 = (double)t256 / (double)((t256 + 255) / 256 * 256) * 950.0, e128 = (double)t128 / (double)((t128 + 511) / 512 * 512) * 620.0;
-      if (e256 < e128) return false;
-    } else if (c128 < c256) return false;
-  }
-  const long long amax = ((long long)(a.a_seg ? (a.M / a.a_seg + 1) * a.a_seg_stride : a.M) + a.a_off + 3) * a.lda + (long long)groups * a.gA;
-  const long long bmax = (long long)a.N * a.ldb + (long long)groups * a.gB;
-  return amax * 2 < (1LL << 32) && bmax * 2 < (1LL << 32);
-}
 static int g_cu_cap = 0;       // experiment knob: the persistent GEMM grids use at most this many CUs (0 = all)
 extern "C" int uvtg_debug_gemm_cus(int n) { g_cu_cap = n > 0 ? n : 0; return 0; }
 static int g_cu_reserved = 0;  // CUs left out of every persistent grid for the communication kernels of a data-parallel run
@@ -1454,6 +1427,34 @@ static int ensure_num_cu() {
     g_num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
   }
   return 0;
+}
+static bool nt256_ok(const GemmArgs& a) {
+  if (g_force_tile == 128) return false;
+  if (a.K % 64 || a.ktap % 64 || a.lda % 8 || a.ldb % 8 || a.N % 8) return false;
+  if (a.ldoF % 8 || a.ldoB % 8 || a.ldoU % 8 || a.ldr % 8 || a.ldrB % 8 || a.ldgp % 8 || a.ldpre_out % 8 || a.ldpos % 8 || a.colscale_n % 8) return false;
+  if (a.gA % 8 || a.gB % 8 || a.gBias % 4 || a.gOut % 8 || a.gPre % 8) return false;
+  const int groups = a.groups > 0 ? a.groups : 1;
+  if (g_force_tile != 256) {  // pick the structure that wastes less of the chip: the persistent 256-wide kernel at ITS best tile height (whole or
+    // partly filled CU rounds, nt256_cost) vs rounds of 512 register-staged 128 x 128 tiles (two per CU = the output area of one 128 x 256 tile,
+    // at 620 / 950 of the persistent kernel's in-loop rate).  (Round 2 compared 256-row tiles only: the 8192-row text GEMMs -- 128 tiles of
+    // 256 rows, half a round -- went to the 128-tile kernel at 443 TF/s although 256 tiles of 128 rows fill exactly one round.)
+    const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128) * groups;
+    const double c128 = (double)((t128 + 511) / 512) * 128.0 * (950.0 / 620.0);
+    const bool gather_ = a.a_seg || a.o_seg || a.a_off || a.o_off || a.ktap != a.K || groups != 1 || a.o_rows || a.pos_map;
+    // the SAME CU count the launch plan will use (reserved communication CUs / the experiment cap subtracted)
+    const int cus = ensure_num_cu() ? 256 : eff_cus();
+    double c256 = 1e30;
+    for (int tm = gather_ ? 4 : 5; tm >= 2; tm--) { const double c = nt256_cost(a.M, a.N, groups, tm, cus); if (c < c256) c256 = c; }
+    static const bool old_choice = getenv("UVTG_NT_OLD_128_CHOICE") != nullptr;
+    if (old_choice) {
+      const long long t256 = (long long)cdiv(a.M, 256) * cdiv(a.N, 256) * groups;
+      const double e256 = (double)t256 / (double)((t256 + 255) / 256 * 256) * 950.0, e128 = (double)t128 / (double)((t128 + 511) / 512 * 512) * 620.0;
+      if (e256 < e128) return false;
+    } else if (c128 < c256) return false;
+  }
+  const long long amax = ((long long)(a.a_seg ? (a.M / a.a_seg + 1) * a.a_seg_stride : a.M) + a.a_off + 3) * a.lda + (long long)groups * a.gA;
+  const long long bmax = (long long)a.N * a.ldb + (long long)groups * a.gB;
+  return amax * 2 < (1LL << 32) && bmax * 2 < (1LL << 32);
 }
 extern "C" int uvtg_set_reserved_cus(int k) {
   g_cu_reserved = k > 0 ? k : 0;

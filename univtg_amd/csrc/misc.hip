@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void unpack_vm_kernel(const bf16_t* packed, co
   {   // the two zero rows that frame the sample (the k = 3 convolution's padding): written here instead of by a zero_frame launch
     const int fs0 = fstart ? fstart[b] : b * (Lv + 2), nk = kept ? kept[b] : Lv;
     if (s == 0) for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + (size_t)fs0 * d + c) = z;
-    if (s == nk - 1) for (int c = lane * 8; c < d; c += 512) *(u32x4*)(vm_pad + (size_t)(fs0 + nk + 1) * d + c) = z;
+    if (s == max(nk, 1) - 1) for (int c = lane * 8; c < d; c += 512)      /* (kept == 0 cannot reach here -- packed_rows() refuses len_v < 1 -- but the bottom row is written even then) */ *(u32x4*)(vm_pad + (size_t)(fs0 + nk + 1) * d + c) = z;
   }
   if (kept && s >= kept[b]) return;                         // ragged frames: a dropped clip has no frame row
   const int pk = pad2pack[b * S + s];
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFina
     const int nk = a.kept ? a.kept[b] : a.Lv;
     const u32x4 z = {0, 0, 0, 0};
     if (u == 0) for (int c = lane * 8; c < 2 * d; c += 512) *(u32x4*)(a.dh2 + (size_t)fs * a.lddh + c) = z;
-    if (u == nk - 1) for (int c = lane * 8; c < 2 * d; c += 512) *(u32x4*)(a.dh2 + (size_t)(fs + nk + 1) * a.lddh + c) = z;
+    if (u == max(nk, 1) - 1) for (int c = lane * 8; c < 2 * d; c += 512) *(u32x4*)(a.dh2 + (size_t)(fs + nk + 1) * a.lddh + c) = z;
   }
   if (a.kept && u >= a.kept[b]) return;
   const bf16_t* h2 = (const bf16_t*)a.h2 + (size_t)(fs + u + 1) * a.ldh;
@@ -756,7 +756,7 @@ template <int NPASS>     // d = 512 * NPASS
 __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFinalArgs h, const SaliencyArgs a) {
   extern __shared__ float sm[];                 // [Lt] logits / alpha | [d] pooled | [16] scratch
   float* s_alpha = sm;
-  float* s_pool = sm + a.Lt;
+  float* s_pool = sm + ((a.Lt + 3) & ~3);      // 16-byte aligned for the f32x4 reads below, whatever the (odd) text length
   float* s_red = s_pool + a.d;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
   const float* xt = a.x0 + ((size_t)b * a.S + a.Lv) * d;      // text rows
@@ -1230,7 +1230,7 @@ int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
 // heads' last layer + activations + text pooling + cosine saliency: ONE launch when every CU gets a sample, else the three per-stage launches
 int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hipStream_t s) {
   static const bool off = getenv("UVTG_HEADFUSE_OFF") != nullptr;      // experiment: always the separate launches
-  const size_t sh = ((size_t)a.Lt + a.d + 16) * sizeof(float);
+  const size_t sh = ((size_t)((a.Lt + 3) & ~3) + a.d + 16) * sizeof(float);
   if (off || h.precise || a.B < 128 || (a.d != 512 && a.d != 1024) || sh > 60 * 1024) {
     if (int e = launch_heads_final_fwd(h, s)) return e;
     return launch_saliency_fwd(a, s);

@@ -167,17 +167,16 @@ class TrainStep:
                               *self._event_args(dims), lens), "uvtg_backward")
         if self.world > 1 or self.overlap:
             if self.time_comm:
+                # one event pair per step, allocated as the steps come: nothing is dropped and nothing synchronises inside a timed
+                # loop (round 3 drained an 8-slot ring with a device sync every 8 steps and threw the drained samples away)
                 if self._comm_ev is None:
-                    self._comm_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
-                    self._comm_i = 0
-                if self._comm_i >= len(self._comm_ev):
-                    self.exposed_comm_ms()               # (drains the ring: one sync every 8 steps, only when timing is on)
-                e0, e1 = self._comm_ev[self._comm_i]
+                    self._comm_ev = []
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self._comm_ev.append((e0, e1))
                 e0.record()
             self._exchange_gradients(dims)
             if self.time_comm:
                 e1.record()
-                self._comm_i += 1
         if optimize:
             self.t += 1
             if self.world == 1 and not self.overlap and not os.environ.get("UVTG_PRENORM_OFF"):
@@ -278,12 +277,19 @@ class TrainStep:
     def exposed_comm_ms(self):
         """Per-step exposed communication times (ms) recorded since the last call (time_comm=True): from the end of uvtg_backward on the
         compute stream to the moment every gradient range is reduced.  Synchronises."""
-        if self._comm_ev is not None:
+        if self._comm_ev:
             torch.cuda.synchronize()
-            self._comm_ms += [a.elapsed_time(b) for a, b in self._comm_ev[: self._comm_i]]
-            self._comm_i = 0
+            self._comm_ms += [a.elapsed_time(b) for a, b in self._comm_ev]
+            self._comm_ev = []
         out, self._comm_ms = self._comm_ms, []
         return out
+
+    def flat_checksum(self):
+        """(sum, sum of squares, first / middle / last element) of the flat parameter buffer in float64 -- data-parallel replicas must agree
+        on it bit for bit after any number of steps (bench.py --gpus N prints the comparison).  Synchronises."""
+        f = self.flat.double()
+        n = f.numel()
+        return [float(f.sum()), float((f * f).sum()), float(f[0]), float(f[n // 2]), float(f[n - 1])]
 
     def _reduce_range(self, lo, hi):
         """SUM all-reduce of grads[lo:hi] on the CURRENT stream, in the configured wire dtype."""
