@@ -34,7 +34,7 @@ typedef struct uvtg_dims {
   int B, Lv, Lt;             /* batch, padded #clips, padded #text tokens (S = Lv + Lt)            */
   int d, H, F, E;            /* hidden_dim, nheads, dim_feedforward, enc_layers                    */
   int Dv, Dt;                /* v_feat_dim (incl. TEF), t_feat_dim                                 */
-  int n_proj;                /* n_input_proj; only 2 (the value every reference script uses)       */
+  int n_proj;                /* n_input_proj: 1, 2 or 3 LinearLayer blocks per modality (model/univtg.py:89-100)  */
   int precise;               /* 0: bf16 MFMA encoder/heads; 1: split-bf16 (fp32-class), forward only */
   int training;              /* 1: keep activations for backward, apply dropout / DropPath         */
   int proj_precise;          /* 1: input projections in split-bf16 even when precise==0 (keeps the
@@ -43,6 +43,9 @@ typedef struct uvtg_dims {
   unsigned long long seed;   /* Philox seed of this step (stochastic ops are counter-based)        */
   int loss_only;             /* 1: the caller consumes only what the dense criterion consumes (a native training step): outputs
                                 at PADDED clip positions may differ from the reference's -- see lens_host below               */
+  int use_txt_pos;           /* --use_txt_pos (model/univtg.py:123): pos of the text rows = Dropout(LayerNorm(x_txt + E[0..Lt))),
+                                model/position_encoding.py:19-41, dropout p = p_in; padded execution only (lens_host ignored)  */
+  int max_q_l;               /* rows of txt_position_embed.position_embeddings.weight (>= Lt); read only with use_txt_pos      */
 } uvtg_dims;
 
 /* ---- parameter table -------------------------------------------------------------------------
@@ -53,11 +56,13 @@ typedef struct uvtg_dims {
  *       norm2.weight, norm2.bias
  *   then (base 12*E): token_type_embeddings.weight,
  *       span_embed.layers.{0,1,2}.{weight,bias}, class_embed.layers.{0,1,2}.{weight,bias},
- *       input_txt_proj.{0,1}.{LayerNorm.weight, LayerNorm.bias, net.1.weight, net.1.bias},
- *       input_vid_proj.{0,1}.{...}, weightedpool.weight
- *   (txt_position_embed.* is NOT in the table: it is unused unless --use_txt_pos, which no reference
- *    script sets, and it receives no gradient in the reference either -- model/univtg.py:123.)
- * uvtg_param_count() = 12*E + 30.  Gradients come back in ONE flat fp32 buffer; parameter i starts
+ *       input_txt_proj.{0..n_proj-1}.{LayerNorm.weight, LayerNorm.bias, net.1.weight, net.1.bias},
+ *       input_vid_proj.{0..n_proj-1}.{...}, weightedpool.weight,
+ *       and -- only with dims.use_txt_pos -- txt_position_embed.position_embeddings.weight [max_q_l, d],
+ *       txt_position_embed.LayerNorm.{weight, bias}
+ *   (without --use_txt_pos the text position table is NOT in the table: the reference does not read it then and it receives no
+ *    gradient there either -- model/univtg.py:123.)
+ * uvtg_param_count() = 12*E + 14 + 8*n_proj (+ 3 with use_txt_pos).  Gradients come back in ONE flat fp32 buffer; parameter i starts
  * at element offsets[i] (uvtg_param_offsets; each start is a multiple of 4 elements). */
 int uvtg_param_count(const uvtg_dims* dm);
 int uvtg_param_numel(const uvtg_dims* dm, int index, long long* numel);

@@ -67,6 +67,30 @@ def test_model_keeps_reference_checkpoint_layout(golden_dir):
     assert len(ordered) == 12 * cfg["enc_layers"] + 30
 
 
+@pytest.mark.parametrize("name", ["tiny_nproj1", "tiny_nproj3", "tiny_txt_pos", "tiny_eval_full"])
+def test_param_table_follows_n_input_proj_and_use_txt_pos(lib, golden_dir, name):
+    """The C-ABI parameter table (uvtg_param_count / _numel / _offsets) == Model._ordered_params() entry by entry for every
+    --n_input_proj (model/univtg.py:89-100) and with --use_txt_pos (three more entries), and the state_dict keeps the checkpoint
+    layout the reference's load_state_dict(strict=True) accepted when the fixture was made."""
+    from univtg_amd.model import Model
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = json.loads(str(z["meta"]))["cfg"]
+    m = Model(cfg["hidden_dim"], cfg["nheads"], cfg["dim_feedforward"], cfg["enc_layers"], cfg["t_feat_dim"], cfg["v_feat_dim"],
+              cfg["input_dropout"], cfg["dropout"], cfg["droppath"], max_q_l=cfg["max_q_l"], n_input_proj=cfg["n_input_proj"],
+              use_txt_pos=cfg["use_txt_pos"])
+    ref = {k[6:]: tuple(z[k].shape) for k in z.files if k.startswith("param/")}
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref and list(m.state_dict().keys()) == list(ref.keys())
+    dims = m._dims(2, 5, 4, cfg["v_feat_dim"], cfg["t_feat_dim"], False)
+    ordered = m._ordered_params()
+    n = lib.uvtg_param_count(C.byref(dims))
+    assert n == len(ordered) == 12 * cfg["enc_layers"] + 14 + 8 * cfg["n_input_proj"] + (3 if cfg["use_txt_pos"] else 0)
+    for i, p_ in enumerate(ordered):
+        ne = C.c_longlong()
+        assert lib.uvtg_param_numel(C.byref(dims), i, C.byref(ne)) == 0 and ne.value == p_.numel(), (i, ne.value, tuple(p_.shape))
+    offs = m._offsets(dims)
+    assert len(offs) == n + 1 and all(o % 4 == 0 for o in offs)
+
+
 def test_no_cpu_fallback(golden_dir):
     """The product refuses CPU tensors instead of silently computing elsewhere."""
     from univtg_amd.model import Model

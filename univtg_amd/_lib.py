@@ -16,14 +16,14 @@ class Dims(C.Structure):
                 ("Dv", C.c_int), ("Dt", C.c_int), ("n_proj", C.c_int),
                 ("precise", C.c_int), ("training", C.c_int), ("proj_precise", C.c_int),
                 ("p_in", C.c_float), ("p_attn", C.c_float), ("p_path", C.c_float),
-                ("seed", C.c_ulonglong), ("loss_only", C.c_int)]
+                ("seed", C.c_ulonglong), ("loss_only", C.c_int), ("use_txt_pos", C.c_int), ("max_q_l", C.c_int)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.struct_size = C.sizeof(Dims)
 
 
-ABI_VERSION = 200          # uvtg_version() this binding was written against
+ABI_VERSION = 300          # uvtg_version() this binding was written against
 
 
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong

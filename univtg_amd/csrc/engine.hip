@@ -14,28 +14,37 @@ namespace {
 
 // ---- parameter table -------------------------------------------------------------------------
 enum { IPW = 0, IPB, OPW, OPB, L1W, L1B, L2W, L2B, N1W, N1B, N2W, N2B, PER_LAYER };
-enum { TOK = 0, SP0W, SP0B, SP1W, SP1B, SP2W, SP2B, CL0W, CL0B, CL1W, CL1B, CL2W, CL2B,
-       TP0G, TP0BE, TP0W, TP0B, TP1G, TP1BE, TP1W, TP1B,
-       VP0G, VP0BE, VP0W, VP0B, VP1G, VP1BE, VP1W, VP1B, POOL, N_TAIL };
+// tail of the table: token-type rows, the two conv heads, then n_proj blocks per modality (text first), the pooling vector and -- with
+// use_txt_pos -- the trainable text position table and its LayerNorm
+enum { TOK = 0, SP0W, SP0B, SP1W, SP1B, SP2W, SP2B, CL0W, CL0B, CL1W, CL1B, CL2W, CL2B, N_FIXED };
+enum { PG = 0, PBE, PW, PB, PER_PROJ };      // one LinearLayer: LayerNorm gamma / beta, Linear weight / bias (model/univtg.py:384-406)
+constexpr int MAXP = 3;                      // n_input_proj <= 3 (model/univtg.py:89-100)
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 struct Dm {
   uvtg_dims c;
-  int S, M, Mv, Mt, Rp, hd, Kpv, Kpt, np;
+  int S, M, Mv, Mt, Rp, hd, Kpv, Kpt, np, nproj;
   explicit Dm(const uvtg_dims& d) : c(d) {
     S = d.Lv + d.Lt; M = d.B * S; Mv = d.B * d.Lv; Mt = d.B * d.Lt; Rp = d.B * (d.Lv + 2);
-    hd = d.H > 0 ? d.d / d.H : 0; Kpv = rup(d.Dv, 64); Kpt = rup(d.Dt, 64); np = PER_LAYER * d.E + N_TAIL;
+    hd = d.H > 0 ? d.d / d.H : 0; Kpv = rup(d.Dv, 64); Kpt = rup(d.Dt, 64); nproj = d.n_proj;
+    np = PER_LAYER * d.E + N_FIXED + 2 * PER_PROJ * nproj + 1 + (d.use_txt_pos ? 3 : 0);
   }
   int tail(int k) const { return PER_LAYER * c.E + k; }
   int lay(int l, int k) const { return PER_LAYER * l + k; }
+  int proj(int which, int blk, int k) const { return tail(N_FIXED + PER_PROJ * ((which == 0 ? nproj : 0) + blk) + k); }   // which: 0 = video, 1 = text
+  int pool() const { return tail(N_FIXED + 2 * PER_PROJ * nproj); }
+  int txtpos(int k) const { return pool() + 1 + k; }      // 0: position_embeddings.weight [max_q_l, d], 1 / 2: LayerNorm gamma / beta
+  int din(int which, int blk) const { return blk == 0 ? (which == 0 ? c.Dv : c.Dt) : c.d; }
+  int kp(int which, int blk) const { return blk == 0 ? (which == 0 ? Kpv : Kpt) : c.d; }
 };
 
 int check_dims(const uvtg_dims* d) {
   if (!d) return -10;
   if (d->struct_size != (int)sizeof(uvtg_dims)) return -18;     // caller built against another layout of the struct (uvtg_version)
   if (d->B <= 0 || d->Lv <= 0 || d->Lt <= 0 || d->E <= 0 || d->H <= 0) return -11;
-  if (d->n_proj != 2) return -12;
+  if (d->n_proj < 1 || d->n_proj > MAXP) return -12;
+  if (d->use_txt_pos && d->max_q_l < d->Lt) return -19;
   if (d->d % 32 || d->F % 8) return -13;
   const int hd = d->d / d->H;
   if (hd * d->H != d->d || (hd != 32 && hd != 64 && hd != 128)) return -14;
@@ -56,17 +65,30 @@ long long pnumel(const Dm& m, int i) {
       default: return d;
     }
   }
-  switch (i - PER_LAYER * m.c.E) {
+  const int t = i - PER_LAYER * m.c.E;
+  switch (t) {
     case TOK: return 2 * d;
     case SP0W: case SP1W: case CL0W: case CL1W: return d * d * 3;
     case SP0B: case SP1B: case CL0B: case CL1B: return d;
     case SP2W: return 2 * d * 3; case SP2B: return 2; case CL2W: return d * 3; case CL2B: return 1;
-    case TP0G: case TP0BE: return m.c.Dt; case TP0W: return d * m.c.Dt;
-    case VP0G: case VP0BE: return m.c.Dv; case VP0W: return d * m.c.Dv;
-    case TP1W: case VP1W: return d * d;
-    case POOL: return d;
-    default: return d;   // TP0B, TP1G, TP1BE, TP1B, VP0B, VP1G, VP1BE, VP1B
+    default: break;
   }
+  const int j = t - N_FIXED;
+  if (j < 2 * PER_PROJ * m.nproj) {
+    const int which = j < PER_PROJ * m.nproj ? 1 : 0, blk = (j % (PER_PROJ * m.nproj)) / PER_PROJ, k = j % PER_PROJ;
+    const long long din = m.din(which, blk);
+    return k == PW ? d * din : (k == PB ? d : din);
+  }
+  const int j2 = j - 2 * PER_PROJ * m.nproj;       // 0: weightedpool.weight, then the text position table + its LayerNorm
+  return j2 == 1 ? (long long)m.c.max_q_l * d : d;
+}
+// is table entry i a weight MATRIX that a weight-gradient launch assigns (everything else is accumulated into zeros)?
+bool assigned_matrix(const Dm& m, int i) {
+  if (i < PER_LAYER * m.c.E) { const int k = i % PER_LAYER; return k == IPW || k == OPW || k == L1W || k == L2W; }
+  const int t = i - PER_LAYER * m.c.E;
+  if (t == SP0W || t == SP1W || t == CL0W || t == CL1W) return true;
+  const int j = t - N_FIXED;
+  return j >= 0 && j < 2 * PER_PROJ * m.nproj && j % PER_PROJ == PW;
 }
 
 struct Arena {
@@ -87,9 +109,10 @@ struct WCache {
   bf16_t *wc0, *wc1, *wc0T, *wc1T;      // conv operands (fast)
   float *wc0F, *wc1F;                   // conv operands (precise)
   float *bc0, *bc1;                     // merged conv biases [2d]
-  float *vp0F, *tp0F;                   // fp32 zero-padded first projection weights [d, Kp]
-  bf16_t *vp0B, *tp0B, *vp1B, *tp1B;    // bf16 projection weights (proj_precise == 0)
-  bf16_t *vp1T, *tp1T, *vp0T, *tp0T;    // dgrad operands
+  // input projections, [modality: 0 = video, 1 = text][block]
+  float* pwF[2][MAXP];                  // fp32 zero-padded first-block weights [d, Kp] (split-bf16 path; later blocks read the parameter itself)
+  bf16_t* pwB[2][MAXP];                 // bf16 weights [d, Kp] (proj_precise == 0)
+  bf16_t* pwT[2][MAXP];                 // dgrad operands [Kp, d]
   size_t bytes;
   WCache(const Dm& m, void* base) {
     Arena a(base);
@@ -108,12 +131,15 @@ struct WCache {
     wc0F = !fast ? a.take<float>(2 * d * 3 * d) : nullptr; wc1F = !fast ? a.take<float>(2 * d * 3 * d) : nullptr;
     bc0 = a.take<float>(2 * d); bc1 = a.take<float>(2 * d);
     const bool pp = m.c.precise || m.c.proj_precise;
-    vp0F = pp ? a.take<float>(d * m.Kpv) : nullptr; tp0F = pp ? a.take<float>(d * m.Kpt) : nullptr;
-    vp0B = !pp ? a.take<bf16_t>(d * m.Kpv) : nullptr; tp0B = !pp ? a.take<bf16_t>(d * m.Kpt) : nullptr;
-    vp1B = !pp ? a.take<bf16_t>(d * d) : nullptr; tp1B = !pp ? a.take<bf16_t>(d * d) : nullptr;
     const bool tr = fast && m.c.training;
-    vp1T = tr ? a.take<bf16_t>(d * d) : nullptr; tp1T = tr ? a.take<bf16_t>(d * d) : nullptr;
-    vp0T = tr ? a.take<bf16_t>((size_t)m.Kpv * d) : nullptr; tp0T = tr ? a.take<bf16_t>((size_t)m.Kpt * d) : nullptr;
+    for (int w = 0; w < 2; w++)
+      for (int b = 0; b < MAXP; b++) {
+        const bool on = b < m.nproj;
+        const size_t Kp = on ? m.kp(w, b) : 0;
+        pwF[w][b] = (on && pp && b == 0) ? a.take<float>(d * Kp) : nullptr;
+        pwB[w][b] = (on && !pp) ? a.take<bf16_t>(d * Kp) : nullptr;
+        pwT[w][b] = (on && tr) ? a.take<bf16_t>(Kp * d) : nullptr;
+      }
     bytes = a.off + 256;
   }
 };
@@ -123,8 +149,11 @@ struct WSpace {
   float* pos; unsigned char* kvalid; float* dps;
   // packed (ragged) execution: tables, packed layer-0 operands, packed conv-head gradient
   PackTables pk; int* lens_dev; bf16_t *xb0p, *ub0p, *g2p;
-  // projections (index 0 = video, 1 = text)
-  void* a1[2]; bf16_t* a1B[2]; float *m0[2], *r0[2], *h1[2]; void* a2[2]; bf16_t* a2B[2]; float *m1[2], *r1[2];
+  // input projections, [modality: 0 = video, 1 = text][block]: the block's GEMM operand LN(x) (+dropout), its bf16 copy for the weight
+  // gradient when the operand itself is fp32, the LayerNorm statistics, and (blocks before the last) the block's fp32 output
+  void* pa[2][MAXP]; bf16_t* paB[2][MAXP]; float *pm[2][MAXP], *pr[2][MAXP], *ph[2][MAXP];
+  // trainable text positions (use_txt_pos): pos rows of the text tokens live behind the clip rows of `pos`; row tables; saved LayerNorm input + statistics
+  float *pos_txt, *tp_xsum, *tp_mean, *tp_rstd; int *pos_row_all, *tp_src;
   // encoder
   float* xin[MAXE + 1]; void *xb[MAXE + 1], *ub[MAXE + 1];
   void *qkv[MAXE], *o[MAXE], *x1b[MAXE], *h[MAXE]; bf16_t* apre[MAXE];
@@ -135,9 +164,10 @@ struct WSpace {
   // saliency
   float *alpha, *cosv, *vnorm, *qnorm, *sal_dq, *sal_dlog;
   // backward scratch
-  float *dvm, *gx[2], *dyF, *delta, *dA2[2], *dA1[2], *tn_scratch; long long tn_scratch_floats;
+  float *dvm, *gx[2], *dyF, *delta, *dA[2], *tn_scratch; long long tn_scratch_floats;
+  float *dpos_txt, *tp_dx;   // use_txt_pos: gradient wrt the text position rows (summed over the layers' q,k operands), and wrt their LayerNorm input
   float* gnorm2;       // sum of squares of the step's gradients, accumulated by uvtg_backward (uvtg_backward_gradnorm2)
-  bf16_t *dh2_pad, *dh1_pad, *dyR, *dvmB, *gxb[2], *dOb, *dyP[2], *dh1b[2];
+  bf16_t *dh2_pad, *dh1_pad, *dyR, *dvmB, *gxb[2], *dOb, *dyP[2], *dhb[2][MAXP];   // dhb[w][b]: gradient wrt the output of projection block b (b < n_proj - 1)
   // per-layer operands of the encoder's weight gradients (LayerNorm-2 / LayerNorm-1 input gradients, activation gradient, dqkv): kept
   // until the end of the encoder backward so that the weight gradients of ALL layers can run as one launch without a reduce pass
   bf16_t *dy2L[MAXE], *dy1L[MAXE], *daL[MAXE], *dqkvL[MAXE];
@@ -149,7 +179,12 @@ struct WSpace {
     const bool tr = m.c.training, fast = !m.c.precise;
     const size_t es = fast ? 2 : 4;                       // compute-dtype element size
     const bool pp = m.c.precise || m.c.proj_precise;
-    pos = a.take<float>((size_t)m.Mv * d); kvalid = a.take<unsigned char>(M); dps = a.take<float>(2 * E * B);
+    const bool tpos = m.c.use_txt_pos != 0;
+    pos = a.take<float>((size_t)(m.Mv + (tpos ? m.Mt : 0)) * d); kvalid = a.take<unsigned char>(M); dps = a.take<float>(2 * E * B);
+    pos_txt = tpos ? pos + (size_t)m.Mv * d : nullptr;
+    pos_row_all = tpos ? a.take<int>(M) : nullptr; tp_src = tpos ? a.take<int>(m.Mt) : nullptr;
+    tp_xsum = (tpos && tr) ? a.take<float>((size_t)m.Mt * d) : nullptr;
+    tp_mean = tpos ? a.take<float>(m.Mt) : nullptr; tp_rstd = tpos ? a.take<float>(m.Mt) : nullptr;
     lens_dev = a.take<int>(2 * B);
     pk.seq_start = a.take<int>(B); pk.seq_count = a.take<int>(B);
     pk.row_sample = a.take<int>(M); pk.row_src = a.take<int>(M); pk.row_pos = a.take<int>(M);
@@ -159,16 +194,15 @@ struct WSpace {
     pk.tin_dst = a.take<int>(m.Mt); pk.vin_cnt = a.take<int>(B);
     xb0p = fast ? a.take<bf16_t>(M * d) : nullptr; ub0p = fast ? a.take<bf16_t>(M * d) : nullptr;
     g2p = (fast && tr) ? a.take<bf16_t>(M * d) : nullptr;
-    for (int i = 0; i < 2; i++) {
-      const size_t R = i == 0 ? m.Mv : m.Mt, Kp = i == 0 ? m.Kpv : m.Kpt;
-      a1[i] = a.take<char>(R * Kp * (pp ? 4 : 2));
-      a1B[i] = (tr && pp) ? a.take<bf16_t>(R * Kp) : nullptr;
-      m0[i] = a.take<float>(R); r0[i] = a.take<float>(R);
-      h1[i] = a.take<float>(R * d);
-      a2[i] = a.take<char>(R * d * (pp ? 4 : 2));
-      a2B[i] = (tr && pp) ? a.take<bf16_t>(R * d) : nullptr;
-      m1[i] = a.take<float>(R); r1[i] = a.take<float>(R);
-    }
+    for (int w = 0; w < 2; w++)
+      for (int b = 0; b < MAXP; b++) {
+        const bool on = b < m.nproj;
+        const size_t R = w == 0 ? m.Mv : m.Mt, Kp = on ? m.kp(w, b) : 0;
+        pa[w][b] = on ? a.take<char>(R * Kp * (pp ? 4 : 2)) : nullptr;
+        paB[w][b] = (on && tr && pp) ? a.take<bf16_t>(R * Kp) : nullptr;
+        pm[w][b] = on ? a.take<float>(R) : nullptr; pr[w][b] = on ? a.take<float>(R) : nullptr;
+        ph[w][b] = (on && b + 1 < m.nproj) ? a.take<float>(R * d) : nullptr;
+      }
     x1 = fast ? nullptr : a.take<float>(M * d);
     float* xpp[2] = {nullptr, nullptr}; void* xbpp[2] = {nullptr, nullptr}; void* ubpp[2] = {nullptr, nullptr};
     for (size_t l = 0; l <= E; l++) {       // layer l reads slot l, writes slot l + 1
@@ -229,15 +263,18 @@ struct WSpace {
       dh2_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d); dh1_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d);
       dOb = a.take<bf16_t>(M * d);
       for (size_t l = 0; l < E; l++) { dy2L[l] = a.take<bf16_t>(M * d); dy1L[l] = a.take<bf16_t>(M * d); daL[l] = a.take<bf16_t>(M * F); dqkvL[l] = a.take<bf16_t>(M * 3 * d); }
-      for (int i = 0; i < 2; i++) {
-        const size_t R = i == 0 ? m.Mv : m.Mt, Kp = i == 0 ? m.Kpv : m.Kpt;
-        dyP[i] = a.take<bf16_t>(R * d); dh1b[i] = a.take<bf16_t>(R * d);
-        dA2[i] = a.take<float>(R * d); dA1[i] = a.take<float>(R * Kp);
+      for (int w = 0; w < 2; w++) {
+        const size_t R = w == 0 ? m.Mv : m.Mt, Kp = w == 0 ? m.Kpv : m.Kpt;
+        dyP[w] = a.take<bf16_t>(R * d);
+        for (int b = 0; b < MAXP; b++) dhb[w][b] = (b + 1 < m.nproj) ? a.take<bf16_t>(R * d) : nullptr;
+        dA[w] = a.take<float>(R * (Kp > d ? Kp : d));        // fp32 dgrad output of the block being processed (blocks run one after the other)
       }
+      dpos_txt = tpos ? a.take<float>((size_t)m.Mt * d) : nullptr; tp_dx = tpos ? a.take<float>((size_t)m.Mt * d) : nullptr;
     } else {
+      dpos_txt = tp_dx = nullptr;
       dvm = gx[0] = gx[1] = dyF = delta = nullptr; dyR = dvmB = gxb[0] = gxb[1] = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dOb = nullptr; gnorm2 = nullptr; tnh_slabs = nullptr; tnh_slab_floats = 0; tnh_tickets = nullptr; tnh_n_tickets = 0;
       for (int l = 0; l < MAXE; l++) dy2L[l] = dy1L[l] = daL[l] = dqkvL[l] = nullptr;
-      for (int i = 0; i < 2; i++) { dyP[i] = dh1b[i] = nullptr; dA2[i] = dA1[i] = nullptr; }
+      for (int w = 0; w < 2; w++) { dyP[w] = nullptr; dA[w] = nullptr; for (int b = 0; b < MAXP; b++) dhb[w][b] = nullptr; }
     }
     bytes = a.off + 256;
   }
@@ -282,6 +319,25 @@ __global__ void add_vec2_kernel(float* dst_a, const float* src_a, float* dst_b, 
   if (i < n) { dst_a[i] += src_a[i]; dst_b[i] += src_b[i]; }
 }
 
+// --use_txt_pos tables: pos_row_all[b*S + s] = row of the [B*Lv + B*Lt, d] pos table that token (b, s) adds to its q,k operand;
+// tp_src[b*Lt + t] = row b*S + Lv + t of the padded token layout (the text rows' LayerNorm input and dropout counter key)
+__global__ void txt_pos_tables_kernel(int B, int Lv, int Lt, int* pos_row_all, int* tp_src) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, S = Lv + Lt;
+  if (i >= B * S) return;
+  const int b = i / S, sidx = i - b * S;
+  pos_row_all[i] = sidx < Lv ? b * Lv + sidx : B * Lv + b * Lt + (sidx - Lv);
+  if (sidx >= Lv) tp_src[b * Lt + (sidx - Lv)] = i;
+}
+// dE[t][c] = sum_b g[(b*Lt + t)][c]: gradient of the text position table rows t < Lt (position_encoding.py:33-36)
+__global__ void txt_pos_table_grad_kernel(const float* g, int B, int Lt, int d, float* dE) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Lt * d) return;
+  const int t = i / d, c = i - t * d;
+  float acc = 0.f;
+  for (int b = 0; b < B; b++) acc += g[((size_t)b * Lt + t) * d + c];
+  dE[i] = acc;
+}
+
 #define TRY(x) do { int e__ = (x); if (e__) return e__; } while (0)
 
 // Packed (ragged) encoder stream, decided identically by uvtg_forward and uvtg_backward from (dims, lens_host):
@@ -297,7 +353,7 @@ __global__ void add_vec2_kernel(float* dst_a, const float* src_a, float* dst_b, 
 enum { PACK_NONE = 0, PACK_FULL = 1, PACK_TEXT = 2, PACK_HALO = 3 };
 constexpr int HALO = 3;
 int pack_mode(const uvtg_dims& c, const int* lens_host) {
-  if (!lens_host || c.precise) return PACK_NONE;
+  if (!lens_host || c.precise || c.use_txt_pos) return PACK_NONE;      // (trainable text positions: padded execution only)
   if (c.training && (c.p_in > 0.f || c.p_attn > 0.f)) return (c.loss_only && c.p_attn <= 0.f) ? PACK_HALO : PACK_TEXT;
   return PACK_FULL;
 }
@@ -340,9 +396,11 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // =================================================================================================
 // public: sizes / tables
 // =================================================================================================
+// 300 (round 4): uvtg_dims gained use_txt_pos / max_q_l (trainable text positions; three more table entries when set) and n_proj accepts
+// 1..3 (the table holds 4 n_proj entries per modality); precise == 2 selects the three-image operand split.
 // 100: round 1 ABI.  200: uvtg_dims gained struct_size (first field, validated) and loss_only; uvtg_decode_rank_nms / uvtg_postprocess_mr take
 // nms_thd as double; uvtg_debug_force_nt_wn / uvtg_set_dynamic_tiles removed ("ABI history").
-extern "C" int uvtg_version(void) { return 200; }
+extern "C" int uvtg_version(void) { return 300; }
 
 extern "C" const char* uvtg_strerror(int code) {
   if (code == 0) return "ok";
@@ -357,7 +415,8 @@ extern "C" const char* uvtg_strerror(int code) {
     case -7: return "gemm: N and every epilogue leading dimension must be multiples of 4";
     case -10: return "null dims";
     case -11: return "dims: non-positive size";
-    case -12: return "dims: n_proj must be 2";
+    case -12: return "dims: n_proj must be 1, 2 or 3";
+    case -19: return "dims: use_txt_pos needs max_q_l >= Lt (rows of txt_position_embed.position_embeddings)";
     case -13: return "dims: hidden_dim must be a multiple of 32 and dim_feedforward of 8";
     case -14: return "dims: hidden_dim / nheads must be 32, 64 or 128";
     case -15: return "dims: precise mode is forward-only (training must be 0)";
@@ -373,7 +432,7 @@ extern "C" const char* uvtg_strerror(int code) {
   }
 }
 
-extern "C" int uvtg_param_count(const uvtg_dims* dm) { return dm ? PER_LAYER * dm->E + N_TAIL : -10; }
+extern "C" int uvtg_param_count(const uvtg_dims* dm) { return dm ? Dm(*dm).np : -10; }
 extern "C" int uvtg_param_numel(const uvtg_dims* dm, int i, long long* numel) {
   if (int e = check_dims(dm)) return e;
   Dm m(*dm);
@@ -426,7 +485,6 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   auto convw = [&](const float* wsrc, bf16_t* dst, int ld, int ntot, int n_off, int kind) {
     cv.w[cv.count] = wsrc; cv.dst[cv.count] = dst; cv.ld[cv.count] = ld; cv.ntot[cv.count] = ntot; cv.n_off[cv.count] = n_off; cv.kind[cv.count] = kind; cv.count++;
   };
-  if (4 * m.c.E + 4 > UVTG_MAX_PREP_OPS) return -17;
   for (int l = 0; l < m.c.E && fast; l++) {
     if (tr) {        // training: ONE pass over the fp32 master writes the forward operand and the dgrad operand
       transp(P[m.lay(l, IPW)], 3 * d, d, w.wqkvT[l], 3 * d, w.wqkv[l]);
@@ -462,24 +520,23 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     convw(P[m.tail(SP1W)], w.wc1T, 3 * d, d, 0, 1);
     convw(P[m.tail(CL1W)], w.wc1T + cw, 3 * d, d, 0, 1);
   }
-  // input projections
-  if (w.vp0F) {
-    TRY(launch_cast_pad_f32(P[m.tail(VP0W)], d, m.c.Dv, w.vp0F, m.Kpv, s));
-    TRY(launch_cast_pad_f32(P[m.tail(TP0W)], d, m.c.Dt, w.tp0F, m.Kpt, s));
-  } else {
-    TRY(launch_cast_pad2_bf16(P[m.tail(VP0W)], d, m.c.Dv, w.vp0B, m.Kpv, P[m.tail(TP0W)], d, m.c.Dt, w.tp0B, m.Kpt, s));
-    if (!tr) {
-      cast(P[m.tail(VP1W)], w.vp1B, (long long)d * d);
-      cast(P[m.tail(TP1W)], w.tp1B, (long long)d * d);
+  // input projections: block 0 is zero-padded to a multiple of 64 columns (Dv = 2818 -> 2880), later blocks are d x d
+  if (4 * m.c.E + 4 + 4 * m.nproj > UVTG_MAX_PREP_OPS) return -17;
+  for (int wm = 0; wm < 2; wm++) {
+    const float* W0 = P[m.proj(wm, 0, PW)];
+    const int D0 = m.din(wm, 0), K0 = m.kp(wm, 0);
+    if (w.pwF[wm][0]) TRY(launch_cast_pad_f32(W0, d, D0, w.pwF[wm][0], K0, s));
+    if (w.pwB[wm][0] && wm == 1)       // (both modalities' first blocks in one launch)
+      TRY(launch_cast_pad2_bf16(P[m.proj(0, 0, PW)], d, m.c.Dv, w.pwB[0][0], m.Kpv, P[m.proj(1, 0, PW)], d, m.c.Dt, w.pwB[1][0], m.Kpt, s));
+    if (tr) {
+      if (hipError_t e = hipMemsetAsync(w.pwT[wm][0], 0, (size_t)K0 * d * 2, s)) return (int)e;      // the padding rows [D0, K0) stay zero
+      transp(W0, d, D0, w.pwT[wm][0], d);
     }
-  }
-  if (tr) {
-    transp(P[m.tail(VP1W)], d, d, w.vp1T, d, w.vp1B);       // (vp1B / tp1B are null with split-bf16 projections: no plain copy then)
-    transp(P[m.tail(TP1W)], d, d, w.tp1T, d, w.tp1B);
-    hipMemsetAsync(w.vp0T, 0, (size_t)m.Kpv * d * 2, s);
-    hipMemsetAsync(w.tp0T, 0, (size_t)m.Kpt * d * 2, s);
-    transp(P[m.tail(VP0W)], d, m.c.Dv, w.vp0T, d);
-    transp(P[m.tail(TP0W)], d, m.c.Dt, w.tp0T, d);
+    for (int b = 1; b < m.nproj; b++) {
+      const float* Wb = P[m.proj(wm, b, PW)];
+      if (tr) transp(Wb, d, d, w.pwT[wm][b], d, w.pwB[wm][b]);       // (pwB is null with split-bf16 projections: no plain copy then)
+      else if (w.pwB[wm][b]) cast(Wb, w.pwB[wm][b], (long long)d * d);
+    }
   }
   TRY(launch_cast_bf16_multi(co, s));
   TRY(launch_transpose_bf16_multi(to, s));
@@ -506,42 +563,60 @@ struct Fwd {
     // packed stream: the video projection runs on the clips that HAVE a packed row only (compact rows, tables pk.vin_*: the feature
     // LayerNorm gathers them from src, dropout counters stay keyed by the padded row), and both modalities write x / x + pos
     // straight into the packed layer-0 operands (text rows through pk.tin_dst); x0 keeps the padded layout.
+    // n_input_proj blocks of LayerNorm -> Dropout -> Linear, ReLU after every block but the last (model/univtg.py:89-100)
     const bool cv = packed && which == 0;
-    const int R = which == 0 ? (packed ? Rv : m.Mv) : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
-    const int L = which == 0 ? m.c.Lv : m.c.Lt, d = m.c.d;
-    const int t0 = which == 0 ? VP0G : TP0G, t1 = which == 0 ? VP1G : TP1G;
+    const int R = which == 0 ? (packed ? Rv : m.Mv) : m.Mt;
+    const int L = which == 0 ? m.c.Lv : m.c.Lt, d = m.c.d, nb = m.nproj;
     const unsigned rs = which == 0 ? UVTG_RNG_IN_VID : UVTG_RNG_IN_TXT;
     const float p_in = tr ? m.c.p_in : 0.f;
-    LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
-    if (cv) { ln.src_rows = ws.pk.vin_src; ln.gather_x = 1; }
-    ln.x = src; ln.ldx = Din; ln.rows = R; ln.D = Din; ln.gamma = P[m.tail(t0)]; ln.beta = P[m.tail(t0 + 1)]; ln.eps = 1e-5f;
-    ln.mean = ws.m0[which]; ln.rstd = ws.r0[which]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs; ln.Dpad = Kp;
-    if (pp) { ln.yF2 = (float*)ws.a1[which]; ln.ldyF2 = Kp; ln.yB = ws.a1B[which]; ln.ldyB = Kp; }
-    else { ln.yB = (bf16_t*)ws.a1[which]; ln.ldyB = Kp; }
-    TRY(launch_ln_fwd(ln, s));
-    GemmArgs g = gemm_base(ws.a1[which], Kp, pp ? (const void*)(which == 0 ? w.vp0F : w.tp0F) : (const void*)(which == 0 ? w.vp0B : w.tp0B),
-                           Kp, R, d, Kp);
-    g.bias = P[m.tail(t0 + 3)]; g.act = 1; g.outF = ws.h1[which]; g.ldoF = d;
-    TRY(run_gemm(g, pp));
-    memset(&ln, 0, sizeof(ln));
-    if (cv) ln.src_rows = ws.pk.vin_src;
-    ln.x = ws.h1[which]; ln.ldx = d; ln.rows = R; ln.D = d; ln.gamma = P[m.tail(t1)]; ln.beta = P[m.tail(t1 + 1)]; ln.eps = 1e-5f;
-    ln.mean = ws.m1[which]; ln.rstd = ws.r1[which]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs + 1; ln.Dpad = d;
-    if (pp) { ln.yF2 = (float*)ws.a2[which]; ln.ldyF2 = d; ln.yB = ws.a2B[which]; ln.ldyB = d; }
-    else { ln.yB = (bf16_t*)ws.a2[which]; ln.ldyB = d; }
-    TRY(launch_ln_fwd(ln, s));
-    GemmArgs g2 = gemm_base(ws.a2[which], d, pp ? (const void*)P[m.tail(t1 + 2)] : (const void*)(which == 0 ? w.vp1B : w.tp1B), d, R, d, d);
-    g2.bias = P[m.tail(t1 + 3)];
-    g2.bias2 = P[m.tail(TOK)] + (which == 0 ? d : 0);          // token-type row 1 = video, 0 = text (univtg.py:114-115)
-    if (cv) { g2.o_rows = ws.pk.vin_dst; g2.f_rows = ws.pk.vin_x0; g2.pos_map = ws.pk.vin_src; }
-    else { g2.o_seg = L; g2.o_seg_stride = m.S; g2.o_off = which == 0 ? 0 : m.c.Lv; if (packed) g2.o_rows = ws.pk.tin_dst; }
-    g2.outF = x0; g2.ldoF = d;
-    if (fast) { g2.outB = packed ? ws.xb0p : (bf16_t*)ws.xb[0]; g2.ldoB = d; g2.outU = packed ? ws.ub0p : (bf16_t*)ws.ub[0]; }
-    else g2.outUF = (float*)ws.ub[0];
-    g2.ldoU = d;
-    if (which == 0) { g2.pos = ws.pos; g2.ldpos = d; g2.pos_rows = R; }
-    TRY(run_gemm(g2, pp));
+    for (int b = 0; b < nb; b++) {
+      const int Din = m.din(which, b), Kp = m.kp(which, b);
+      const bool lastb = b == nb - 1;
+      LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
+      if (cv) { ln.src_rows = ws.pk.vin_src; ln.gather_x = b == 0; }
+      ln.x = b == 0 ? src : ws.ph[which][b - 1]; ln.ldx = Din; ln.rows = R; ln.D = Din;
+      ln.gamma = P[m.proj(which, b, PG)]; ln.beta = P[m.proj(which, b, PBE)]; ln.eps = 1e-5f;
+      ln.mean = ws.pm[which][b]; ln.rstd = ws.pr[which][b]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs + b; ln.Dpad = Kp;
+      if (pp) { ln.yF2 = (float*)ws.pa[which][b]; ln.ldyF2 = Kp; ln.yB = ws.paB[which][b]; ln.ldyB = Kp; }
+      else { ln.yB = (bf16_t*)ws.pa[which][b]; ln.ldyB = Kp; }
+      TRY(launch_ln_fwd(ln, s));
+      const void* W = pp ? (b == 0 ? (const void*)w.pwF[which][0] : (const void*)P[m.proj(which, b, PW)]) : (const void*)w.pwB[which][b];
+      GemmArgs g = gemm_base(ws.pa[which][b], Kp, W, Kp, R, d, Kp);
+      g.bias = P[m.proj(which, b, PB)];
+      if (!lastb) {
+        g.act = 1; g.outF = ws.ph[which][b]; g.ldoF = d;
+        TRY(run_gemm(g, pp));
+        continue;
+      }
+      g.bias2 = P[m.tail(TOK)] + (which == 0 ? d : 0);          // token-type row 1 = video, 0 = text (univtg.py:114-115)
+      if (cv) { g.o_rows = ws.pk.vin_dst; g.f_rows = ws.pk.vin_x0; g.pos_map = ws.pk.vin_src; }
+      else { g.o_seg = L; g.o_seg_stride = m.S; g.o_off = which == 0 ? 0 : m.c.Lv; if (packed) g.o_rows = ws.pk.tin_dst; }
+      g.outF = x0; g.ldoF = d;
+      if (fast) { g.outB = packed ? ws.xb0p : (bf16_t*)ws.xb[0]; g.ldoB = d; g.outU = packed ? ws.ub0p : (bf16_t*)ws.ub[0]; }
+      else g.outUF = (float*)ws.ub[0];
+      g.ldoU = d;
+      if (which == 0) { g.pos = ws.pos; g.ldpos = d; g.pos_rows = R; }
+      TRY(run_gemm(g, pp));
+    }
     return 0;
+  }
+
+  // --use_txt_pos (model/univtg.py:123, model/position_encoding.py:19-41): pos of the text rows = Dropout(LayerNorm(x0_txt + E[0..Lt))), the
+  // same tensor in every layer.  One LayerNorm launch over the projected text rows of x0 writes it behind the clip rows of the pos table and
+  // rewrites the text rows of layer 0's q,k operand as x + pos; later layers pick it up through the pos_row table.
+  int text_positions(const float* x0) {
+    const int d = m.c.d;
+    hipLaunchKernelGGL(txt_pos_tables_kernel, dim3(cdiv(m.M, 256)), dim3(256), 0, s, m.c.B, m.c.Lv, m.c.Lt, ws.pos_row_all, ws.tp_src);
+    UVTG_CHECK_LAUNCH();
+    LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
+    ln.x = x0; ln.ldx = d; ln.rows = m.Mt; ln.D = d; ln.Dpad = d; ln.src_rows = ws.tp_src; ln.gather_x = 1;
+    ln.addtab = P[m.txtpos(0)]; ln.add_L = m.c.Lt; ln.xsum = ws.tp_xsum;
+    ln.gamma = P[m.txtpos(1)]; ln.beta = P[m.txtpos(2)]; ln.eps = 1e-5f; ln.mean = ws.tp_mean; ln.rstd = ws.tp_rstd;
+    ln.p_drop = tr ? m.c.p_in : 0.f; ln.seed = m.c.seed; ln.stream_id = UVTG_RNG_TXT_POS;
+    ln.yF = ws.pos_txt; ln.ldyF = d;
+    ln.u_from_x = 1; ln.ldyU = d;
+    if (fast) ln.yU = (bf16_t*)ws.ub[0]; else ln.yUF = (float*)ws.ub[0];
+    return launch_ln_fwd(ln, s);
   }
 
   int layer(int l, float* memory_out) {
@@ -600,6 +675,7 @@ struct Fwd {
     ln.mean = ws.mean2[l]; ln.rstd = ws.rstd2[l]; ln.Dpad = d; ln.S = S; ln.Lv = m.c.Lv;
     if (fast) { ln.xB = ws.y2b[l]; ln.ldxB = d; } else { ln.x = ws.y2[l]; ln.ldx = d; }
     if (packed) ln.pos_row = ws.pk.row_pos;
+    else if (m.c.use_txt_pos && !last) ln.pos_row = ws.pos_row_all;      // text rows add their trainable positions too (the last layer has no next q,k operand)
     if (!last) {
       if (!fast) { ln.yF = ws.xin[l + 1]; ln.ldyF = d; }
       ln.pos = ws.pos; ln.ldyU = d;
@@ -659,7 +735,7 @@ SaliencyArgs sal_args(const Dm& m, const float* const* P, WSpace& ws, const floa
                       float* pooled, float* sal) {
   SaliencyArgs a; memset(&a, 0, sizeof(a));
   a.x0 = x0; a.S = m.S; a.Lv = m.c.Lv; a.Lt = m.c.Lt; a.B = m.c.B; a.d = m.c.d; a.txt_mask = tmask; a.vid_mask = vmask;
-  a.w_pool = P[m.tail(POOL)]; a.alpha = ws.alpha; a.pooled = pooled; a.cosv = ws.cosv; a.sal = sal; a.vnorm = ws.vnorm; a.qnorm = ws.qnorm;
+  a.w_pool = P[m.pool()]; a.alpha = ws.alpha; a.pooled = pooled; a.cosv = ws.cosv; a.sal = sal; a.vnorm = ws.vnorm; a.qnorm = ws.qnorm;
   return a;
 }
 
@@ -703,6 +779,7 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   TRY(f.project(0, src_vid, x0));
   if (f.packed && f.Rv < m.Mv) TRY(launch_fill_dropped_rows(x0, ws.pk, pmode == PACK_FULL, m.c.B, m.S, m.c.Lv, m.c.d, s));
   TRY(f.project(1, src_txt, x0));
+  if (m.c.use_txt_pos) TRY(f.text_positions(x0));
   uvtg_prof_section(0, 0, s);
   for (int l = 0; l < m.c.E; l++) TRY(f.layer(l, memory));
   uvtg_prof_section(0, 1, s);
@@ -741,7 +818,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   const bool packed = pmode != PACK_NONE;
   int M = m.M;
   if (packed) TRY(packed_rows(m, lens_host, pmode, &M));
-  long long off[PER_LAYER * MAXE + N_TAIL + 1];
+  long long off[PER_LAYER * MAXE + N_FIXED + 2 * PER_PROJ * MAXP + 4 + 1];
   { long long o = 0; for (int i = 0; i < m.np; i++) { off[i] = o; o += (pnumel(m, i) + 3) / 4 * 4; } off[m.np] = o; }
   auto G = [&](int idx) { return grads + off[idx]; };
   uvtg_prof_section(3, 0, s);
@@ -751,10 +828,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   {
     ZeroRanges zr; zr.count = 0;
     for (int i = 0; i < m.np; i++) {
-      const int k = i < PER_LAYER * E ? i % PER_LAYER : -1, t = i < PER_LAYER * E ? -1 : i - PER_LAYER * E;
-      const bool assigned = k == IPW || k == OPW || k == L1W || k == L2W || t == SP0W || t == SP1W || t == CL0W || t == CL1W ||
-                            t == TP0W || t == TP1W || t == VP0W || t == VP1W;
-      if (assigned) continue;
+      if (assigned_matrix(m, i)) continue;
       if (zr.count >= UVTG_MAX_ZERO_RANGES) return -17;
       zr.off[zr.count] = off[i]; zr.n[zr.count] = (int)(off[i + 1] - off[i]); zr.count++;
     }
@@ -945,69 +1019,77 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     g = gemm_base(dqkv, 3 * d, w.wqkvT[l], 3 * d, M, d, 3 * d);        // dx = dqkv Wqkv + dy1
     g.residB = dp_attn ? ws.dyR : dy1; g.ldrB = d; g.outB = ws.gxb[1]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
+    if (m.c.use_txt_pos) {   // d pos_txt += dq,dk (text rows) Wq,k: the text rows' positions enter every layer's q,k operand (univtg.py:123)
+      g = gemm_base(dqkv, 3 * d, w.wqkvT[l], 3 * d, m.Mt, d, 2 * d);
+      g.a_seg = m.c.Lt; g.a_seg_stride = S; g.a_off = Lv;
+      if (l != E - 1) { g.resid = ws.dpos_txt; g.ldr = d; }
+      g.outF = ws.dpos_txt; g.ldoF = d;
+      TRY(launch_gemm_nt_bf16(g, s));
+    }
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
     if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
   }
   TRY(tn_flush());                               // the deferred weight gradients of all encoder layers, inside the encoder section
   uvtg_prof_section(1, 1, s);
   const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]
+  // ---------------- trainable text positions ----------------
+  if (m.c.use_txt_pos) {       // pos_txt = Dropout(LayerNorm(x0_txt + E)): LayerNorm backward -> d(x0_txt + E), table rows summed over the batch
+    LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
+    lb.g = ws.dpos_txt; lb.ldg = d; lb.x = ws.tp_xsum; lb.ldx = d; lb.mean = ws.tp_mean; lb.rstd = ws.tp_rstd; lb.gamma = P[m.txtpos(1)];
+    lb.rows = m.Mt; lb.D = d; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = UVTG_RNG_TXT_POS; lb.src_rows = ws.tp_src;
+    lb.dgamma = G(m.txtpos(1)); lb.dbeta = G(m.txtpos(2)); lb.dxF = ws.tp_dx; lb.lddxF = d; lb.rs_seg = 1;
+    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
+    TRY(launch_ln_bwd(lb, s));
+    hipLaunchKernelGGL(txt_pos_table_grad_kernel, dim3(cdiv(m.c.Lt * d, 256)), dim3(256), 0, s, ws.tp_dx, B, m.c.Lt, d, G(m.txtpos(0)));
+    UVTG_CHECK_LAUNCH();
+  }
   // ---------------- saliency branch ----------------
   SaliencyArgs sa = sal_args(m, P, ws, x0, src_txt_mask, src_vid_mask, (float*)txt_mem_proj, nullptr);
-  sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0B = dx0; sa.dw_pool = G(m.tail(POOL));
+  sa.g_txt_rows = m.c.use_txt_pos ? ws.tp_dx : nullptr;
+  sa.g_sal = g_saliency; sa.g_pooled = g_txt_mem; sa.g_vid = g_vid_mem; sa.gv_sb = g_vid_sb; sa.gv_st = g_vid_st; sa.g_vrow = g_vrow; sa.pos_idx = pos_idx; sa.dx0B = dx0; sa.dw_pool = G(m.pool());
   if (packed) { sa.dx0_map = ws.pk.grad_map; sa.vout_map = ws.pk.vin_of; }
   sa.dq = ws.sal_dq; sa.dlog = ws.sal_dlog; sa.out_vid = ws.dyP[0]; sa.out_txt = ws.dyP[1];
   TRY(launch_saliency_bwd(sa, s));
   // ---------------- input projections ----------------
   for (int which = 0; which < 2; which++) {
     const bool cv = packed && which == 0;      // compact clip rows (see Fwd::project)
-    const int R = which == 0 ? (packed ? compact_clip_rows(m, lens_host, pmode) : m.Mv) : m.Mt, Din = which == 0 ? m.c.Dv : m.c.Dt, Kp = which == 0 ? m.Kpv : m.Kpt;
-    const int L = which == 0 ? Lv : m.c.Lt, roff = which == 0 ? 0 : Lv;
-    const int t0 = which == 0 ? VP0G : TP0G, t1 = which == 0 ? VP1G : TP1G;
+    const int R = which == 0 ? (packed ? compact_clip_rows(m, lens_host, pmode) : m.Mv) : m.Mt, nb = m.nproj;
     const unsigned rs = which == 0 ? UVTG_RNG_IN_VID : UVTG_RNG_IN_TXT;
     const float* src = which == 0 ? src_vid : src_txt;
     const bool pp = m.c.proj_precise != 0;
-    const bf16_t* a2b = pp ? ws.a2B[which] : (const bf16_t*)ws.a2[which];
-    const bf16_t* a1b = pp ? ws.a1B[which] : (const bf16_t*)ws.a1[which];
     // (ws.dyP[which] = bf16(dx0 + saliency-branch gradients), packed per modality by launch_saliency_bwd)
-    // the two weight gradients of a modality reduce over the same rows: ONE launch (more tiles -> fewer row splits, one reduce pass) once
-    // the second one's operand (dh1b) exists; small / odd shapes keep the per-gradient launches
-    GemmTNBatch pb; pb.count = 2;
-    pb.g[0] = tn_group(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, G(m.tail(t1 + 3)));
-    pb.g[1] = tn_group(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, G(m.tail(t0 + 3)));
-    pb.g[0].splits = pb.g[1].splits = splits_v;
+    // Blocks from the last to the first: gout = gradient wrt the block's Linear output (ReLU mask applied for the blocks that have one);
+    // dgrad -> fp32 gradient wrt the block's LayerNorm output -> LayerNorm backward (same dropout mask) -> parameter gradients and, for
+    // blocks > 0, the gradient wrt the previous block's output.  The weight gradients of a modality reduce over the same rows: they go out
+    // as ONE launch at the end (more tiles -> fewer row splits, one reduce pass); small / odd shapes keep the per-gradient launches.
+    const bf16_t* gout[MAXP];
+    gout[nb - 1] = ws.dyP[which];
+    for (int b = nb - 1; b >= 0; b--) {
+      const int Din = m.din(which, b), Kp = m.kp(which, b);
+      GemmArgs g = gemm_base(gout[b], d, w.pwT[which][b], d, R, Kp, d);
+      g.outF = ws.dA[which]; g.ldoF = Kp;
+      TRY(launch_gemm_nt_bf16(g, s));
+      LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
+      lb.g = ws.dA[which]; lb.ldg = Kp; lb.x = b == 0 ? src : ws.ph[which][b - 1]; lb.ldx = Din; lb.mean = ws.pm[which][b]; lb.rstd = ws.pr[which][b];
+      lb.gamma = P[m.proj(which, b, PG)]; lb.rows = R; lb.D = Din; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs + b;
+      lb.dgamma = G(m.proj(which, b, PG)); lb.dbeta = G(m.proj(which, b, PBE)); lb.rs_seg = 1;
+      if (b > 0) { lb.dxB = ws.dhb[which][b - 1]; lb.lddxB = d; lb.relu_from_x = 1; gout[b - 1] = ws.dhb[which][b - 1]; }
+      if (cv) { lb.src_rows = ws.pk.vin_src; lb.gather_x = b == 0; }
+      lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
+      TRY(launch_ln_bwd(lb, s));
+    }
+    GemmTNBatch pb; pb.count = nb;
+    for (int b = 0; b < nb; b++) {
+      const bf16_t* ab = pp ? ws.paB[which][b] : (const bf16_t*)ws.pa[which][b];
+      pb.g[b] = tn_group(gout[b], d, ab, m.kp(which, b), R, d, m.din(which, b), G(m.proj(which, b, PW)), m.din(which, b), G(m.proj(which, b, PB)));
+      pb.g[b].splits = splits_v;
+    }
     static const bool pbatch_off = getenv("UVTG_TN_PROJBATCH_OFF") != nullptr;
-    const bool proj_batch = !pbatch_off && R >= 2048 && gemm_tn_batch_ok(pb);
-    if (!proj_batch) {
-      TRY(wgrad(ws.dyP[which], d, a2b, d, R, d, d, G(m.tail(t1 + 2)), d, 1, G(m.tail(t1 + 3)), 0, R, splits_v));
-    }
-    GemmArgs g = gemm_base(ws.dyP[which], d, which == 0 ? w.vp1T : w.tp1T, d, R, d, d);
-    g.outF = ws.dA2[which]; g.ldoF = d;
-    TRY(launch_gemm_nt_bf16(g, s));
-    LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
-    lb.g = ws.dA2[which]; lb.ldg = d; lb.x = ws.h1[which]; lb.ldx = d; lb.mean = ws.m1[which]; lb.rstd = ws.r1[which];
-    lb.gamma = P[m.tail(t1)]; lb.rows = R; lb.D = d; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs + 1;
-    lb.dgamma = G(m.tail(t1)); lb.dbeta = G(m.tail(t1 + 1)); lb.dxB = ws.dh1b[which]; lb.lddxB = d; lb.rs_seg = 1; lb.relu_from_x = 1;
-    if (cv) lb.src_rows = ws.pk.vin_src;
-    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
-    TRY(launch_ln_bwd(lb, s));
-    if (proj_batch) {
-      TRY(launch_gemm_tn_batch(pb, s));
-    } else {
-      TRY(wgrad(ws.dh1b[which], d, a1b, Kp, R, d, Din, G(m.tail(t0 + 2)), Din, 1, G(m.tail(t0 + 3)), 0, R, splits_v));
-    }
-    g = gemm_base(ws.dh1b[which], d, which == 0 ? w.vp0T : w.tp0T, d, R, Kp, d);
-    g.outF = ws.dA1[which]; g.ldoF = Kp;
-    TRY(launch_gemm_nt_bf16(g, s));
-    memset(&lb, 0, sizeof(lb));
-    lb.g = ws.dA1[which]; lb.ldg = Kp; lb.x = src; lb.ldx = Din; lb.mean = ws.m0[which]; lb.rstd = ws.r0[which];
-    lb.gamma = P[m.tail(t0)]; lb.rows = R; lb.D = Din; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs;
-    lb.dgamma = G(m.tail(t0)); lb.dbeta = G(m.tail(t0 + 1)); lb.rs_seg = 1;
-    if (cv) { lb.src_rows = ws.pk.vin_src; lb.gather_x = 1; }
-    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
-    TRY(launch_ln_bwd(lb, s));
+    if (!pbatch_off && nb > 1 && R >= 2048 && gemm_tn_batch_ok(pb)) TRY(launch_gemm_tn_batch(pb, s));
+    else for (int b = 0; b < nb; b++) TRY(launch_gemm_tn_bf16(pb.g[b], s));
   }
   // token-type rows: row 1 (video) / row 0 (text) receive the bias gradient of their modality's second projection (univtg.py:114-115), one launch
-  hipLaunchKernelGGL(add_vec2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + d, G(m.tail(VP1B)), G(m.tail(TOK)), G(m.tail(TP1B)), d);
+  hipLaunchKernelGGL(add_vec2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, G(m.tail(TOK)) + d, G(m.proj(0, m.nproj - 1, PB)), G(m.tail(TOK)), G(m.proj(1, m.nproj - 1, PB)), d);
   UVTG_CHECK_LAUNCH();
   TRY(launch_sqsum_ranges(grads, zr_keep, ws.gnorm2, s));      // the gradients no weight-gradient launch assigned
   uvtg_prof_section(3, 1, s);

@@ -989,6 +989,7 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
         const int c = k * 256 + lane * 4;
         f32x4 g = ldg(c);
         const f32x4 xt = *(const f32x4*)(x + c), dq = *(const f32x4*)(a.dq + (size_t)b * d + c), wp = *(const f32x4*)(a.w_pool + c);
+        if (a.g_txt_rows) { const f32x4 t4 = *(const f32x4*)(a.g_txt_rows + ((size_t)b * a.Lt + t) * d + c); g += t4; }
 #pragma unroll
         for (int e = 0; e < 4; e++) { g[e] += al * dq[e] + dl * wp[e]; dw[k][e] += dl * xt[e]; }
         u32x2 o; o[0] = pack_bf2(g[0], g[1]); o[1] = pack_bf2(g[2], g[3]);
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(256) void saliency_rows_generic_kernel(const Salien
     const float al = a.alpha[b * a.Lt + t], dl = a.dlog[b * a.Lt + t];
     bf16_t* out = a.out_txt + ((size_t)b * a.Lt + t) * d;
     for (int c = lane; c < d; c += 64) {
-      out[c] = f2bf(g0(c) + al * a.dq[(size_t)b * d + c] + dl * a.w_pool[c]);
+      out[c] = f2bf(g0(c) + al * a.dq[(size_t)b * d + c] + dl * a.w_pool[c] + (a.g_txt_rows ? a.g_txt_rows[((size_t)b * a.Lt + t) * d + c] : 0.f));
       if (a.dw_pool) atomicAdd(a.dw_pool + c, dl * x[c]);
     }
   }

@@ -97,11 +97,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     const bf16_t* xbr = a.x ? nullptr : a.xB + (size_t)xrow * a.ldxB;
     float v[NV][VEC];
     float sum = 0.f;
+    const float* addr = a.addtab ? a.addtab + (size_t)(row % a.add_L) * D : nullptr;     // text position embedding row (position_encoding.py:33-38)
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * VEC;
-      if (c < D) { if (xr) loadv<VEC>(xr + c, v[i]); else loadb<VEC>(xbr + c, v[i]); }
-      else {
+      if (c < D) {
+        if (xr) loadv<VEC>(xr + c, v[i]); else loadb<VEC>(xbr + c, v[i]);
+        if (addr) {
+          float t[VEC];
+          loadv<VEC>(addr + c, t);
+#pragma unroll
+          for (int e = 0; e < VEC; e++) v[i][e] += t[e];
+          if (a.xsum) storev<VEC>(a.xsum + (size_t)row * D + c, v[i]);
+        }
+      } else {
 #pragma unroll
         for (int e = 0; e < VEC; e++) v[i][e] = 0.f;
       }
@@ -155,7 +164,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
         if (a.yF) storev<VEC>(a.yF + (size_t)row * a.ldyF + c, y);
         if (a.yF2) storev<VEC>(a.yF2 + (size_t)row * a.ldyF2 + c, y);
         if (a.yB) storeb<VEC>(a.yB + (size_t)row * a.ldyB + c, y);
-        if (a.yU || a.yUF) {
+        if ((a.yU || a.yUF) && a.u_from_x) {       // u = x + LN(x + table): the row read above minus the table, at the row's padded position
+          float u[VEC], t[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; e++) t[e] = 0.f;
+          if (addr) loadv<VEC>(addr + c, t);
+#pragma unroll
+          for (int e = 0; e < VEC; e++) u[e] = y[e] + (v[i][e] - t[e]);
+          if (a.yU) storeb<VEC>(a.yU + (size_t)lrow * a.ldyU + c, u);
+          if (a.yUF) storev<VEC>(a.yUF + (size_t)lrow * a.ldyU + c, u);
+        } else if (a.yU || a.yUF) {
           float u[VEC];
           if (posr) {
             float pv[VEC];
@@ -777,6 +795,7 @@ static bool al(const void* p, int ld_elems, int bytes_per, int want) {
 
 static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
+  if (a.addtab && (a.D > 2048 || a.add_L <= 0)) return -4;      // (only the generic kernel adds the table)
   const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.xB, a.ldxB, 2, 8) && al(a.yF, a.ldyF, 4, 16) && al(a.yF2, a.ldyF2, 4, 16) &&
                        al(a.yB, a.ldyB, 2, 8) && al(a.yU, a.ldyU, 2, 8) && al(a.yUF, a.ldyU, 4, 16) &&
                        al(a.yP, a.ldyP, 2, 8) && al(a.yPF, a.ldyP, 4, 16) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16) &&
@@ -786,7 +805,7 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
                       al(a.yP, a.ldyP, 2, 4) && al(a.yPF, a.ldyP, 4, 8) && al(a.gamma, 0, 4, 8) && al(a.beta, 0, 4, 8) &&
                       al(a.pos, a.D, 4, 8);
   const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.yB, a.ldyB, 2, 16) && al(a.yU, a.ldyU, 2, 16) && al(a.yP, a.ldyP, 2, 16);
-  if (a.D > 2048 && a.D <= 3072 && a.D % 2 == 0 && align8 && a.x && !a.yF && !a.pos && !a.pos_row && !a.yU && !a.yUF && !a.yP && !a.yPF) {
+  if (a.D > 2048 && a.D <= 3072 && a.D % 2 == 0 && align8 && a.x && !a.yF && !a.pos && !a.pos_row && !a.yU && !a.yUF && !a.yP && !a.yPF && !a.addtab) {
     static const bool wave_off = getenv("UVTG_LN_WIDE_WAVE_OFF") != nullptr;     // experiment: the block-per-row kernel
     const int dmax = a.Dpad > a.D ? a.Dpad : a.D;
     if (!wave_off && dmax <= 3072 && (a.ldx % 2 == 0) && (!a.yB || a.ldyB % 4 == 0) && (!a.yF2 || a.ldyF2 % 4 == 0) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16))

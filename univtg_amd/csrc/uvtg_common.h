@@ -103,7 +103,7 @@ __device__ __forceinline__ void philox4(unsigned long long seed, unsigned long l
 __device__ __forceinline__ float u01(unsigned x) { return (x >> 8) * (1.0f / 16777216.0f); }
 
 // RNG stream ids (ctr_hi) so that every stochastic op draws from its own stream.
-enum { UVTG_RNG_IN_VID = 0x100, UVTG_RNG_IN_TXT = 0x200, UVTG_RNG_ATTN = 0x300, UVTG_RNG_PATH = 0x400 };
+enum { UVTG_RNG_IN_VID = 0x100, UVTG_RNG_IN_TXT = 0x200, UVTG_RNG_ATTN = 0x300, UVTG_RNG_PATH = 0x400, UVTG_RNG_TXT_POS = 0x500 };
 
 #define UVTG_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

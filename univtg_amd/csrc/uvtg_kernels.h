@@ -110,6 +110,10 @@ struct LnFwdArgs {
   // compact row streams (the input projection of the kept clips only): src_rows[row] = the row's index in the padded layout.  It keys
   // the dropout counters (same mask as the padded execution) and, with gather_x, is the row of x that is read; outputs stay compact.
   const int* src_rows; int gather_x;
+  // trainable text positions (model/position_encoding.py:19-41; generic kernel only): the LayerNorm input is x + addtab[row % add_L];
+  // xsum (optional, fp32 [rows, D]) receives that sum (saved for backward); with u_from_x the yU / yUF output is y + x (the row as it was
+  // read, without the table) written at row src_rows[row] -- the text rows' q,k operand x + pos of layer 0
+  const float* addtab; int add_L; float* xsum; int u_from_x;
 };
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
 
@@ -267,6 +271,7 @@ struct SaliencyArgs {             // weighted text pooling + cosine saliency (mo
   bf16_t* out_vid; bf16_t* out_txt;   // bf16 [B*Lv, d] / [B*Lt, d]: dx0 + saliency-branch gradients, re-packed per modality
   const int* vout_map;            // clip row (b*Lv + t) -> row of out_vid (compact input projection), < 0: not written; null: identity
   float* dw_pool;                 // [d] atomically accumulated
+  const float* g_txt_rows;        // optional fp32 [B*Lt, d]: extra gradient on the text rows of x0 (the trainable text positions' LayerNorm input)
 };
 int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s);
 int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hipStream_t s);   // heads_final_fwd + saliency_fwd, fused when B >= 128

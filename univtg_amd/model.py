@@ -118,7 +118,7 @@ class _UniVTGFunction(torch.autograd.Function):
         ptrs = model._param_ptrs(params)
         wcache = model._prepare(dims, ptrs, params)
         lens = None
-        if model.packed and not dims.precise and not model.return_memory:
+        if model.packed and not dims.precise and not model.return_memory and not model.use_txt_pos:
             # packed (ragged) encoder stream: the valid lengths come back from the masks (one device->host sync; the reference's
             # own loop synchronises every step too, main/train_vlp_ddp.py:71-73)
             hl = torch.stack([src_vid_mask.sum(1), src_txt_mask.sum(1)]).to(torch.int32).cpu().reshape(-1).tolist()
@@ -173,10 +173,8 @@ class Model(nn.Module):
         super().__init__()
         if span_loss_type != "l1":
             raise NotImplementedError("span_loss_type='ce' is not implemented by the reference forward either (univtg.py:137-138)")
-        if use_txt_pos:
-            raise NotImplementedError("--use_txt_pos is never set by the reference scripts and is not on the accelerated path")
-        if n_input_proj != 2:
-            raise NotImplementedError("only n_input_proj=2 (the value of every reference script) is implemented")
+        if n_input_proj not in (1, 2, 3):
+            raise ValueError("n_input_proj must be 1, 2 or 3 (model/univtg.py:89-100 builds at most three LinearLayer blocks)")
         # precision: "auto" (default) = the arithmetic follows the call: fp32x3 (split-bf16 operands, fp32-class) for calls under
         #                 torch.no_grad() -- the inference path of main/inference_mr.py:88-193, where north_star asks for span indices
         #                 after NMS identical to the fp32 reference -- and bf16 MFMA operands when a backward will follow (training);
@@ -189,7 +187,8 @@ class Model(nn.Module):
         self.hidden_dim, self.nheads, self.dim_feedforward, self.enc_layers = d, nheads, dim_feedforward, enc_layers
         self.txt_dim, self.vid_dim = txt_dim, vid_dim
         self.input_dropout, self.dropout, self.droppath = float(input_dropout), float(dropout), float(droppath)
-        self.span_loss_type, self.max_v_l, self.use_txt_pos, self.n_input_proj = span_loss_type, max_v_l, use_txt_pos, n_input_proj
+        self.span_loss_type, self.max_v_l, self.use_txt_pos, self.n_input_proj = span_loss_type, max_v_l, bool(use_txt_pos), n_input_proj
+        self.max_q_l = max_q_l
         # proj_precise: True  = input projections always in split-bf16 (fp32-class; saliency within 1e-4 of the fp32 reference),
         #               False = always plain bf16 operands,
         #               "auto" (default) = split-bf16 for inference calls (no gradient), plain bf16 when a backward will follow
@@ -203,7 +202,7 @@ class Model(nn.Module):
         self.packed = bool(packed)
         # ---- parameters, registered in the reference's order / names ----
         self.transformer = _encoder_bag(d, dim_feedforward, enc_layers)
-        self.txt_position_embed = _Bag()                                    # unused unless use_txt_pos (kept for ckpt parity)
+        self.txt_position_embed = _Bag()                                    # read only with use_txt_pos (always kept for ckpt parity)
         self.txt_position_embed.position_embeddings = _Bag()
         self.txt_position_embed.position_embeddings.weight = nn.Parameter(torch.randn(max_q_l, d))
         self.txt_position_embed.LayerNorm = _ln_bag(d)
@@ -239,6 +238,9 @@ class Model(nn.Module):
             for blk in proj:
                 ps += [blk.LayerNorm.weight, blk.LayerNorm.bias, blk.net[1].weight, blk.net[1].bias]
         ps.append(self.weightedpool.weight)
+        if self.use_txt_pos:      # --use_txt_pos (model/univtg.py:123): the trainable text positions join the table (and get gradients)
+            ps += [self.txt_position_embed.position_embeddings.weight, self.txt_position_embed.LayerNorm.weight,
+                   self.txt_position_embed.LayerNorm.bias]
         return ps
 
     def _dims(self, B, Lv, Lt, Dv, Dt, training):
@@ -253,7 +255,8 @@ class Model(nn.Module):
                          p_in=self.input_dropout if self.training else 0.0,
                          p_attn=self.dropout if self.training else 0.0,
                          p_path=self.droppath if self.training else 0.0,
-                         seed=(self._seed * 1000003 + self._step) & 0xFFFFFFFFFFFFFFFF)
+                         seed=(self._seed * 1000003 + self._step) & 0xFFFFFFFFFFFFFFFF,
+                         use_txt_pos=int(self.use_txt_pos), max_q_l=self.max_q_l)
 
     def _param_ptrs(self, params):
         arr = (C.c_void_p * len(params))()
@@ -264,7 +267,7 @@ class Model(nn.Module):
         return arr
 
     def _offsets(self, dims):
-        key = (dims.d, dims.F, dims.E, dims.Dv, dims.Dt)
+        key = (dims.d, dims.F, dims.E, dims.Dv, dims.Dt, dims.n_proj, dims.use_txt_pos, dims.max_q_l)
         if key not in self._off_cache:
             lib = _lib.load()
             n = lib.uvtg_param_count(C.byref(dims))
