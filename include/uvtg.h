@@ -35,9 +35,9 @@ typedef struct uvtg_dims {
   int d, H, F, E;            /* hidden_dim, nheads, dim_feedforward, enc_layers                    */
   int Dv, Dt;                /* v_feat_dim (incl. TEF), t_feat_dim                                 */
   int n_proj;                /* n_input_proj: 1, 2 or 3 LinearLayer blocks per modality (model/univtg.py:89-100)  */
-  int precise;               /* 0: bf16 MFMA encoder/heads; 1: split-bf16 (fp32-class), forward only */
+  int precise;               /* 0: bf16 MFMA encoder/heads; 1: split-operand fp16 hi+lo images, three products (fp32-class), forward only */
   int training;              /* 1: keep activations for backward, apply dropout / DropPath         */
-  int proj_precise;          /* 1: input projections in split-bf16 even when precise==0 (keeps the
+  int proj_precise;          /* 1: input projections on split operands even when precise==0 (keeps the
                                 saliency logits within 1e-4 of the fp32 reference)                 */
   float p_in, p_attn, p_path;/* input_dropout, dropout (attention), droppath                       */
   unsigned long long seed;   /* Philox seed of this step (stochastic ops are counter-based)        */
@@ -163,10 +163,16 @@ int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coef,
 int uvtg_forward_saliency_stats(const uvtg_dims* dm, void* workspace, const float** cosv, const float** vnorm, const float** qnorm);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels the engine launches) ----- */
-/* C[M,N] = A[M,K] * W[N,K]^T + bias (nn.Linear).  bf16: A,W bf16, C fp32.  f32x3: A,W fp32. act: 0/1 relu/2 gelu */
+/* C[M,N] = A[M,K] * W[N,K]^T + bias (nn.Linear).  bf16: A,W bf16, C fp32.  act: 0/1 relu/2 gelu */
 int uvtg_linear_bf16(const void* A, const void* W, const float* bias, float* C, int M, int N, int K, int act,
                      uvtg_stream_t stream);
-int uvtg_linear_f32x3(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act,
+/* The same in the precise ("fp32x3") arithmetic: both operands as fp16 hi | lo IMAGES, x = (hi + lo) / scale to ~22 bits, the product as
+ * hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  uvtg_split_f16 builds the images of an fp32 [rows, cols]
+ * matrix: dst is fp16 [rows, 2 * kp] (hi image in columns [0, kp), lo image in [kp, 2 kp), columns [cols, kp) zero, kp a multiple of 64;
+ * is_weight selects the operand scale: activations x16, weights x64).  uvtg_linear_split: A [M, 2 Kp] (activation images), W [N, 2 Kp]
+ * (weight images), C fp32 [M, N]. */
+int uvtg_split_f16(const float* src, void* dst, int rows, int cols, int kp, int is_weight, uvtg_stream_t stream);
+int uvtg_linear_split(const void* A, const void* W, const float* bias, float* C, int M, int N, int Kp, int act,
                       uvtg_stream_t stream);
 /* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 operands, fp32 atomic accumulate), dbias[N] += colsum(dY) (may be NULL) */
 int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits,

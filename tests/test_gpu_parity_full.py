@@ -59,35 +59,13 @@ def config2(dev):
         {k: float(v) for k, v in losses.items()}
 
 
-def _nms_margin(rows, thd, max_after=10):
-    """min |hull-IoU - thd| over the pairs the greedy NMS compares (utils/temporal_nms.py:25-74): how close the reference's own
-    keep/suppress decisions come to flipping."""
-    from oracle import postproc_oracle as P
-    rows = rows[:1000]
-    alive, kept, margin = [True] * len(rows), 0, 1.0
-    for h in range(len(rows)):
-        if not alive[h]:
-            continue
-        if sum(alive) <= 1 or kept >= max_after:
-            break
-        for j in range(h + 1, len(rows)):
-            if alive[j]:
-                iou = P.hull_iou(rows[h][:2], rows[j][:2])
-                margin = min(margin, abs(iou - thd))
-                if iou > thd:
-                    alive[j] = False
-        alive[h] = False
-        kept += 1
-    return margin
-
-
 def test_config2_full_size_fp32x3_forward_and_post_nms_indices(dev, config2):
     """north_star at production size (B=256, E=4, d=1024).
     (a) the post-processing tail itself (decode, mask, stable rank, round_multiple, hull-IoU NMS) is BIT-EXACT: fed with the
         oracle's outputs it returns, for all 256 samples, exactly the reference algorithm's ranked rows, keep-set and windows;
-    (b) the fp32x3 forward keeps saliency within 1e-4 and feeds the tail outputs within ~1e-5 of the oracle's: every sample whose
-        post-NMS indices differ must be a boundary case of the reference's own decisions (two scores, a hull-IoU vs the threshold, or a
-        window vs a rounding boundary closer than the measured output error) -- fp32 results from two different BLAS differ the same way."""
+    (b) the fp32x3 forward (fp16 hi/lo operand images, three products: ~22 bits) keeps saliency within 1e-4 and pred_* within 2e-5 of the
+        oracle's, and forward + tail give the reference's ranking and keep-set for EVERY sample; a sample may differ only where the fp32 and
+        the fp64 oracle disagree on it (the reference itself is then decided by rounding noise) -- see _reference_is_ambiguous."""
     from oracle import postproc_oracle as P
     from univtg_amd import ops
     cfg, params, inputs, tg, _, ref, _ = config2
@@ -129,41 +107,79 @@ def test_config2_full_size_fp32x3_forward_and_post_nms_indices(dev, config2):
     e_log = float((out["pred_logits"].cpu() - ref["pred_logits"]).abs().max())
     e_spn = float((out["pred_spans"].cpu() - ref["pred_spans"]).abs().max())
     print(f"\n[config2 fp32x3] saliency err {e_sal:.2e}  pred_logits err {e_log:.2e}  pred_spans err {e_spn:.2e}")
-    assert e_sal < 1e-4 and e_log < 3e-4 and e_spn < 3e-4
-    e_w = e_spn * float(durations.max()) + 1e-4                                  # window error in seconds (+ the 4-decimal grid)
-    sc = pl_ref[..., 0].copy()
-    sc[~tm.astype(bool)] = 0
+    assert e_sal < 1e-4 and e_log < 2e-5 and e_spn < 2e-5       # (measured ~1e-6 with the fp16 hi/lo split; the bf16 split of rounds 1-3 gave 1.2e-5)
     for clip_length, (pre, ref_nms, ref_keep) in cases.items():
         win, order, keep, nk, _ = ops.postprocess_mr(out["pred_logits"], out["pred_spans"], None, tsd, tmd, dud, clip_length=clip_length)
         order, keep, nk = order.cpu().tolist(), keep.cpu().tolist(), nk.cpu().tolist()
-        exact, explained, unexplained = 0, {"score near-tie": 0, "IoU at threshold": 0, "rounding boundary": 0}, []
-        for b in range(B):
-            if order[b] == ref_order[b] and keep[b][: nk[b]] == ref_keep[b]:
-                exact += 1
-                continue
-            gaps = [abs(float(sc[b, order[b][i]]) - float(sc[b, ref_order[b][i]])) for i in range(Lv) if order[b][i] != ref_order[b][i]]
-            if gaps:
-                if max(gaps) <= 4 * e_log:
-                    explained["score near-tie"] += 1
-                else:
-                    unexplained.append((b, "rank", max(gaps)))
-                continue
-            if clip_length > 0:
-                w = np.array(ref_pre[b])[:, :2] / clip_length
-                if np.abs(np.abs(w - np.floor(w)) - 0.5).min() <= e_w / clip_length:
-                    explained["rounding boundary"] += 1
-                    continue
-            hull_min = max(min(r[1] - r[0] for r in pre[b] if r[1] > r[0]), 1e-3)
-            if _nms_margin(pre[b], 0.7) <= 4 * e_w / hull_min:
-                explained["IoU at threshold"] += 1
-            else:
-                unexplained.append((b, "keep", _nms_margin(pre[b], 0.7)))
-        print(f"[config2 fp32x3 forward + tail, clip_length={clip_length}] identical ranking + keep-set: {exact}/{B}; boundary cases of the "
-              f"reference's own decisions: {explained}; unexplained: {len(unexplained)}")
-        assert not unexplained, unexplained
-        # measured 254/256 for both settings (the other two: score near-ties of the reference's own ranking, counted above); every
-        # sample that is not bit-identical must be such a boundary case, and there may be at most four of them
-        assert exact >= B - 4 and exact + sum(explained.values()) == B
+        diff = [b for b in range(B) if not (order[b] == ref_order[b] and keep[b][: nk[b]] == ref_keep[b])]
+        print(f"[config2 fp32x3 forward + tail, clip_length={clip_length}] identical ranking + keep-set: {B - len(diff)}/{B}")
+        # Round 4 rule: every sample must be bit-identical -- a sample may differ only where the REFERENCE ITSELF is
+        # ambiguous, i.e. where the fp32 oracle and the fp64 oracle disagree on that same sample's indices
+        for b in diff:
+            assert _reference_is_ambiguous(cfg, params, inputs, tg, durations, b, clip_length, ref_order[b], ref_keep[b]), (clip_length, b)
+        assert len(diff) <= 1, diff
+
+
+def _oracle_tail(pl, ps, ts, tm, durations, clip_length):
+    """the reference's ranking + post-NMS keep indices (oracle/postproc_oracle.py) for a batch of model outputs"""
+    from oracle import postproc_oracle as P
+    order = P.ranked_clip_indices(pl, tm)
+    pre = P.decode_windows(pl, ps, ts, tm, durations)
+    if clip_length > 0:
+        pre = [P.round_multiple(p, clip_length) for p in pre]
+    nms = [P.temporal_nms(p[:1000], 0.7, 10) for p in pre]
+    return order, [_ref_keep(pre[b], nms[b]) for b in range(len(pre))]
+
+
+def _reference_is_ambiguous(cfg, params, inputs, tg, durations, b, clip_length, order32, keep32):
+    """Sample b in DOUBLE precision through the oracle: if the fp64 reference ranks / keeps other clips than the fp32 reference did, the
+    sample's indices are decided by fp32 rounding noise of the reference itself, not by the implementation under test."""
+    from oracle import univtg_oracle as O
+    p64 = {k: v.double() for k, v in params.items()}
+    i64 = {k: v[b:b + 1].double() for k, v in inputs.items()}
+    with torch.no_grad():
+        o64 = O.forward(p64, cfg, **i64)
+    order, keep = _oracle_tail(o64["pred_logits"].float().numpy(), o64["pred_spans"].float().numpy(), tg["timestamp"][b:b + 1].numpy(),
+                               tg["timestamp_mask"][b:b + 1].numpy(), [float(durations[b])], clip_length)
+    return order[0] != order32 or keep[0] != keep32
+
+
+@pytest.mark.parametrize("seeds", [(201, 202), (301, 302), (401, 402)])
+def test_post_nms_indices_identical_for_every_sample_three_seeds(dev, seeds):
+    """north_star's index clause at BASELINE config-2 size on three more (weights, batch) draws: the default drop-in model (precision
+    'auto' -> the split-operand fp32x3 arithmetic under no_grad) + the device post-processing give, for ALL 256 samples, exactly the
+    ranking and the post-NMS keep-set of the fp32 reference algorithm, raw and with round_multiple; saliency within 1e-4."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import ops
+    _threads()
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0)
+    params = O.init_params(cfg, seed=seeds[0])
+    inputs, tg = O.make_batch(cfg, 256, 75, 32, seed=seeds[1], ragged=True)
+    with torch.no_grad():
+        ref = O.forward(params, cfg, **inputs)
+    B = 256
+    durations = torch.tensor([float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(B)])
+    model, _ = build(cfg, params, dev, "auto", proj_precise="auto")
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(inputs, dev))
+    valid = inputs["src_vid_mask"].bool()
+    e_sal = float((out["saliency_scores"].cpu() - ref["saliency_scores"])[valid].abs().max())
+    e_log = float((out["pred_logits"].cpu() - ref["pred_logits"]).abs().max())
+    e_spn = float((out["pred_spans"].cpu() - ref["pred_spans"]).abs().max())
+    print(f"\n[seeds {seeds}] saliency err {e_sal:.2e}  pred_logits err {e_log:.2e}  pred_spans err {e_spn:.2e}")
+    assert e_sal < 1e-4 and e_log < 2e-5 and e_spn < 2e-5
+    tsd, tmd, dud = tg["timestamp"].to(dev), tg["timestamp_mask"].to(dev), durations.to(dev)
+    for clip_length in (0.0, 2.0):
+        ref_order, ref_keep = _oracle_tail(ref["pred_logits"].numpy(), ref["pred_spans"].numpy(), tg["timestamp"].numpy(), tg["timestamp_mask"].numpy(),
+                                           durations.tolist(), clip_length)
+        win, order, keep, nk, _ = ops.postprocess_mr(out["pred_logits"], out["pred_spans"], None, tsd, tmd, dud, clip_length=clip_length)
+        order, keep, nk = order.cpu().tolist(), keep.cpu().tolist(), nk.cpu().tolist()
+        diff = [b for b in range(B) if not (order[b] == ref_order[b] and keep[b][: nk[b]] == ref_keep[b])]
+        print(f"[seeds {seeds}, clip_length={clip_length}] identical ranking + keep-set: {B - len(diff)}/{B}")
+        for b in diff:
+            assert _reference_is_ambiguous(cfg, params, inputs, tg, durations, b, clip_length, ref_order[b], ref_keep[b]), (clip_length, b)
+        assert len(diff) <= 1, diff
 
 
 def test_config2_full_size_bf16_losses_gradients_and_index_agreement(dev, config2):
@@ -226,7 +242,7 @@ def _philox_rng(seed, cfg, B, Lv, Lt, p_in, p_path):
             "dp_scale": t(R.droppath_scales(seed, E, B, p_path))}
 
 
-def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True):
+def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True, proj_precise="auto"):
     """The EXACT bench.py path at one BASELINE shape: native TrainStep, train mode, input dropout 0.5 + DropPath 0.1, packed="auto" with
     the collate's host-side lengths (loss-only packing).  The device Philox masks are regenerated on the host and handed to the oracle;
     the five losses, pred_logits at the valid positions and EVERY parameter gradient must agree."""
@@ -238,7 +254,7 @@ def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True):
     inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=seeds[1], ragged=True)
     res = {}
     for packed in ((False, "auto") if compare_padded else ("auto",)):
-        model, crit = build(cfg, params, dev, "auto", proj_precise="auto")      # the default drop-in model, as bench.py builds it
+        model, crit = build(cfg, params, dev, "auto", proj_precise=proj_precise)      # as bench.py builds it (--proj precise: True)
         model.train()
         model.set_seed(777)
         step = TrainStep(model, crit, grad_clip=0.1, packed=packed)
@@ -246,10 +262,10 @@ def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True):
         batch["_lens_host"] = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
         losses = step.step(batch, to_dev(tg, dev), optimize=False)
         torch.cuda.synchronize()
-        res[packed] = (losses.cpu(), step.grads.clone(), model, step.pred_logits.clone())
-    l1, g1, model, pl1 = res["auto"]
+        res[packed] = (losses.cpu(), step.grads.clone(), model, step.pred_logits.clone(), step.sal.clone())
+    l1, g1, model, pl1, sal1 = res["auto"]
     if compare_padded:      # the two executions draw the same masks and compute the same rows: equal to re-association noise
-        l0, g0, _, pl0 = res[False]
+        l0, g0, _, pl0, _ = res[False]
         assert float((l0 - l1).abs().max()) < 2e-3 * max(1.0, float(l0.abs().max()))
         gg0, gg1 = g0.double(), g1.double()
         assert float((gg0 @ gg1) / (gg0.norm() * gg1.norm())) > 0.9995
@@ -262,6 +278,10 @@ def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True):
     O.total_loss(ref_losses, cfg).backward()
     vmask = inputs["src_vid_mask"].bool()
     e = float((pl1.cpu() - ref["pred_logits"].detach())[vmask].abs().max())     # (loss-only packing: padded positions beyond the conv halo differ)
+    e_sal = float((sal1.cpu() - ref["saliency_scores"].detach())[vmask].abs().max())
+    print(f"\n[{tag}] train-mode saliency_scores err {e_sal:.2e} (proj_precise={proj_precise})")
+    if proj_precise is True:      # north_star's saliency tolerance on the TIMED configuration (split-operand input projections under dropout)
+        assert e_sal < 1e-4, e_sal
     lerr = {}
     for i, k in enumerate(("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")):
         got, want = float(l1[i]), float(ref_losses[k])
@@ -289,7 +309,7 @@ def test_bench_path_trainstep_dropout_replayed_through_oracle(dev):
     """Config 2 at full size (B=256, L_v=75, L_t=32, d=1024, E=4): what `python bench.py` times.  (Under input dropout the native step's
     packed stream keeps the valid clips, the three padded clips inside the conv heads' receptive field of a valid position -- each with
     its own mask -- and the valid text tokens: exact for everything a loss can see, unlike round 1's shared-mask representative.)"""
-    _replay_bench_path(dev, "config2", 256, 75, 32, (201, 202))
+    _replay_bench_path(dev, "config2", 256, 75, 32, (201, 202), proj_precise=True)
 
 
 def test_config3_bench_path_replayed_through_oracle(dev):

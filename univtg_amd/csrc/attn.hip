@@ -53,6 +53,13 @@ __device__ __forceinline__ s16x8 pack8_lo(const float* v) {   // residual after 
   for (int e = 0; e < 8; e++) o[e] = (short)f2bf(v[e] - bf2f(f2bf(v[e])));
   return o;
 }
+// fp16 hi / lo images of 8 values times a power-of-two scale (the precise mode's operand split, uvtg_common.h split_f16)
+__device__ __forceinline__ void pack8_split(const float* v, float scale, s16x8& hi, s16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; e++) { unsigned short h, l; split_f16(v[e] * scale, h, l); hi[e] = (short)h; lo[e] = (short)l; }
+}
+// operand scales of the precise attention: q, k, v x16, probabilities x1024 (p <= 1); folded back into the score scale / the final 1 / l
+constexpr float ATT_QKV_S = 16.0f, ATT_P_S = 1024.0f;
 __device__ __forceinline__ s16x8 cat4(s16x4 a, s16x4 b) { return (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
 // The backward kernels evaluate p = exp(s - lse) as exp2(s * log2(e) - lse * log2(e)): one v_fma + one v_exp per element.  A query row
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
       float v[8];
       const float* p = (const float*)a.qkv + off;
       *(f32x4*)v = *(const f32x4*)p; *(f32x4*)(v + 4) = *(const f32x4*)(p + 4);
-      qh[ks] = pack8(v); ql[ks] = pack8_lo(v);
+      pack8_split(v, ATT_QKV_S, qh[ks], ql[ks]);
     }
   }
   f32x16 oacc[HD / 32];
@@ -176,10 +183,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         }
         const int ko = KS::off(r, c >> 1) + (c & 1) * 4, vo = r * VSTR + c * 4;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const bf16_t kh_ = f2bf(kf[e]), vh_ = f2bf(vf[e]);
-          sK[0][ko + e] = kh_; sK[NP - 1][ko + e] = f2bf(kf[e] - bf2f(kh_));
-          sV[0][vo + e] = vh_; sV[NP - 1][vo + e] = f2bf(vf[e] - bf2f(vh_));
+        for (int e = 0; e < 4; e++) {       // fp16 hi / lo images (x16): the three-product split carries ~22 bits (uvtg_common.h)
+          unsigned short kh_, kl_, vh_, vl_;
+          split_f16(kf[e] * ATT_QKV_S, kh_, kl_); split_f16(vf[e] * ATT_QKV_S, vh_, vl_);
+          sK[0][ko + e] = kh_; sK[NP - 1][ko + e] = kl_;
+          sV[0][vo + e] = vh_; sV[NP - 1][vo + e] = vl_;
         }
       }
     }
@@ -200,10 +208,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         const s16x8 kf = *(const s16x8*)(&sK[0][o]);
         if constexpr (PRECISE) {
           const s16x8 kl = *(const s16x8*)(&sK[NP - 1][o]);
-          sc[kb] = mfma32(kl, qh[ks], sc[kb]);
-          sc[kb] = mfma32(kf, ql[ks], sc[kb]);
-        }
-        sc[kb] = mfma32(kf, qh[ks], sc[kb]);
+          sc[kb] = mfma32h(kl, qh[ks], sc[kb]);
+          sc[kb] = mfma32h(kf, ql[ks], sc[kb]);
+          sc[kb] = mfma32h(kf, qh[ks], sc[kb]);
+        } else sc[kb] = mfma32(kf, qh[ks], sc[kb]);
       }
     }
     // online softmax in the log2 domain: t = s log2(e) + bias (one v_fma per element; the running maximum m_run is a log2-domain value too)
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         const f32x4 bk = *(const f32x4*)(&sBias[kb * 32 + 8 * j + 4 * g]);      // keys kb*32 + 8 j + 4 g + (0..3) = registers 4 j .. 4 j + 3
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          sc[kb][4 * j + e] = fmaf(sc[kb][4 * j + e], LOG2E, bk[e]);
+          sc[kb][4 * j + e] = fmaf(sc[kb][4 * j + e], PRECISE ? LOG2E / (ATT_QKV_S * ATT_QKV_S) : LOG2E, bk[e]);
           mx = fmaxf(mx, sc[kb][4 * j + e]);
         }
       }
@@ -256,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
       for (int hf = 0; hf < 2; hf++) {
-        const s16x8 pb = pack8(&pv[kb][8 * hf]);
-        s16x8 pl;
-        if constexpr (PRECISE) pl = pack8_lo(&pv[kb][8 * hf]);
+        s16x8 pb, pl;
+        if constexpr (PRECISE) pack8_split(&pv[kb][8 * hf], ATT_P_S, pb, pl);
+        else pb = pack8(&pv[kb][8 * hf]);
         const int kr = kb * 32 + 16 * hf + 4 * g + (i16 >> 2);
 #pragma unroll
         for (int dvb = 0; dvb < HD / 32; dvb++) {
@@ -266,10 +274,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
           const s16x8 vf = cat4(lds_tr16(&sV[0][kr * VSTR + col]), lds_tr16(&sV[0][(kr + 8) * VSTR + col]));
           if constexpr (PRECISE) {
             const s16x8 vl = cat4(lds_tr16(&sV[NP - 1][kr * VSTR + col]), lds_tr16(&sV[NP - 1][(kr + 8) * VSTR + col]));
-            oacc[dvb] = mfma32(vl, pb, oacc[dvb]);
-            oacc[dvb] = mfma32(vf, pl, oacc[dvb]);
-          }
-          oacc[dvb] = mfma32(vf, pb, oacc[dvb]);
+            oacc[dvb] = mfma32h(vl, pb, oacc[dvb]);
+            oacc[dvb] = mfma32h(vf, pl, oacc[dvb]);
+            oacc[dvb] = mfma32h(vf, pb, oacc[dvb]);
+          } else oacc[dvb] = mfma32(vf, pb, oacc[dvb]);
         }
       }
   }
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     }
     if (q_raw < S && a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run * 0.6931471805599453f + __logf(l_run);
   } else if (q_raw < S) {
-    const float inv = 1.0f / l_run;
+    const float inv = PRECISE ? 1.0f / (l_run * (ATT_QKV_S * ATT_P_S)) : 1.0f / l_run;
 #pragma unroll
     for (int dvb = 0; dvb < HD / 32; dvb++)
 #pragma unroll
@@ -320,8 +328,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
           u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
           *(u32x2*)((bf16_t*)a.o + off) = t;
         } else {
-          f32x4 t = {v[0], v[1], v[2], v[3]};
-          *(f32x4*)((float*)a.o + off) = t;
+          if (a.o) { f32x4 t = {v[0], v[1], v[2], v[3]}; *(f32x4*)((float*)a.o + off) = t; }
+          if (a.oS) {          // fp16 hi | lo images for the split-operand out-projection GEMM
+            u32x2 hi, lo; split4_f16(v, UVTG_SPLIT_A_SCALE, hi, lo);
+            unsigned short* o = a.oS + (rowbase + q_raw) * a.ldoS + h * HD + dv;
+            *(u32x2*)o = hi; *(u32x2*)(o + a.img_o) = lo;
+          }
         }
       }
     if (a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run * 0.6931471805599453f + __logf(l_run);

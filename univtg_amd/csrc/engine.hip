@@ -107,10 +107,11 @@ constexpr int MAXE = 16;
 struct WCache {
   bf16_t *wqkv[MAXE], *wo[MAXE], *w1[MAXE], *w2[MAXE], *wqkvT[MAXE], *woT[MAXE], *w1T[MAXE], *w2T[MAXE];
   bf16_t *wc0, *wc1, *wc0T, *wc1T;      // conv operands (fast)
-  float *wc0F, *wc1F;                   // conv operands (precise)
+  // precise mode: every weight as fp16 hi | lo images [N, 2 K] scaled by UVTG_SPLIT_W_SCALE (split-operand GEMMs, uvtg_common.h)
+  unsigned short *wqkvS[MAXE], *woS[MAXE], *w1S[MAXE], *w2S[MAXE], *wc0S, *wc1S;
   float *bc0, *bc1;                     // merged conv biases [2d]
   // input projections, [modality: 0 = video, 1 = text][block]
-  float* pwF[2][MAXP];                  // fp32 zero-padded first-block weights [d, Kp] (split-bf16 path; later blocks read the parameter itself)
+  unsigned short* pwS[2][MAXP];         // fp16 hi | lo images [d, 2 Kp] of the (zero-padded) weights: split-operand projections
   bf16_t* pwB[2][MAXP];                 // bf16 weights [d, Kp] (proj_precise == 0)
   bf16_t* pwT[2][MAXP];                 // dgrad operands [Kp, d]
   size_t bytes;
@@ -124,11 +125,13 @@ struct WCache {
       const bool tr = fast && m.c.training;
       wqkvT[l] = tr ? a.take<bf16_t>(3 * d * d) : nullptr; woT[l] = tr ? a.take<bf16_t>(d * d) : nullptr;
       w1T[l] = tr ? a.take<bf16_t>(F * d) : nullptr; w2T[l] = tr ? a.take<bf16_t>(d * F) : nullptr;
+      wqkvS[l] = !fast ? a.take<unsigned short>(2 * 3 * d * d) : nullptr; woS[l] = !fast ? a.take<unsigned short>(2 * d * d) : nullptr;
+      w1S[l] = !fast ? a.take<unsigned short>(2 * F * d) : nullptr; w2S[l] = !fast ? a.take<unsigned short>(2 * d * F) : nullptr;
     }
     wc0 = fast ? a.take<bf16_t>(2 * d * 3 * d) : nullptr; wc1 = fast ? a.take<bf16_t>(2 * d * 3 * d) : nullptr;
     wc0T = (fast && m.c.training) ? a.take<bf16_t>(d * 6 * d) : nullptr;
     wc1T = (fast && m.c.training) ? a.take<bf16_t>(2 * d * 3 * d) : nullptr;
-    wc0F = !fast ? a.take<float>(2 * d * 3 * d) : nullptr; wc1F = !fast ? a.take<float>(2 * d * 3 * d) : nullptr;
+    wc0S = !fast ? a.take<unsigned short>(2 * 2 * d * 3 * d) : nullptr; wc1S = !fast ? a.take<unsigned short>(2 * 2 * d * 3 * d) : nullptr;
     bc0 = a.take<float>(2 * d); bc1 = a.take<float>(2 * d);
     const bool pp = m.c.precise || m.c.proj_precise;
     const bool tr = fast && m.c.training;
@@ -136,7 +139,7 @@ struct WCache {
       for (int b = 0; b < MAXP; b++) {
         const bool on = b < m.nproj;
         const size_t Kp = on ? m.kp(w, b) : 0;
-        pwF[w][b] = (on && pp && b == 0) ? a.take<float>(d * Kp) : nullptr;
+        pwS[w][b] = (on && pp) ? a.take<unsigned short>(2 * d * Kp) : nullptr;
         pwB[w][b] = (on && !pp) ? a.take<bf16_t>(d * Kp) : nullptr;
         pwT[w][b] = (on && tr) ? a.take<bf16_t>(Kp * d) : nullptr;
       }
@@ -214,8 +217,8 @@ struct WSpace {
         if (l == 0) xin[0] = x0;
         else if (!fast) { if (l <= 2) xpp[l - 1] = a.take<float>(M * d); xin[l] = xpp[(l - 1) % 2]; }
         else xin[l] = nullptr;
-        if (fast) { if (l <= 1) xbpp[l] = a.take<char>(M * d * es); xb[l] = xbpp[l % 2]; }
-        else xb[l] = xin[l];
+        if (l <= 1) xbpp[l] = a.take<char>(M * d * es);      // fast: bf16 rows; precise: fp16 hi | lo images [M, 2d] (the same bytes)
+        xb[l] = xbpp[l % 2];
         if (l <= 1) ubpp[l] = a.take<char>(M * d * es);
         ub[l] = ubpp[l % 2];
       }
@@ -228,7 +231,7 @@ struct WSpace {
       y1[l] = fast ? nullptr : (own ? a.take<float>(M * d) : y1[0]);
       y1b[l] = fast ? (own ? a.take<bf16_t>(M * d) : y1b[0]) : nullptr;
       mean1[l] = own ? a.take<float>(M) : mean1[0]; rstd1[l] = own ? a.take<float>(M) : rstd1[0];
-      x1b[l] = fast ? (own ? (void*)a.take<char>(M * d * es) : x1b[0]) : (void*)x1;
+      x1b[l] = own ? (void*)a.take<char>(M * d * es) : x1b[0];      // fast: bf16 LN1 output; precise: its fp16 hi | lo images (x1 keeps the fp32 residual)
       apre[l] = tr ? a.take<bf16_t>(M * F) : nullptr;
       h[l] = own ? (void*)a.take<char>(M * F * es) : h[0];
       y2[l] = fast ? nullptr : (own ? a.take<float>(M * d) : y2[0]);
@@ -478,6 +481,10 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   CastOps co; co.count = 0;
   TransposeOps to; to.count = 0;
   ConvWOps cv; cv.count = 0; cv.N = d; cv.C = d;
+  SplitOps so; so.count = 0; so.scale = UVTG_SPLIT_W_SCALE;
+  auto split = [&](const float* src, unsigned short* dst, int rows, int cols, int kp, int conv = 0) {
+    so.src[so.count] = src; so.dst[so.count] = dst; so.rows[so.count] = rows; so.cols[so.count] = cols; so.kp[so.count] = kp; so.conv[so.count] = conv; so.count++;
+  };
   auto cast = [&](const float* src, bf16_t* dst, long long n) { co.src[co.count] = src; co.dst[co.count] = dst; co.n[co.count] = n; co.count++; };
   auto transp = [&](const float* src, int rows, int cols, bf16_t* dst, int ld, bf16_t* plain = nullptr) {
     to.src[to.count] = src; to.dst[to.count] = dst; to.plain[to.count] = plain; to.rows[to.count] = rows; to.cols[to.count] = cols; to.ld[to.count] = ld; to.count++;
@@ -485,6 +492,13 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   auto convw = [&](const float* wsrc, bf16_t* dst, int ld, int ntot, int n_off, int kind) {
     cv.w[cv.count] = wsrc; cv.dst[cv.count] = dst; cv.ld[cv.count] = ld; cv.ntot[cv.count] = ntot; cv.n_off[cv.count] = n_off; cv.kind[cv.count] = kind; cv.count++;
   };
+  if (4 * m.c.E + 4 + 2 * MAXP > UVTG_MAX_PREP_OPS) return -17;
+  for (int l = 0; l < m.c.E && !fast; l++) {
+    split(P[m.lay(l, IPW)], w.wqkvS[l], 3 * d, d, d);
+    split(P[m.lay(l, OPW)], w.woS[l], d, d, d);
+    split(P[m.lay(l, L1W)], w.w1S[l], F, d, d);
+    split(P[m.lay(l, L2W)], w.w2S[l], d, F, F);
+  }
   for (int l = 0; l < m.c.E && fast; l++) {
     if (tr) {        // training: ONE pass over the fp32 master writes the forward operand and the dgrad operand
       transp(P[m.lay(l, IPW)], 3 * d, d, w.wqkvT[l], 3 * d, w.wqkv[l]);
@@ -505,11 +519,11 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     convw(P[m.tail(CL0W)], w.wc0 + cw, 3 * d, 0, 0, 0);
     convw(P[m.tail(SP1W)], w.wc1, 3 * d, 0, 0, 0);
     convw(P[m.tail(CL1W)], w.wc1 + cw, 3 * d, 0, 0, 0);
-  } else {
-    TRY(launch_conv_w_fwd(P[m.tail(SP0W)], d, d, nullptr, w.wc0F, 3 * d, s));
-    TRY(launch_conv_w_fwd(P[m.tail(CL0W)], d, d, nullptr, w.wc0F + cw, 3 * d, s));
-    TRY(launch_conv_w_fwd(P[m.tail(SP1W)], d, d, nullptr, w.wc1F, 3 * d, s));
-    TRY(launch_conv_w_fwd(P[m.tail(CL1W)], d, d, nullptr, w.wc1F + cw, 3 * d, s));
+  } else {        // tap-major forward operands [n][tap * d + c] as split images (rows of 2 x 3d)
+    split(P[m.tail(SP0W)], w.wc0S, d, 3 * d, 3 * d, d);
+    split(P[m.tail(CL0W)], w.wc0S + 2 * cw, d, 3 * d, 3 * d, d);
+    split(P[m.tail(SP1W)], w.wc1S, d, 3 * d, 3 * d, d);
+    split(P[m.tail(CL1W)], w.wc1S + 2 * cw, d, 3 * d, 3 * d, d);
   }
   hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, P[m.tail(SP0B)], P[m.tail(CL0B)], w.bc0, P[m.tail(SP1B)], P[m.tail(CL1B)], w.bc1, d);
   UVTG_CHECK_LAUNCH();
@@ -525,7 +539,8 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
   for (int wm = 0; wm < 2; wm++) {
     const float* W0 = P[m.proj(wm, 0, PW)];
     const int D0 = m.din(wm, 0), K0 = m.kp(wm, 0);
-    if (w.pwF[wm][0]) TRY(launch_cast_pad_f32(W0, d, D0, w.pwF[wm][0], K0, s));
+    for (int b = 0; b < m.nproj; b++)
+      if (w.pwS[wm][b]) split(P[m.proj(wm, b, PW)], w.pwS[wm][b], d, m.din(wm, b), m.kp(wm, b));
     if (w.pwB[wm][0] && wm == 1)       // (both modalities' first blocks in one launch)
       TRY(launch_cast_pad2_bf16(P[m.proj(0, 0, PW)], d, m.c.Dv, w.pwB[0][0], m.Kpv, P[m.proj(1, 0, PW)], d, m.c.Dt, w.pwB[1][0], m.Kpt, s));
     if (tr) {
@@ -538,6 +553,7 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
       else if (w.pwB[wm][b]) cast(Wb, w.pwB[wm][b], (long long)d * d);
     }
   }
+  TRY(launch_split_f16_multi(so, s));
   TRY(launch_cast_bf16_multi(co, s));
   TRY(launch_transpose_bf16_multi(to, s));
   TRY(launch_conv_w_multi(cv, s));
@@ -555,8 +571,16 @@ struct Fwd {
   bool packed = false; int Mrows = 0;     // packed (ragged) encoder stream: Mrows <= B * S rows (see misc.hip)
   bool halo = false; int Rf = 0;          // loss-only stream: ragged conv-head frames of Rf rows in all (else B * (Lv + 2))
   int Rv = 0;                             // packed: clip rows of the compact video input projection (pk.vin_*)
-  int run_gemm(GemmArgs& g, bool x3) { return x3 ? launch_gemm_nt_f32x3(g, s) : launch_gemm_nt_bf16(g, s); }
+  // x3: split-operand launch.  The callers describe ONE image (lda / ldb = its column count = the distance between the hi and lo images of
+  // a row); rows are twice as long, and so is the distance between the weight groups of a grouped launch.
+  int run_gemm(GemmArgs& g, bool x3) {
+    if (!x3) return launch_gemm_nt_bf16(g, s);
+    g.img_a = g.lda; g.img_b = g.ldb; g.lda *= 2; g.ldb *= 2; g.gB *= 2;
+    return launch_gemm_nt_split(g, s);
+  }
   void set_out(GemmArgs& g, void* p, int ld) { if (fast) { g.outB = (bf16_t*)p; g.ldoB = ld; } else { g.outF = (float*)p; g.ldoF = ld; } }
+  // precise mode: the output as fp16 hi | lo images (the next GEMM's operand), `ld` columns per image
+  void set_split(GemmArgs& g, void* p, int ld) { g.outS = (unsigned short*)p; g.ldoS = 2 * ld; g.img_o = ld; }
 
   // one modality of the input projection (model/univtg.py:91-100,399-406) -> rows of x0 / xb[0] / ub[0]
   int project(int which, const float* src, float* x0) {
@@ -577,10 +601,10 @@ struct Fwd {
       ln.x = b == 0 ? src : ws.ph[which][b - 1]; ln.ldx = Din; ln.rows = R; ln.D = Din;
       ln.gamma = P[m.proj(which, b, PG)]; ln.beta = P[m.proj(which, b, PBE)]; ln.eps = 1e-5f;
       ln.mean = ws.pm[which][b]; ln.rstd = ws.pr[which][b]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs + b; ln.Dpad = Kp;
-      if (pp) { ln.yF2 = (float*)ws.pa[which][b]; ln.ldyF2 = Kp; ln.yB = ws.paB[which][b]; ln.ldyB = Kp; }
+      if (pp) { ln.yS = (unsigned short*)ws.pa[which][b]; ln.ldyS = 2 * Kp; ln.imgS = Kp; ln.sscale = UVTG_SPLIT_A_SCALE; ln.yB = ws.paB[which][b]; ln.ldyB = Kp; }
       else { ln.yB = (bf16_t*)ws.pa[which][b]; ln.ldyB = Kp; }
       TRY(launch_ln_fwd(ln, s));
-      const void* W = pp ? (b == 0 ? (const void*)w.pwF[which][0] : (const void*)P[m.proj(which, b, PW)]) : (const void*)w.pwB[which][b];
+      const void* W = pp ? (const void*)w.pwS[which][b] : (const void*)w.pwB[which][b];
       GemmArgs g = gemm_base(ws.pa[which][b], Kp, W, Kp, R, d, Kp);
       g.bias = P[m.proj(which, b, PB)];
       if (!lastb) {
@@ -593,7 +617,7 @@ struct Fwd {
       else { g.o_seg = L; g.o_seg_stride = m.S; g.o_off = which == 0 ? 0 : m.c.Lv; if (packed) g.o_rows = ws.pk.tin_dst; }
       g.outF = x0; g.ldoF = d;
       if (fast) { g.outB = packed ? ws.xb0p : (bf16_t*)ws.xb[0]; g.ldoB = d; g.outU = packed ? ws.ub0p : (bf16_t*)ws.ub[0]; }
-      else g.outUF = (float*)ws.ub[0];
+      else { set_split(g, ws.xb[0], d); g.outUS = (unsigned short*)ws.ub[0]; }       // precise: x and x + pos as split images
       g.ldoU = d;
       if (which == 0) { g.pos = ws.pos; g.ldpos = d; g.pos_rows = R; }
       TRY(run_gemm(g, pp));
@@ -615,7 +639,8 @@ struct Fwd {
     ln.p_drop = tr ? m.c.p_in : 0.f; ln.seed = m.c.seed; ln.stream_id = UVTG_RNG_TXT_POS;
     ln.yF = ws.pos_txt; ln.ldyF = d;
     ln.u_from_x = 1; ln.ldyU = d;
-    if (fast) ln.yU = (bf16_t*)ws.ub[0]; else ln.yUF = (float*)ws.ub[0];
+    if (fast) ln.yU = (bf16_t*)ws.ub[0];
+    else { ln.yUS = (unsigned short*)ws.ub[0]; ln.ldyS = 2 * d; ln.imgS = d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     return launch_ln_fwd(ln, s);
   }
 
@@ -624,14 +649,14 @@ struct Fwd {
     const void* xb_in = (packed && l == 0) ? (const void*)ws.xb0p : ws.xb[l];
     const void* ub_in = (packed && l == 0) ? (const void*)ws.ub0p : ws.ub[l];
     const bool last = l == m.c.E - 1;
-    const void* Wqkv = fast ? (const void*)w.wqkv[l] : (const void*)P[m.lay(l, IPW)];
-    const size_t es = fast ? 2 : 4;
+    const void* Wqkv = fast ? (const void*)w.wqkv[l] : (const void*)w.wqkvS[l];
+    const size_t es = fast ? 2 : 4;          // bytes per element of the operand rows (precise: two fp16 images)
     // q,k from (x + pos); v from x  (transformer_encoder_droppath.py:116-117)
     const bool one_launch = (2 * d) % 256 == 0;      // A-operand switch at a tile boundary: q,k columns read x + pos, v columns read x
     GemmArgs g = gemm_base(ub_in, d, Wqkv, d, M, one_launch ? 3 * d : 2 * d, d);
     if (one_launch) { g.A2 = xb_in; g.a2_n0 = 2 * d; }
     g.bias = P[m.lay(l, IPB)]; g.colscale = 1.0f / sqrtf((float)m.hd); g.colscale_n = d;
-    set_out(g, ws.qkv[l], 3 * d);
+    set_out(g, ws.qkv[l], 3 * d);            // (precise: fp32 q | k | v -- the attention kernel splits them itself)
     TRY(run_gemm(g, !fast));
     if (!one_launch) {
       g = gemm_base(xb_in, d, (const char*)Wqkv + (size_t)2 * d * d * es, d, M, d, d);
@@ -640,13 +665,15 @@ struct Fwd {
       TRY(run_gemm(g, !fast));
     }
     AttnArgs at; memset(&at, 0, sizeof(at));
-    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
+    at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
+    if (fast) { at.o = ws.o[l]; at.ldo = d; }
+    else { at.oS = (unsigned short*)ws.o[l]; at.ldoS = 2 * d; at.img_o = d; at.ldo = d; }      // precise: o leaves as split images
     if (packed) { at.seq_start = ws.pk.seq_start; at.seq_count = ws.pk.seq_count; at.row_sample = ws.pk.row_sample; at.total_rows = M; }
     at.B = m.c.B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = tr ? m.c.p_attn : 0.f; at.seed = m.c.seed; at.layer = l;
     at.precise = !fast;
     TRY(launch_attn_fwd(at, s));
     // out-proj + DropPath + residual -> y1 ; LN1
-    g = gemm_base(ws.o[l], d, fast ? (const void*)w.wo[l] : (const void*)P[m.lay(l, OPW)], d, M, d, d);
+    g = gemm_base(ws.o[l], d, fast ? (const void*)w.wo[l] : (const void*)w.woS[l], d, M, d, d);
     g.bias = P[m.lay(l, OPB)];
     if (fast) { g.residB = (const bf16_t*)xb_in; g.ldrB = d; g.outB = ws.y1b[l]; g.ldoB = d; }
     else { g.resid = ws.xin[l]; g.ldr = d; g.outF = ws.y1[l]; g.ldoF = d; }
@@ -656,15 +683,15 @@ struct Fwd {
     ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
     ln.mean = ws.mean1[l]; ln.rstd = ws.rstd1[l]; ln.Dpad = d;
     if (fast) { ln.xB = ws.y1b[l]; ln.ldxB = d; ln.yB = (bf16_t*)ws.x1b[l]; ln.ldyB = d; }
-    else { ln.x = ws.y1[l]; ln.ldx = d; ln.yF = ws.x1; ln.ldyF = d; }
+    else { ln.x = ws.y1[l]; ln.ldx = d; ln.yF = ws.x1; ln.ldyF = d; ln.yS = (unsigned short*)ws.x1b[l]; ln.ldyS = 2 * d; ln.imgS = d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     TRY(launch_ln_fwd(ln, s));
     // FFN: linear1 + GELU, linear2 + DropPath + residual -> y2 ; LN2
-    g = gemm_base(ws.x1b[l], d, fast ? (const void*)w.w1[l] : (const void*)P[m.lay(l, L1W)], d, M, F, d);
+    g = gemm_base(ws.x1b[l], d, fast ? (const void*)w.w1[l] : (const void*)w.w1S[l], d, M, F, d);
     g.bias = P[m.lay(l, L1B)]; g.act = 2;
     if (tr) { g.outPre = ws.apre[l]; g.ldpre_out = F; }
-    set_out(g, ws.h[l], F);
+    if (fast) set_out(g, ws.h[l], F); else set_split(g, ws.h[l], F);
     TRY(run_gemm(g, !fast));
-    g = gemm_base(ws.h[l], F, fast ? (const void*)w.w2[l] : (const void*)P[m.lay(l, L2W)], F, M, d, F);
+    g = gemm_base(ws.h[l], F, fast ? (const void*)w.w2[l] : (const void*)w.w2S[l], F, M, d, F);
     g.bias = P[m.lay(l, L2B)];
     if (fast) { g.residB = (const bf16_t*)ws.x1b[l]; g.ldrB = d; g.outB = ws.y2b[l]; g.ldoB = d; }
     else { g.resid = ws.x1; g.ldr = d; g.outF = ws.y2[l]; g.ldoF = d; }
@@ -676,17 +703,18 @@ struct Fwd {
     if (fast) { ln.xB = ws.y2b[l]; ln.ldxB = d; } else { ln.x = ws.y2[l]; ln.ldx = d; }
     if (packed) ln.pos_row = ws.pk.row_pos;
     else if (m.c.use_txt_pos && !last) ln.pos_row = ws.pos_row_all;      // text rows add their trainable positions too (the last layer has no next q,k operand)
+    if (!fast) { ln.ldyS = 2 * d; ln.imgS = d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     if (!last) {
       if (!fast) { ln.yF = ws.xin[l + 1]; ln.ldyF = d; }
       ln.pos = ws.pos; ln.ldyU = d;
       if (fast) { ln.yB = (bf16_t*)ws.xb[l + 1]; ln.ldyB = d; ln.yU = (bf16_t*)ws.ub[l + 1]; }
-      else ln.yUF = (float*)ws.ub[l + 1];
+      else { ln.yS = (unsigned short*)ws.xb[l + 1]; ln.yUS = (unsigned short*)ws.ub[l + 1]; }
     } else if (packed) {
       ln.yB = (bf16_t*)ws.xb[l + 1]; ln.ldyB = d;             // packed encoder output; expanded into the conv frame below
     } else {
       if (memory_out) { ln.yF = memory_out; ln.ldyF = d; }
       ln.ldyP = d;
-      if (fast) ln.yP = (bf16_t*)ws.vm_pad; else ln.yPF = (float*)ws.vm_pad;
+      if (fast) ln.yP = (bf16_t*)ws.vm_pad; else ln.yPS = (unsigned short*)ws.vm_pad;
     }
     TRY(launch_ln_fwd(ln, s));
     if (last && packed) TRY(launch_unpack_vm((const bf16_t*)ws.xb[l + 1], ws.pk, halo, m.c.B, S, m.c.Lv, d, (bf16_t*)ws.vm_pad, s));
@@ -711,13 +739,13 @@ struct Fwd {
       else { g.a_seg = Lv; g.a_seg_stride = Lv + 2; g.a_off = 0; g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1; }
     };
     // conv layer 0 of both heads as one 3-tap GEMM, N = 2d (model/univtg.py:84-85,375-382)
-    GemmArgs g = gemm_base(ws.vm_pad, d, fast ? (const void*)w.wc0 : (const void*)w.wc0F, 3 * d, m.Mv, 2 * d, 3 * d);
+    GemmArgs g = gemm_base(ws.vm_pad, d, fast ? (const void*)w.wc0 : (const void*)w.wc0S, 3 * d, m.Mv, 2 * d, 3 * d);
     g.ktap = d; frame(g);
     g.bias = w.bc0; g.act = 1;
-    set_out(g, ws.h1_pad, 2 * d);
+    if (fast) set_out(g, ws.h1_pad, 2 * d); else set_split(g, ws.h1_pad, 2 * d);
     TRY(run_gemm(g, !fast));
     // conv layer 1: two groups (span | class), each d -> d
-    g = gemm_base(ws.h1_pad, 2 * d, fast ? (const void*)w.wc1 : (const void*)w.wc1F, 3 * d, m.Mv, d, 3 * d);
+    g = gemm_base(ws.h1_pad, 2 * d, fast ? (const void*)w.wc1 : (const void*)w.wc1S, 3 * d, m.Mv, d, 3 * d);
     g.ktap = d; frame(g);
     g.groups = 2; g.gA = d; g.gB = (long long)d * 3 * d; g.gBias = d; g.gOut = d;
     g.bias = w.bc1; g.act = 1;
@@ -1180,11 +1208,21 @@ extern "C" int uvtg_linear_bf16(const void* A, const void* W, const float* bias,
   g.bias = bias; g.act = act; g.outF = C; g.ldoF = N;
   return launch_gemm_nt_bf16(g, (hipStream_t)st);
 }
-extern "C" int uvtg_linear_f32x3(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, uvtg_stream_t st) {
+// split-operand ("fp32x3") GEMM at kernel level: uvtg_split_f16 builds the fp16 hi | lo images [rows, 2 kp] of an fp32 matrix (columns
+// [cols, kp) zero; kp a multiple of 64; activations scaled by 16, weights by 64 -- uvtg_common.h), uvtg_linear_split multiplies two of them
+extern "C" int uvtg_split_f16(const float* src, void* dst, int rows, int cols, int kp, int is_weight, uvtg_stream_t st) {
+  if (!src || !dst) return -20;
+  if (rows <= 0 || cols <= 0 || kp < cols || kp % 64) return -11;
+  SplitOps so; so.count = 1; so.scale = is_weight ? UVTG_SPLIT_W_SCALE : UVTG_SPLIT_A_SCALE;
+  so.src[0] = src; so.dst[0] = (unsigned short*)dst; so.rows[0] = rows; so.cols[0] = cols; so.kp[0] = kp; so.conv[0] = 0;
+  return launch_split_f16_multi(so, (hipStream_t)st);
+}
+extern "C" int uvtg_linear_split(const void* A, const void* W, const float* bias, float* C, int M, int N, int Kp, int act, uvtg_stream_t st) {
   if (!A || !W || !C) return -20;
-  GemmArgs g = gemm_base(A, K, W, K, M, N, K);
+  GemmArgs g = gemm_base(A, 2 * Kp, W, 2 * Kp, M, N, Kp);
+  g.img_a = Kp; g.img_b = Kp;
   g.bias = bias; g.act = act; g.outF = C; g.ldoF = N;
-  return launch_gemm_nt_f32x3(g, (hipStream_t)st);
+  return launch_gemm_nt_split(g, (hipStream_t)st);
 }
 extern "C" int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits, uvtg_stream_t st) {
   if (!dY || !X || !dW) return -20;

@@ -27,12 +27,31 @@ __device__ __forceinline__ int map_row(int m, int seg, int stride, int off) {
   return seg ? (m / seg) * stride + (m % seg) + off : m + off;
 }
 
-template <bool X3>
+// K tile kt of a (possibly segmented) reduction -> element offsets inside an A row (conv tap row shift included) and a B row.
+// Plain launches: kseg == 0.  Split-operand launches: segment s = kt / (kseg / BK) reads image (a_sel >> 4 s) & 15 of A and image
+// (b_sel >> 4 s) & 15 of B; the conv taps apply to the position inside the segment.
+template <int BK_> __device__ __forceinline__ void nt_k_offsets(const GemmArgs& p, int kt, long long& ka, long long& kb, int& kin) {
+  int k0 = kt * BK_;
+  long long aimg = 0, bimg = 0;
+  if (p.kseg) {
+    const int sgm = k0 / p.kseg;
+    k0 -= sgm * p.kseg;
+    aimg = (long long)((p.a_sel >> (4 * sgm)) & 15u) * p.img_a;
+    bimg = (long long)((p.b_sel >> (4 * sgm)) & 15u) * p.img_b;
+  }
+  const int tap = k0 / p.ktap;
+  ka = (long long)tap * p.lda + (k0 - tap * p.ktap) + aimg;
+  kb = k0 + bimg;
+  kin = k0;
+}
+
+// HALF: fp16 operand images + v_mfma_f32_32x32x16_f16 (the split-operand precise mode); else bf16 operands.
+template <bool HALF>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma clang fp contract(off)            // (epilogue rounding identical to the persistent kernel's)
-  constexpr int BK = X3 ? 32 : 64;
+  constexpr int BK = 64;
   constexpr int TILE = BM * BK;
-  constexpr int NT = X3 ? 4 : 2;            // operand tiles per stage (A,B[,Alo,Blo])
+  constexpr int NT = 2;                     // operand tiles per stage (A, B)
   using SW = Swz<BK>;
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NT * TILE];
 
@@ -43,8 +62,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int gz = blockIdx.z;
 
-  const char* Ab = (const char*)((p.A2 && n0 >= p.a2_n0) ? p.A2 : p.A) + (size_t)gz * p.gA * (X3 ? 4 : 2);
-  const char* Bb = (const char*)p.B + (size_t)gz * p.gB * (X3 ? 4 : 2);
+  const char* Ab = (const char*)((p.A2 && n0 >= p.a2_n0) ? p.A2 : p.A) + (size_t)gz * p.gA * 2;
+  const char* Bb = (const char*)p.B + (size_t)gz * p.gB * 2;
 
   // per-thread staging coordinates: 4 x 16-byte pieces of A and of B per K tile
   int srow[4], sch[4];
@@ -58,20 +77,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     aoff[i] = (size_t)max(map_row(m, p.a_seg, p.a_seg_stride, p.a_off), 0) * p.lda;
     boff[i] = (size_t)n * p.ldb;
   }
-  const int nk = (p.K + BK - 1) / BK;
+  const int kcols = p.kseg ? p.kseg : p.K;             // columns of one reduction segment (the K tail is zero-filled per segment)
+  const int nk = p.kseg ? p.n_seg * (p.kseg / BK) : (p.K + BK - 1) / BK;
 
   u32x4 ra[4], rb[4];
   auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / p.ktap, kk = k0 - tap * p.ktap;
+    long long ka, kb; int kin;
+    nt_k_offsets<BK>(p, kt, ka, kb, kin);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      constexpr int EPC = X3 ? 4 : 8;       // elements per 16-byte piece
-      const int kc = sch[i] * EPC;
-      const bool ok = (k0 + kc) < p.K;
+      const int kc = sch[i] * 8;
+      const bool ok = (kin + kc) < kcols;
       u32x4 z = {0, 0, 0, 0};
-      ra[i] = ok ? *(const u32x4*)(Ab + ((aoff[i] + (size_t)tap * p.lda + kk + kc) * (X3 ? 4 : 2))) : z;
-      rb[i] = ok ? *(const u32x4*)(Bb + ((boff[i] + k0 + kc) * (X3 ? 4 : 2))) : z;
+      ra[i] = ok ? *(const u32x4*)(Ab + ((long long)aoff[i] + ka + kc) * 2) : z;
+      rb[i] = ok ? *(const u32x4*)(Bb + ((long long)boff[i] + kb + kc) * 2) : z;
     }
   };
   auto sstore = [&](int stage) {
@@ -79,28 +98,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = srow[i];
-      if constexpr (!X3) {
-        const int off = r * BK + ((sch[i] ^ SW::f(r)) * 8);
-        *(u32x4*)(base + off) = ra[i];
-        *(u32x4*)(base + TILE + off) = rb[i];
-      } else {
-        // piece = 4 floats -> 4 hi + 4 lo bf16 (8 bytes each)
-        const int off = r * BK + (((sch[i] >> 1) ^ SW::f(r)) * 8) + (sch[i] & 1) * 4;
-        float fa[4], fb[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { fa[e] = __uint_as_float(ra[i][e]); fb[e] = __uint_as_float(rb[i][e]); }
-        bf16_t ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          ah[e] = f2bf(fa[e]); al[e] = f2bf(fa[e] - bf2f(ah[e]));
-          bh[e] = f2bf(fb[e]); bl[e] = f2bf(fb[e] - bf2f(bh[e]));
-        }
-        u32x2 v;
-        v[0] = ah[0] | ((unsigned)ah[1] << 16); v[1] = ah[2] | ((unsigned)ah[3] << 16); *(u32x2*)(base + off) = v;
-        v[0] = bh[0] | ((unsigned)bh[1] << 16); v[1] = bh[2] | ((unsigned)bh[3] << 16); *(u32x2*)(base + TILE + off) = v;
-        v[0] = al[0] | ((unsigned)al[1] << 16); v[1] = al[2] | ((unsigned)al[3] << 16); *(u32x2*)(base + 2 * TILE + off) = v;
-        v[0] = bl[0] | ((unsigned)bl[1] << 16); v[1] = bl[2] | ((unsigned)bl[3] << 16); *(u32x2*)(base + 3 * TILE + off) = v;
-      }
+      const int off = r * BK + ((sch[i] ^ SW::f(r)) * 8);
+      *(u32x4*)(base + off) = ra[i];
+      *(u32x4*)(base + TILE + off) = rb[i];
     }
   };
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     const bf16_t* base = smem + (kt & 1) * NT * TILE;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
-      s16x8 a[2], b[2], al[2], bl[2];
+      s16x8 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int ra_ = wm * 64 + i * 32 + l31, rb_ = wn * 64 + i * 32 + l31;
@@ -128,18 +128,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         const int ob = rb_ * BK + (((2 * ks + g) ^ SW::f(rb_)) * 8);
         a[i] = *(const s16x8*)(base + oa);
         b[i] = *(const s16x8*)(base + TILE + ob);
-        if constexpr (X3) { al[i] = *(const s16x8*)(base + 2 * TILE + oa); bl[i] = *(const s16x8*)(base + 3 * TILE + ob); }
       }
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          if constexpr (X3) {
-            acc[i][j] = mfma32(al[i], b[j], acc[i][j]);
-            acc[i][j] = mfma32(a[i], bl[j], acc[i][j]);
-          }
-          acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-        }
+        for (int j = 0; j < 2; j++) acc[i][j] = HALF ? mfma32h(a[i], b[j], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
     }
     if (kt + 1 < nk) sstore((kt + 1) & 1);
     __syncthreads();
@@ -187,6 +180,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     size_t orow = (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off), frow = orow;
     bool okB = true;                                // the non-outF outputs of this row are written (row tables: < 0 drops them)
     if (p.o_rows) { const int t = p.o_rows[m]; okB = t >= 0; if (p.f_rows) frow = (size_t)p.f_rows[m]; orow = okB ? (size_t)t : 0; }
+    if constexpr (HALF) v *= p.accscale;            // operand scales of the split images folded back
     v += bv;
     if (n < p.colscale_n) v *= p.colscale;
     if (p.outPre && okB) {
@@ -195,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     }
     if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     else if (p.act == 2) {      // (the bf16 mode shares ONE GELU with the persistent kernel: both tile paths must give the same bits)
-      if constexpr (X3) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+      if constexpr (HALF) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
       else { v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]); }
     }
     if (p.actgrad) {
@@ -203,7 +197,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       const float q0 = __uint_as_float(t[0] << 16), q1 = __uint_as_float(t[0] & 0xffff0000u);
       const float q2 = __uint_as_float(t[1] << 16), q3 = __uint_as_float(t[1] & 0xffff0000u);
       if (p.actgrad == 1) { v[0] = q0 > 0.f ? v[0] : 0.f; v[1] = q1 > 0.f ? v[1] : 0.f; v[2] = q2 > 0.f ? v[2] : 0.f; v[3] = q3 > 0.f ? v[3] : 0.f; }
-      else if constexpr (X3) { v[0] *= gelu_erf_grad(q0); v[1] *= gelu_erf_grad(q1); v[2] *= gelu_erf_grad(q2); v[3] *= gelu_erf_grad(q3); }
       else { v[0] *= gelu_fast_grad(q0); v[1] *= gelu_fast_grad(q1); v[2] *= gelu_fast_grad(q2); v[3] *= gelu_fast_grad(q3); }
     }
     if (p.rowscale) { const float rs = p.rowscale[p.row_sample ? p.row_sample[m] : m / p.rs_seg]; v = rs == 0.f ? (f32x4){0.f, 0.f, 0.f, 0.f} : v * rs; }
@@ -218,11 +211,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       u32x2 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]);
       *(u32x2*)(p.outB + go + orow * p.ldoB + n) = t;
     }
-    if ((p.outU || p.outUF) && okB) {
+    if constexpr (HALF) {
+      if (p.outS && okB) {
+        const float vv[4] = {v[0], v[1], v[2], v[3]};
+        u32x2 hi, lo; split4_f16(vv, p.sscale, hi, lo);
+        unsigned short* o = p.outS + go + orow * p.ldoS + n;
+        *(u32x2*)o = hi; *(u32x2*)(o + p.img_o) = lo;
+      }
+    }
+    if ((p.outU || p.outUF || (HALF && p.outUS)) && okB) {
       f32x4 u = v;
       if (p.pos && m < p.pos_rows) { const f32x4 t = *(const f32x4*)(p.pos + (size_t)(p.pos_map ? p.pos_map[m] : m) * p.ldpos + n); u += t; }
       if (p.outU) { u32x2 t; t[0] = pack_bf2(u[0], u[1]); t[1] = pack_bf2(u[2], u[3]); *(u32x2*)(p.outU + orow * p.ldoU + n) = t; }
       if (p.outUF) *(f32x4*)(p.outUF + orow * p.ldoU + n) = u;
+      if constexpr (HALF) {
+        if (p.outUS) {
+          const float uu[4] = {u[0], u[1], u[2], u[3]};
+          u32x2 hi, lo; split4_f16(uu, p.sscale, hi, lo);
+          unsigned short* o = p.outUS + orow * p.ldoS + n;
+          *(u32x2*)o = hi; *(u32x2*)(o + p.img_o) = lo;
+        }
+      }
     }
   }
 }
@@ -304,10 +313,14 @@ __global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = 
 // bodies without the rest: 0 = general; 1 = bias, column scale, row factor, bf16 residual (EOP), bf16 out (q,k,v / out-proj / FFN2 /
 // dgrads: 24 of the 40 launches); 2 = bias, pre-activation copy, GELU, bf16 out (FFN1); 3 = GELU' of the bf16 pre-activation (EOP),
 // bf16 out (the activation-gradient GEMM).
-template <bool GATHER, int TM, bool EOP, int ORD, int EPI>
+// HALF: split-operand precise mode -- fp16 operand images, segmented reduction (hi.hi, hi.lo, lo.hi: GemmArgs.kseg / a_sel / b_sel),
+// v_mfma_f32_32x32x16_f16; general epilogue only, fp32 residual, exact erf GELU, re-split outputs outS / outUS for the next GEMM.
+template <bool GATHER, int TM, bool EOP, int ORD, int EPI, bool HALF = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma clang fp contract(off)            // every instantiation must round the epilogue alike (the tile paths are compared bit for bit)
   static_assert(!(EPI != 0 && GATHER), "the specialised epilogues have the plain row mapping");
+  static_assert(!HALF || (EPI == 0 && !EOP), "the split-operand mode uses the general epilogue without a bf16 operand");
+  auto MF = [](s16x8 a, s16x8 b, f32x16 c) -> f32x16 { if constexpr (HALF) return mfma32h(a, b, c); else return mfma32(a, b, c); };
   static_assert(EPI != 2 || !EOP, "FFN1 has no epilogue operand");
   static_assert(EPI != 3 || EOP, "the activation gradient reads its pre-activation");
   static_assert(TM < 5 || ((TM + 4 + 1) / 2 <= TM), "320-row tiles: at most one staging piece per A-fragment group of a k-step");
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M - p.m_begin + BM - 1) / BM;
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
-  const int nk = p.K / KB;
+  const int nk = HALF ? p.n_seg * (p.kseg / KB) : p.K / KB;
   const int sr_ = lane >> 3, sc_ = lane & 7;
 
   auto tile_origin = [&](int t, int& gz, int& m0, int& n0) {
@@ -367,7 +380,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     if (p.act == 101 || p.act == 103) ka = 0;
     if (p.act == 102 || p.act == 103) kb = 0;
 #endif
-    if constexpr (GATHER) {
+    if constexpr (HALF) {          // segment of the split reduction -> operand images; the conv taps apply inside the segment
+      int k0 = kt * KB;
+      const int sgm = k0 / p.kseg;
+      k0 -= sgm * p.kseg;
+      const unsigned ai = (p.a_sel >> (4 * sgm)) & 15u, bi = (p.b_sel >> (4 * sgm)) & 15u;
+      kb = (unsigned)(k0 + (int)bi * p.img_b) * 2u;
+      if constexpr (GATHER) { const int tap = k0 / p.ktap; ka = (unsigned)(tap * p.lda + (k0 - tap * p.ktap) + (int)ai * p.img_a) * 2u; }
+      else ka = (unsigned)(k0 + (int)ai * p.img_a) * 2u;
+    } else if constexpr (GATHER) {
       const int k0 = kt * KB, tap = k0 / p.ktap;
       ka = (unsigned)(tap * p.lda + (k0 - tap * p.ktap)) * 2u;
     }
@@ -492,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma unroll
           for (int i = 0; i < TM; i++) {
 #pragma unroll
-            for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[i], fb[ks & 1][j], acc[i][j]);
+            for (int j = 0; j < TN; j++) acc[i][j] = MF(fa[i], fb[ks & 1][j], acc[i][j]);
             if (ks < 3) {
               fa[i] = *(const s16x8*)(base + aoff[i] + (((2 * ks + 2 + g) ^ swz) << 4));
               if (i < TN) fb[(ks + 1) & 1][i] = *(const s16x8*)(base + boff[i] + (((2 * ks + 2 + g) ^ swz) << 4));
@@ -544,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+          for (int j = 0; j < TN; j++) acc[i][j] = MF(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
       }
       // pin the software pipeline the source expresses (hipcc otherwise sinks every fragment read next to its MFMAs and moves the
       // pieces to the head): R reads up front; per k-step (MFMA, read) pairs, then the VMEM issues two at a time between MFMAs
@@ -626,6 +647,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
               const int t = s_tab[0][rl]; okB = t >= 0; if (p.f_rows) frow = (size_t)s_tab[1][rl]; orow = okB ? (size_t)t : 0;
             }
           }
+          if constexpr (HALF) {          // operand scales of the split images folded back first
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] *= p.accscale;
+          }
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = (v[e] + bv[e]) * cs;
           if ((EPI == 2 || (EPI == 0 && p.outPre)) && okB) {
@@ -637,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
           } else if (EPI == 2 || (EPI == 0 && p.act == 2)) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = gelu_fast(v[e]);
+            for (int e = 0; e < 8; e++) v[e] = HALF ? gelu_erf(v[e]) : gelu_fast(v[e]);
           }
           u32x4 eop = {0, 0, 0, 0};
           if constexpr (GROUPS) eop = ecur;
@@ -674,7 +699,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             u32x4 t; t[0] = pack_bf2(v[0], v[1]); t[1] = pack_bf2(v[2], v[3]); t[2] = pack_bf2(v[4], v[5]); t[3] = pack_bf2(v[6], v[7]);
             *(u32x4*)(p.outB + go + orow * p.ldoB + n) = t;
           }
-          if (!SIMPLE && (p.outU || p.outUF) && okB) {
+          if constexpr (HALF) {
+            if (p.outS && okB) {
+              const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
+              u32x2 h0, l0, h1, l1; split4_f16(va, p.sscale, h0, l0); split4_f16(vb, p.sscale, h1, l1);
+              unsigned short* o = p.outS + go + orow * p.ldoS + n;
+              *(u32x4*)o = (u32x4){h0[0], h0[1], h1[0], h1[1]};
+              *(u32x4*)(o + p.img_o) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+            }
+          }
+          if (!SIMPLE && (p.outU || p.outUF || (HALF && p.outUS)) && okB) {
             if (p.pos && m < p.pos_rows) {
               const float* pp = p.pos + (size_t)((GATHER && p.pos_map) ? s_tab[GATHER ? 2 : 0][wm * (32 * TM) + i * 32 + row] : m) * p.ldpos + n;
               const f32x4 r0 = *(const f32x4*)pp, r1 = *(const f32x4*)(pp + 4);
@@ -689,6 +723,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
               float* op = p.outUF + orow * p.ldoU + n;
               *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
               *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
+            if constexpr (HALF) {
+              if (p.outUS) {
+                const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
+                u32x2 h0, l0, h1, l1; split4_f16(va, p.sscale, h0, l0); split4_f16(vb, p.sscale, h1, l1);
+                unsigned short* o = p.outUS + orow * p.ldoS + n;
+                *(u32x4*)o = (u32x4){h0[0], h0[1], h1[0], h1[1]};
+                *(u32x4*)(o + p.img_o) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+              }
             }
           }
         }
@@ -1540,6 +1583,22 @@ extern "C" int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, i
   out3[0] = 64 * pl.tm1; out3[1] = pl.rows1; out3[2] = 64 * pl.tm2;
   return 0;
 }
+// split-operand (fp16 images) instantiations: one staging order per tile height (the defaults of nt_order), general epilogue
+template <int TM> static int launch_nt256_half(const GemmArgs& b, int grid, bool gather, hipStream_t s) {
+  constexpr int smem = TM == 5 ? 147456 : 131072;
+  constexpr int ORD = TM >= 4 ? 1 : 0;
+  static bool attr = false;
+  if (!attr) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, false, ORD, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+    if constexpr (TM < 5) { if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, TM, false, ORD, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e; }
+    attr = true;
+  }
+  if (gather) {
+    if constexpr (TM < 5) hipLaunchKernelGGL((gemm_nt256_kernel<true, TM, false, ORD, 0, true>), dim3(grid), dim3(512), smem, s, b);
+    else return -21;
+  } else hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, false, ORD, 0, true>), dim3(grid), dim3(512), smem, s, b);
+  return 0;
+}
 template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int grid, bool gather, bool eop, int epi, hipStream_t s) {
   constexpr int smem = TM == 5 ? 147456 : 131072;
   static bool attr = false;
@@ -1599,7 +1658,7 @@ static void nt_trace_launch(const GemmArgs& b, int tm, int grid, bool gather, bo
   hipLaunchKernelGGL(nt_trace_set_kernel, dim3(1), dim3(1), 0, s, ptr);
 }
 #endif
-static int launch_nt256(const GemmArgs& a, hipStream_t s) {
+static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
   if (int e = ensure_num_cu()) return e;
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
@@ -1628,6 +1687,13 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s) {
 #ifdef UVTG_NT_TRACE
     nt_trace_launch(b, best_tm, grid, gather, eop, s);
 #endif
+    if (half) {       // split-operand launch: family 1, ALGORITHMIC flops (one product per element; the kernel runs three MFMA segments)
+      uvtg_prof_begin_launch(1, 2.0 * rows * b.N * b.K * b.groups, s);
+      rc = best_tm == 5 ? launch_nt256_half<5>(b, grid, gather, s) : best_tm == 4 ? launch_nt256_half<4>(b, grid, gather, s)
+         : (best_tm == 3 ? launch_nt256_half<3>(b, grid, gather, s) : launch_nt256_half<2>(b, grid, gather, s));
+      uvtg_prof_end_launch(1, s);
+      continue;
+    }
     uvtg_prof_begin_launch(3, 2.0 * rows * b.N * b.K * b.groups, s);
     {   // algorithmic bytes of the launch: both operands once, every output once, the epilogue operands once
       const double mn = (double)rows * b.N * b.groups;
@@ -1657,8 +1723,19 @@ int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_gemm_nt_f32x3(const GemmArgs& a, hipStream_t s) {
-  if (int e = check_nt(a, 4)) return e;
+// Split-operand GEMM (the precise "fp32x3" mode): a.A / a.B hold fp16 hi | lo images (a.img_a / a.img_b elements apart inside a row), a.K is
+// the column count of ONE image (a multiple of 64: the producers zero-pad), a.ktap counts columns of one image too.  Three reduction segments:
+// hi.hi, hi.lo, lo.hi.  Both tile structures take it (the persistent 256-wide kernel where it pays, the 128 x 128 kernel for small shapes).
+int launch_gemm_nt_split(const GemmArgs& a0, hipStream_t s) {
+  GemmArgs a = a0;
+  if (a.K % 64 || a.img_a % 8 || a.img_b % 8 || a.img_a < a.K || a.img_b < a.K) return -2;
+  if ((a.outS || a.outUS) && (a.ldoS % 8 || a.img_o % 8 || a.img_o < a.N)) return -2;
+  if (a.residB || a.gradPre || a.outPre || a.outB || a.outU) return -6;       // forward-only mode: fp32 / split outputs, fp32 residual
+  a.kseg = a.K; a.n_seg = 3; a.a_sel = 0x100u; a.b_sel = 0x010u;          // (A image, B image) per segment: (hi, hi), (hi, lo), (lo, hi)
+  if (a.accscale == 0.f) a.accscale = 1.0f / (UVTG_SPLIT_A_SCALE * UVTG_SPLIT_W_SCALE);
+  if (a.sscale == 0.f) a.sscale = UVTG_SPLIT_A_SCALE;
+  if (int e = check_nt(a, 2)) return e;
+  if (nt256_ok(a)) return launch_nt256(a, s, true);
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
   uvtg_prof_begin_launch(1, 2.0 * a.M * a.N * a.K * grid.z, s);
   hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, s, a);

@@ -1153,6 +1153,41 @@ int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int
   UVTG_CHECK_LAUNCH();
   return 0;
 }
+// fp16 hi | lo images of fp32 matrices (split-operand GEMM operands), one thread per 4 columns of one image row
+__global__ __launch_bounds__(256) void split_f16_multi_kernel(const SplitOps ops) {
+  const int op = blockIdx.y;
+  const int rows = ops.rows[op], cols = ops.cols[op], kp = ops.kp[op], conv = ops.conv[op];
+  const float* src = ops.src[op];
+  unsigned short* dst = ops.dst[op];
+  const long long n4 = (long long)rows * (kp / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / (kp / 4)), c = (int)(i % (kp / 4)) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int k = c + e;
+      float x = 0.f;
+      if (k < cols) x = conv ? src[((size_t)r * conv + (k % conv)) * 3 + k / conv] : src[(size_t)r * cols + k];
+      v[e] = x;
+    }
+    u32x2 hi, lo; split4_f16(v, ops.scale, hi, lo);
+    unsigned short* o = dst + (size_t)r * 2 * kp + c;
+    *(u32x2*)o = hi; *(u32x2*)(o + kp) = lo;
+  }
+}
+int launch_split_f16_multi(const SplitOps& ops, hipStream_t s) {
+  if (ops.count <= 0) return 0;
+  long long mx = 0;
+  for (int i = 0; i < ops.count; i++) {
+    if (ops.kp[i] % 4 || ops.kp[i] < ops.cols[i]) return -2;
+    const long long n4 = (long long)ops.rows[i] * (ops.kp[i] / 4);
+    mx = n4 > mx ? n4 : mx;
+  }
+  const unsigned bx = (unsigned)((mx + 255) / 256);
+  hipLaunchKernelGGL(split_f16_multi_kernel, dim3(bx < 2048 ? bx : 2048, ops.count), dim3(256), 0, s, ops);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
 int launch_cast_bf16_multi(const CastOps& ops, hipStream_t s) {
   if (ops.count <= 0) return 0;
   long long mx = 0;

@@ -25,6 +25,33 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
+// ---- fp16 hi/lo operand split of the precise ("fp32x3") GEMM mode -------------------------------------------------------------
+// x * scale = hi + lo + O(2^-22 |x|): hi = fp16(x s) carries 11 significant bits, lo = fp16(x s - hi) the next 11 (lo may be an fp16
+// subnormal: v_mfma_f32_32x32x16_f16 keeps subnormal inputs on gfx950 -- tools/mfma_f16_probe.hip, profiles/r04_mfma_f16_subnormal_probe.txt
+// -- so its absolute error is <= 2^-25).  A product a.w is then hi_a hi_w + hi_a lo_w + lo_a hi_w (three fp16 MFMAs, fp32 accumulation)
+// with the dropped lo.lo term at 2^-22: fp32-class, where the round-1..3 bf16 hi/lo split (8 + 8 bits) stopped at 2^-16.
+// Operand scales (powers of two, folded back by GemmArgs.accscale): activations x16, weights x64 -- both keep |x s| far below fp16's
+// 65504 for LayerNorm outputs / GELU / ReLU activations and for any sane weight, and lift the lo parts out of the subnormal range.
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+#define UVTG_SPLIT_A_SCALE 16.0f
+#define UVTG_SPLIT_W_SCALE 64.0f
+__device__ __forceinline__ void split_f16(float x, unsigned short& hi, unsigned short& lo) {
+  x = fminf(fmaxf(x, -65000.f), 65000.f);
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  hi = __builtin_bit_cast(unsigned short, h); lo = __builtin_bit_cast(unsigned short, l);
+}
+// four consecutive columns -> the 8-byte hi group and the 8-byte lo group
+__device__ __forceinline__ void split4_f16(const float (&v)[4], float scale, u32x2& hi, u32x2& lo) {
+  unsigned short h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) split_f16(v[e] * scale, h[e], l[e]);
+  hi[0] = h[0] | ((unsigned)h[1] << 16); hi[1] = h[2] | ((unsigned)h[3] << 16);
+  lo[0] = l[0] | ((unsigned)l[1] << 16); lo[1] = l[2] | ((unsigned)l[3] << 16);
+}
+__device__ __forceinline__ f32x16 mfma32h(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

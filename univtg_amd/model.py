@@ -175,7 +175,7 @@ class Model(nn.Module):
             raise NotImplementedError("span_loss_type='ce' is not implemented by the reference forward either (univtg.py:137-138)")
         if n_input_proj not in (1, 2, 3):
             raise ValueError("n_input_proj must be 1, 2 or 3 (model/univtg.py:89-100 builds at most three LinearLayer blocks)")
-        # precision: "auto" (default) = the arithmetic follows the call: fp32x3 (split-bf16 operands, fp32-class) for calls under
+        # precision: "auto" (default) = the arithmetic follows the call: fp32x3 (fp16 hi+lo operand images, three MFMA products: ~22 bits, fp32-class) for calls under
         #                 torch.no_grad() -- the inference path of main/inference_mr.py:88-193, where north_star asks for span indices
         #                 after NMS identical to the fp32 reference -- and bf16 MFMA operands when a backward will follow (training);
         #            "bf16"   = bf16 operands for every call (fast inference, opt-in: post-NMS top-1 agrees with fp32 for ~98 % of the
@@ -189,9 +189,9 @@ class Model(nn.Module):
         self.input_dropout, self.dropout, self.droppath = float(input_dropout), float(dropout), float(droppath)
         self.span_loss_type, self.max_v_l, self.use_txt_pos, self.n_input_proj = span_loss_type, max_v_l, bool(use_txt_pos), n_input_proj
         self.max_q_l = max_q_l
-        # proj_precise: True  = input projections always in split-bf16 (fp32-class; saliency within 1e-4 of the fp32 reference),
+        # proj_precise: True  = input projections always on split (fp16 hi+lo) operands (fp32-class; saliency within 1e-4 of the fp32 reference),
         #               False = always plain bf16 operands,
-        #               "auto" (default) = split-bf16 for inference calls (no gradient), plain bf16 when a backward will follow
+        #               "auto" (default) = split operands for inference calls (no gradient), plain bf16 when a backward will follow
         if proj_precise not in (True, False, "auto"):
             raise ValueError("proj_precise must be True, False or 'auto'")
         self.precision, self.proj_precise, self.return_memory = precision, proj_precise, False

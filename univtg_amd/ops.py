@@ -35,13 +35,26 @@ def linear_bf16(a_bf16, w_bf16, bias=None, act=0):
     return out
 
 
+def split_f16(x, is_weight=False):
+    """fp16 hi | lo operand images [rows, 2 * kp] of an fp32 matrix (kp = columns rounded up to 64); see include/uvtg.h."""
+    _need_cuda(x)
+    x = _f32c(x)
+    rows, cols = x.shape
+    kp = (cols + 63) // 64 * 64
+    out = torch.empty(rows, 2 * kp, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().uvtg_split_f16(_ptr(x), _ptr(out), rows, cols, kp, int(is_weight), _stream()), "uvtg_split_f16")
+    return out
+
+
 def linear_f32x3(a, w, bias=None, act=0):
+    """nn.Linear in the precise arithmetic: fp32 operands -> fp16 hi | lo images -> three-product split GEMM (uvtg_linear_split)."""
     _need_cuda(a)
     a, w = _f32c(a), _f32c(w)
     M, K = a.shape
     N = w.shape[0]
+    sa, sw = split_f16(a, False), split_f16(w, True)
     out = torch.empty(M, N, device=a.device)
-    _lib.check(_lib.load().uvtg_linear_f32x3(_ptr(a), _ptr(w), _ptr(bias), _ptr(out), M, N, K, act, _stream()), "uvtg_linear_f32x3")
+    _lib.check(_lib.load().uvtg_linear_split(_ptr(sa), _ptr(sw), _ptr(bias), _ptr(out), M, N, sa.shape[1] // 2, act, _stream()), "uvtg_linear_split")
     return out
 
 
