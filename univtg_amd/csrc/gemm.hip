@@ -34,8 +34,9 @@ template <int BK_> __device__ __forceinline__ void nt_k_offsets(const GemmArgs& 
   int k0 = kt * BK_;
   long long aimg = 0, bimg = 0;
   if (p.kseg) {
-    const int sgm = k0 / p.kseg;
-    k0 -= sgm * p.kseg;
+    const int tps = (p.kseg + BK_ - 1) / BK_;          // K tiles per segment (the last one zero-filled beyond kseg)
+    const int sgm = kt / tps;
+    k0 = (kt - sgm * tps) * BK_;
     aimg = (long long)((p.a_sel >> (4 * sgm)) & 15u) * p.img_a;
     bimg = (long long)((p.b_sel >> (4 * sgm)) & 15u) * p.img_b;
   }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     boff[i] = (size_t)n * p.ldb;
   }
   const int kcols = p.kseg ? p.kseg : p.K;             // columns of one reduction segment (the K tail is zero-filled per segment)
-  const int nk = p.kseg ? p.n_seg * (p.kseg / BK) : (p.K + BK - 1) / BK;
+  const int nk = p.kseg ? p.n_seg * ((p.kseg + BK - 1) / BK) : (p.K + BK - 1) / BK;
 
   u32x4 ra[4], rb[4];
   auto gload = [&](int kt) {
@@ -1728,9 +1729,9 @@ int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
 // hi.hi, hi.lo, lo.hi.  Both tile structures take it (the persistent 256-wide kernel where it pays, the 128 x 128 kernel for small shapes).
 int launch_gemm_nt_split(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
-  if (a.K % 64 || a.img_a % 8 || a.img_b % 8 || a.img_a < a.K || a.img_b < a.K) return -2;
+  if (a.K % 8 || a.img_a % 8 || a.img_b % 8 || a.img_a < a.K || a.img_b < a.K) return -2;
   if ((a.outS || a.outUS) && (a.ldoS % 8 || a.img_o % 8 || a.img_o < a.N)) return -2;
-  if (a.residB || a.gradPre || a.outPre || a.outB || a.outU) return -6;       // forward-only mode: fp32 / split outputs, fp32 residual
+  if (a.residB || a.gradPre || a.outPre) return -6;       // no bf16 epilogue operand in this mode (fp32 residual; fp32 / bf16 / split outputs)
   a.kseg = a.K; a.n_seg = 3; a.a_sel = 0x100u; a.b_sel = 0x010u;          // (A image, B image) per segment: (hi, hi), (hi, lo), (lo, hi)
   if (a.accscale == 0.f) a.accscale = 1.0f / (UVTG_SPLIT_A_SCALE * UVTG_SPLIT_W_SCALE);
   if (a.sscale == 0.f) a.sscale = UVTG_SPLIT_A_SCALE;
