@@ -1729,7 +1729,7 @@ int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
 // hi.hi, hi.lo, lo.hi.  Both tile structures take it (the persistent 256-wide kernel where it pays, the 128 x 128 kernel for small shapes).
 int launch_gemm_nt_split(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
-  if (a.K % 8 || a.img_a % 8 || a.img_b % 8 || a.img_a < a.K || a.img_b < a.K) return -2;
+  if (a.K % 8 || a.img_a % 8 || a.img_b % 8 || a.img_a < (a.ktap > 0 && a.ktap < a.K ? a.ktap : a.K) || a.img_b < a.K) return -2;   // (conv taps: an A image holds ONE tap's columns)
   if ((a.outS || a.outUS) && (a.ldoS % 8 || a.img_o % 8 || a.img_o < a.N)) return -2;
   if (a.residB || a.gradPre || a.outPre) return -6;       // no bf16 epilogue operand in this mode (fp32 residual; fp32 / bf16 / split outputs)
   a.kseg = a.K; a.n_seg = 3; a.a_sel = 0x100u; a.b_sel = 0x010u;          // (A image, B image) per segment: (hi, hi), (hi, lo), (lo, hi)
