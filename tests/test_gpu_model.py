@@ -158,13 +158,47 @@ def test_losses_and_grads_match_reference(dev, golden_dir, name):
         a, r = named[k].grad.cpu().double().flatten(), g.double().flatten()
         cos = float((a @ r) / (a.norm() * r.norm() + 1e-30))
         ratio = float(a.norm() / (r.norm() + 1e-30))
-        if cos < 0.985 or abs(ratio - 1) > 0.05:
+        # tiny_hl: only the class head feeds the encoder (no span losses), gradients 5x smaller; at d = 64 three biases land at 6-7.5 %
+        # (bf16 noise at toy width: the same loss subset at production width is within 0.3 % / cosine 0.9993, test_hl_loss_subset_production_width)
+        if cos < 0.985 or abs(ratio - 1) > (0.09 if name == "tiny_hl" else 0.05):
             bad[k] = (cos, ratio)
     assert not bad, bad
     # parameters the reference leaves without a gradient: none here either, or (flat gradient buffer) exactly zero
     for k in meta["no_grad_params"]:
         assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
     assert {k for k, p in named.items() if p.grad is None} <= set(meta["no_grad_params"])
+
+
+def test_hl_loss_subset_production_width(dev):
+    """dset_type 'hl' / 'vs' (losses = labels + saliency, model/univtg.py:439-440) at d = 1024, E = 4 against the oracle's fp32 autograd:
+    every parameter gradient within 1.5 % in norm, cosine >= 0.998; span_embed gets no gradient."""
+    from oracle import univtg_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0, losses=("labels", "saliency"))
+    params = O.init_params(cfg, seed=51)
+    inputs, tg = O.make_batch(cfg, 16, 75, 32, seed=52, ragged=True, curve=True)
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lo = O.criterion(O.forward(p2, cfg, **inputs), tg, cfg)
+    O.total_loss(lo, cfg).backward()
+    model, crit = build(cfg, params, dev, "bf16")
+    assert crit.losses == ["labels", "saliency"]
+    model.eval()
+    losses = crit(model(**to_dev(inputs, dev)), to_dev(tg, dev))
+    assert set(losses) == {"loss_f", "loss_s_inter", "loss_s_intra"}
+    sum(losses[k] * crit.weight_dict[k] for k in losses).backward()
+    named = dict(model.named_parameters())
+    bad = {}
+    for k, p in p2.items():
+        if k.startswith("txt_position_embed"):
+            continue
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k       # span_embed.*: no span loss
+            continue
+        a, r = named[k].grad.cpu().double().flatten(), p.grad.double().flatten()
+        cos, ratio = float((a @ r) / (a.norm() * r.norm() + 1e-30)), float(a.norm() / (r.norm() + 1e-30))
+        if cos < 0.998 or abs(ratio - 1) > 0.015:
+            bad[k] = (cos, ratio)
+    assert not bad, bad
 
 
 def test_criterion_matches_oracle_fp32(dev, golden_dir):
