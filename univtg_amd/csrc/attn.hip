@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
           if (a.o) { f32x4 t = {v[0], v[1], v[2], v[3]}; *(f32x4*)((float*)a.o + off) = t; }
           if (a.oS) {          // fp16 hi | lo images for the split-operand out-projection GEMM
             u32x2 hi, lo; split4_f16(v, UVTG_SPLIT_A_SCALE, hi, lo);
-            unsigned short* o = a.oS + (rowbase + q_raw) * a.ldoS + h * HD + dv;
-            *(u32x2*)o = hi; *(u32x2*)(o + a.img_o) = lo;
+            unsigned short* o = a.oS + (rowbase + q_raw) * a.ldoS + split_col(h * HD + dv);
+            *(u32x2*)o = hi; *(u32x2*)(o + 32) = lo;
           }
         }
       }

@@ -49,6 +49,7 @@ int check_dims(const uvtg_dims* d) {
   const int hd = d->d / d->H;
   if (hd * d->H != d->d || (hd != 32 && hd != 64 && hd != 128)) return -14;
   if (d->precise && d->training) return -15;
+  if (d->precise && d->F % 32) return -13;       // split operand rows are made of whole 32-column blocks (uvtg_common.h, split_col)
   if (d->Dv <= 0 || d->Dt <= 0) return -16;
   // (d % 32 == 0 and F % 8 == 0 make every weight MATRIX a multiple of 4 elements: the matrices the weight-gradient launches assign
   // have no alignment padding behind them in the flat gradient buffer, so the clipping norm over the whole buffer sees no unwritten word)
@@ -420,7 +421,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -11: return "dims: non-positive size";
     case -12: return "dims: n_proj must be 1, 2 or 3";
     case -19: return "dims: use_txt_pos needs max_q_l >= Lt (rows of txt_position_embed.position_embeddings)";
-    case -13: return "dims: hidden_dim must be a multiple of 32 and dim_feedforward of 8";
+    case -13: return "dims: hidden_dim must be a multiple of 32 and dim_feedforward of 8 (of 32 in the precise mode)";
     case -14: return "dims: hidden_dim / nheads must be 32, 64 or 128";
     case -15: return "dims: precise mode is forward-only (training must be 0)";
     case -16: return "dims: feature dims must be positive";
@@ -571,16 +572,16 @@ struct Fwd {
   bool packed = false; int Mrows = 0;     // packed (ragged) encoder stream: Mrows <= B * S rows (see misc.hip)
   bool halo = false; int Rf = 0;          // loss-only stream: ragged conv-head frames of Rf rows in all (else B * (Lv + 2))
   int Rv = 0;                             // packed: clip rows of the compact video input projection (pk.vin_*)
-  // x3: split-operand launch.  The callers describe ONE image (lda / ldb = its column count = the distance between the hi and lo images of
-  // a row); rows are twice as long, and so is the distance between the weight groups of a grouped launch.
+  // x3: split-operand launch.  The callers describe the operands in REAL columns; a split row holds two elements per real column (hi / lo
+  // images interleaved in 32-column blocks, uvtg_common.h), so every K-side size and offset doubles.
   int run_gemm(GemmArgs& g, bool x3) {
     if (!x3) return launch_gemm_nt_bf16(g, s);
-    g.img_a = g.lda; g.img_b = g.ldb; g.lda *= 2; g.ldb *= 2; g.gB *= 2;
+    g.K *= 2; g.ktap *= 2; g.lda *= 2; g.ldb *= 2; g.gA *= 2; g.gB *= 2;
     return launch_gemm_nt_split(g, s);
   }
   void set_out(GemmArgs& g, void* p, int ld) { if (fast) { g.outB = (bf16_t*)p; g.ldoB = ld; } else { g.outF = (float*)p; g.ldoF = ld; } }
-  // precise mode: the output as fp16 hi | lo images (the next GEMM's operand), `ld` columns per image
-  void set_split(GemmArgs& g, void* p, int ld) { g.outS = (unsigned short*)p; g.ldoS = 2 * ld; g.img_o = ld; }
+  // precise mode: the output as a split row (the next GEMM's operand), `ld` real columns
+  void set_split(GemmArgs& g, void* p, int ld) { g.outS = (unsigned short*)p; g.ldoS = 2 * ld; }
 
   // one modality of the input projection (model/univtg.py:91-100,399-406) -> rows of x0 / xb[0] / ub[0]
   int project(int which, const float* src, float* x0) {
@@ -601,7 +602,7 @@ struct Fwd {
       ln.x = b == 0 ? src : ws.ph[which][b - 1]; ln.ldx = Din; ln.rows = R; ln.D = Din;
       ln.gamma = P[m.proj(which, b, PG)]; ln.beta = P[m.proj(which, b, PBE)]; ln.eps = 1e-5f;
       ln.mean = ws.pm[which][b]; ln.rstd = ws.pr[which][b]; ln.p_drop = p_in; ln.seed = m.c.seed; ln.stream_id = rs + b; ln.Dpad = Kp;
-      if (pp) { ln.yS = (unsigned short*)ws.pa[which][b]; ln.ldyS = 2 * Kp; ln.imgS = Kp; ln.sscale = UVTG_SPLIT_A_SCALE; ln.yB = ws.paB[which][b]; ln.ldyB = Kp; }
+      if (pp) { ln.yS = (unsigned short*)ws.pa[which][b]; ln.ldyS = 2 * Kp; ln.sscale = UVTG_SPLIT_A_SCALE; ln.yB = ws.paB[which][b]; ln.ldyB = Kp; }
       else { ln.yB = (bf16_t*)ws.pa[which][b]; ln.ldyB = Kp; }
       TRY(launch_ln_fwd(ln, s));
       const void* W = pp ? (const void*)w.pwS[which][b] : (const void*)w.pwB[which][b];
@@ -640,7 +641,7 @@ struct Fwd {
     ln.yF = ws.pos_txt; ln.ldyF = d;
     ln.u_from_x = 1; ln.ldyU = d;
     if (fast) ln.yU = (bf16_t*)ws.ub[0];
-    else { ln.yUS = (unsigned short*)ws.ub[0]; ln.ldyS = 2 * d; ln.imgS = d; ln.sscale = UVTG_SPLIT_A_SCALE; }
+    else { ln.yUS = (unsigned short*)ws.ub[0]; ln.ldyS = 2 * d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     return launch_ln_fwd(ln, s);
   }
 
@@ -667,7 +668,7 @@ struct Fwd {
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
     if (fast) { at.o = ws.o[l]; at.ldo = d; }
-    else { at.oS = (unsigned short*)ws.o[l]; at.ldoS = 2 * d; at.img_o = d; at.ldo = d; }      // precise: o leaves as split images
+    else { at.oS = (unsigned short*)ws.o[l]; at.ldoS = 2 * d; at.ldo = d; }      // precise: o leaves as a split row
     if (packed) { at.seq_start = ws.pk.seq_start; at.seq_count = ws.pk.seq_count; at.row_sample = ws.pk.row_sample; at.total_rows = M; }
     at.B = m.c.B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = tr ? m.c.p_attn : 0.f; at.seed = m.c.seed; at.layer = l;
     at.precise = !fast;
@@ -683,7 +684,7 @@ struct Fwd {
     ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
     ln.mean = ws.mean1[l]; ln.rstd = ws.rstd1[l]; ln.Dpad = d;
     if (fast) { ln.xB = ws.y1b[l]; ln.ldxB = d; ln.yB = (bf16_t*)ws.x1b[l]; ln.ldyB = d; }
-    else { ln.x = ws.y1[l]; ln.ldx = d; ln.yF = ws.x1; ln.ldyF = d; ln.yS = (unsigned short*)ws.x1b[l]; ln.ldyS = 2 * d; ln.imgS = d; ln.sscale = UVTG_SPLIT_A_SCALE; }
+    else { ln.x = ws.y1[l]; ln.ldx = d; ln.yF = ws.x1; ln.ldyF = d; ln.yS = (unsigned short*)ws.x1b[l]; ln.ldyS = 2 * d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     TRY(launch_ln_fwd(ln, s));
     // FFN: linear1 + GELU, linear2 + DropPath + residual -> y2 ; LN2
     g = gemm_base(ws.x1b[l], d, fast ? (const void*)w.w1[l] : (const void*)w.w1S[l], d, M, F, d);
@@ -703,7 +704,7 @@ struct Fwd {
     if (fast) { ln.xB = ws.y2b[l]; ln.ldxB = d; } else { ln.x = ws.y2[l]; ln.ldx = d; }
     if (packed) ln.pos_row = ws.pk.row_pos;
     else if (m.c.use_txt_pos && !last) ln.pos_row = ws.pos_row_all;      // text rows add their trainable positions too (the last layer has no next q,k operand)
-    if (!fast) { ln.ldyS = 2 * d; ln.imgS = d; ln.sscale = UVTG_SPLIT_A_SCALE; }
+    if (!fast) { ln.ldyS = 2 * d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     if (!last) {
       if (!fast) { ln.yF = ws.xin[l + 1]; ln.ldyF = d; }
       ln.pos = ws.pos; ln.ldyU = d;
@@ -1219,8 +1220,7 @@ extern "C" int uvtg_split_f16(const float* src, void* dst, int rows, int cols, i
 }
 extern "C" int uvtg_linear_split(const void* A, const void* W, const float* bias, float* C, int M, int N, int Kp, int act, uvtg_stream_t st) {
   if (!A || !W || !C) return -20;
-  GemmArgs g = gemm_base(A, 2 * Kp, W, 2 * Kp, M, N, Kp);
-  g.img_a = Kp; g.img_b = Kp;
+  GemmArgs g = gemm_base(A, 2 * Kp, W, 2 * Kp, M, N, 2 * Kp);
   g.bias = bias; g.act = act; g.outF = C; g.ldoF = N;
   return launch_gemm_nt_split(g, (hipStream_t)st);
 }

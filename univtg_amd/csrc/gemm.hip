@@ -27,26 +27,8 @@ __device__ __forceinline__ int map_row(int m, int seg, int stride, int off) {
   return seg ? (m / seg) * stride + (m % seg) + off : m + off;
 }
 
-// K tile kt of a (possibly segmented) reduction -> element offsets inside an A row (conv tap row shift included) and a B row.
-// Plain launches: kseg == 0.  Split-operand launches: segment s = kt / (kseg / BK) reads image (a_sel >> 4 s) & 15 of A and image
-// (b_sel >> 4 s) & 15 of B; the conv taps apply to the position inside the segment.
-template <int BK_> __device__ __forceinline__ void nt_k_offsets(const GemmArgs& p, int kt, long long& ka, long long& kb, int& kin) {
-  int k0 = kt * BK_;
-  long long aimg = 0, bimg = 0;
-  if (p.kseg) {
-    const int tps = (p.kseg + BK_ - 1) / BK_;          // K tiles per segment (the last one zero-filled beyond kseg)
-    const int sgm = kt / tps;
-    k0 = (kt - sgm * tps) * BK_;
-    aimg = (long long)((p.a_sel >> (4 * sgm)) & 15u) * p.img_a;
-    bimg = (long long)((p.b_sel >> (4 * sgm)) & 15u) * p.img_b;
-  }
-  const int tap = k0 / p.ktap;
-  ka = (long long)tap * p.lda + (k0 - tap * p.ktap) + aimg;
-  kb = k0 + bimg;
-  kin = k0;
-}
-
-// HALF: fp16 operand images + v_mfma_f32_32x32x16_f16 (the split-operand precise mode); else bf16 operands.
+// HALF: split-operand precise mode -- rows hold fp16 hi / lo images interleaved in 32-column blocks (uvtg_common.h, split_col): a 64-element
+// K tile is 32 real columns, k-steps 0, 1 = hi halves, 2, 3 = lo halves; products hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16.
 template <bool HALF>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma clang fp contract(off)            // (epilogue rounding identical to the persistent kernel's)
@@ -78,20 +60,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     aoff[i] = (size_t)max(map_row(m, p.a_seg, p.a_seg_stride, p.a_off), 0) * p.lda;
     boff[i] = (size_t)n * p.ldb;
   }
-  const int kcols = p.kseg ? p.kseg : p.K;             // columns of one reduction segment (the K tail is zero-filled per segment)
-  const int nk = p.kseg ? p.n_seg * ((p.kseg + BK - 1) / BK) : (p.K + BK - 1) / BK;
+  const int nk = (p.K + BK - 1) / BK;
 
   u32x4 ra[4], rb[4];
   auto gload = [&](int kt) {
-    long long ka, kb; int kin;
-    nt_k_offsets<BK>(p, kt, ka, kb, kin);
+    const int k0 = kt * BK;
+    const int tap = k0 / p.ktap, kk = k0 - tap * p.ktap;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int kc = sch[i] * 8;
-      const bool ok = (kin + kc) < kcols;
+      const bool ok = (k0 + kc) < p.K;
       u32x4 z = {0, 0, 0, 0};
-      ra[i] = ok ? *(const u32x4*)(Ab + ((long long)aoff[i] + ka + kc) * 2) : z;
-      rb[i] = ok ? *(const u32x4*)(Bb + ((long long)boff[i] + kb + kc) * 2) : z;
+      ra[i] = ok ? *(const u32x4*)(Ab + ((aoff[i] + (size_t)tap * p.lda + kk + kc) * 2)) : z;
+      rb[i] = ok ? *(const u32x4*)(Bb + ((boff[i] + k0 + kc) * 2)) : z;
     }
   };
   auto sstore = [&](int stage) {
@@ -119,6 +100,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   for (int kt = 0; kt < nk; kt++) {
     if (kt + 1 < nk) gload(kt + 1);
     const bf16_t* base = smem + (kt & 1) * NT * TILE;
+    if constexpr (HALF) {
+      s16x8 a[4][2], b[4][2];                 // all four k-steps of the tile: hi halves (0, 1), lo halves (2, 3)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const int ra_ = wm * 64 + i * 32 + l31, rb_ = wn * 64 + i * 32 + l31;
+          a[ks][i] = *(const s16x8*)(base + ra_ * BK + (((2 * ks + g) ^ SW::f(ra_)) * 8));
+          b[ks][i] = *(const s16x8*)(base + TILE + rb_ * BK + (((2 * ks + g) ^ SW::f(rb_)) * 8));
+        }
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            acc[i][j] = mfma32h(a[2 + h][i], b[h][j], acc[i][j]);      // lo . hi
+            acc[i][j] = mfma32h(a[h][i], b[2 + h][j], acc[i][j]);      // hi . lo
+            acc[i][j] = mfma32h(a[h][i], b[h][j], acc[i][j]);          // hi . hi
+          }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       s16x8 a[2], b[2];
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = HALF ? mfma32h(a[i], b[j], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
     }
     if (kt + 1 < nk) sstore((kt + 1) & 1);
     __syncthreads();
@@ -216,8 +219,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       if (p.outS && okB) {
         const float vv[4] = {v[0], v[1], v[2], v[3]};
         u32x2 hi, lo; split4_f16(vv, p.sscale, hi, lo);
-        unsigned short* o = p.outS + go + orow * p.ldoS + n;
-        *(u32x2*)o = hi; *(u32x2*)(o + p.img_o) = lo;
+        unsigned short* o = p.outS + orow * p.ldoS + split_col((int)go + n);
+        *(u32x2*)o = hi; *(u32x2*)(o + 32) = lo;
       }
     }
     if ((p.outU || p.outUF || (HALF && p.outUS)) && okB) {
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         if (p.outUS) {
           const float uu[4] = {u[0], u[1], u[2], u[3]};
           u32x2 hi, lo; split4_f16(uu, p.sscale, hi, lo);
-          unsigned short* o = p.outUS + orow * p.ldoS + n;
-          *(u32x2*)o = hi; *(u32x2*)(o + p.img_o) = lo;
+          unsigned short* o = p.outUS + orow * p.ldoS + split_col(n);
+          *(u32x2*)o = hi; *(u32x2*)(o + 32) = lo;
         }
       }
     }
@@ -314,8 +317,10 @@ __global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = 
 // bodies without the rest: 0 = general; 1 = bias, column scale, row factor, bf16 residual (EOP), bf16 out (q,k,v / out-proj / FFN2 /
 // dgrads: 24 of the 40 launches); 2 = bias, pre-activation copy, GELU, bf16 out (FFN1); 3 = GELU' of the bf16 pre-activation (EOP),
 // bf16 out (the activation-gradient GEMM).
-// HALF: split-operand precise mode -- fp16 operand images, segmented reduction (hi.hi, hi.lo, lo.hi: GemmArgs.kseg / a_sel / b_sel),
-// v_mfma_f32_32x32x16_f16; general epilogue only, fp32 residual, exact erf GELU, re-split outputs outS / outUS for the next GEMM.
+// HALF: split-operand precise mode -- rows of fp16 hi / lo images interleaved in 32-column blocks (uvtg_common.h): staging, LDS image and
+// fragment reads are the bf16 kernel's; the K-tile body issues hi.hi, hi.lo, lo.hi from the four fragment sets (6 MFMA groups instead of 4 per
+// K tile: 2/3 of the LDS and staging traffic per MFMA) on v_mfma_f32_32x32x16_f16; general epilogue only, fp32 residual, exact erf GELU,
+// re-split outputs outS / outUS for the next GEMM.
 template <bool GATHER, int TM, bool EOP, int ORD, int EPI, bool HALF = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma clang fp contract(off)            // every instantiation must round the epilogue alike (the tile paths are compared bit for bit)
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M - p.m_begin + BM - 1) / BM;
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
-  const int nk = HALF ? p.n_seg * (p.kseg / KB) : p.K / KB;
+  const int nk = p.K / KB;
   const int sr_ = lane >> 3, sc_ = lane & 7;
 
   auto tile_origin = [&](int t, int& gz, int& m0, int& n0) {
@@ -381,15 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     if (p.act == 101 || p.act == 103) ka = 0;
     if (p.act == 102 || p.act == 103) kb = 0;
 #endif
-    if constexpr (HALF) {          // segment of the split reduction -> operand images; the conv taps apply inside the segment
-      int k0 = kt * KB;
-      const int sgm = k0 / p.kseg;
-      k0 -= sgm * p.kseg;
-      const unsigned ai = (p.a_sel >> (4 * sgm)) & 15u, bi = (p.b_sel >> (4 * sgm)) & 15u;
-      kb = (unsigned)(k0 + (int)bi * p.img_b) * 2u;
-      if constexpr (GATHER) { const int tap = k0 / p.ktap; ka = (unsigned)(tap * p.lda + (k0 - tap * p.ktap) + (int)ai * p.img_a) * 2u; }
-      else ka = (unsigned)(k0 + (int)ai * p.img_a) * 2u;
-    } else if constexpr (GATHER) {
+    if constexpr (GATHER) {
       const int k0 = kt * KB, tap = k0 / p.ktap;
       ka = (unsigned)(tap * p.lda + (k0 - tap * p.ktap)) * 2u;
     }
@@ -496,7 +493,67 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       constexpr int G0 = ORD == 0 ? 0 : (NP + 1) / 2, G1 = ORD == 0 ? 0 : NP - (NP + 1) / 2;          // pieces issued under k-step 0 / 1
       constexpr int E2 = (NPF * 4 + 1) / 2, E3 = NPF * 4 - E2;  // epilogue-operand loads under k-step 2 / 3
       constexpr int Mf = TM * TN, R = TM + TN;
-      if constexpr (TM >= 5) {
+      if constexpr (HALF) {
+        // Split-operand K tile: 32 real columns, hi halves in k-steps 0 / 1, lo halves in k-steps 2 / 3 of the staged 64 elements.
+        // Three MFMA groups per half h: hi.hi, hi.lo, lo.hi.  Fragment registers are refilled in place right behind their last use (A hi
+        // after the hi.lo group, B lo after it too, A lo after the lo.hi group); only B hi -- needed by the first group of the next half
+        // while the last group of this one still reads it -- has two buffers: 2 TM + 3 TN fragment sets.
+        auto rdA = [&](int i, int q) { return *(const s16x8*)(base + aoff[i] + (((2 * q + g) ^ swz) << 4)); };
+        auto rdB = [&](int j, int q) { return *(const s16x8*)(base + boff[j] + (((2 * q + g) ^ swz) << 4)); };
+        s16x8 ah[TM], al[TM], bh[2][TN], bl[TN];
+        if (ORD == 0) {
+#pragma unroll
+          for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) ah[i] = rdA(i, 0);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bh[0][j] = rdB(j, 0);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bl[j] = rdB(j, 2);
+#pragma unroll
+        for (int i = 0; i < TM; i++) al[i] = rdA(i, 2);
+        if (ORD == 1) {
+#pragma unroll
+          for (int i = 0; i < G0; i++) piece(sbase, ka, kb, i);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = MF(ah[i], bh[0][j], acc[i][j]);          // hi . hi   (columns 0..15)
+#pragma unroll
+        for (int j = 0; j < TN; j++) bh[1][j] = rdB(j, 1);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = MF(ah[i], bl[j], acc[i][j]);             // hi . lo
+          ah[i] = rdA(i, 1);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) bl[j] = rdB(j, 3);
+        if (ORD == 1) {
+#pragma unroll
+          for (int i = G0; i < NP; i++) piece(sbase, ka, kb, i);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = MF(al[i], bh[0][j], acc[i][j]);          // lo . hi
+          al[i] = rdA(i, 3);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = MF(ah[i], bh[1][j], acc[i][j]);          // hi . hi   (columns 16..31)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = MF(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = MF(al[i], bh[1][j], acc[i][j]);
+      } else if constexpr (TM >= 5) {
         // 320-row tiles: 160 accumulator registers leave no room for two sets of A fragments.  Each A fragment is refilled for the
         // next k-step right behind its own TN MFMAs (the refill then has the other (TM - 1) TN MFMAs of this k-step and i TN of the
         // next one to land: >= 8 MFMAs); only the B fragments, used by every MFMA of a k-step, stay double-buffered.
@@ -704,9 +761,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             if (p.outS && okB) {
               const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
               u32x2 h0, l0, h1, l1; split4_f16(va, p.sscale, h0, l0); split4_f16(vb, p.sscale, h1, l1);
-              unsigned short* o = p.outS + go + orow * p.ldoS + n;
+              unsigned short* o = p.outS + orow * p.ldoS + split_col((int)go + n);
               *(u32x4*)o = (u32x4){h0[0], h0[1], h1[0], h1[1]};
-              *(u32x4*)(o + p.img_o) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+              *(u32x4*)(o + 32) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
             }
           }
           if (!SIMPLE && (p.outU || p.outUF || (HALF && p.outUS)) && okB) {
@@ -729,9 +786,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
               if (p.outUS) {
                 const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
                 u32x2 h0, l0, h1, l1; split4_f16(va, p.sscale, h0, l0); split4_f16(vb, p.sscale, h1, l1);
-                unsigned short* o = p.outUS + orow * p.ldoS + n;
+                unsigned short* o = p.outUS + orow * p.ldoS + split_col(n);
                 *(u32x4*)o = (u32x4){h0[0], h0[1], h1[0], h1[1]};
-                *(u32x4*)(o + p.img_o) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+                *(u32x4*)(o + 32) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
               }
             }
           }
@@ -1689,7 +1746,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
     nt_trace_launch(b, best_tm, grid, gather, eop, s);
 #endif
     if (half) {       // split-operand launch: family 1, ALGORITHMIC flops (one product per element; the kernel runs three MFMA segments)
-      uvtg_prof_begin_launch(1, 2.0 * rows * b.N * b.K * b.groups, s);
+      uvtg_prof_begin_launch(1, 1.0 * rows * b.N * b.K * b.groups, s);       // (K counts both images: 2 M N K / 2)
       rc = best_tm == 5 ? launch_nt256_half<5>(b, grid, gather, s) : best_tm == 4 ? launch_nt256_half<4>(b, grid, gather, s)
          : (best_tm == 3 ? launch_nt256_half<3>(b, grid, gather, s) : launch_nt256_half<2>(b, grid, gather, s));
       uvtg_prof_end_launch(1, s);
@@ -1724,21 +1781,21 @@ int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-// Split-operand GEMM (the precise "fp32x3" mode): a.A / a.B hold fp16 hi | lo images (a.img_a / a.img_b elements apart inside a row), a.K is
-// the column count of ONE image (a multiple of 64: the producers zero-pad), a.ktap counts columns of one image too.  Three reduction segments:
-// hi.hi, hi.lo, lo.hi.  Both tile structures take it (the persistent 256-wide kernel where it pays, the 128 x 128 kernel for small shapes).
+// Split-operand GEMM (the precise "fp32x3" mode): a.A / a.B rows hold the fp16 hi / lo images interleaved in 32-column blocks; a.K, a.lda,
+// a.ldb, a.ktap, a.gA, a.gB count elements of such rows (two per real column; the producers zero-pad to whole 64-element K tiles).  Both
+// tile structures take it: the persistent 256-wide kernel where it pays, the 128 x 128 kernel for small shapes.
 int launch_gemm_nt_split(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
-  if (a.K % 8 || a.img_a % 8 || a.img_b % 8 || a.img_a < (a.ktap > 0 && a.ktap < a.K ? a.ktap : a.K) || a.img_b < a.K) return -2;   // (conv taps: an A image holds ONE tap's columns)
-  if ((a.outS || a.outUS) && (a.ldoS % 8 || a.img_o % 8 || a.img_o < a.N)) return -2;
+  if (a.K % 64 || (a.ktap > 0 && a.ktap < a.K && a.ktap % 64)) return -2;       // whole K tiles: 32 real columns with both images
+  if ((a.outS || a.outUS) && a.ldoS % 64) return -2;
   if (a.residB || a.gradPre || a.outPre) return -6;       // no bf16 epilogue operand in this mode (fp32 residual; fp32 / bf16 / split outputs)
-  a.kseg = a.K; a.n_seg = 3; a.a_sel = 0x100u; a.b_sel = 0x010u;          // (A image, B image) per segment: (hi, hi), (hi, lo), (lo, hi)
   if (a.accscale == 0.f) a.accscale = 1.0f / (UVTG_SPLIT_A_SCALE * UVTG_SPLIT_W_SCALE);
   if (a.sscale == 0.f) a.sscale = UVTG_SPLIT_A_SCALE;
   if (int e = check_nt(a, 2)) return e;
+  const double alg_flops = (double)a.M * a.N * a.K * (a.groups > 0 ? a.groups : 1);       // 2 x M x N x (K / 2 real columns): ALGORITHMIC flops
   if (nt256_ok(a)) return launch_nt256(a, s, true);
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
-  uvtg_prof_begin_launch(1, 2.0 * a.M * a.N * a.K * grid.z, s);
+  uvtg_prof_begin_launch(1, alg_flops, s);
   hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, s, a);
   uvtg_prof_end_launch(1, s);
   UVTG_CHECK_LAUNCH();

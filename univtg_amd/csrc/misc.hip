@@ -1153,7 +1153,7 @@ int launch_transpose_bf16(const float* src, int rows, int cols, bf16_t* dst, int
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-// fp16 hi | lo images of fp32 matrices (split-operand GEMM operands), one thread per 4 columns of one image row
+// fp16 hi / lo images of fp32 matrices in the interleaved row layout (split-operand GEMM operands), one thread per 4 real columns of a row
 __global__ __launch_bounds__(256) void split_f16_multi_kernel(const SplitOps ops) {
   const int op = blockIdx.y;
   const int rows = ops.rows[op], cols = ops.cols[op], kp = ops.kp[op], conv = ops.conv[op];
@@ -1171,15 +1171,15 @@ __global__ __launch_bounds__(256) void split_f16_multi_kernel(const SplitOps ops
       v[e] = x;
     }
     u32x2 hi, lo; split4_f16(v, ops.scale, hi, lo);
-    unsigned short* o = dst + (size_t)r * 2 * kp + c;
-    *(u32x2*)o = hi; *(u32x2*)(o + kp) = lo;
+    unsigned short* o = dst + (size_t)r * 2 * kp + split_col(c);
+    *(u32x2*)o = hi; *(u32x2*)(o + 32) = lo;
   }
 }
 int launch_split_f16_multi(const SplitOps& ops, hipStream_t s) {
   if (ops.count <= 0) return 0;
   long long mx = 0;
   for (int i = 0; i < ops.count; i++) {
-    if (ops.kp[i] % 4 || ops.kp[i] < ops.cols[i]) return -2;
+    if (ops.kp[i] % 32 || ops.kp[i] < ops.cols[i]) return -2;
     const long long n4 = (long long)ops.rows[i] * (ops.kp[i] / 4);
     mx = n4 > mx ? n4 : mx;
   }

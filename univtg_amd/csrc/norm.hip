@@ -53,18 +53,19 @@ template <int VEC> __device__ __forceinline__ void storeb(bf16_t* p, const float
   else *p = f2bf(v[0]);
 }
 
-// fp16 hi | lo images of VEC consecutive columns (split-operand GEMM operands)
-template <int VEC> __device__ __forceinline__ void stores(unsigned short* p, int img, const float (&v)[VEC], float scale) {
+// fp16 hi / lo images of VEC consecutive columns starting at real column c of a split operand row (interleaved layout, split_col)
+template <int VEC> __device__ __forceinline__ void stores(unsigned short* row, int c, const float (&v)[VEC], float scale) {
+  unsigned short* p = row + split_col(c);
   if constexpr (VEC == 8) {
     const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
     u32x2 h0, l0, h1, l1; split4_f16(a, scale, h0, l0); split4_f16(b, scale, h1, l1);
-    *(u32x4*)p = (u32x4){h0[0], h0[1], h1[0], h1[1]}; *(u32x4*)(p + img) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+    *(u32x4*)p = (u32x4){h0[0], h0[1], h1[0], h1[1]}; *(u32x4*)(p + 32) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
   } else if constexpr (VEC == 4) {
     u32x2 h, l; split4_f16(v, scale, h, l);
-    *(u32x2*)p = h; *(u32x2*)(p + img) = l;
+    *(u32x2*)p = h; *(u32x2*)(p + 32) = l;
   } else {
 #pragma unroll
-    for (int e = 0; e < VEC; e++) { unsigned short h, l; split_f16(v[e] * scale, h, l); p[e] = h; p[img + e] = l; }
+    for (int e = 0; e < VEC; e++) { unsigned short h, l; split_f16(v[e] * scale, h, l); p[e] = h; p[32 + e] = l; }     // (VEC <= 2 at even c: same 32-block)
   }
 }
 
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
           }
         }
         if (a.yF) storev<VEC>(a.yF + (size_t)row * a.ldyF + c, y);
-        if (a.yS) stores<VEC>(a.yS + (size_t)row * a.ldyS + c, a.imgS, y, a.sscale);
+        if (a.yS) stores<VEC>(a.yS + (size_t)row * a.ldyS, c, y, a.sscale);
         if (a.yB) storeb<VEC>(a.yB + (size_t)row * a.ldyB + c, y);
         if ((a.yU || a.yUF || a.yUS) && a.u_from_x) {       // u = x + LN(x + table): the row read above minus the table, at the row's padded position
           float u[VEC], t[VEC];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
           for (int e = 0; e < VEC; e++) u[e] = y[e] + (v[i][e] - t[e]);
           if (a.yU) storeb<VEC>(a.yU + (size_t)lrow * a.ldyU + c, u);
           if (a.yUF) storev<VEC>(a.yUF + (size_t)lrow * a.ldyU + c, u);
-          if (a.yUS) stores<VEC>(a.yUS + (size_t)lrow * a.ldyS + c, a.imgS, u, a.sscale);
+          if (a.yUS) stores<VEC>(a.yUS + (size_t)lrow * a.ldyS, c, u, a.sscale);
         } else if (a.yU || a.yUF || a.yUS) {
           float u[VEC];
           if (posr) {
@@ -202,12 +203,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
           }
           if (a.yU) storeb<VEC>(a.yU + (size_t)row * a.ldyU + c, u);
           if (a.yUF) storev<VEC>(a.yUF + (size_t)row * a.ldyU + c, u);
-          if (a.yUS) stores<VEC>(a.yUS + (size_t)row * a.ldyS + c, a.imgS, u, a.sscale);
+          if (a.yUS) stores<VEC>(a.yUS + (size_t)row * a.ldyS, c, u, a.sscale);
         }
         if (is_vid) {
           if (a.yP) storeb<VEC>(a.yP + prow * a.ldyP + c, y);
           if (a.yPF) storev<VEC>(a.yPF + prow * a.ldyP + c, y);
-          if (a.yPS) stores<VEC>(a.yPS + prow * a.ldyS + c, a.imgS, y, a.sscale);
+          if (a.yPS) stores<VEC>(a.yPS + prow * a.ldyS, c, y, a.sscale);
         }
       }
     }
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     if (a.Dpad > D) {
       for (int c = D + lane; c < a.Dpad; c += 64) {
         if (a.yB) a.yB[(size_t)row * a.ldyB + c] = 0;
-        if (a.yS) { a.yS[(size_t)row * a.ldyS + c] = 0; a.yS[(size_t)row * a.ldyS + a.imgS + c] = 0; }
+        if (a.yS) { a.yS[(size_t)row * a.ldyS + split_col(c)] = 0; a.yS[(size_t)row * a.ldyS + split_col(c) + 32] = 0; }
       }
     }
   }
@@ -616,14 +617,14 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwdArgs a) {
         loadv<2>(a.beta + c, bt);
 #pragma unroll
         for (int e = 0; e < 2; e++) y[e] = ((v[k][e] - mean) * rstd * gm[e] + bt[e]) * ks[k & 1][e];
-        if (a.yS) stores<2>(a.yS + (size_t)row * a.ldyS + c, a.imgS, y, a.sscale);
+        if (a.yS) stores<2>(a.yS + (size_t)row * a.ldyS, c, y, a.sscale);
         if (a.yB) storeb<2>(a.yB + (size_t)row * a.ldyB + c, y);
       }
     }
     if (a.Dpad > D) {
       for (int c = D + tid; c < a.Dpad; c += 256) {
         if (a.yB) a.yB[(size_t)row * a.ldyB + c] = 0;
-        if (a.yS) { a.yS[(size_t)row * a.ldyS + c] = 0; a.yS[(size_t)row * a.ldyS + a.imgS + c] = 0; }
+        if (a.yS) { a.yS[(size_t)row * a.ldyS + split_col(c)] = 0; a.yS[(size_t)row * a.ldyS + split_col(c) + 32] = 0; }
       }
     }
   }
@@ -688,12 +689,12 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a
       }
     }
     // (columns [D, Dpad) are written as zeros: the GEMM operand is zero-padded to whole K tiles)
-    if (a.yS) {      // fp16 hi | lo images of the split-operand projection GEMM (y == 0 in the padding columns: both images get zeros)
-      unsigned short* o = a.yS + (size_t)row * a.ldyS + c;
-      if (c + 3 < (a.Dpad > D ? a.Dpad : D)) { u32x2 h, l; split4_f16(y, a.sscale, h, l); *(u32x2*)o = h; *(u32x2*)(o + a.imgS) = l; }
+    if (a.yS) {      // fp16 hi / lo images of the split-operand projection GEMM (y == 0 in the padding columns: both images get zeros)
+      unsigned short* o = a.yS + (size_t)row * a.ldyS + split_col(c);       // (c is a multiple of 4: the quad stays inside one 32-column block)
+      if (c + 3 < (a.Dpad > D ? a.Dpad : D)) { u32x2 h, l; split4_f16(y, a.sscale, h, l); *(u32x2*)o = h; *(u32x2*)(o + 32) = l; }
       else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) if (c + e < (a.Dpad > D ? a.Dpad : D)) { unsigned short h, l; split_f16(y[e] * a.sscale, h, l); o[e] = h; o[a.imgS + e] = l; }
+        for (int e = 0; e < 4; e++) if (c + e < (a.Dpad > D ? a.Dpad : D)) { unsigned short h, l; split_f16(y[e] * a.sscale, h, l); o[e] = h; o[32 + e] = l; }
       }
     }
     if (a.yB) {
@@ -817,20 +818,20 @@ static bool al(const void* p, int ld_elems, int bytes_per, int want) {
 static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
   if (a.addtab && (a.D > 2048 || a.add_L <= 0)) return -4;      // (only the generic kernel adds the table)
-  const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.xB, a.ldxB, 2, 8) && al(a.yF, a.ldyF, 4, 16) && al(a.yS, a.ldyS, 2, 8) && al(a.yS, a.imgS, 2, 8) && al(a.yUS, a.ldyS, 2, 8) && al(a.yPS, a.ldyS, 2, 8) &&
+  const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.xB, a.ldxB, 2, 8) && al(a.yF, a.ldyF, 4, 16) && al(a.yS, a.ldyS, 2, 8) && al(a.yUS, a.ldyS, 2, 8) && al(a.yPS, a.ldyS, 2, 8) &&
                        al(a.yB, a.ldyB, 2, 8) && al(a.yU, a.ldyU, 2, 8) && al(a.yUF, a.ldyU, 4, 16) &&
                        al(a.yP, a.ldyP, 2, 8) && al(a.yPF, a.ldyP, 4, 16) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16) &&
                        al(a.pos, a.D, 4, 16);
-  const bool align8 = al(a.x, a.ldx, 4, 8) && al(a.xB, a.ldxB, 2, 4) && al(a.yF, a.ldyF, 4, 8) && al(a.yS, a.ldyS, 2, 4) && al(a.yS, a.imgS, 2, 4) && al(a.yUS, a.ldyS, 2, 4) && al(a.yPS, a.ldyS, 2, 4) &&
+  const bool align8 = al(a.x, a.ldx, 4, 8) && al(a.xB, a.ldxB, 2, 4) && al(a.yF, a.ldyF, 4, 8) && al(a.yS, a.ldyS, 2, 4) && al(a.yUS, a.ldyS, 2, 4) && al(a.yPS, a.ldyS, 2, 4) &&
                       al(a.yB, a.ldyB, 2, 4) && al(a.yU, a.ldyU, 2, 4) && al(a.yUF, a.ldyU, 4, 8) &&
                       al(a.yP, a.ldyP, 2, 4) && al(a.yPF, a.ldyP, 4, 8) && al(a.gamma, 0, 4, 8) && al(a.beta, 0, 4, 8) &&
                       al(a.pos, a.D, 4, 8);
   const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.yB, a.ldyB, 2, 16) && al(a.yU, a.ldyU, 2, 16) && al(a.yP, a.ldyP, 2, 16) &&
-                       al(a.yS, a.ldyS, 2, 16) && al(a.yS, a.imgS, 2, 16) && al(a.yUS, a.ldyS, 2, 16) && al(a.yPS, a.ldyS, 2, 16);
+                       al(a.yS, a.ldyS, 2, 16) && al(a.yUS, a.ldyS, 2, 16) && al(a.yPS, a.ldyS, 2, 16);
   if (a.D > 2048 && a.D <= 3072 && a.D % 2 == 0 && align8 && a.x && !a.yF && !a.pos && !a.pos_row && !a.yU && !a.yUF && !a.yP && !a.yPF && !a.addtab && !a.yUS && !a.yPS) {
     static const bool wave_off = getenv("UVTG_LN_WIDE_WAVE_OFF") != nullptr;     // experiment: the block-per-row kernel
     const int dmax = a.Dpad > a.D ? a.Dpad : a.D;
-    if (!wave_off && dmax <= 3072 && (a.ldx % 2 == 0) && (!a.yB || a.ldyB % 4 == 0) && (!a.yS || (a.ldyS % 4 == 0 && a.imgS % 4 == 0)) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16))
+    if (!wave_off && dmax <= 3072 && (a.ldx % 2 == 0) && (!a.yB || a.ldyB % 4 == 0) && (!a.yS || a.ldyS % 4 == 0) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16))
       hipLaunchKernelGGL((ln_fwd_wide_wave_kernel<12>), dim3(cdiv(a.rows, 4)), dim3(256), 0, s, a);     // wave per row
     else
       hipLaunchKernelGGL((ln_fwd_wide_kernel<6>), dim3(min(a.rows, 4096)), dim3(256), 0, s, a);         // block per row (see the kernel)

@@ -32,7 +32,13 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 // with the dropped lo.lo term at 2^-22: fp32-class, where the round-1..3 bf16 hi/lo split (8 + 8 bits) stopped at 2^-16.
 // Operand scales (powers of two, folded back by GemmArgs.accscale): activations x16, weights x64 -- both keep |x s| far below fp16's
 // 65504 for LayerNorm outputs / GELU / ReLU activations and for any sane weight, and lift the lo parts out of the subnormal range.
+// LAYOUT of a split operand row: the two images are interleaved in blocks of 32 columns -- real column c lives at element
+// split_col(c) (hi) and split_col(c) + 32 (lo) -- so that ONE 64-element K tile of the GEMM kernels (128 bytes, staged exactly like a bf16
+// K tile) carries 32 real columns with both images: k-steps 0, 1 are the hi halves, k-steps 2, 3 the lo halves, and the K-tile body issues
+// hi.hi, hi.lo and lo.hi from the same staged bytes and the same fragment reads (6 MFMA groups per 4 fragment sets: 2/3 of the LDS and
+// staging traffic per MFMA of three separate passes).  Rows are zero-padded to a multiple of 64 real columns by their producers.
 typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+__host__ __device__ __forceinline__ int split_col(int c) { return ((c >> 5) << 6) | (c & 31); }
 #define UVTG_SPLIT_A_SCALE 16.0f
 #define UVTG_SPLIT_W_SCALE 64.0f
 __device__ __forceinline__ void split_f16(float x, unsigned short& hi, unsigned short& lo) {

@@ -43,17 +43,15 @@ struct GemmArgs {
   // o_rows[m] (< 0: not written); outF goes to f_rows[m] (null: the affine o_seg row); pos is read at row pos_map[m] (null: m)
   const int* o_rows; const int* f_rows; const int* pos_map;
   // ---- split-operand ("fp32x3") mode: launch_gemm_nt_split -----------------------------------------------------------------------
-  // A and B rows hold fp16 IMAGES (hi | lo) of the fp32 operand, image j at columns [j * img, j * img + kseg) (uvtg_common.h, split_f16).
-  // The reduction runs over n_seg segments of kseg columns: segment s multiplies image (a_sel >> 4 s) & 15 of A by image
-  // (b_sel >> 4 s) & 15 of B -- hi.hi, hi.lo, lo.hi -- on v_mfma_f32_32x32x16_f16; the conv taps apply inside a segment.
-  // Epilogue: the accumulator is multiplied by accscale (1 / (A scale x W scale)) first; fp32 residual / outputs as above, plus
-  // outS / outUS: the value (/ value + pos) re-split (x sscale) for the next GEMM: image j of row m at outS[m * ldoS + j * img_o + n].
-  int kseg, n_seg; unsigned a_sel, b_sel; int img_a, img_b;
+  // A and B rows hold the fp16 hi / lo images of the fp32 operand interleaved in 32-column blocks (uvtg_common.h, split_col): K, lda, ldb,
+  // ktap, gA, gB count ELEMENTS of such rows (two per real column).  Every 64-element K tile yields hi.hi + hi.lo + lo.hi on
+  // v_mfma_f32_32x32x16_f16.  Epilogue: the accumulator is multiplied by accscale (1 / (A scale x W scale)) first; fp32 residual / outputs
+  // as above, plus outS / outUS: the value (/ value + pos) re-split (x sscale) for the next GEMM, row m at outS[m * ldoS + split_col(n)].
   float accscale;
-  unsigned short* outS; unsigned short* outUS; int ldoS, img_o; float sscale;
+  unsigned short* outS; unsigned short* outUS; int ldoS; float sscale;
 };
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s);
-int launch_gemm_nt_split(const GemmArgs& a, hipStream_t s);     // K = columns of ONE image; kseg / n_seg / selectors are filled in here
+int launch_gemm_nt_split(const GemmArgs& a, hipStream_t s);
 
 // C[N,K] (+)= P[M,N]^T * Q[M,K]  (reduction over rows; fp32 atomic accumulation, split over M)
 struct GemmTNArgs {
@@ -109,9 +107,10 @@ struct LnFwdArgs {
   // outputs (any may be null); Dpad: columns [D, Dpad) of the bf16/f32 GEMM operand are zero-filled
   float* yF; int ldyF;
   bf16_t* yB; int ldyB; int Dpad;
-  // split-operand GEMM operand (precise mode): fp16 hi | lo images of y * sscale (uvtg_common.h split_f16), image j of row r at
-  // yS[r * ldyS + j * imgS + c], zero padding to Dpad in both images; yUS = the same for y + pos, yPS for the zero-framed conv layout
-  unsigned short* yS; unsigned short* yUS; unsigned short* yPS; int ldyS, imgS; float sscale;
+  // split-operand GEMM operand (precise mode): fp16 hi / lo images of y * sscale in the interleaved row layout (uvtg_common.h split_col):
+  // column c of row r at yS[r * ldyS + split_col(c)] (hi) and + 32 (lo), zero padding to Dpad; yUS = the same for y + pos, yPS for the
+  // zero-framed conv layout
+  unsigned short* yS; unsigned short* yUS; unsigned short* yPS; int ldyS; float sscale;
   // (y + pos) for rows that are video tokens: row -> (b = row / S, s = row % S), s < Lv
   const float* pos; int S, Lv;  // pos [B*Lv, D]
   const int* pos_row;           // packed rows: row -> row of the pos table (or -1); replaces the (S, Lv) arithmetic, no yP / yPF
@@ -157,7 +156,7 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
 struct AttnArgs {
   const void* qkv; int ldqkv;   // bf16 (or fp32 when precise) [B*S, 3d]: q | k | v, q pre-scaled
   void* o; int ldo;             // bf16 / fp32 [B*S, d] (precise: optional when oS is given)
-  unsigned short* oS; int ldoS, img_o;   // precise: fp16 hi | lo images of o (x UVTG_SPLIT_A_SCALE) for the split-operand out-projection
+  unsigned short* oS; int ldoS;   // precise: fp16 hi / lo images of o (x UVTG_SPLIT_A_SCALE, interleaved row layout) for the split-operand out-projection
   float* lse;                   // [B, H, S]
   const unsigned char* kvalid;  // [B, S] 1 = real key
   int B, S, H, hd;
@@ -235,8 +234,8 @@ struct TransposeOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_
 struct ConvWOps {     // kind 0: forward operand (dst[n][tap*C + c]), 1: dgrad operand (dst[c][tap'*Ntot + n_off + n] = w[n][c][2 - tap'])
   const float* w[16]; bf16_t* dst[16]; int ld[16], ntot[16], n_off[16], kind[16]; int N, C, count;
 };
-// split-operand weights / standalone operand splits: dst [rows, 2 * kp] fp16 = hi | lo images of src * scale, image columns [cols, kp)
-// zero.  conv != 0: src is a Conv1d weight (rows, conv, 3) and image column tap * conv + c reads src[n][c][tap] (the tap-major forward operand)
+// split-operand weights / standalone operand splits: dst [rows, 2 * kp] fp16 = hi / lo images of src * scale in the interleaved row layout
+// (uvtg_common.h split_col), columns [cols, kp) zero.  conv != 0: src is a Conv1d weight (rows, conv, 3) and image column tap * conv + c reads src[n][c][tap] (the tap-major forward operand)
 struct SplitOps { const float* src[UVTG_MAX_PREP_OPS]; unsigned short* dst[UVTG_MAX_PREP_OPS]; int rows[UVTG_MAX_PREP_OPS], cols[UVTG_MAX_PREP_OPS],
                   kp[UVTG_MAX_PREP_OPS], conv[UVTG_MAX_PREP_OPS]; float scale; int count; };
 int launch_split_f16_multi(const SplitOps& ops, hipStream_t s);

@@ -249,6 +249,9 @@ class TrainStep:
         vals = [int(x) for x in lv] + [int(x) for x in lt]
         if len(vals) != 2 * B:
             raise ValueError("_lens_host must hold B clip counts and B token counts")
+        Lv, Lt = inputs["src_vid"].shape[1], inputs["src_txt"].shape[1]
+        if self.packed == "auto" and all(v == Lv for v in vals[:B]) and all(v == Lt for v in vals[B:]):
+            return None                  # nothing is padded: the packed stream would be the same rows behind gather tables
         self._lens_arr = (C.c_int * (2 * B))(*vals)     # read synchronously by the engine (row count only; tables come from the masks)
         return self._lens_arr
 
