@@ -6,7 +6,7 @@ The reference draws its masks from torch's generator (nn.Dropout, drop_path: mod
 mask VALUES are therefore not comparable, only the semantics given a mask -- which is what these helpers pin."""
 import numpy as np
 
-RNG_IN_VID, RNG_IN_TXT, RNG_ATTN, RNG_PATH = 0x100, 0x200, 0x300, 0x400
+RNG_IN_VID, RNG_IN_TXT, RNG_ATTN, RNG_PATH, RNG_TXT_POS = 0x100, 0x200, 0x300, 0x400, 0x500
 _M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 _W0, _W1 = 0x9E3779B9, 0xBB67AE85
 _LO = np.uint64(0xFFFFFFFF)

