@@ -287,7 +287,7 @@ const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* workspace);
 
 
 /* ---- measurement hooks (bench.py): HIP events around every launch of the GEMM kernels, recorded on the launch
- * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-bf16, 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,
+ * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-operand (fp16 hi / lo images; flops = algorithmic 2 M N K), 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,
  * persistent), 4: attention forward, 5: attention backward (all its kernels; FLOPs counted on the padded S: 4 S^2 hd per
  * (sample, head) forward, 10 S^2 hd backward), 6: LayerNorm forward launches, 7: LayerNorm backward launches (for 6 / 7 the
  * "flops" entry carries the algorithmic BYTES of the row streams: input + every output + the position rows added into the +pos outputs).

@@ -37,7 +37,8 @@ def test_linear_bf16(dev, M, N, K, act):
     assert relerr(got, ref) < 2e-5, relerr(got, ref)               # fp32 accumulation of exact bf16 products
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (130, 96, 2880), (515, 1024, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (130, 96, 2880), (515, 1024, 1024),
+                                   (8192, 1024, 2818), (20158, 1024, 1024)])     # the last two: the persistent 256-wide kernel's split instantiations
 def test_linear_f32x3(dev, M, N, K):
     from univtg_amd import ops
     g = torch.Generator().manual_seed(M * 7 + K)
@@ -48,7 +49,8 @@ def test_linear_f32x3(dev, M, N, K):
     ref = a.double() @ w.double().t() + b.double()
     fp32 = a @ w.t() + b
     e3, e32 = relerr(got, ref), relerr(fp32, ref)
-    assert e3 < 2e-5, (e3, e32)                                     # split-bf16: ~2^-16 relative, fp32 class
+    print(f"\n[linear_f32x3 {M}x{N}x{K}] split-operand rel err {e3:.2e}, torch fp32 GEMM {e32:.2e}")
+    assert e3 < 2e-6, (e3, e32)                                     # fp16 hi + lo images: ~2^-22 relative (the bf16 split of rounds 1-3: 2^-16)
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(256, 128, 128, 1), (1000, 136, 200, 3), (4096, 256, 2824, 4)])

@@ -550,7 +550,7 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     }
     for (int b = 1; b < m.nproj; b++) {
       const float* Wb = P[m.proj(wm, b, PW)];
-      if (tr) transp(Wb, d, d, w.pwT[wm][b], d, w.pwB[wm][b]);       // (pwB is null with split-bf16 projections: no plain copy then)
+      if (tr) transp(Wb, d, d, w.pwT[wm][b], d, w.pwB[wm][b]);       // (pwB is null with split-operand projections: no plain copy then)
       else if (w.pwB[wm][b]) cast(Wb, w.pwB[wm][b], (long long)d * d);
     }
   }

@@ -3,9 +3,11 @@
 //  gemm_nt : C[M,N] = A[M,K] * B[N,K]^T  + fused epilogue.  Every Linear / Conv1d(k=3) forward and
 //            every dgrad of the hot path (model/univtg.py:399-406,375-382;
 //            model/transformer_encoder_droppath.py:117-125) runs through it.
-//            bf16 variant: operands bf16, 128x128x64 tiles, ds_read_b128 fragments.
-//            f32x3 variant: operands fp32 in HBM, split on the fly into bf16 hi+lo while staging and
-//            multiplied as hi*hi + hi*lo + lo*hi (~2^-16 relative, fp32-class accuracy at 3 MFMAs).
+//            bf16: operands bf16, persistent (64 TM) x 256 x 64 tiles with LDS-DMA staging (large shapes) or 128x128x64
+//            register-staged tiles (small shapes), ds_read_b128 fragments.
+//            split-operand ("fp32x3") variant of both: operand rows hold fp16 hi / lo images interleaved in 32-column blocks
+//            (uvtg_common.h), one staged 64-element K tile yields hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16
+//            (~2^-22 relative: fp32-class accuracy at 3 MFMAs per product).
 //  gemm_tn : C[N,K] += P[M,N]^T * Q[M,K] (weight gradients): both operands are row-major in the
 //            reduction dimension, fragments come from ds_read_b64_tr_b16 transposing LDS reads.
 #include "uvtg_kernels.h"

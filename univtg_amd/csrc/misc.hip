@@ -1129,12 +1129,6 @@ int launch_cast_f32(const bf16_t* src, float* dst, long long n, hipStream_t s) {
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s) {
-  const long long n = (long long)rows * ld;
-  hipLaunchKernelGGL(cast_pad_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst, ld);
-  UVTG_CHECK_LAUNCH();
-  return 0;
-}
 int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s) {
   const long long n = (long long)rows * ld;
   hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst, ld);

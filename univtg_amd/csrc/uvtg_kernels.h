@@ -7,7 +7,7 @@
 // GEMM  C[M,N] = A[M,K] * B[N,K]^T   (both operands K-contiguous), fused epilogue.
 // ---------------------------------------------------------------------------------------------
 struct GemmArgs {
-  const void* A;      // bf16 (fast) or fp32 (x3) [rows, lda]
+  const void* A;      // bf16 [rows, lda], or (launch_gemm_nt_split) fp16 split rows
   // optional second A operand (same layout) for the output columns n >= a2_n0 (a multiple of 256): one launch computes
   // [A | A2-columns] -- the q,k projections read x + pos and the v projection reads x (transformer_encoder_droppath.py:116-117)
   const void* A2; int a2_n0;
@@ -220,7 +220,6 @@ int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* e
 constexpr int UVTG_SQSUM_FLOATS = 32 + 64 * 32;
 int launch_sqsum_ranges(const float* base, const ZeroRanges& r, float* sqsum, hipStream_t s);     // sqsum[0] += sum of squares over the ranges + the 64 slots
 int launch_sqsum(const float* x, long long n, float* sqsum, hipStream_t s);
-int launch_cast_pad_f32(const float* src, int rows, int cols, float* dst, int ld, hipStream_t s);
 int launch_cast_pad_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s);
 int launch_cast_pad2_bf16(const float* src0, int rows0, int cols0, bf16_t* dst0, int ld0, const float* src1, int rows1, int cols1, bf16_t* dst1, int ld1,
                           hipStream_t s);
