@@ -206,7 +206,24 @@ def run_infer(args, dev):
             key = f"{name}/{'fp32x3' if prec == 'auto' else 'bf16'}{'_packed' if packed else ''}"
             res[key] = dict(ms_per_batch=round(wall, 3), ms_event_median=round(per[n // 2], 3), clips_per_sec=round(B * Lv / wall * 1e3, 1),
                             samples_per_sec=round(B / wall * 1e3, 1))
-            if name == "config2_B256" and prec == "auto":           # roofline of the fp32x3 GEMM (family 1: gemm_nt_kernel<split-bf16>)
+            if prec == "auto" and not packed:                       # the same call replayed from a HIP graph (univtg_amd/graph.py)
+                from univtg_amd.graph import GraphedInference
+                run = GraphedInference(model, clip_length=2.0, eval_mode="add")
+
+                def gcall(i):
+                    inp, ts, tm, dur = batches[i % 2]
+                    return run(inp["src_txt"], inp["src_txt_mask"], inp["src_vid"], inp["src_vid_mask"], ts, tm, dur)
+                for i in range(4):
+                    gcall(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    gcall(i)
+                torch.cuda.synchronize()
+                gw = (time.perf_counter() - t0) / n * 1e3
+                res[key + "_hipgraph"] = dict(ms_per_batch=round(gw, 3), clips_per_sec=round(B * Lv / gw * 1e3, 1), samples_per_sec=round(B / gw * 1e3, 1))
+                del run
+            if name == "config2_B256" and prec == "auto":           # roofline of the split-operand GEMM (family 1)
                 lib.uvtg_profile_start()
                 for i in range(3):
                     call(i)
@@ -215,22 +232,24 @@ def run_infer(args, dev):
                 floor = lib.uvtg_profile_event_floor_ms()
                 raw = ms[1] + floor * cnt[1]
                 ach = fl[1] / (raw * 1e-3) / 1e12 if raw > 0 else 0.0
-                roof = dict(bound="mfma", kernel="gemm_nt_kernel<split-bf16> (fp32x3: hi*hi + hi*lo + lo*hi)", achieved=round(ach, 2), peak=round(2500.0 / 3, 1),
+                roof = dict(bound="mfma", kernel="split-operand GEMM (fp32x3: fp16 hi / lo images, hi*hi + hi*lo + lo*hi; gemm_nt256_kernel<..., HALF> / gemm_nt_kernel<true>)", achieved=round(ach, 2), peak=round(2500.0 / 3, 1),
                             unit="TFLOP/s", frac=round(ach / (2500.0 / 3), 4), traffic=None,
-                            note="achieved = sum(2MNK) ALGORITHMIC flops / event-pair time over the launches; every product costs 3 bf16 MFMAs, so the "
+                            note="achieved = sum(2MNK) ALGORITHMIC flops / event-pair time over the launches; every product costs 3 fp16 MFMAs, so the "
                                  "effective peak is 2.5 PFLOP/s / 3; executed MFMA rate = 3 x achieved",
                             executed_mfma_tflops=round(3 * ach, 1), launches_per_batch=int(cnt[1] // 3), avg_launch_us=round(raw * 1e3 / max(1, cnt[1]), 2))
             del model
     head = res["config2_B32/fp32x3"]
     out = dict(metric="clips/sec inference (L=75,d=1024) forward + post-processing", value=head["clips_per_sec"], unit="clips/s", n_gpus=1,
                steps=max(10, args.steps), warmup=max(3, args.warmup), ms_per_step=head["ms_per_batch"], higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype="fp32x3 (split-bf16, fp32-class)", data="synthetic",
+               vs_baseline=None, dtype="fp32x3 (fp16 hi + lo operand images, three products: fp32-class)", data="synthetic",
                config=dict(workload="QVHighlights inference shape (BASELINE config 2 eval, scripts/qvhl_inference.sh: eval batch 32): model(...) under "
                                     "torch.no_grad() with the DEFAULT precision ('auto' -> fp32x3) + uvtg_postprocess_mr (decode, rank, round_multiple 2 s, "
                                     "hull-IoU NMS 0.7, eval_mode add saliency), padded execution, ragged lengths len_v~U{38..75}; timing = host wall clock per "
                                     "batch incl. the Python boundary and per-call allocations", baseline_config=2, per_gpu_batch=32, mode="infer"),
                cases=res, roofline=roof, cpu_baseline=None,
-               note="cases: <shape>/<precision>[_packed]; config1_B1 = batch-1 latency with CLIP-only features (D_v=514); bf16 = opt-in fast mode "
+               note="cases: <shape>/<precision>[_packed][_hipgraph]; _hipgraph = the same call (forward + post-processing) captured once per shape and "
+                    "replayed as a HIP graph (univtg_amd.graph.GraphedInference; inputs copied into the graph's static buffers per call); "
+                    "config1_B1 = batch-1 latency with CLIP-only features (D_v=514); bf16 = opt-in fast mode "
                     "(post-NMS top-1 identical to fp32 for ~98 % of the samples); packed = Model(packed=True): encoder on valid rows + one "
                     "representative padded clip per sample, one device->host read of the mask sums per call")
     print(json.dumps(out))

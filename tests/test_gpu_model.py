@@ -813,6 +813,48 @@ def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
     assert not bad, bad
 
 
+def test_hip_graph_inference_replays_the_eager_call(dev):
+    """univtg_amd.graph.GraphedInference: forward (precise arithmetic under no_grad) + device post-processing captured into a HIP graph per
+    input shape.  The replay must give the eager call's bits for every batch of that shape, a second shape gets its own graph, and a
+    parameter update invalidates the captured operand cache (re-capture)."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import ops
+    from univtg_amd.graph import GraphedInference
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512, input_dropout=0.0, dropout=0.0,
+                     droppath=0.0)
+    params = O.init_params(cfg, seed=61)
+    model, _ = build(cfg, params, dev, "auto", proj_precise="auto")
+    model.eval()
+    run = GraphedInference(model, clip_length=2.0)
+
+    def batch(B, Lv, Lt, seed):
+        inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=seed, ragged=True)
+        dur = torch.tensor([float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(B)])
+        return to_dev(inputs, dev), tg["timestamp"].to(dev), tg["timestamp_mask"].to(dev), dur.to(dev)
+
+    def eager(inp, ts, tm, dur):
+        with torch.no_grad():
+            out = model(**inp)
+            win, order, keep, nk, sal = ops.postprocess_mr(out["pred_logits"], out["pred_spans"], out["saliency_scores"], ts, tm, dur, clip_length=2.0)
+        return dict(pred_logits=out["pred_logits"], pred_spans=out["pred_spans"], windows=win, order=order, keep=keep, n_keep=nk, saliency=sal)
+
+    def same(got, want):
+        for k, v in want.items():
+            assert torch.equal(got[k], v), k
+    for seed in (1, 2, 3):                                    # three batches of one shape through ONE graph
+        b = batch(8, 30, 10, seed)
+        same(run(b[0]["src_txt"], b[0]["src_txt_mask"], b[0]["src_vid"], b[0]["src_vid_mask"], *b[1:]), eager(*b))
+    assert len(run._graphs) == 1
+    b2 = batch(3, 75, 12, 4)                                  # another shape: its own graph
+    same(run(b2[0]["src_txt"], b2[0]["src_txt_mask"], b2[0]["src_vid"], b2[0]["src_vid_mask"], *b2[1:]), eager(*b2))
+    assert len(run._graphs) == 2
+    with torch.no_grad():                                     # parameter update -> the graph is re-captured with fresh operands
+        model.weightedpool.weight.mul_(1.5)
+        model.class_embed.layers[2].bias.add_(0.25)
+    b = batch(8, 30, 10, 5)
+    same(run(b[0]["src_txt"], b[0]["src_txt_mask"], b[0]["src_vid"], b[0]["src_vid_mask"], *b[1:]), eager(*b))
+
+
 def test_bench_two_rank_control_flow(dev):
     """bench.py launched the way the driver launches N>1 (torch.distributed.run, one process per rank), with gloo and both ranks
     on cuda:0 so that it runs on a 1-GPU box: every rank must take part in every collective (an instrumented step that only
