@@ -1542,12 +1542,9 @@ static bool nt256_ok(const GemmArgs& a) {
     // at 620 / 950 of the persistent kernel's in-loop rate).  (Round 2 compared 256-row tiles only: the 8192-row text GEMMs -- 128 tiles of
     // 256 rows, half a round -- went to the 128-tile kernel at 443 TF/s although 256 tiles of 128 rows fill exactly one round.)
     const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128) * groups;
-    {   // small launches (inference batches: M = 32 x 107 rows): when even the 128 x 128 tiles do not fill the chip, both structures run ONE
-        // round and the launch time is one tile's K loop -- the 128-tile kernel's is half as long and twice as many CUs work on it
-        static const bool small_off = getenv("UVTG_NT_SMALLM_OFF") != nullptr;
-        const int cus_ = ensure_num_cu() ? 256 : eff_cus();
-        if (!small_off && t128 <= cus_) return false;
-    }
+    // (Round 4, measured and dropped -- profiles/r04_ab_small_m_heuristic.txt: sending single-round small-M launches (inference batches, M = 32 x 107
+    // rows) to the 128 x 128 kernel for twice the tile count made every inference case SLOWER -- batch 32 1.63 -> 1.70 ms, batch 1 bf16
+    // 0.65 -> 0.74 ms: its register-staged K loop is longer per tile than half a 128 x 256 tile of the LDS-DMA kernel.)
     const double c128 = (double)((t128 + 511) / 512) * 128.0 * (950.0 / 620.0);
     const bool gather_ = a.a_seg || a.o_seg || a.a_off || a.o_off || a.ktap != a.K || groups != 1 || a.o_rows || a.pos_map;
     // the SAME CU count the launch plan will use (reserved communication CUs / the experiment cap subtracted)
