@@ -201,6 +201,49 @@ def test_hl_loss_subset_production_width(dev):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("nproj,txt_pos", [(3, True), (1, False)])
+def test_boundary_options_production_width(dev, nproj, txt_pos):
+    """--n_input_proj 1 / 3 and --use_txt_pos at d = 1024, E = 4, D_v = 2818 (the persistent GEMM kernels, the wide feature LayerNorm, the
+    per-layer position-gradient GEMM) against the oracle: precise forward within 1e-5, bf16 losses / gradients (incl. the text position table
+    and its LayerNorm) in direction and norm."""
+    from oracle import univtg_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = O.make_cfg(input_dropout=0.0, droppath=0.0, dropout=0.0, n_input_proj=nproj, use_txt_pos=txt_pos, max_q_l=40)
+    params = O.init_params(cfg, seed=71)
+    inputs, tg = O.make_batch(cfg, 24, 75, 32, seed=72, ragged=True)
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(p2, cfg, **inputs)
+    lo = O.criterion(ref, tg, cfg)
+    O.total_loss(lo, cfg).backward()
+    m32, _ = build(cfg, params, dev, "fp32x3")
+    m32.eval()
+    with torch.no_grad():
+        o32 = m32(**to_dev(inputs, dev))
+    valid = inputs["src_vid_mask"].bool()
+    assert float((o32["saliency_scores"].cpu() - ref["saliency_scores"].detach())[valid].abs().max()) < 1e-5
+    for k in ("pred_logits", "pred_spans"):
+        assert float((o32[k].cpu() - ref[k].detach()).abs().max()) < 1e-5, k
+    model, crit = build(cfg, params, dev, "bf16")
+    model.eval()
+    losses = crit(model(**to_dev(inputs, dev)), to_dev(tg, dev))
+    sum(losses[k] * crit.weight_dict[k] for k in losses).backward()
+    for k in lo:
+        assert abs(float(losses[k]) - float(lo[k])) < 2e-2 * max(1.0, abs(float(lo[k]))), (k, float(losses[k]), float(lo[k]))
+    named, bad = dict(model.named_parameters()), {}
+    for k, p in p2.items():
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            continue
+        assert named[k].grad is not None, k
+        a, r = named[k].grad.cpu().double().flatten(), p.grad.double().flatten()
+        if k == "txt_position_embed.position_embeddings.weight":       # rows >= L_t are never read: zero gradient on both sides
+            assert float(a.view(-1, cfg.hidden_dim)[32:].abs().max()) == 0.0
+        cos, ratio = float((a @ r) / (a.norm() * r.norm() + 1e-30)), float(a.norm() / (r.norm() + 1e-30))
+        if cos < 0.997 or abs(ratio - 1) > (0.04 if k == "input_vid_proj.0.LayerNorm.weight" else 0.02):
+            bad[k] = (cos, ratio)
+    assert not bad, bad
+    assert ("txt_position_embed.LayerNorm.weight" in {k for k, p in p2.items() if p.grad is not None}) == txt_pos
+
+
 def test_criterion_matches_oracle_fp32(dev, golden_dir):
     """The criterion kernels alone (fp32 math) on the reference's own outputs: losses + input gradients."""
     from oracle import univtg_oracle as O
