@@ -281,6 +281,32 @@ def encoder_flops(lens, B, Lv, Lt, packed_halo):
     return alg, exe
 
 
+def quick_roofline(lib, step, batches, B, Lv, Lt, halo, k=3):
+    """Dominant-GEMM and encoder-section rooflines of `step` on `batches` (k instrumented steps each; single rank): the same event-pair
+    measurements the headline's `roofline` / `roofline_encoder` objects come from, for the companion variant."""
+    from univtg_amd import _lib
+    lib.uvtg_profile_start()
+    for i in range(k):
+        step.step(*batches[i % len(batches)])
+    ms, fl, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_longlong * 8)()
+    _lib.check(lib.uvtg_profile_stop(ms, fl, n), "uvtg_profile_stop")
+    floor = lib.uvtg_profile_event_floor_ms()
+    raw = ms[3] + floor * n[3]
+    ach = fl[3] / (raw * 1e-3) / 1e12 if raw > 0 else 0.0
+    lib.uvtg_profile_sections_start()
+    for i in range(k):
+        step.step(*batches[i % len(batches)])
+    sm, sn = (C.c_double * 4)(), (C.c_longlong * 4)()
+    _lib.check(lib.uvtg_profile_sections_stop(sm, sn), "uvtg_profile_sections_stop")
+    t_enc = max((sm[0] + sm[1]) / k * 1e-3, 1e-9)
+    lens = [bt[0]["_lens_host"] for bt in batches]
+    _, exe = encoder_flops(lens, B, Lv, Lt, halo)
+    return dict(roofline=dict(kernel="gemm_nt256_kernel", achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
+                              launches_per_step=int(n[3] // k), avg_launch_us=round(raw * 1e3 / max(1, n[3]), 2)),
+                t_encoder_ms=round(t_enc * 1e3, 3),
+                roofline_encoder=dict(achieved=round(exe / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(exe / t_enc / 2.5e15, 4)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,6 +434,8 @@ def main():
             clip_positions_per_sec_incl_padded=round(B * Lv * 30 / el, 1),
             encoder_rows_fraction=round(sum(sum(min(Lv, x + 3) for x in a) + sum(b) for a, b in lens_o) / (len(lens_o) * B * (Lv + Lt)), 4) if (packed and not other_full) else 1.0,
             executed_encoder_tflop_per_step=round(exe_o / 1e12, 3))
+        comp["variant_" + ("A" if other_full else "B")].update(quick_roofline(_lib.load(), step, ob, B, Lv, Lt, bool(packed) and not other_full,
+                                                                               max(1, args.profile_steps)))
         if not other_full and packed and not args.no_padded_compare:        # the same ragged batches through the padded executions
             for kind in ("padded", "allrows"):
                 step_p = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=False if kind == "padded" else "auto", loss_only=False)

@@ -678,15 +678,16 @@ def test_edge_shapes_vs_oracle(dev, B, Lv, Lt, d, H, ragged):
     assert worst > 0.95, worst
 
 
-@pytest.mark.parametrize("B,Lv,Lt,d,H,E", [(6, 30, 10, 256, 4, 2), (256, 75, 32, 1024, 8, 4), (3, 150, 12, 128, 2, 2), (5, 128, 32, 256, 2, 2)])
-def test_packed_ragged_stream_matches_padded(dev, B, Lv, Lt, d, H, E):
+@pytest.mark.parametrize("B,Lv,Lt,d,H,E,nproj", [(6, 30, 10, 256, 4, 2, 2), (256, 75, 32, 1024, 8, 4, 2), (3, 150, 12, 128, 2, 2, 2), (5, 128, 32, 256, 2, 2, 2),
+                                                (6, 30, 10, 256, 4, 2, 1), (6, 30, 10, 256, 4, 2, 3)])      # the compact projection with 1 / 3 blocks
+def test_packed_ragged_stream_matches_padded(dev, B, Lv, Lt, d, H, E, nproj):
     """Packed encoder stream (valid clips + ONE representative padded clip + valid text per sample, include/uvtg.h lens_host)
     against the padded execution of the same ragged batch: same outputs at every clip position (padded ones included), same
     losses, same parameter gradients up to bf16 rounding of the re-associated sums."""
     from oracle import univtg_oracle as O
     from univtg_amd.trainer import TrainStep
     cfg = O.make_cfg(hidden_dim=d, nheads=H, dim_feedforward=d, enc_layers=E, v_feat_dim=66 if d < 1024 else 2818,
-                     t_feat_dim=40 if d < 1024 else 512, max_q_l=max(Lt, 4), input_dropout=0.0, dropout=0.0, droppath=0.0)
+                     t_feat_dim=40 if d < 1024 else 512, max_q_l=max(Lt, 4), input_dropout=0.0, dropout=0.0, droppath=0.0, n_input_proj=nproj)
     params = O.init_params(cfg, seed=41)
     inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=42, ragged=True)
     ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
