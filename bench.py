@@ -485,7 +485,10 @@ def main():
         if fam[dom] == "gemm_nt256_kernel" and pmc:
             with open(pmc) as f:
                 pj = json.load(f)
-            if pj.get("kernel_src_sha") == kernel_src_sha():
+            if (pj.get("variant", "A"), pj.get("config", 2)) != (args.variant, args.config):
+                traffic_note = (f"{os.path.relpath(pmc, ROOT)} was taken on config {pj.get('config', 2)} variant {pj.get('variant', 'A')} (the default workload), "
+                                f"not on this one: not quoted")
+            elif pj.get("kernel_src_sha") == kernel_src_sha():
                 traffic = pj["traffic_bytes_per_launch"]
                 traffic_ratio = round(traffic / alg_bytes, 3) if alg_bytes else None
                 traffic_note = (f"measured by separate rocprofv3 --pmc passes of this command on these kernels ({os.path.relpath(pmc, ROOT)}, kernel source "

@@ -35,7 +35,7 @@ for cal in (f"{R}/gpurun_out/fetch_calibration.json", f"{R}/profiles/r04_fetch_c
             break
 head = open(f"{R}/tools/.git_head").read().strip() if os.path.exists(f"{R}/tools/.git_head") else "unknown"
 fb, wb = fetch * 1024 * factor, write * 1024
-js = {"kernel_src_sha": kernel_src_sha(), "git_head": head, "fetch_factor": factor, "fetch_factor_source": fsrc, "kernel": "gemm_nt256_kernel<*> (all instantiations, launch-weighted)",
+js = {"kernel_src_sha": kernel_src_sha(), "git_head": head, "config": 2, "variant": "A", "fetch_factor": factor, "fetch_factor_source": fsrc, "kernel": "gemm_nt256_kernel<*> (all instantiations, launch-weighted)",
       "command": "tools/pmc_nt256.sh: rocprofv3 --pmc <pass> --kernel-include-regex 'gemm_nt256_kernel<[^>]*false>' -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-companions --profile-steps 0  (three separate passes: FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE | SQ_*)",
       "launches_averaged": n, "per_instantiation": {k: {c: v[1] for c, v in d.items()} for k, d in {**p0}.items()},
       "FETCH_SIZE_KB_raw": round(fetch, 1), "WRITE_SIZE_KB_raw": round(write, 1),
