@@ -91,6 +91,24 @@ def test_param_table_follows_n_input_proj_and_use_txt_pos(lib, golden_dir, name)
     assert len(offs) == n + 1 and all(o % 4 == 0 for o in offs)
 
 
+def test_plain_c_consumer_links_and_runs(lib, tmp_path):
+    """include/uvtg.h is valid C99 and a program with no Python / torch / HIP headers links libuvtg.so and walks the size and parameter-table
+    queries (examples/c_abi_probe.c): the boundary is a C ABI, not a Python extension."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "c_abi_probe")
+    libdir = os.path.join(ROOT, "univtg_amd")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_probe.c"), "-o", exe,
+                        "-L" + libdir, "-luvtg", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "version 300 params 78 " in out.stdout and "n_proj=3 use_txt_pos=1 params 89" in out.stdout and "bad struct_size -> -18" in out.stdout
+
+
 def test_no_cpu_fallback(golden_dir):
     """The product refuses CPU tensors instead of silently computing elsewhere."""
     from univtg_amd.model import Model
