@@ -166,6 +166,7 @@ def _reference_is_ambiguous(cfg, params, inputs, tg, durations, b, clip_length, 
     order, keep = _oracle_tail(o64["pred_logits"].float().numpy(), o64["pred_spans"].float().numpy(), tg["timestamp"][b:b + 1].numpy(),
                                tg["timestamp_mask"][b:b + 1].numpy(), [float(durations[b])], clip_length)
     if order[0] != order32 or keep[0] != keep32:
+        print(f"   sample {b}: the fp64 oracle ranks / keeps differently from the fp32 oracle")
         return True
     l64 = o64["pred_logits"][0, :, 0]
     valid = inputs["src_vid_mask"][b].bool()
