@@ -13,7 +13,8 @@ from univtg_amd import _lib
 from univtg_amd.model import build_model
 from univtg_amd.trainer import TrainStep
 
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2
+full = "--full" in sys.argv          # SURVEY 8d variant A (all-ones masks: the round-4 headline workload)
 wl = bench.CONFIGS[cfg]
 dev = torch.device("cuda:0")
 torch.manual_seed(2018)
@@ -21,7 +22,7 @@ model, crit = build_model(bench.model_args(max_v_l=wl["L_v"]))
 model.to(dev).train(); crit.to(dev).train(); model.set_seed(2018)
 step = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed="auto")
 lens = bench.mixed_length_lens(wl["B"], seed=0) if cfg == 5 else None
-batch = bench.synth_batch(wl["B"], wl["L_v"], wl["L_t"], bench.MODEL["D_v"], bench.MODEL["D_t"], 0, dev, lens)
+batch = bench.synth_batch(wl["B"], wl["L_v"], wl["L_t"], bench.MODEL["D_v"], bench.MODEL["D_t"], 0, dev, lens, full=full)
 for _ in range(8):
     step.step(*batch)
 torch.cuda.synchronize()

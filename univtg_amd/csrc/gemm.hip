@@ -323,6 +323,10 @@ __global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = 
 // fragment reads are the bf16 kernel's; the K-tile body issues hi.hi, hi.lo, lo.hi from the four fragment sets (6 MFMA groups instead of 4 per
 // K tile: 2/3 of the LDS and staging traffic per MFMA) on v_mfma_f32_32x32x16_f16; general epilogue only, fp32 residual, exact erf GELU,
 // re-split outputs outS / outUS for the next GEMM.
+#ifndef UVTG_NT_GROUPS_MAX_TM
+#define UVTG_NT_GROUPS_MAX_TM 4      // experiment switches of the epilogue-operand prefetch (3 / 0 = the round-3 behaviour)
+#define UVTG_NT_EOP_RING 1
+#endif
 template <bool GATHER, int TM, bool EOP, int ORD, int EPI, bool HALF = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma clang fp contract(off)            // every instantiation must round the epilogue alike (the tile paths are compared bit for bit)
@@ -670,7 +674,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
-      constexpr bool GROUPS = EOP && TM < 4;      // (256-row tiles have no registers for a group in flight: direct loads at use)
+      // Epilogue operand (bf16 residual / pre-activation), one 16-byte piece per lane and q iteration.  Round 4 (tools/nt_trace.py,
+      // profiles/r04_nt_tile_phases_variantA.txt): with the piece loaded AT USE inside the rolled q loop, the 256- and 320-row tiles' epilogues
+      // were chains of 16-20 exposed load round trips -- 13-16 us per tile against 4-5 us for the same stores without an operand.  Now:
+      //   GROUPS: a whole 32-row group (4 pieces) is fetched one group ahead into the dead fragment registers (<= 192 rows since round 2;
+      //           256-row tiles with the plain row mapping since round 4: no scratch);
+      //   RING  : the heights that have no 16 registers to spare (320 rows, 256-row gather) keep TWO pieces in flight instead.  (Whole groups
+      //           behind a ring for the first one were tried for them too: 8-140 B of scratch whatever pinned the loads -- not kept.)
+      constexpr bool GROUPS = EOP && (TM < 4 || (TM == 4 && !GATHER && UVTG_NT_GROUPS_MAX_TM >= 4));
+      constexpr bool RING = EOP && !GROUPS && UVTG_NT_EOP_RING && !(TM >= 5 && EPI == 0);      // (320 rows + the general epilogue: 28 B of scratch with the ring -- stays at direct loads)
+      auto eop_piece = [&](int pc) {             // piece pc = 4 i + q of the wave's (32 TM) x 64 operand block (clamped: loaded, not used)
+        pc = min(pc, 4 * TM - 1);
+        const int m = min(m0 + wm * (32 * TM) + (pc >> 2) * 32 + (pc & 3) * 8 + (lane >> 3), p.M - 1);
+        const size_t orow = GATHER ? (size_t)map_row(m, p.o_seg, p.o_seg_stride, p.o_off) : (size_t)m;
+        return *(const u32x4*)(esrc + orow * eld + (ncol ? n : 0));
+      };
+      [[maybe_unused]] u32x4 ring0 = {0, 0, 0, 0}, ring1 = {0, 0, 0, 0};
+      if constexpr (RING) { ring0 = eop_piece(0); ring1 = eop_piece(1); }
       if (GROUPS && NPF < TM) {
 #pragma unroll
         for (int q = 0; q < 4; q++) fetch_group(NPF, q);
@@ -694,6 +714,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         for (int q = 0; q < 4; q++) {
           const u32x4 ecur = e0;
           e0 = e1; e1 = e2; e2 = e3;
+          [[maybe_unused]] u32x4 ring_cur = ring0;
+          if constexpr (RING) { ring0 = ring1; ring1 = eop_piece(4 * i + q + 2); }      // (issued on every path, before the row guard below)
           const int row = q * 8 + (lane >> 3);
           const int m = m0 + wm * (32 * TM) + i * 32 + row;
           const f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
@@ -726,6 +748,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
           }
           u32x4 eop = {0, 0, 0, 0};
           if constexpr (GROUPS) eop = ecur;
+          else if constexpr (RING) eop = ring_cur;
           else if constexpr (EOP) eop = *(const u32x4*)(esrc + orow * eld + n);
           if (EOP && (EPI == 3 || (EPI == 0 && p.actgrad && !p.residB))) {
 #pragma unroll
