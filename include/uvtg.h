@@ -174,6 +174,25 @@ int uvtg_linear_bf16(const void* A, const void* W, const float* bias, float* C, 
 int uvtg_split_f16(const float* src, void* dst, int rows, int cols, int kp, int is_weight, uvtg_stream_t stream);
 int uvtg_linear_split(const void* A, const void* W, const float* bias, float* C, int M, int N, int Kp, int act,
                       uvtg_stream_t stream);
+/* Both GEMMs with the split-K workspace uvtg_forward gives its small launches (<= half as many 128 x 256 tiles as the chip has CUs: inference
+ * batches): K is cut into <= 4 parts, one workgroup each; the parts meet through fp32 partial-tile slabs and one ticket per tile, the part that
+ * arrives last sums ALL parts in part order (bit-reproducible) and runs the epilogue.  sk_ws: uvtg_linear_sk_ws_floats() floats, 16-byte
+ * aligned; its first 256 words (the tickets) must be ZERO before the first call (the kernel leaves them zero).  Shapes that do not qualify run
+ * exactly as uvtg_linear_bf16 / uvtg_linear_split do.  uvtg_debug_nt_splitk(n): at most n parts per tile from now on (0 / 1 = never split,
+ * default 4); uvtg_debug_nt_splitk_parts: host arithmetic only, the parts an M x N x K launch (K in staged elements: 2 x real columns for split
+ * operands) would get on `cus` compute units (0 = not split). */
+long long uvtg_linear_sk_ws_floats(void);
+int uvtg_linear_bf16_sk(const void* A, const void* W, const float* bias, float* C, int M, int N, int K, int act, float* sk_ws,
+                        uvtg_stream_t stream);
+int uvtg_linear_split_sk(const void* A, const void* W, const float* bias, float* C, int M, int N, int Kp, int act, float* sk_ws,
+                         uvtg_stream_t stream);
+/* Launches of at most one 128 x 256 tile per compute unit run a single-tile variant of the persistent kernel (three-stage staging ring: the K
+ * loop of such a launch is a chain of memory round trips, not of MFMAs; results bit-identical).  uvtg_debug_nt_small(0) sends them through the
+ * persistent two-stage kernel again (parity tests / A-B measurements), 1 restores the default. */
+int uvtg_debug_nt_small(int on);
+int uvtg_debug_nt_splitk(int max_parts);
+int uvtg_debug_nt_splitk_parts(int M, int N, int K, int groups, int cus);
+int uvtg_debug_nt_small_tile(int M, int N, int K, int groups, int cus);      /* its tile: 128 = 128 x 128, 256 = 128 x 256, 0 = not a single-tile launch */
 /* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 operands, fp32 atomic accumulate), dbias[N] += colsum(dY) (may be NULL) */
 int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits,
                     uvtg_stream_t stream);

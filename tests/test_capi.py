@@ -142,6 +142,27 @@ def test_hot_kernels_resources():
         assert k["waves_per_simd"] >= 2, (k["name"], k["vgpr"])
 
 
+def test_nt_small_launch_plan(lib):
+    """Tile shape and K parts of the NT launches that fit one tile per CU (host arithmetic; the estimates behind it are fitted on
+    tools/nt_trace_infer.py): 128 x 128 tiles while they fit one per CU, else 128 x 256; a K split (<= 4 parts, >= 4 K tiles each, never
+    more workgroups than CUs, no empty part) only where the shorter K loop pays for the last arriver's fold."""
+    tile = lambda M, N, K, groups=1, cus=256: lib.uvtg_debug_nt_small_tile(M, N, K, groups, cus)
+    parts = lambda M, N, K, groups=1, cus=256: lib.uvtg_debug_nt_splitk_parts(M, N, K, groups, cus)
+    assert (tile(3424, 1024, 2048), parts(3424, 1024, 2048)) == (128, 0)        # eval batch 32 (split operands: K counts both images): 216 tiles fill the chip
+    assert (tile(3424, 1024, 1024), parts(3424, 1024, 1024)) == (128, 0)        # ... bf16
+    assert (tile(1712, 1024, 2048), parts(1712, 1024, 2048)) == (128, 2)        # batch 16: 108 tiles x 2 parts
+    assert (tile(3424, 3072, 2048), parts(3424, 3072, 2048)) == (0, 0)          # QKV at batch 32: 324 tiles of 128 x 256 -- the persistent kernel
+    assert (tile(107, 1024, 2048), parts(107, 1024, 2048)) == (128, 4)          # batch 1: 8 tiles, capped at 4 parts
+    assert parts(107, 1024, 512) == 2 and parts(107, 1024, 256) == 0            # 8 K tiles: two parts of 4; 4 K tiles: too short to split
+    assert parts(107, 1024, 64 * 9) == 2                                        # 9 K tiles: 2 parts (5 + 4), not 3 parts of 3
+    assert (tile(2400, 1024, 5760), parts(2400, 1024, 5760)) == (256, 3)        # video projection at batch 32: 76 wide tiles x 3 parts beat 152 unsplit narrow ones
+    assert (tile(2400, 1024, 2048), parts(2400, 1024, 2048)) == (128, 0)        # ... its second block (K = 1024) does not
+    assert (tile(8192, 1024, 1024), parts(8192, 1024, 1024)) == (256, 0)        # the training step's text rows: one 128 x 256 tile per CU, never split
+    assert tile(8192, 1024, 1024, cus=248) == 0                                 # ... with CUs reserved for communication: the persistent kernel
+    assert (tile(27392, 1024, 1024), parts(27392, 1024, 1024)) == (0, 0)
+    assert parts(0, 1024, 1024) < 0 and tile(0, 1024, 1024) < 0
+
+
 def test_nt_tile_height_choice(lib):
     """The persistent NT GEMM's tile-height choice is host arithmetic: pin the decisions the measured shapes rest on
     (tools/tm5_ab.sh) so that a change of the cost model shows up here, without a GPU."""

@@ -256,6 +256,58 @@ def test_nt_tile_sizes_agree(dev):
         lib.uvtg_debug_force_nt_tile(0)
 
 
+@pytest.mark.parametrize("precise", [False, True])
+def test_nt_small_launches(dev, precise):
+    """The single-tile variants of the persistent NT GEMM (launches of at most one 128 x 128 / 128 x 256 tile per CU: three-stage staging
+    ring) give the persistent kernel's results bit for bit; with a workspace, launches of <= half as many tiles as CUs (inference batches)
+    also split K: same products, the K range summed in <= 4 parts folded in part order -- within fp32 summation noise of the unsplit launch,
+    bit-reproducible from call to call (the fold does not depend on which part arrives last), tickets left zero, and every launch the rule
+    excludes unchanged."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    ws = ops.sk_workspace(dev)
+    lin = ops.linear_f32x3 if precise else ops.linear_bf16
+    g = torch.Generator().manual_seed(23)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    #       M     N     K   act  (batch 32 encoder GEMM; batch 1; the video projection's K; ragged M / N with a K tail part; text rows)
+    shapes = [(3424, 1024, 1024, 0), (107, 1024, 1024, 2), (1200, 1024, 2880 if not precise else 2816, 1), (333, 520, 1344, 0), (1024, 1024, 512, 0)]
+    try:
+        for (M, N, K, act) in shapes:
+            a = torch.randn(M, K, generator=g).to(dev)
+            w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+            b = torch.randn(N, generator=g).to(dev)
+            if not precise:
+                a, w = bf(a), bf(w)
+            ref = a.double() @ w.double().t() + b.double()
+            ref = torch.relu(ref) if act == 1 else (torch.nn.functional.gelu(ref) if act == 2 else ref)
+            tol = 2e-6 if precise else 2e-5
+            _lib.check(lib.uvtg_debug_nt_small(0))
+            persistent = lin(a, w, b, act)
+            assert relerr(persistent, ref) < tol
+            for mode in (1, 2):                                                            # 128 x 128 tiles where they fit / 128 x 256 tiles only
+                _lib.check(lib.uvtg_debug_nt_small(mode))
+                assert torch.equal(lin(a, w, b, act), persistent), (M, N, K, mode)          # the ring alone: bit-identical
+                got = lin(a, w, b, act, sk_ws=ws)
+                assert int(ws[:256].view(torch.int32).abs().sum()) == 0                   # tickets handed back zero
+                assert relerr(got, ref) < tol, (M, N, K, mode, relerr(got, ref))
+                if mode == 1:
+                    parts = lib.uvtg_debug_nt_splitk_parts(M, N, (2 if precise else 1) * ((K + 63) // 64 * 64), 1, cus)
+                    assert (parts >= 2) == (M != 3424), (M, N, K, parts)                    # 216 tiles of 128 x 128: no split
+                    assert torch.equal(got, persistent) == (parts == 0), (M, N, K)          # (a split launch DID take another summation order)
+                for _ in range(4):
+                    assert torch.equal(lin(a, w, b, act, sk_ws=ws), got), (M, N, K, mode)   # arrival order does not matter
+        # excluded launches: more tiles than CUs / the split switched off -> the unsplit results, bit for bit
+        _lib.check(lib.uvtg_debug_nt_small(1))
+        a = bf(torch.randn(20000, 1024, generator=g).to(dev)); w = bf((torch.randn(1024, 1024, generator=g) / 32).to(dev))
+        assert lib.uvtg_debug_nt_splitk_parts(20000, 1024, 1024, 1, cus) == 0
+        assert torch.equal(ops.linear_bf16(a, w), ops.linear_bf16(a, w, sk_ws=ws))
+        _lib.check(lib.uvtg_debug_nt_splitk(0))
+        assert torch.equal(ops.linear_bf16(a[:1024], w), ops.linear_bf16(a[:1024], w, sk_ws=ws))
+    finally:
+        _lib.check(lib.uvtg_debug_nt_splitk(4))
+        _lib.check(lib.uvtg_debug_nt_small(1))
+
+
 def test_nt256_tile_heights_agree(dev):
     """Every tile-height instantiation of the persistent GEMM gives identical results (same products, same K order)."""
     from univtg_amd import _lib, ops

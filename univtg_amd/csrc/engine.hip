@@ -176,6 +176,8 @@ struct WSpace {
   // until the end of the encoder backward so that the weight gradients of ALL layers can run as one launch without a reduce pass
   bf16_t *dy2L[MAXE], *dy1L[MAXE], *daL[MAXE], *dqkvL[MAXE];
   float* tnh_slabs; long long tnh_slab_floats; unsigned* tnh_tickets; int tnh_n_tickets;
+  // split-K of the forward's small NT launches (uvtg_kernels.h, GemmArgs::sk_*): partial-tile slabs + tickets (zeroed by the forward's first kernel)
+  float* sk_slab; unsigned* sk_tickets;
   size_t bytes;
   WSpace(const Dm& m, void* base, float* x0) {
     Arena a(base);
@@ -190,6 +192,7 @@ struct WSpace {
     tp_xsum = (tpos && tr) ? a.take<float>((size_t)m.Mt * d) : nullptr;
     tp_mean = tpos ? a.take<float>(m.Mt) : nullptr; tp_rstd = tpos ? a.take<float>(m.Mt) : nullptr;
     lens_dev = a.take<int>(2 * B);
+    sk_tickets = a.take<unsigned>(UVTG_SK_UNITS); sk_slab = a.take<float>((size_t)UVTG_SK_UNITS * UVTG_SK_TILE_FLOATS);
     pk.seq_start = a.take<int>(B); pk.seq_count = a.take<int>(B);
     pk.row_sample = a.take<int>(M); pk.row_src = a.take<int>(M); pk.row_pos = a.take<int>(M);
     pk.pad2pack = a.take<int>(M); pk.grad_map = a.take<int>(M); pk.kvalid = a.take<unsigned char>(M);
@@ -575,6 +578,7 @@ struct Fwd {
   // x3: split-operand launch.  The callers describe the operands in REAL columns; a split row holds two elements per real column (hi / lo
   // images interleaved in 32-column blocks, uvtg_common.h), so every K-side size and offset doubles.
   int run_gemm(GemmArgs& g, bool x3) {
+    g.sk_slab = ws.sk_slab; g.sk_tickets = ws.sk_tickets; g.sk_cap_units = UVTG_SK_UNITS;
     if (!x3) return launch_gemm_nt_bf16(g, s);
     g.K *= 2; g.ktap *= 2; g.lda *= 2; g.ldb *= 2; g.gA *= 2; g.gB *= 2;
     return launch_gemm_nt_split(g, s);
@@ -803,7 +807,7 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   {
     const bool dp = f.tr && m.c.p_path > 0.f;       // (the DropPath factors of the step are drawn by the same launch)
     TRY(launch_seq_prep(src_vid_mask, src_txt_mask, m.c.B, m.c.Lv, m.c.Lt, m.c.d, dim_t, ws.pos, ws.kvalid, f.packed ? ws.pk.vin_of : nullptr, s,
-                        dp ? ws.dps : nullptr, 2 * m.c.E * m.c.B, m.c.p_path, m.c.seed));
+                        dp ? ws.dps : nullptr, 2 * m.c.E * m.c.B, m.c.p_path, m.c.seed, ws.sk_tickets, UVTG_SK_UNITS));
   }
   TRY(f.project(0, src_vid, x0));
   if (f.packed && f.Rv < m.Mv) TRY(launch_fill_dropped_rows(x0, ws.pk, pmode == PACK_FULL, m.c.B, m.S, m.c.Lv, m.c.d, s));
@@ -1222,6 +1226,24 @@ extern "C" int uvtg_linear_split(const void* A, const void* W, const float* bias
   if (!A || !W || !C) return -20;
   GemmArgs g = gemm_base(A, 2 * Kp, W, 2 * Kp, M, N, 2 * Kp);
   g.bias = bias; g.act = act; g.outF = C; g.ldoF = N;
+  return launch_gemm_nt_split(g, (hipStream_t)st);
+}
+// the same two GEMMs with the split-K workspace the engine's forward gives its small launches: sk_ws = uvtg_linear_sk_ws_floats() floats,
+// 16-byte aligned, its first 256 words (the tickets) ZERO before the first call (the kernel leaves them zero)
+static void set_sk_ws(GemmArgs& g, float* sk_ws) {
+  g.sk_tickets = (unsigned*)sk_ws; g.sk_slab = sk_ws + UVTG_SK_UNITS; g.sk_cap_units = UVTG_SK_UNITS;
+}
+extern "C" long long uvtg_linear_sk_ws_floats(void) { return UVTG_SK_UNITS + (long long)UVTG_SK_UNITS * UVTG_SK_TILE_FLOATS; }
+extern "C" int uvtg_linear_bf16_sk(const void* A, const void* W, const float* bias, float* C, int M, int N, int K, int act, float* sk_ws, uvtg_stream_t st) {
+  if (!A || !W || !C || !sk_ws || ((uintptr_t)sk_ws & 15)) return -20;
+  GemmArgs g = gemm_base(A, K, W, K, M, N, K);
+  g.bias = bias; g.act = act; g.outF = C; g.ldoF = N; set_sk_ws(g, sk_ws);
+  return launch_gemm_nt_bf16(g, (hipStream_t)st);
+}
+extern "C" int uvtg_linear_split_sk(const void* A, const void* W, const float* bias, float* C, int M, int N, int Kp, int act, float* sk_ws, uvtg_stream_t st) {
+  if (!A || !W || !C || !sk_ws || ((uintptr_t)sk_ws & 15)) return -20;
+  GemmArgs g = gemm_base(A, 2 * Kp, W, 2 * Kp, M, N, 2 * Kp);
+  g.bias = bias; g.act = act; g.outF = C; g.ldoF = N; set_sk_ws(g, sk_ws);
   return launch_gemm_nt_split(g, (hipStream_t)st);
 }
 extern "C" int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits, uvtg_stream_t st) {

@@ -327,27 +327,45 @@ __global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = 
 #define UVTG_NT_GROUPS_MAX_TM 4      // experiment switches of the epilogue-operand prefetch (3 / 0 = the round-3 behaviour)
 #define UVTG_NT_EOP_RING 1
 #endif
-template <bool GATHER, int TM, bool EOP, int ORD, int EPI, bool HALF = false>
+// SMALL (general epilogue; TM = 2: 128 x 256 tiles, TM = 1: 128 x 128): the launches with at most one tile per CU (inference batches: M = 32 x
+// 107 rows are 108 tiles of 128 x 256, batch 1 is 4).  Such a launch leaves CUs idle while every busy one walks its whole K loop at the rate
+// operands reach ONE CU (0.9 - 1.1 us per 48 KB K tile, tools/nt_trace_infer.py), so this variant (a) has no next tile to prefetch and spends
+// its LDS on a THREE-stage ring instead: K tile t + 2 is in flight while t is multiplied (counted vmcnt: the wait at the head of a K tile
+// leaves the newest tile's pieces outstanding); (b) comes in a NARROW shape that doubles the workgroups and halves the epilogues -- same
+// products, same K order, same epilogue as every other instantiation: bit-identical results; and (c) when the launcher asks for it (p.sk > 1:
+// at most half as many tiles as CUs) runs a grid of `ntiles x p.sk` workgroups, one K range of one tile each.  The parts of a tile meet like the split parts of the hybrid weight-gradient kernel below: publish the fp32 partial (write-through,
+// the accumulator registers in lane order), take a ticket, and the part that draws the last ticket reads the OTHER parts behind one
+// agent-scope acquire, sums all of them in part order (the result does not depend on the arrival order) and runs the epilogue; nothing spins.
+template <bool GATHER, int TM, bool EOP, int ORD, int EPI, bool HALF = false, bool SMALL = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma clang fp contract(off)            // every instantiation must round the epilogue alike (the tile paths are compared bit for bit)
   static_assert(!(EPI != 0 && GATHER), "the specialised epilogues have the plain row mapping");
   static_assert(!HALF || (EPI == 0 && !EOP), "the split-operand mode uses the general epilogue without a bf16 operand");
   auto MF = [](s16x8 a, s16x8 b, f32x16 c) -> f32x16 { if constexpr (HALF) return mfma32h(a, b, c); else return mfma32(a, b, c); };
+  static_assert(!SMALL || (TM <= 2 && EPI == 0 && ORD == 0), "single-tile variant: 128 x 128 / 128 x 256 tiles, general epilogue, pieces issued at the head of a K tile");
+  static_assert(TM >= 2 || SMALL, "TM = 1 exists in the single-tile variant only");
   static_assert(EPI != 2 || !EOP, "FFN1 has no epilogue operand");
   static_assert(EPI != 3 || EOP, "the activation gradient reads its pre-activation");
   static_assert(TM < 5 || ((TM + 4 + 1) / 2 <= TM), "320-row tiles: at most one staging piece per A-fragment group of a k-step");
   constexpr bool SIMPLE = EPI != 0;
-  constexpr int TB = 256, KB = 64, TN = 2, BM = 64 * TM, PA = TM, PB = 4, NP = PA + PB;
-  constexpr int BOFF = BM * 128 > 32768 ? BM * 128 : 32768, SSTR = BOFF + 32768;      // (320-row tiles: 40 KB of A rows per stage)
+  // NARROW (the single-tile variant at TM = 1): 128 x 128 tiles, the eight waves as 4 x 2 (32 x 64 outputs each) -- as many tiles as 64 x 256
+  // ones would give, at 32 instead of 40 KB of staging per K tile (these launches are bound by operand delivery, not by the MFMAs)
+  constexpr bool NARROW = SMALL && TM == 1;
+  constexpr int TB = NARROW ? 128 : 256, KB = 64, TN = 2, WR = NARROW ? 4 : 2, BM = WR * 32 * TM, PA = BM / 64, PB = TB / 64, NP = PA + PB;
+  // (320-row tiles: 40 KB of A rows per stage; SMALL: 16 KB of A rows + 32 KB of B rows, three stages; the epilogue's 64 KB of fp32 staging
+  // then start at the head of the ring -- nothing is in flight by then)
+  constexpr int BOFF = SMALL ? BM * 128 : (BM * 128 > 32768 ? BM * 128 : 32768), SSTR = BOFF + TB * 128;
+  static_assert(!SMALL || ((NP == 6 || NP == 4) && 3 * SSTR >= 65536), "the counted wait below is written for four / six pieces per K tile");
+  using Yes = std::true_type; using No = std::false_type;
   constexpr int RT = BM > 256 ? 512 : 256;       // tile rows covered by the per-row staging tables (one thread per row)
   // epilogue-operand groups (32 rows x 64 columns = 4 x 16 B per lane each) fetched during the last K tile; the remaining ones are
   // fetched inside the epilogue one group ahead, into the registers the fragments no longer need
-  constexpr int NPF = !EOP ? 0 : (TM >= 4 ? 0 : (TM == 3 ? 1 : 2));
+  constexpr int NPF = !EOP ? 0 : (TM >= 4 ? 0 : (TM == 3 || TM == 1 ? 1 : 2));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   __shared__ float s_rs[RT];               // per-row factors (DropPath / frame mask) of the tile in its epilogue
   __shared__ int s_tab[GATHER ? 3 : 1][RT]; // GATHER: the tile rows' entries of the output-row tables (o_rows, f_rows, pos_map)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3, g = lane >> 5, l31 = lane & 31;
+  const int wm = NARROW ? wave >> 1 : wave >> 2, wn = NARROW ? wave & 1 : wave & 3, g = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + TB - 1) / TB, tiles_m = (p.M - p.m_begin + BM - 1) / BM;
   const int per_group = tiles_m * tiles_n;
   const int ntiles = per_group * p.groups;
@@ -409,16 +427,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   for (int j = 0; j < TN; j++) boff[j] = BOFF + (wn * 64 + j * 32 + l31) * 128;
 
   int tile = blockIdx.x;
+  [[maybe_unused]] int sk_part = 0;
+  int kt_begin = 0, kt_end = nk;           // this workgroup's K tiles (SMALL with p.sk > 1: one part of the tile's K range)
+  [[maybe_unused]] const int sk_parts = SMALL ? (p.sk > 1 ? p.sk : 1) : 1;
+  if constexpr (SMALL) {
+    sk_part = tile / ntiles; tile -= sk_part * ntiles;
+    const int per = (nk + sk_parts - 1) / sk_parts;
+    kt_begin = sk_part * per; kt_end = min(kt_begin + per, nk);
+    if (sk_part >= sk_parts) return;
+  }
   if (tile >= ntiles) return;
   int gz, m0, n0;
   tile_origin(tile, gz, m0, n0);
   set_offsets(gz, m0, n0);
   {
     unsigned ka, kb;
-    k_offsets(0, ka, kb);
+    k_offsets(kt_begin, ka, kb);
 #pragma unroll
     for (int i = 0; i < NP; i++) piece(smem256, ka, kb, i);
+    if constexpr (SMALL) {
+      if (kt_begin + 1 < kt_end) {
+        k_offsets(kt_begin + 1, ka, kb);
+#pragma unroll
+        for (int i = 0; i < NP; i++) piece(smem256 + SSTR, ka, kb, i);
+      }
+    }
   }
+  [[maybe_unused]] int st = 0;             // SMALL: ring stage of the K tile being multiplied
   // this lane's 8 output columns
   const int c8 = (lane & 7) * 8;
   int it = 0;
@@ -432,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int next = tile + gridDim.x;
+    const int next = SMALL ? ntiles : tile + gridDim.x;      // (SMALL: one unit per workgroup)
     int ngz = gz, nm0 = m0, nn0 = n0;
     const int n = n0 + wn * 64 + c8;
     const bool ncol = n < p.N;
@@ -472,14 +507,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 
     // ---- one K tile: barrier, fragment reads of k-step 0, then the MFMAs of every k-step cover the reads of the next one, the
     // staging pieces of the next K tile (k-steps 0, 1) and -- LAST only -- the epilogue-operand block (k-steps 2, 3) ----
-    auto ktile = [&](int kt, auto last_tag) {
+    // PREF: the K tile issues staging pieces (always, except the last two K tiles of the SMALL ring: nothing left to fetch);
+    // DRAIN (SMALL): the wait at its head is vmcnt(0) (the last K tile), else it leaves the newest six pieces (K tile kt + 1) in flight
+    auto ktile = [&](int kt, auto last_tag, auto pref_tag, auto drain_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
-      const int cur = it & 1;
-      __syncthreads();                       // vmcnt(0) + barrier: K tile `it` landed, the other stage is free
-      unsigned ka, kb;
-      k_offsets(LAST ? 0 : kt + 1, ka, kb);
-      unsigned char* sbase = smem256 + (cur ^ 1) * SSTR;
-      const unsigned char* base = smem256 + cur * SSTR;
+      constexpr bool PREF = decltype(pref_tag)::value;
+      [[maybe_unused]] constexpr bool DRAIN = decltype(drain_tag)::value;
+      static_assert(SMALL || PREF, "only the ring has K tiles without staging");
+      unsigned ka = 0, kb = 0;
+      unsigned char* sbase; const unsigned char* base;
+      if constexpr (SMALL) {
+        if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // K tile kt landed (this wave's pieces; the barrier covers the others')
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();        // ... and every wave is done reading the stage K tile kt + 2 goes to
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PREF) k_offsets(kt + 2, ka, kb);
+        sbase = smem256 + (st >= 1 ? st - 1 : 2) * SSTR;
+        base = smem256 + st * SSTR;
+      } else {
+        const int cur = it & 1;
+        __syncthreads();                       // vmcnt(0) + barrier: K tile `it` landed, the other stage is free
+        k_offsets(LAST ? 0 : kt + 1, ka, kb);
+        sbase = smem256 + (cur ^ 1) * SSTR;
+        base = smem256 + cur * SSTR;
+      }
       if constexpr (LAST) {
         // row factor of tile row (tid & 255), fetched under the last K tile: in the epilogue the lookup -- two DEPENDENT loads per
         // q iteration, rowscale[row_sample[m]] -- was a latency chain of its own (8.5-10 us epilogues with DropPath vs 5 without).
@@ -507,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         auto rdA = [&](int i, int q) { return *(const s16x8*)(base + aoff[i] + (((2 * q + g) ^ swz) << 4)); };
         auto rdB = [&](int j, int q) { return *(const s16x8*)(base + boff[j] + (((2 * q + g) ^ swz) << 4)); };
         s16x8 ah[TM], al[TM], bh[2][TN], bl[TN];
-        if (ORD == 0) {
+        if (PREF && ORD == 0) {
 #pragma unroll
           for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
         }
@@ -596,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         sgb_sb<0, TM, TN, false, 0>();
       } else {
       s16x8 fa[2][TM], fb[2][TN];
-      if (ORD == 0) {
+      if (PREF && ORD == 0) {
 #pragma unroll
         for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
       }
@@ -633,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       }
       // pin the software pipeline the source expresses (hipcc otherwise sinks every fragment read next to its MFMAs and moves the
       // pieces to the head): R reads up front; per k-step (MFMA, read) pairs, then the VMEM issues two at a time between MFMAs
-      if (ORD == 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+      if (PREF && ORD == 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
       sgb_kstep<Mf, R, true, G0>();
       sgb_kstep<Mf, R, true, G1>();
@@ -641,19 +694,95 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       sgb_kstep<Mf, R, false, LAST ? E3 : 0>();
       }
       it++;
+      if constexpr (SMALL) st = st == 2 ? 0 : st + 1;
     };
+    if constexpr (SMALL) {
+      int kt = kt_begin;
+      for (; kt + 2 < kt_end; kt++) {
+        ktile(kt, No{}, Yes{}, No{});
 #ifdef UVTG_NT_TRACE
-    for (int kt = 0; kt + 1 < nk; kt++) { ktile(kt, std::false_type{}); if (kt == 0) NT_STAMP(1); }
+        if (kt == kt_begin) NT_STAMP(1);
+#endif
+      }
+      if (kt + 1 < kt_end) { ktile(kt, No{}, No{}, No{}); kt++; }
+      ktile(kt, Yes{}, No{}, Yes{});
+    } else {
+#ifdef UVTG_NT_TRACE
+    for (int kt = kt_begin; kt + 1 < kt_end; kt++) { ktile(kt, No{}, Yes{}, Yes{}); if (kt == kt_begin) NT_STAMP(1); }
 #else
-    for (int kt = 0; kt + 1 < nk; kt++) ktile(kt, std::false_type{});
+    for (int kt = kt_begin; kt + 1 < kt_end; kt++) ktile(kt, No{}, Yes{}, Yes{});
 #endif
     // last K tile of this output tile: the pieces now belong to K tile 0 of the next tile (or, without one, re-load this tile's)
     if (next < ntiles) tile_origin(next, ngz, nm0, nn0);
     set_offsets(ngz, nm0, nn0);
-    ktile(nk - 1, std::true_type{});
+    ktile(kt_end - 1, Yes{}, Yes{}, Yes{});
+    }
     NT_STAMP(2);
+    [[maybe_unused]] bool sk_last = true;
+    if constexpr (SMALL) if (sk_parts > 1) {
+      // lane-order image of the accumulators: float4 group (i, j, r4) of wave w at floats ((w * TM * TN * 4 + (i * TN + j) * 4 + r4) * 64 + lane) * 4
+      constexpr int TILE_F = BM * TB;
+      const unsigned vo = (unsigned)lane * 16u;
+      const int wbase = wave * (TM * TN * 4);
+      {
+        float* slab = p.sk_slab + ((size_t)tile * sk_parts + sk_part) * TILE_F;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, TILE_F * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+              const f32x4 v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo, (wbase + (i * TN + j) * 4 + r4) * 1024, 16);      // aux 16 = sc1: write-through
+            }
+      }
+      __shared__ unsigned s_ticket;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores (and the dead prefetch) ...
+      __syncthreads();                                        // ... before ONE lane takes the ticket
+      if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.sk_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      sk_last = s_ticket == (unsigned)(sk_parts - 1);
+      if (sk_last) {
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines of the other parts' slabs
+          __hip_atomic_store(p.sk_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the tickets are left zero for the next launch
+        }
+        __syncthreads();
+        // Sum of ALL parts in part order, this part's term from its registers: the other (<= 3) slabs of each 32 x 32 accumulator block are
+        // fetched branch-free -- an absent part (o >= sk) and the own one read through an EMPTY buffer resource (out-of-range loads return
+        // zero without touching memory) -- so the loads of all blocks are in flight together (one round trip, not one per part).
+        const int S = sk_parts;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            u32x4 buf[4][4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+              const bool fetch = o < S && o != sk_part;
+              const float* os = p.sk_slab + ((size_t)tile * S + (fetch ? o : 0)) * TILE_F;
+              const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)os, 0, fetch ? TILE_F * 4 : 0, 0x00020000);
+#pragma unroll
+              for (int r4 = 0; r4 < 4; r4++) buf[o][r4] = __builtin_amdgcn_raw_buffer_load_b128(ro, vo, (wbase + (i * TN + j) * 4 + r4) * 1024, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              float sum = 0.f;
+#pragma unroll
+              for (int o = 0; o < 4; o++) {
+                const float x = o == sk_part ? acc[i][j][r] : __uint_as_float(buf[o][r >> 2][r & 3]);
+                sum = o == 0 ? x : (o < S ? sum + x : sum);
+              }
+              acc[i][j][r] = sum;
+            }
+          }
+      }
+    }
     // ---------------- epilogue of `tile`, out of the stage consumed last ----------------
-    if (p.act >= 100 && p.act <= 103) {   // measurement aid: main loop only (101-103: latency probes of the measurement build)
+    if (SMALL && !sk_last) {
+      // (the tile's sums are some other part's to finish)
+    } else if (p.act >= 100 && p.act <= 103) {   // measurement aid: main loop only (101-103: latency probes of the measurement build)
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; i++)
@@ -672,7 +801,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       if (tid < RT) s_rs[tid] = rs_reg;
       if constexpr (GATHER) { if (tid < RT) { s_tab[0][tid] = tab_reg[0]; s_tab[1][tid] = tab_reg[1]; s_tab[2][tid] = tab_reg[2]; } }
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
-      float* wbuf = (float*)(smem256 + ((it - 1) & 1) * SSTR) + wave * 2048;    // [32][64] fp32, wave-private
+      float* wbuf = (float*)(smem256 + (SMALL ? 0 : ((it - 1) & 1) * SSTR)) + wave * 2048;    // [32][64] fp32, wave-private
       const float cs = (n < p.colscale_n) ? p.colscale : 1.0f;
       // Epilogue operand (bf16 residual / pre-activation), one 16-byte piece per lane and q iteration.  Round 4 (tools/nt_trace.py,
       // profiles/r04_nt_tile_phases_variantA.txt): with the piece loaded AT USE inside the rolled q loop, the 256- and 320-row tiles' epilogues
@@ -1707,6 +1836,82 @@ template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int gri
 #undef NT256_GO
   return 0;
 }
+// single-tile instantiations (SMALL: 128-row tiles, three-stage ring, optional split-K, general epilogue): bf16 with / without the bf16
+// epilogue operand, split operands
+template <int TM> static int launch_nt256_small(const GemmArgs& b, int grid, bool gather, bool eop, bool half, hipStream_t s) {
+  constexpr int smem = TM == 1 ? 3 * 32768 : 3 * 49152;       // three stages of 128 x 128 / 128 x 256 operand rows
+  static bool attr = false;
+#define NTSK_ATTR(G, E, H) if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<G, TM, E, 0, 0, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+  if (!attr) {
+    NTSK_ATTR(false, false, false) NTSK_ATTR(false, true, false) NTSK_ATTR(true, false, false) NTSK_ATTR(true, true, false)
+    NTSK_ATTR(false, false, true) NTSK_ATTR(true, false, true)
+    attr = true;
+  }
+#undef NTSK_ATTR
+#define NTSK_GO(G, E, H) hipLaunchKernelGGL((gemm_nt256_kernel<G, TM, E, 0, 0, H, true>), dim3(grid), dim3(512), smem, s, b)
+  if (half) { if (eop) return -6; if (gather) NTSK_GO(true, false, true); else NTSK_GO(false, false, true); }
+  else if (gather) { if (eop) NTSK_GO(true, true, false); else NTSK_GO(true, false, false); }
+  else { if (eop) NTSK_GO(false, true, false); else NTSK_GO(false, false, false); }
+#undef NTSK_GO
+  return 0;
+}
+// Parts per tile of a small launch (0 = no split).  The K loop of a 128-row tile is a latency chain of ~1.2-1.5 us per K tile whatever the
+// chip does besides, and the last arriver folds `parts` slabs of 128 KB alone (~2 us each from L2 / Infinity Cache): K-loop time / parts +
+// fold time x parts has its minimum near 4 at the encoder's K, so: at most g_nt_splitk_max (4) parts, at least 4 K tiles each, never more
+// workgroups than CUs (every part must be resident with the others only for SPEED -- nothing waits).
+static int g_nt_splitk_max = -1;
+static int g_nt_small = -1;          // the single-tile (three-stage ring) variant for launches of at most one tile per CU: 1 on (default), 0 off
+extern "C" int uvtg_debug_nt_small(int on) { if (on < 0 || on > 2) return -21; g_nt_small = on; return 0; }       // (2: 128-row tiles only)
+extern "C" int uvtg_debug_nt_splitk(int max_parts) { if (max_parts < 0 || max_parts > 4) return -21; g_nt_splitk_max = max_parts; return 0; }
+static int nt256_splitk_parts(long long tiles, int nk, int cus, int cap_units) {
+  if (g_nt_splitk_max < 0) g_nt_splitk_max = getenv("UVTG_NT_SPLITK_MAX") ? atoi(getenv("UVTG_NT_SPLITK_MAX")) : 4;
+  if (g_nt_splitk_max < 2 || tiles < 1 || tiles * 2 > cus || tiles > cap_units) return 0;
+  long long parts = cus / tiles;
+  if (parts > g_nt_splitk_max) parts = g_nt_splitk_max;
+  if (parts > 4) parts = 4;                   // (the kernel's fold holds at most 4 parts)
+  if (parts > nk / 4) parts = nk / 4;
+  if (parts * tiles > cap_units) parts = cap_units / tiles;
+  if (parts < 2) return 0;
+  const int per = cdiv(nk, (int)parts);
+  parts = cdiv(nk, per);                      // no empty part
+  return parts >= 2 ? (int)parts : 0;
+}
+// Tile shape (tm = 1: 128 x 128, tm = 2: 128 x 256) and K parts of a launch that fits one tile per CU; {0, 0}: not such a launch.  Narrow
+// tiles put twice the workgroups on a chip the launch cannot fill anyway, halve every epilogue and stage 32 instead of 48 KB per K tile; a K
+// split shortens the serial K loop, but its last arriver publishes, waits for a ticket and folds alone.  Estimated microseconds, fitted on
+// tools/nt_trace_infer.py at batch 1 / 32 (profiles/r04_nt_small_tile_phases.txt; split operands): K tile 0.68 / 1.10 us, epilogue 4 / 7 us,
+// split: + 3 + 0.7 x parts / + 7 + 1.5 x parts for the part that finishes the tile.  The choice needs to be right only where the candidates
+// differ by more than noise: batch 32 encoder GEMMs (216 narrow tiles, no split: 29 us against 39 for 108 wide ones x 2 parts), batch 32
+// video projection (K = 2880: 76 wide tiles x 3 parts: 52 us against 68 for 152 unsplit narrow ones), batch 1 (8 narrow tiles x 4 parts).
+struct SmallPlan { int tm, parts; };
+#ifndef UVTG_NT_SMALL_TK1
+#define UVTG_NT_SMALL_TK1 0.68
+#endif
+static long long nt_small_tiles(int rows, int N, int groups, int tm) {
+  return (long long)cdiv(rows, 128) * cdiv(N, tm == 1 ? 128 : 256) * groups;
+}
+static SmallPlan nt256_small_plan(int rows, int N, int groups, int nk, int cus, int cap_units, bool have_ws, int mode) {
+  SmallPlan best{0, 0}; double bc = 1e30;
+  for (int tm = 1; tm <= 2; tm++) {                     // 1: 128 x 128 tiles, 2: 128 x 256
+    if (tm == 1 && mode == 2) continue;                 // (experiment switch: 128 x 256 tiles only)
+    const long long tiles = nt_small_tiles(rows, N, groups, tm);
+    if (tiles > cus) continue;
+    int parts = have_ws ? nt256_splitk_parts(tiles, nk, cus, cap_units) : 0;
+    if (parts < 2) parts = 1;
+    const double cost = cdiv(nk, parts) * (tm == 1 ? UVTG_NT_SMALL_TK1 : 1.10) + (tm == 1 ? 4.0 : 7.0) + (parts > 1 ? (tm == 1 ? 3.0 + 0.7 * parts : 7.0 + 1.5 * parts) : 0.0);
+    if (cost < bc) { bc = cost; best = SmallPlan{tm, parts}; }
+  }
+  return best;
+}
+extern "C" int uvtg_debug_nt_splitk_parts(int M, int N, int K, int groups, int cus) {       // host arithmetic only (tests): parts a launch of this shape would get
+  if (M <= 0 || N <= 0 || K < 64 || groups <= 0 || cus <= 0) return -20;
+  const SmallPlan sp = nt256_small_plan(M, N, groups, K / 64, cus, UVTG_SK_UNITS, true, 1);
+  return sp.parts > 1 ? sp.parts : 0;
+}
+extern "C" int uvtg_debug_nt_small_tile(int M, int N, int K, int groups, int cus) {         // ... and its tile width (128: 128 x 128, 256: 128 x 256; 0: not a single-tile launch)
+  if (M <= 0 || N <= 0 || K < 64 || groups <= 0 || cus <= 0) return -20;
+  return 128 * nt256_small_plan(M, N, groups, K / 64, cus, UVTG_SK_UNITS, true, 1).tm;
+}
 // Staging order per tile height (TM = 2, 3, 4, 5; the 320-row tiles were only measured interleaved).  Measured on the whole training step (tools/ord_ab.sh, same box, two rounds): the
 // interleaved order wins 5-10 % on the bare main loop at every height (tools/nt_ab.py) but only the 256-row tiles keep a gain once the
 // real epilogues run (conv / K = 3072 launches -7 %); 192-row tiles LOSE 3 % (their K tile has 24 MFMAs to cover the same pieces), so
@@ -1768,14 +1973,27 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
     b.m_begin = part == 0 ? 0 : plan.rows1;
     b.M = (part == 0 && plan.rows1) ? plan.rows1 : M_all;
     const int rows = b.M - b.m_begin;
-    const long long tiles = (long long)cdiv(rows, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
-    const int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
+    long long tiles = (long long)cdiv(rows, 64 * best_tm) * cdiv(b.N, 256) * b.groups;
+    int grid = (int)(tiles < eff_cus() ? tiles : eff_cus());
+    // At most one tile per CU: the single-tile variant (three-stage ring; bit-identical results) -- 128 x 128 tiles while those still fit
+    // one per CU, and cut along K too where the caller gave the launch a workspace and the tiles leave half the chip idle and the shorter K
+    // loop pays for the fold (nt256_small_plan; b.sk = parts per tile, 0 = the persistent kernel).
+    b.sk = 0;
+    int small_tm = 0;
+    if (g_nt_small < 0) g_nt_small = getenv("UVTG_NT_SMALL_OFF") ? 0 : (getenv("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
+    if (g_nt_small && !plan.rows1 && best_tm == 2 && tiles <= eff_cus() && !g_force_tile && !g_force_bm && !(b.act >= 100 && b.act <= 103)) {
+      const SmallPlan sp = nt256_small_plan(rows, b.N, b.groups, b.K / 64, eff_cus(), b.sk_cap_units, b.sk_slab && b.sk_tickets, g_nt_small);
+      small_tm = sp.tm; b.sk = sp.parts;
+      tiles = nt_small_tiles(rows, b.N, b.groups, small_tm);
+      grid = (int)tiles * b.sk;
+    }
 #ifdef UVTG_NT_TRACE
-    nt_trace_launch(b, best_tm, grid, gather, eop, s);
+    nt_trace_launch(b, small_tm ? small_tm : best_tm, grid, gather, eop, s);
 #endif
+
     if (half) {       // split-operand launch: family 1, ALGORITHMIC flops (one product per element; the kernel runs three MFMA segments)
       uvtg_prof_begin_launch(1, 1.0 * rows * b.N * b.K * b.groups, s);       // (K counts both images: 2 M N K / 2)
-      rc = best_tm == 5 ? launch_nt256_half<5>(b, grid, gather, s) : best_tm == 4 ? launch_nt256_half<4>(b, grid, gather, s)
+      rc = small_tm == 1 ? launch_nt256_small<1>(b, grid, gather, eop, true, s) : small_tm == 2 ? launch_nt256_small<2>(b, grid, gather, eop, true, s) : best_tm == 5 ? launch_nt256_half<5>(b, grid, gather, s) : best_tm == 4 ? launch_nt256_half<4>(b, grid, gather, s)
          : (best_tm == 3 ? launch_nt256_half<3>(b, grid, gather, s) : launch_nt256_half<2>(b, grid, gather, s));
       uvtg_prof_end_launch(1, s);
       continue;
@@ -1788,7 +2006,8 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
       by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0));
       uvtg_prof_add_bytes(3, by);
     }
-    if (nt_order(best_tm) == 0)
+    if (small_tm) rc = small_tm == 1 ? launch_nt256_small<1>(b, grid, gather, eop, false, s) : launch_nt256_small<2>(b, grid, gather, eop, false, s);
+    else if (nt_order(best_tm) == 0)
       rc = best_tm == 5 ? launch_nt256_tm<5, 0>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
     else
       rc = best_tm == 5 ? launch_nt256_tm<5, 1>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 1>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 1>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 1>(b, grid, gather, eop, epi, s));

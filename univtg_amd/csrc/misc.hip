@@ -13,9 +13,11 @@ namespace {
 // dps (optional): the n_dp = 2 E B DropPath factors of the step, drawn by the first blocks of this launch (was its own 5 us launch)
 __global__ void seq_prep_kernel(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
                                 const float* dim_t, float* pos, unsigned char* kvalid, const int* skip,
-                                float* dps, int n_dp, float p_path, unsigned long long seed) {
+                                float* dps, int n_dp, float p_path, unsigned long long seed, unsigned* zero_words, int n_zero) {
   const int row = blockIdx.x;             // (b, t) over B*Lv
   const int b = row / Lv, t = row % Lv;
+  if (row == 0 && zero_words)             // (the split-K tickets of the forward's small GEMMs: zero whatever an aborted call left behind)
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
   if (dps) {
     const int i = row * blockDim.x + threadIdx.x;
     if (i < n_dp) {
@@ -1084,12 +1086,12 @@ int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S,
 }
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
                     const float* dim_t, float* pos, unsigned char* kvalid, const int* skip, hipStream_t s,
-                    float* dps, int n_dp, float p_path, unsigned long long seed) {
+                    float* dps, int n_dp, float p_path, unsigned long long seed, unsigned* zero_words, int n_zero) {
   if (dps && (long long)B * Lv * 256 < n_dp) {        // (never at real shapes: the grid has B * Lv blocks of 256 threads)
     if (int e = launch_droppath_scales(dps, n_dp / B, B, p_path, seed, s)) return e;
     dps = nullptr;
   }
-  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, skip, dps, n_dp, p_path, seed);
+  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, skip, dps, n_dp, p_path, seed, zero_words, n_zero);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

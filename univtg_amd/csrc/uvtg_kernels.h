@@ -49,7 +49,15 @@ struct GemmArgs {
   // as above, plus outS / outUS: the value (/ value + pos) re-split (x sscale) for the next GEMM, row m at outS[m * ldoS + split_col(n)].
   float accscale;
   unsigned short* outS; unsigned short* outUS; int ldoS; float sscale;
+  // ---- split-K of small launches (persistent 256-wide kernel, 128-row tiles): when a launch has at most half as many tiles as the chip has
+  // CUs, its launcher may cut K into `sk` parts (one workgroup each): every part publishes its fp32 partial tile to sk_slab (write-through),
+  // takes a ticket, and the part that draws the last one sums ALL parts in part order (bit-reproducible) and runs the epilogue.  The caller
+  // provides sk_slab (sk_cap_units x 128 x 256 floats) and sk_tickets (sk_cap_units words, ZERO before the launch; the kernel leaves them zero);
+  // null = never split.  `sk` is set by the launcher.
+  float* sk_slab; unsigned* sk_tickets; int sk_cap_units; int sk;
 };
+constexpr int UVTG_SK_UNITS = 256;                 // capacity the engine's workspace provides
+constexpr int UVTG_SK_TILE_FLOATS = 128 * 256;
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s);
 int launch_gemm_nt_split(const GemmArgs& a, hipStream_t s);
 
@@ -209,7 +217,8 @@ int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S,
 int launch_ragged_to_padded(const void* packed, int src_bf16, const int* offsets, int B, int Lmax, int D, float* out, float* mask, hipStream_t s);
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
                     const float* dim_t, float* pos, unsigned char* kvalid, const int* skip /* [B*Lv], < 0: row not needed; may be NULL */, hipStream_t s,
-                    float* dps = nullptr, int n_dp = 0, float p_path = 0.f, unsigned long long seed = 0 /* optional: also draw the DropPath factors */);
+                    float* dps = nullptr, int n_dp = 0, float p_path = 0.f, unsigned long long seed = 0 /* optional: also draw the DropPath factors */,
+                    unsigned* zero_words = nullptr, int n_zero = 0 /* optional: words the launch zeroes (split-K tickets) */);
 int launch_droppath_scales(float* scales, int n_layers2, int B, float p, unsigned long long seed, hipStream_t s);
 int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
 int launch_cast_f32(const bf16_t* src, float* dst, long long n, hipStream_t s);

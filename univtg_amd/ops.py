@@ -24,12 +24,21 @@ def to_bf16_bits(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def linear_bf16(a_bf16, w_bf16, bias=None, act=0):
-    """C = act(A W^T + b): A [M,K] bf16, W [N,K] bf16 -> fp32 [M,N]."""
+def sk_workspace(device) -> torch.Tensor:
+    """Split-K workspace of the small-launch GEMM entry points (tickets zeroed; include/uvtg.h: uvtg_linear_*_sk)."""
+    return torch.zeros(int(_lib.load().uvtg_linear_sk_ws_floats()), device=device)
+
+
+def linear_bf16(a_bf16, w_bf16, bias=None, act=0, sk_ws=None):
+    """C = act(A W^T + b): A [M,K] bf16, W [N,K] bf16 -> fp32 [M,N].  sk_ws (sk_workspace()): small launches may split K."""
     _need_cuda(a_bf16)
     M, K = a_bf16.shape
     N = w_bf16.shape[0]
     out = torch.empty(M, N, device=a_bf16.device)
+    if sk_ws is not None:
+        _lib.check(_lib.load().uvtg_linear_bf16_sk(_ptr(a_bf16.contiguous()), _ptr(w_bf16.contiguous()), _ptr(bias), _ptr(out),
+                                                   M, N, K, act, _ptr(sk_ws), _stream()), "uvtg_linear_bf16_sk")
+        return out
     _lib.check(_lib.load().uvtg_linear_bf16(_ptr(a_bf16.contiguous()), _ptr(w_bf16.contiguous()), _ptr(bias), _ptr(out),
                                             M, N, K, act, _stream()), "uvtg_linear_bf16")
     return out
@@ -46,7 +55,7 @@ def split_f16(x, is_weight=False):
     return out
 
 
-def linear_f32x3(a, w, bias=None, act=0):
+def linear_f32x3(a, w, bias=None, act=0, sk_ws=None):
     """nn.Linear in the precise arithmetic: fp32 operands -> fp16 hi | lo images -> three-product split GEMM (uvtg_linear_split)."""
     _need_cuda(a)
     a, w = _f32c(a), _f32c(w)
@@ -54,6 +63,10 @@ def linear_f32x3(a, w, bias=None, act=0):
     N = w.shape[0]
     sa, sw = split_f16(a, False), split_f16(w, True)
     out = torch.empty(M, N, device=a.device)
+    if sk_ws is not None:
+        _lib.check(_lib.load().uvtg_linear_split_sk(_ptr(sa), _ptr(sw), _ptr(bias), _ptr(out), M, N, sa.shape[1] // 2, act, _ptr(sk_ws), _stream()),
+                   "uvtg_linear_split_sk")
+        return out
     _lib.check(_lib.load().uvtg_linear_split(_ptr(sa), _ptr(sw), _ptr(bias), _ptr(out), M, N, sa.shape[1] // 2, act, _stream()), "uvtg_linear_split")
     return out
 
