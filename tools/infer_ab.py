@@ -1,4 +1,4 @@
-"""eager inference call timing (default precision and bf16) at batch 1 / 32 / 64, for in-box A/Bs of launch heuristics (env switches)"""
+"""eager inference call timing (default precision and bf16) at batch 1 / 32 / 64 (INFER_AB_BATCHES, INFER_AB_PRECS), for in-box A/Bs of launch heuristics (env switches)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -7,8 +7,10 @@ from univtg_amd import ops
 from univtg_amd.model import build_model
 dev = torch.device("cuda:0")
 res = []
-for B, Dv in ((1, 514), (32, 2818), (64, 2818)):
-    for prec in ("auto", "bf16"):
+BATCHES = [int(b) for b in os.environ.get("INFER_AB_BATCHES", "1,32,64").split(",")]
+PRECS = os.environ.get("INFER_AB_PRECS", "auto,bf16").split(",")
+for B, Dv in [(b, 514 if b == 1 else 2818) for b in BATCHES]:
+    for prec in PRECS:
         torch.manual_seed(2018)
         model, _ = build_model(bench.model_args(max_v_l=75, v_feat_dim=Dv, precision=prec))
         model.to(dev).eval()

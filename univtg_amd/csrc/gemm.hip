@@ -764,7 +764,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
               const float* os = p.sk_slab + ((size_t)tile * S + (fetch ? o : 0)) * TILE_F;
               const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)os, 0, fetch ? TILE_F * 4 : 0, 0x00020000);
 #pragma unroll
-              for (int r4 = 0; r4 < 4; r4++) buf[o][r4] = __builtin_amdgcn_raw_buffer_load_b128(ro, vo, (wbase + (i * TN + j) * 4 + r4) * 1024, 0);
+              for (int r4 = 0; r4 < 4; r4++)         // (aux 17 = sc0 | sc1: system-scope loads -- served beyond the L2, whatever an earlier launch left there)
+                buf[o][r4] = __builtin_amdgcn_raw_buffer_load_b128(ro, vo, (wbase + (i * TN + j) * 4 + r4) * 1024, 17);
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -1865,7 +1866,8 @@ extern "C" int uvtg_debug_nt_small(int on) { if (on < 0 || on > 2) return -21; g
 extern "C" int uvtg_debug_nt_splitk(int max_parts) { if (max_parts < 0 || max_parts > 4) return -21; g_nt_splitk_max = max_parts; return 0; }
 static int nt256_splitk_parts(long long tiles, int nk, int cus, int cap_units) {
   if (g_nt_splitk_max < 0) g_nt_splitk_max = getenv("UVTG_NT_SPLITK_MAX") ? atoi(getenv("UVTG_NT_SPLITK_MAX")) : 4;
-  if (g_nt_splitk_max < 2 || tiles < 1 || tiles * 2 > cus || tiles > cap_units) return 0;
+  static const int max_tiles = getenv("UVTG_NT_SPLITK_MAX_TILES") ? atoi(getenv("UVTG_NT_SPLITK_MAX_TILES")) : 1 << 30;      // experiment: no split above this many tiles
+  if (g_nt_splitk_max < 2 || tiles < 1 || tiles * 2 > cus || tiles > cap_units || tiles > max_tiles) return 0;
   long long parts = cus / tiles;
   if (parts > g_nt_splitk_max) parts = g_nt_splitk_max;
   if (parts > 4) parts = 4;                   // (the kernel's fold holds at most 4 parts)
