@@ -190,6 +190,9 @@ int uvtg_linear_split_sk(const void* A, const void* W, const float* bias, float*
  * loop of such a launch is a chain of memory round trips, not of MFMAs; results bit-identical).  uvtg_debug_nt_small(0) sends them through the
  * persistent two-stage kernel again (parity tests / A-B measurements), 1 restores the default. */
 int uvtg_debug_nt_small(int on);
+/* Persistent NT kernel, plain row mapping: bit (rows / 64 - 2) of `mask` = the staging pieces of tile height 128 / 192 / 256 are issued by one
+ * wave per SIMD for both waves of that SIMD ("loader waves"; default 7; results bit-identical either way -- parity tests / A-B measurements). */
+int uvtg_debug_nt_loader_waves(int mask);
 int uvtg_debug_nt_splitk(int max_parts);
 int uvtg_debug_nt_splitk_parts(int M, int N, int K, int groups, int cus);
 int uvtg_debug_nt_small_tile(int M, int N, int K, int groups, int cus);      /* its tile: 128 = 128 x 128, 256 = 128 x 256, 0 = not a single-tile launch */

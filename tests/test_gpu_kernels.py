@@ -308,6 +308,30 @@ def test_nt_small_launches(dev, precise):
         _lib.check(lib.uvtg_debug_nt_small(1))
 
 
+def test_nt_loader_waves_bit_identical(dev):
+    """Staging by one wave per SIMD ("loader waves", the default at tile heights 128 - 256) and by every wave for itself give the same bits:
+    same LDS image, same products, same K order (every specialised epilogue the kernel-level entry point reaches, every height)."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(41)
+    try:
+        _lib.check(lib.uvtg_debug_force_nt_tile(256))
+        for (M, N, K, act) in [(19850, 1024, 1024, 0), (5000, 3080, 192, 1), (9000, 520, 1024, 2)]:
+            a = bf(torch.randn(M, K, generator=g).to(dev))
+            w = bf((torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev))
+            b = torch.randn(N, generator=g).to(dev)
+            for bm in (128, 192, 256):
+                _lib.check(lib.uvtg_debug_force_nt_bm(bm))
+                _lib.check(lib.uvtg_debug_nt_loader_waves(0))
+                own = ops.linear_bf16(a, w, b, act)
+                _lib.check(lib.uvtg_debug_nt_loader_waves(7))
+                assert torch.equal(ops.linear_bf16(a, w, b, act), own), (M, N, K, bm)
+    finally:
+        lib.uvtg_debug_nt_loader_waves(7)
+        lib.uvtg_debug_force_nt_bm(0)
+        lib.uvtg_debug_force_nt_tile(0)
+
+
 def test_nt256_tile_heights_agree(dev):
     """Every tile-height instantiation of the persistent GEMM gives identical results (same products, same K order)."""
     from univtg_amd import _lib, ops

@@ -169,6 +169,45 @@ def test_losses_and_grads_match_reference(dev, golden_dir, name):
     assert {k for k, p in named.items() if p.grad is None} <= set(meta["no_grad_params"])
 
 
+def test_nt_loader_waves_do_not_change_the_train_step(dev):
+    """The persistent NT GEMM's staging by one wave per SIMD (default) against every wave staging for itself, through a whole bf16 train-mode
+    forward + criterion + backward at production width (the specialised bf16 / FFN / GELU' epilogues only the engine reaches; B = 192 puts
+    the launches on 128 - 256-row tiles of the persistent kernel): outputs bit for bit, and every parameter gradient that is bit-stable from
+    run to run."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import _lib
+    lib = _lib.load()
+    cfg = O.make_cfg(input_dropout=0.5, droppath=0.1, dropout=0.1)
+    params = O.init_params(cfg, seed=61)
+    inputs, tg = O.make_batch(cfg, 192, 75, 32, seed=62, ragged=True, curve=True)
+    ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    res = []
+    try:
+        for mask in (0, 0, 7):
+            _lib.check(lib.uvtg_debug_nt_loader_waves(mask))
+            model, crit = build(cfg, params, dev, "bf16", proj_precise=False)
+            model.train(); crit.train(); model.set_seed(77)
+            out = model(**ind)
+            ld = crit(out, tgd)
+            sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
+            res.append(({k: out[k].detach().clone() for k in ("pred_logits", "pred_spans", "saliency_scores")},
+                        {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        lib.uvtg_debug_nt_loader_waves(7)
+    for k, v in res[0][0].items():
+        assert torch.equal(v, res[2][0][k]), k
+    # gradients: whatever is bit-stable from run to run of the SAME build (everything but the sums that meet through fp32 atomics: LayerNorm
+    # gamma / beta and the like) must not move either
+    stable = [k for k, v in res[0][1].items() if torch.equal(v, res[1][1][k])]
+    assert len(res[0][1]) > 70 and len(stable) >= 40, (len(res[0][1]), len(stable))
+    assert any(k.endswith("linear1.weight") for k in stable) and any("in_proj_weight" in k for k in stable)
+    for k, v in res[0][1].items():
+        if k in stable:
+            assert torch.equal(v, res[2][1][k]), k
+        else:
+            assert float((v - res[2][1][k]).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-9, k
+
+
 def test_hl_loss_subset_production_width(dev):
     """dset_type 'hl' / 'vs' (losses = labels + saliency, model/univtg.py:439-440) at d = 1024, E = 4 against the oracle's fp32 autograd:
     every parameter gradient within 1.5 % in norm, cosine >= 0.998; span_embed gets no gradient."""

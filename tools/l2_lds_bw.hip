@@ -97,6 +97,19 @@ int main(int argc, char** argv) {
     printf("calib: %zu bytes per kernel (stream_kernel<4,2,true>, stream_kernel<4,2,false>, calib_linear_kernel)\n", bytes);
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "ld")) {
+    // row-stride sweep (round 4): does the 2 KB stride of a K = 1024 bf16 operand (every row of a tile on the same few L2 channels?) cost
+    // delivery bandwidth?  Same pattern, rows `ld` bytes apart; buffer sized for the largest stride
+    char* big; CK(hipMalloc(&big, (size_t)256 * 256 * 8192 + 4096)); CK(hipMemset(big, 1, (size_t)256 * 256 * 8192 + 4096));
+    for (int l : {2048, 2048 + 64, 2048 + 128, 2048 + 256, 2048 + 512, 4096, 4096 + 128, 6144, 6144 + 128, 8192 - 128}) {
+      printf("row stride %d B\n", l);
+      for (int share : {1, 4}) {
+        run<8, 1, true>(big, l, ktiles, reps, share, 256, sink, "lds");
+        run<8, 2, true>(big, l, ktiles, reps, share, 256, sink, "lds");
+      }
+    }
+    return 0;
+  }
   for (int grid : {256, 64, 8}) {
     for (int share : {1, 4}) {
       run<8, 1, true>(buf, ld, ktiles, reps, share, grid, sink, "lds");

@@ -336,7 +336,14 @@ __global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = 
 // at most half as many tiles as CUs) runs a grid of `ntiles x p.sk` workgroups, one K range of one tile each.  The parts of a tile meet like the split parts of the hybrid weight-gradient kernel below: publish the fp32 partial (write-through,
 // the accumulator registers in lane order), take a ticket, and the part that draws the last ticket reads the OTHER parts behind one
 // agent-scope acquire, sums all of them in part order (the result does not depend on the arrival order) and runs the epilogue; nothing spins.
-template <bool GATHER, int TM, bool EOP, int ORD, int EPI, bool HALF = false, bool SMALL = false>
+// LW ("loader waves", round 4; plain row mapping, tile heights 128 - 256): the staging pieces of a K tile are issued by waves 0..3 only -- one
+// per SIMD, each for itself and for the wave it shares the SIMD with (w + 4), all at the head of the K tile.  An LDS-DMA issue holds its
+// wave's instruction stream for ~60-180 cycles (MI355X_MICROARCH.md); with every wave issuing its pieces right behind the barrier both waves
+// of a SIMD are held at the same time, with one loader per SIMD the other wave multiplies meanwhile.  Measured (profiles/r04_ab_nt_loader_waves.txt):
+// the kernel +2 % (872 -> 889 TFLOP/s), the step -0.8 % -- against the interleaved order (ORD = 1) at 256 rows and the head order elsewhere;
+// nothing at 320 rows.  (The model behind it -- ~1000 idle pipe cycles per K tile from simultaneous DMA issue -- predicted ten times that:
+// the issue stall is NOT what the K loop waits for.)  Same products, same K order: results are bit-identical.
+template <bool GATHER, int TM, bool EOP, int ORD, int EPI, bool HALF = false, bool SMALL = false, bool LW = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
 #pragma clang fp contract(off)            // every instantiation must round the epilogue alike (the tile paths are compared bit for bit)
   static_assert(!(EPI != 0 && GATHER), "the specialised epilogues have the plain row mapping");
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   auto MF = [](s16x8 a, s16x8 b, f32x16 c) -> f32x16 { if constexpr (HALF) return mfma32h(a, b, c); else return mfma32(a, b, c); };
   static_assert(!SMALL || (TM <= 2 && EPI == 0 && ORD == 0), "single-tile variant: 128 x 128 / 128 x 256 tiles, general epilogue, pieces issued at the head of a K tile");
   static_assert(TM >= 2 || SMALL, "TM = 1 exists in the single-tile variant only");
+  static_assert(!LW || (ORD == 0 && !SMALL && !HALF), "loader waves: pieces at the head of the K tile, persistent bf16 kernel");
   static_assert(EPI != 2 || !EOP, "FFN1 has no epilogue operand");
   static_assert(EPI != 3 || EOP, "the activation gradient reads its pre-activation");
   static_assert(TM < 5 || ((TM + 4 + 1) / 2 <= TM), "320-row tiles: at most one staging piece per A-fragment group of a k-step");
@@ -378,7 +386,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     gz = l / per_group; l -= gz * per_group;
     m0 = p.m_begin + (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
   };
-  unsigned aofs[PA], bofs[PB];   // byte offsets of this lane's staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
+  constexpr int LWF = LW ? 2 : 1;          // staging rows per issuing wave: its own, (LW) and those of wave + 4
+  unsigned aofs[LWF * PA], bofs[LWF * PB];   // byte offsets of this lane's staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
   const char* Abase = (const char*)p.A;      // A operand of the tile being loaded (A2 for the column tiles from a2_n0 on)
   auto set_offsets = [&](int gz, int m0, int n0) {
     Abase = (const char*)((p.A2 && n0 >= p.a2_n0) ? p.A2 : p.A);
@@ -387,17 +396,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     int sr = sr_, sc = sc_;
     if constexpr (TM >= 5) asm volatile("" : "+v"(sr), "+v"(sc));
 #pragma unroll
-    for (int i = 0; i < PA; i++) {
-      const int r = (wave * PA + i) * 8 + sr;
-      const int c = (sc ^ ((r >> 1) & 7)) * 8;
-      const int am = GATHER ? max(map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off), 0) : min(m0 + r, p.M - 1);
-      aofs[i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
-    }
+    for (int h = 0; h < LWF; h++) {
+      const int vw = (wave + 4 * h) & 7;        // (LW: h = 1 are the rows of the wave on the same SIMD; meaningless, and unused, on waves 4..7)
 #pragma unroll
-    for (int i = 0; i < PB; i++) {
-      const int r = (wave * PB + i) * 8 + sr;
-      const int c = (sc ^ ((r >> 1) & 7)) * 8;
-      bofs[i] = (unsigned)(((size_t)min(n0 + r, p.N - 1) * p.ldb + c + (size_t)gz * p.gB) * 2);
+      for (int i = 0; i < PA; i++) {
+        const int r = (vw * PA + i) * 8 + sr;
+        const int c = (sc ^ ((r >> 1) & 7)) * 8;
+        const int am = GATHER ? max(map_row(min(m0 + r, p.M - 1), p.a_seg, p.a_seg_stride, p.a_off), 0) : min(m0 + r, p.M - 1);
+        aofs[h * PA + i] = (unsigned)(((size_t)am * p.lda + c + (size_t)gz * p.gA) * 2);
+      }
+#pragma unroll
+      for (int i = 0; i < PB; i++) {
+        const int r = (vw * PB + i) * 8 + sr;
+        const int c = (sc ^ ((r >> 1) & 7)) * 8;
+        bofs[h * PB + i] = (unsigned)(((size_t)min(n0 + r, p.N - 1) * p.ldb + c + (size_t)gz * p.gB) * 2);
+      }
     }
   };
   // byte offsets (A, B) of K tile kt inside the operand rows; the conv taps switch the A row every ktap columns
@@ -415,9 +428,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       ka = (unsigned)(tap * p.lda + (k0 - tap * p.ktap)) * 2u;
     }
   };
-  auto piece = [&](unsigned char* sbase, unsigned ka, unsigned kb, int i) {      // staging piece i of NP: A pieces first
-    if (i < PA) __builtin_amdgcn_global_load_lds((gbl_void_t*)(Abase + (aofs[i < PA ? i : 0] + ka)), (lds_void_t*)(sbase + (wave * PA + i) * 1024), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[i >= PA ? i - PA : 0] + kb)), (lds_void_t*)(sbase + BOFF + (wave * PB + (i - PA)) * 1024), 16, 0, 0);
+  auto piece = [&](unsigned char* sbase, unsigned ka, unsigned kb, int idx) {      // staging piece idx of NP (LW: of 2 NP, the second NP for wave + 4): A pieces first
+    const int h = idx / NP, i = idx % NP, vw = (wave + 4 * h) & 7;
+    if (i < PA) __builtin_amdgcn_global_load_lds((gbl_void_t*)(Abase + (aofs[h * PA + (i < PA ? i : 0)] + ka)), (lds_void_t*)(sbase + (vw * PA + i) * 1024), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)p.B + (bofs[h * PB + (i >= PA ? i - PA : 0)] + kb)), (lds_void_t*)(sbase + BOFF + (vw * PB + (i - PA)) * 1024), 16, 0, 0);
+  };
+  // every staging piece of one K tile this wave is responsible for, at the head of the K tile (ORD == 0)
+  auto pieces_head = [&](unsigned char* sbase, unsigned ka, unsigned kb) {
+    if constexpr (LW) {
+      if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < 2 * NP; i++) piece(sbase, ka, kb, i);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
+    }
   };
   int aoff[TM], boff[TN];
   const int swz = (l31 >> 1) & 7;           // identical for every 32-row fragment of the wave
@@ -443,13 +469,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   {
     unsigned ka, kb;
     k_offsets(kt_begin, ka, kb);
-#pragma unroll
-    for (int i = 0; i < NP; i++) piece(smem256, ka, kb, i);
+    pieces_head(smem256, ka, kb);
     if constexpr (SMALL) {
       if (kt_begin + 1 < kt_end) {
         k_offsets(kt_begin + 1, ka, kb);
-#pragma unroll
-        for (int i = 0; i < NP; i++) piece(smem256 + SSTR, ka, kb, i);
+        pieces_head(smem256 + SSTR, ka, kb);
       }
     }
   }
@@ -560,10 +584,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         auto rdA = [&](int i, int q) { return *(const s16x8*)(base + aoff[i] + (((2 * q + g) ^ swz) << 4)); };
         auto rdB = [&](int j, int q) { return *(const s16x8*)(base + boff[j] + (((2 * q + g) ^ swz) << 4)); };
         s16x8 ah[TM], al[TM], bh[2][TN], bl[TN];
-        if (PREF && ORD == 0) {
-#pragma unroll
-          for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
-        }
+        if (PREF && ORD == 0) pieces_head(sbase, ka, kb);
 #pragma unroll
         for (int i = 0; i < TM; i++) ah[i] = rdA(i, 0);
 #pragma unroll
@@ -617,10 +638,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         // next k-step right behind its own TN MFMAs (the refill then has the other (TM - 1) TN MFMAs of this k-step and i TN of the
         // next one to land: >= 8 MFMAs); only the B fragments, used by every MFMA of a k-step, stay double-buffered.
         s16x8 fa[TM], fb[2][TN];
-        if (ORD == 0) {
-#pragma unroll
-          for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
-        }
+        if (ORD == 0) pieces_head(sbase, ka, kb);
 #pragma unroll
         for (int i = 0; i < TM; i++) fa[i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
 #pragma unroll
@@ -641,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             if (ORD == 1 && ks == 1 && G0 + i < NP) piece(sbase, ka, kb, G0 + i);
           }
         }
-        if (ORD == 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+        if (ORD == 0 && !LW) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
         sgb_sb<0, TM, TN, true, G0>();
         sgb_sb<0, TM, TN, true, G1>();
@@ -649,10 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
         sgb_sb<0, TM, TN, false, 0>();
       } else {
       s16x8 fa[2][TM], fb[2][TN];
-      if (PREF && ORD == 0) {
-#pragma unroll
-        for (int i = 0; i < NP; i++) piece(sbase, ka, kb, i);
-      }
+      if (PREF && ORD == 0) pieces_head(sbase, ka, kb);
 #pragma unroll
       for (int i = 0; i < TM; i++) fa[0][i] = *(const s16x8*)(base + aoff[i] + ((g ^ swz) << 4));
 #pragma unroll
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       }
       // pin the software pipeline the source expresses (hipcc otherwise sinks every fragment read next to its MFMAs and moves the
       // pieces to the head): R reads up front; per k-step (MFMA, read) pairs, then the VMEM issues two at a time between MFMAs
-      if (PREF && ORD == 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+      if (PREF && ORD == 0 && !LW) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
       sgb_kstep<Mf, R, true, G0>();
       sgb_kstep<Mf, R, true, G1>();
@@ -1837,6 +1852,29 @@ template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int gri
 #undef NT256_GO
   return 0;
 }
+// loader-wave instantiations: plain row mapping, pieces at the head of the K tile, tile heights 128 / 192 / 256
+static int g_nt_lw = -1;
+extern "C" int uvtg_debug_nt_loader_waves(int mask) { if (mask < 0 || mask > 7) return -21; g_nt_lw = mask; return 0; }
+template <int TM> static int launch_nt256_lw(const GemmArgs& b, int grid, bool eop, int epi, hipStream_t s) {
+  constexpr int smem = 131072;
+  static_assert(TM <= 4, "320-row tiles keep every wave staging for itself (measured: no gain)");
+  static bool attr = false;
+#define NTLW_ATTR(E, P) if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, E, 0, P, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
+  if (!attr) {
+    NTLW_ATTR(false, 0) NTLW_ATTR(false, 1) NTLW_ATTR(true, 1) NTLW_ATTR(false, 2) NTLW_ATTR(true, 3)
+    if constexpr (TM < 4) { NTLW_ATTR(true, 0) }       // (general epilogue + operand at 256 / 320 rows: 16-40 B of scratch with the second set of piece offsets -- not built)
+    attr = true;
+  }
+#undef NTLW_ATTR
+#define NTLW_GO(E, P) hipLaunchKernelGGL((gemm_nt256_kernel<false, TM, E, 0, P, false, false, true>), dim3(grid), dim3(512), smem, s, b)
+  if (epi == 1) { if (eop) NTLW_GO(true, 1); else NTLW_GO(false, 1); }
+  else if (epi == 2 && !eop) NTLW_GO(false, 2);
+  else if (epi == 3 && eop) NTLW_GO(true, 3);
+  else if (eop) { if constexpr (TM < 4) NTLW_GO(true, 0); else return -100; }
+  else NTLW_GO(false, 0);
+#undef NTLW_GO
+  return 0;
+}
 // single-tile instantiations (SMALL: 128-row tiles, three-stage ring, optional split-K, general epilogue): bf16 with / without the bf16
 // epilogue operand, split operands
 template <int TM> static int launch_nt256_small(const GemmArgs& b, int grid, bool gather, bool eop, bool half, hipStream_t s) {
@@ -2008,7 +2046,11 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
       by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0));
       uvtg_prof_add_bytes(3, by);
     }
+    if (g_nt_lw < 0) g_nt_lw = getenv("UVTG_NT_LW") ? atoi(getenv("UVTG_NT_LW")) & 7 : 7;      // bit (TM - 2) = loader waves at that tile height (128 / 192 / 256 rows)
+    const int lw_mask = g_nt_lw;
     if (small_tm) rc = small_tm == 1 ? launch_nt256_small<1>(b, grid, gather, eop, false, s) : launch_nt256_small<2>(b, grid, gather, eop, false, s);
+    else if (!gather && best_tm <= 4 && ((lw_mask >> (best_tm - 2)) & 1) && !(eop && epi == 0 && best_tm >= 4))
+      rc = best_tm == 4 ? launch_nt256_lw<4>(b, grid, eop, epi, s) : (best_tm == 3 ? launch_nt256_lw<3>(b, grid, eop, epi, s) : launch_nt256_lw<2>(b, grid, eop, epi, s));
     else if (nt_order(best_tm) == 0)
       rc = best_tm == 5 ? launch_nt256_tm<5, 0>(b, grid, gather, eop, epi, s) : best_tm == 4 ? launch_nt256_tm<4, 0>(b, grid, gather, eop, epi, s) : (best_tm == 3 ? launch_nt256_tm<3, 0>(b, grid, gather, eop, epi, s) : launch_nt256_tm<2, 0>(b, grid, gather, eop, epi, s));
     else
