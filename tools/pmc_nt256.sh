@@ -2,7 +2,7 @@
 # Three separate rocprofv3 --pmc passes over the bench command (kernel filter: the persistent NT GEMM), then the per-launch
 # HBM traffic + MFMA-busy summary bench.py quotes as roofline.traffic.  Outputs: gpurun_out/pmc_nt_{0,1,2}.txt, gpurun_out/pmc_nt256.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
-export PMC_EXTRA="--kernel-include-regex gemm_nt256_kernel<[^>]*false,.(true|false)>"      # the bf16 instantiations (template argument HALF = false; persistent and single-tile)
+export PMC_EXTRA="--kernel-include-regex gemm_nt256_kernel<([^,]*,){5}.false,"      # the bf16 instantiations (sixth template argument HALF = false: persistent, loader-wave and single-tile instantiations)
 bash $R/tools/pmc.sh nt "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- \
   python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-companions --profile-steps 0 > /dev/null
 python - <<'PY'
@@ -36,7 +36,7 @@ for cal in (f"{R}/gpurun_out/fetch_calibration.json", f"{R}/profiles/r04_fetch_c
 head = open(f"{R}/tools/.git_head").read().strip() if os.path.exists(f"{R}/tools/.git_head") else "unknown"
 fb, wb = fetch * 1024 * factor, write * 1024
 js = {"kernel_src_sha": kernel_src_sha(), "git_head": head, "config": 2, "variant": "A", "fetch_factor": factor, "fetch_factor_source": fsrc, "kernel": "gemm_nt256_kernel<*> (all instantiations, launch-weighted)",
-      "command": "tools/pmc_nt256.sh: rocprofv3 --pmc <pass> --kernel-include-regex 'gemm_nt256_kernel<[^>]*false,.(true|false)>' -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-companions --profile-steps 0  (three separate passes: FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE | SQ_*)",
+      "command": "tools/pmc_nt256.sh: rocprofv3 --pmc <pass> --kernel-include-regex 'gemm_nt256_kernel<([^,]*,){5}.false,' -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-companions --profile-steps 0  (three separate passes: FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE | SQ_*)",
       "launches_averaged": n, "per_instantiation": {k: {c: v[1] for c, v in d.items()} for k, d in {**p0}.items()},
       "FETCH_SIZE_KB_raw": round(fetch, 1), "WRITE_SIZE_KB_raw": round(write, 1),
       "fetch_bytes_corrected": int(fb), "write_bytes": int(wb), "traffic_bytes_per_launch": int(fb + wb),
