@@ -407,7 +407,7 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // 1..3 (the table holds 4 n_proj entries per modality); precise == 2 selects the three-image operand split.
 // 100: round 1 ABI.  200: uvtg_dims gained struct_size (first field, validated) and loss_only; uvtg_decode_rank_nms / uvtg_postprocess_mr take
 // nms_thd as double; uvtg_debug_force_nt_wn / uvtg_set_dynamic_tiles removed ("ABI history").
-// 301: additive -- uvtg_linear_bf16_sk / uvtg_linear_split_sk / uvtg_linear_sk_ws_floats, uvtg_debug_nt_small / _splitk / _splitk_parts / _small_tile;
+// 301: additive -- uvtg_linear_bf16_sk / uvtg_linear_split_sk / uvtg_linear_sk_ws_floats, uvtg_debug_nt_small / _splitk / _splitk_parts / _small_tile / _loader_waves;
 // uvtg_workspace_bytes grew by the forward's split-K slabs (32 MB) and tickets
 extern "C" int uvtg_version(void) { return 301; }
 
