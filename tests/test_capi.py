@@ -163,6 +163,29 @@ def test_nt_small_launch_plan(lib):
     assert parts(0, 1024, 1024) < 0 and tile(0, 1024, 1024) < 0
 
 
+def test_nt_small_launch_plan_invariants(lib):
+    """Properties of the single-tile launch plan over a sweep of shapes (host arithmetic): a planned launch never has more workgroups than
+    CUs, a split has 2..4 parts of >= 4 K tiles with no empty part, launches beyond one tile per CU are left to the persistent kernel."""
+    import itertools
+    cdiv = lambda a, b: -(-a // b)
+    for M, N, K, groups, cus in itertools.product((1, 75, 107, 128, 129, 1024, 2400, 3424, 6848, 8192, 27392), (256, 520, 1024, 2048, 3072),
+                                                  (64, 256, 512, 576, 1024, 2048, 5760, 6144), (1, 2), (256, 248, 64)):
+        tile = lib.uvtg_debug_nt_small_tile(M, N, K, groups, cus)
+        parts = lib.uvtg_debug_nt_splitk_parts(M, N, K, groups, cus)
+        assert tile in (0, 128, 256) and 0 <= parts <= 4 and parts != 1, (M, N, K, groups, cus, tile, parts)
+        t128 = cdiv(M, 128) * cdiv(N, 128) * groups
+        t256 = cdiv(M, 128) * cdiv(N, 256) * groups
+        if tile == 0:
+            assert parts == 0 and t256 > cus, (M, N, K, groups, cus)
+            continue
+        tiles = t128 if tile == 128 else t256
+        assert tiles <= cus and tiles * max(parts, 1) <= cus, (M, N, K, groups, cus, tile, parts)
+        if parts:
+            nk = K // 64
+            per = cdiv(nk, parts)
+            assert tiles * 2 <= cus and per >= 4 and (parts - 1) * per < nk, (M, N, K, groups, cus, tile, parts)
+
+
 def test_nt_tile_height_choice(lib):
     """The persistent NT GEMM's tile-height choice is host arithmetic: pin the decisions the measured shapes rest on
     (tools/tm5_ab.sh) so that a change of the cost model shows up here, without a GPU."""
