@@ -117,38 +117,84 @@ def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev, lens_v=None, full=False):
     return inputs, targets
 
 
-def cpu_baseline(batch, steps=3):
-    """CPU baseline (reported, not optimised against): a model composed of the SAME torch.nn modules the reference composes
-    (oracle/nn_baseline.py: nn.MultiheadAttention(need_weights=True) on the (S, B, d) layout, nn.LayerNorm, nn.Dropout, nn.Conv1d, ...;
-    /root/reference itself does not exist on the GPU box) + the oracle's criterion, fp32, TRAIN mode, on the GPU run's own synthetic batch at
-    the full B: 1 warm-up + `steps` timed fwd + criterion + bwd steps."""
+def cpu_baseline(batch, steps=2):
+    """CPU baseline (reported, not optimised against; SURVEY 8d, north_star: "the reference's own PyTorch CPU forward is timed on the host
+    cores of the same box in the same run").  kind = "reference": the REAL showlab/UniVTG model path -- build_model() -> Model.forward +
+    SetCriterion + backward (model/univtg.py:105-155,195-351,409-450), imported from oracle/_ref/uvtg_reference_model.zip, the archive
+    __graft_entry__.build() packs from /root/reference where that tree exists (oracle/build_ref.py; git-ignored, ships with the built tree
+    like the .so) -- fp32, TRAIN mode, the GPU run's own synthetic batch at the full B: 1 warm-up + `steps` timed steps.  The port
+    (oracle/nn_baseline.py: the same torch.nn modules composed the same way + the oracle's criterion) is timed once beside it so that the
+    ratio of the two is on the same box; it is the fallback (kind = "port") only when the archive is absent."""
     from oracle import univtg_oracle as O
     from oracle.nn_baseline import NNBaseline
     torch.set_num_threads(min(os.cpu_count() or 1, 32))          # more threads than this only adds contention on the 2-socket host
     inputs, tg = batch
     cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
-    model = NNBaseline(cfg)
-    model.load_state_dict(O.init_params(cfg, seed=0), strict=True)
-    model.train()
+    params = O.init_params(cfg, seed=0)
     cpu_in = {k: v.cpu() for k, v in inputs.items() if torch.is_tensor(v)}
     cpu_tg = {k: v.cpu() for k, v in tg.items() if torch.is_tensor(v) and not k.startswith("_")}
     B, Lv = cpu_in["src_vid"].shape[:2]
 
-    def one():
-        model.zero_grad(set_to_none=True)
+    def timed(one, n):
+        one()                                                    # warm-up
+        ts = [one() for _ in range(n)]
+        return ts
+
+    ref_times, ref_fwd, ref_note, manifest = None, None, None, None
+    try:
+        from oracle.build_ref import import_ref_model
+        from oracle.make_golden import ref_args
+        ref_univtg, manifest = import_ref_model()
+        rmodel, rcrit = ref_univtg.build_model(ref_args(cfg))
+        rmodel.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+        rmodel.train(); rcrit.train()
+        fwd = []
+
+        def ref_one():
+            rmodel.zero_grad(set_to_none=True)
+            t0 = time.perf_counter()
+            out = rmodel(**cpu_in)
+            t1 = time.perf_counter()
+            ld = rcrit(out, cpu_tg)
+            sum(ld[k] * rcrit.weight_dict[k] for k in ld if k in rcrit.weight_dict).backward()
+            fwd.append(t1 - t0)
+            return time.perf_counter() - t0
+        ref_times = timed(ref_one, steps)
+        ref_fwd = fwd[1:]
+        del rmodel, rcrit
+    except ImportError as e:
+        ref_note = f"reference archive not usable: {e}"
+
+    port = NNBaseline(cfg)
+    port.load_state_dict(params, strict=True)
+    port.train()
+
+    def port_one():
+        port.zero_grad(set_to_none=True)
         t0 = time.perf_counter()
-        out = model(**cpu_in)
+        out = port(**cpu_in)
         O.total_loss(O.criterion(out, cpu_tg, cfg), cfg).backward()
         return time.perf_counter() - t0
-    one()                                                        # warm-up
-    times = [one() for _ in range(steps)]
-    t = sum(times)
-    return dict(value=steps * B * Lv / t, unit="clips/s", cores=torch.get_num_threads(), kind="port", flavour="port-nn-modules",
-                torch=torch.__version__, host_cpus=os.cpu_count(),
-                sample=f"the reference's module composition rebuilt from torch.nn (oracle/nn_baseline.py: nn.MultiheadAttention with need_weights=True on "
-                       f"(S,B,d), nn.LayerNorm / nn.Dropout / nn.Linear / nn.Conv1d / nn.Embedding; pinned to the oracle by tests/test_oracle_golden.py) + the "
-                       f"oracle's criterion: fwd+criterion+bwd, fp32, TRAIN mode (input dropout 0.5 + DropPath 0.1), the GPU run's own batch at the full "
-                       f"B={B}: {steps} timed steps after 1 warm-up ({t:.2f} s total, {t / steps:.2f} s per step, min {min(times):.2f} s)")
+    port_times = timed(port_one, 1 if ref_times else max(steps, 3))
+    port_rate = len(port_times) * B * Lv / sum(port_times)
+    common = dict(unit="clips/s", cores=torch.get_num_threads(), torch=torch.__version__, host_cpus=os.cpu_count())
+    port_line = dict(value=round(port_rate, 1), step_s=[round(t, 2) for t in port_times], flavour="port-nn-modules",
+                     what="oracle/nn_baseline.py (the reference's module composition rebuilt from torch.nn, pinned to the oracle) + the oracle's criterion, same batch, same threads")
+    if ref_times:
+        t = sum(ref_times)
+        rate = len(ref_times) * B * Lv / t
+        return dict(value=rate, kind="reference", **common,
+                    forward_only_clips_per_sec=round(len(ref_fwd) * B * Lv / sum(ref_fwd), 1),
+                    reference_archive_sha256=manifest["members"], port_beside_it=port_line, port_over_reference=round(port_rate / rate, 3),
+                    sample=f"the reference itself (showlab/UniVTG model/univtg.py build_model -> Model.forward + SetCriterion + backward, imported unmodified from "
+                           f"oracle/_ref/uvtg_reference_model.zip): fp32, TRAIN mode (input dropout 0.5 + DropPath 0.1), the GPU run's own synthetic batch at the full "
+                           f"B={B} (L_v={Lv}, all-ones masks): {len(ref_times)} timed steps after 1 warm-up ({t:.2f} s total, {t / len(ref_times):.2f} s per step, "
+                           f"min {min(ref_times):.2f} s; forward alone {sum(ref_fwd) / len(ref_fwd):.2f} s)")
+    t = sum(port_times)
+    return dict(value=port_rate, kind="port", flavour="port-nn-modules", **common, fallback_reason=ref_note,
+                sample=f"FALLBACK (no reference archive in this tree): the reference's module composition rebuilt from torch.nn (oracle/nn_baseline.py, pinned to the "
+                       f"oracle by tests/test_oracle_golden.py) + the oracle's criterion: fwd+criterion+bwd, fp32, TRAIN mode, the GPU run's own batch at the full "
+                       f"B={B}: {len(port_times)} timed steps after 1 warm-up ({t:.2f} s total, {t / len(port_times):.2f} s per step)")
 
 
 def kernel_src_sha():
@@ -307,6 +353,68 @@ def quick_roofline(lib, step, batches, B, Lv, Lt, halo, k=3):
                 roofline_encoder=dict(achieved=round(exe / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(exe / t_enc / 2.5e15, 4)))
 
 
+def companion_config(cid, dev, precise, lib, k_prof=2, steps=10):
+    """One other BASELINE config on this GPU, inside the driver-run line: a fresh model + TrainStep at the config's
+    shape, variant B (ragged valid lengths on the packed loss-only stream, `value` = VALID clips), 3 warm-up + `steps` timed steps + the
+    instrumented steps of quick_roofline.  Same step, same arithmetic as the headline."""
+    from univtg_amd.model import build_model
+    from univtg_amd.trainer import TrainStep
+    wl = CONFIGS[cid]
+    B, Lv, Lt = wl["B"], wl["L_v"], wl["L_t"]
+    torch.manual_seed(2018)
+    model, crit = build_model(model_args(max_v_l=Lv, proj_precise=precise))
+    model.to(dev).train()
+    crit.to(dev).train()
+    model.set_seed(2018)
+    step = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed="auto")
+    lens_fn = (lambda s_: mixed_length_lens(B, seed=s_)) if cid == 5 else (lambda s_: None)
+    bt = [synth_batch(B, Lv, Lt, MODEL["D_v"], MODEL["D_t"], 7000 + i, dev, lens_fn(7000 + i), full=False) for i in range(2)]
+    for i in range(3):
+        step.step(*bt[i % 2])
+    el, per = timed_steps(step, bt, steps)
+    lens = [b[0]["_lens_host"] for b in bt]
+    valid = sum(sum(a) for a, _ in lens) / len(lens)
+    out = dict(what=wl["what"] + "; variant B: " + wl["lens"], per_gpu_batch=B, L_v=Lv, L_t=Lt, steps=steps,
+               ms_per_step=round(el / steps * 1e3, 3), ms_per_step_event_median=round(per[len(per) // 2], 3),
+               valid_clips_per_sec=round(valid * steps / el, 1), clip_positions_per_sec_incl_padded=round(B * Lv * steps / el, 1),
+               losses=[round(x, 5) for x in step.losses[:5].tolist()])
+    out.update(quick_roofline(lib, step, bt, B, Lv, Lt, True, k_prof))
+    del step, model, crit, bt
+    torch.cuda.empty_cache()
+    return out
+
+
+def companion_infer(dev, n=20):
+    """The inference call (model(...) under no_grad at the default precision + uvtg_postprocess_mr; main/inference_mr.py:88-193) at the
+    reference's eval batch 32 and at batch 1 with CLIP-only features (BASELINE config 1's shape), inside the driver-run line."""
+    from univtg_amd import ops
+    from univtg_amd.model import build_model
+    res = {}
+    for name, B, Lv, Lt, Dv in (("config2_eval_B32", 32, 75, 32, MODEL["D_v"]), ("config1_B1", 1, 75, 32, 514)):
+        batches = [infer_batch(B, Lv, Lt, Dv, MODEL["D_t"], 50 + i, dev) for i in range(2)]
+        torch.manual_seed(2018)
+        model, _ = build_model(model_args(max_v_l=Lv, v_feat_dim=Dv, precision="auto", packed=False))
+        model.to(dev).eval()
+
+        def call(i):
+            inp, ts, tm, dur = batches[i % 2]
+            with torch.no_grad():
+                out = model(**inp)
+                return ops.postprocess_mr(out["pred_logits"], out["pred_spans"], out["saliency_scores"], ts, tm, dur, clip_length=2.0, eval_mode="add")
+        for i in range(4):
+            call(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            call(i)
+        torch.cuda.synchronize()
+        w = (time.perf_counter() - t0) / n * 1e3
+        res[name] = dict(ms_per_batch=round(w, 3), clips_per_sec=round(B * Lv / w * 1e3, 1), precision="fp32x3 (default under no_grad)", batches=n)
+        del model
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +426,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3, help="extra instrumented steps for the roofline line")
     ap.add_argument("--no-padded-compare", action="store_true", help="variant B: skip the extra timing of the padded / all-clip-rows executions")
     ap.add_argument("--no-companions", action="store_true", help="headline only: skip the ragged-batch (variant B) and bf16-projection companion timings")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config 3 / 4 / 5 and inference companions of the default line")
     ap.add_argument("--packed", default="auto", choices=["auto", "off"], help="encoder row stream (auto = exact packed stream)")
     ap.add_argument("--variant", default=None, choices=["A", "B"],
                     help="SURVEY 8d: A = all-ones masks -- every clip position is executed (default for config 2: the shape 'L=75, d=1024, batch=256' "
@@ -456,6 +565,11 @@ def main():
         model.proj_precise = precise
         for i in range(2):
             step.step(*batches[i % 2])
+        # every other BASELINE config that fits one GPU, and the inference call, in the SAME driver-run line
+        if args.config == 2 and not args.no_other_configs:
+            for cid in (3, 4, 5):
+                comp[f"config{cid}"] = companion_config(cid, dev, precise, _lib.load())
+            comp["inference"] = companion_infer(dev)
 
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch, on the launch stream ----
     lib = _lib.load()

@@ -208,6 +208,40 @@ def test_nt_loader_waves_do_not_change_the_train_step(dev):
             assert float((v - res[2][1][k]).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-9, k
 
 
+def test_trainstep_survives_a_projection_mode_flip_between_steps(dev):
+    """`Model.proj_precise` is a public attribute and changes the workspace / operand-cache LAYOUT at an unchanged
+    (B, L_v, L_t) -- split operands take 4 B per element where bf16 takes 2.  A TrainStep that first ran bf16 projections and then precise ones
+    must re-allocate (it used to write past both buffers); the flipped step must equal a fresh TrainStep's."""
+    from oracle import univtg_oracle as O
+    from univtg_amd.trainer import TrainStep
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                     input_dropout=0.5, dropout=0.0, droppath=0.1)
+    params = O.init_params(cfg, seed=11)
+    inputs, tg = O.make_batch(cfg, 16, 40, 12, seed=12, ragged=True)
+    batch, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+
+    def fresh(mode):
+        model, crit = build(cfg, params, dev, "auto", proj_precise=mode)
+        model.train(); model.set_seed(5)
+        return model, TrainStep(model, crit, grad_clip=0.1, packed=False)
+    model, step = fresh(False)
+    step.step(batch, tgd, optimize=False)
+    small = (step.ws.numel(), step.wcache.numel())
+    guard = torch.full((1 << 20,), 7, dtype=torch.uint8, device=dev)      # something for an overrun to land in
+    model.proj_precise = True
+    model.set_seed(5)
+    l_flip = step.step(batch, tgd, optimize=False).clone()
+    g_flip = step.grads.clone()
+    torch.cuda.synchronize()
+    assert step.ws.numel() > small[0] or step.wcache.numel() > small[1], "the precise layout is larger: the step must have re-allocated"
+    assert bool((guard == 7).all())
+    model2, step2 = fresh(True)
+    l_new = step2.step(batch, tgd, optimize=False)
+    assert torch.equal(l_flip, l_new), (l_flip, l_new)
+    gg0, gg1 = g_flip.double(), step2.grads.double()
+    assert float((gg0 @ gg1) / (gg0.norm() * gg1.norm())) > 0.999999
+
+
 def test_hl_loss_subset_production_width(dev):
     """dset_type 'hl' / 'vs' (losses = labels + saliency, model/univtg.py:439-440) at d = 1024, E = 4 against the oracle's fp32 autograd:
     every parameter gradient within 1.5 % in norm, cosine >= 0.998; span_embed gets no gradient."""

@@ -282,7 +282,7 @@ def _philox_rng(seed, cfg, B, Lv, Lt, p_in, p_path):
             "dp_scale": t(R.droppath_scales(seed, E, B, p_path))}
 
 
-def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True, proj_precise="auto"):
+def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True, proj_precise="auto", ragged=True):
     """The EXACT bench.py path at one BASELINE shape: native TrainStep, train mode, input dropout 0.5 + DropPath 0.1, packed="auto" with
     the collate's host-side lengths (loss-only packing).  The device Philox masks are regenerated on the host and handed to the oracle;
     the five losses, pred_logits at the valid positions and EVERY parameter gradient must agree."""
@@ -291,7 +291,9 @@ def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True, proj_pre
     _threads()
     cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1, max_v_l=Lv)
     params = O.init_params(cfg, seed=seeds[0])
-    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=seeds[1], ragged=True)
+    inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=seeds[1], ragged=ragged)
+    if not ragged:      # SURVEY 8d variant A: all-ones masks, every position executed -- the rows bench.py's headline times
+        assert bool(inputs["src_vid_mask"].bool().all()) and bool(inputs["src_txt_mask"].bool().all())
     res = {}
     for packed in ((False, "auto") if compare_padded else ("auto",)):
         model, crit = build(cfg, params, dev, "auto", proj_precise=proj_precise)      # as bench.py builds it (--proj precise: True)
@@ -337,7 +339,7 @@ def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True, proj_pre
           + ", ".join(f"{k} {v:.1e}" for k, v in lerr.items())
           + f"; {len(rep)} gradients; worst cosine {worst_cos[1][0]:.5f} ({worst_cos[0]}), worst norm ratio {worst_ratio[1][1]:.4f} ({worst_ratio[0]})")
     assert len(rep) == 78
-    assert e < 4e-2, e
+    assert e < 2e-2, e              # measured 8.7e-3 (bf16 encoder operands under dropout)
     assert max(lerr.values()) < 3e-2, lerr
     # floors: the measured level (round 2: worst cosine 0.9965, norm within 1.8 %) minus a small margin -- the noise is the plain-bf16
     # 2818-wide input projection under dropout
@@ -346,11 +348,15 @@ def _replay_bench_path(dev, tag, B, Lv, Lt, seeds, compare_padded=True, proj_pre
     assert not bad, sorted(bad.items())
 
 
-def test_bench_path_trainstep_dropout_replayed_through_oracle(dev):
-    """Config 2 at full size (B=256, L_v=75, L_t=32, d=1024, E=4): what `python bench.py` times.  (Under input dropout the native step's
-    packed stream keeps the valid clips, the three padded clips inside the conv heads' receptive field of a valid position -- each with
-    its own mask -- and the valid text tokens: exact for everything a loss can see, unlike round 1's shared-mask representative.)"""
-    _replay_bench_path(dev, "config2", 256, 75, 32, (201, 202), proj_precise=True)
+@pytest.mark.parametrize("ragged", [True, False], ids=["variantB_ragged", "variantA_all_ones"])
+def test_bench_path_trainstep_dropout_replayed_through_oracle(dev, ragged):
+    """Config 2 at full size (B=256, L_v=75, L_t=32, d=1024, E=4): what `python bench.py` times.  `variantA_all_ones` is the HEADLINE
+    workload itself (SURVEY 8d variant A: all-ones masks, every position executed, padded execution, split-operand projections, train mode);
+    `variantB_ragged` is the companion line.  (Under input dropout the native step's packed stream keeps the valid clips, the three padded
+    clips inside the conv heads' receptive field of a valid position -- each with its own mask -- and the valid text tokens: exact for
+    everything a loss can see, unlike round 1's shared-mask representative.)"""
+    _replay_bench_path(dev, "config2-" + ("B" if ragged else "A"), 256, 75, 32, (201, 202), proj_precise=True, ragged=ragged,
+                       compare_padded=ragged)
 
 
 def test_config3_bench_path_replayed_through_oracle(dev):

@@ -133,7 +133,11 @@ class TrainStep:
         Lt, Dt = src_txt.shape[1], src_txt.shape[2]
         dims = model._dims(B, Lv, Lt, Dv, Dt, True)
         dims.loss_only = int(self.loss_only)
-        if self._shape != (B, Lv, Lt):
+        # (re)allocate on a new shape AND whenever the library's own layout for these dims outgrows the buffers: `Model.proj_precise`,
+        # `precision`, `n_input_proj`, `use_txt_pos` all change the workspace / operand-cache layout at an unchanged (B, L_v, L_t) -- the split
+        # operands take 4 B per element where bf16 takes 2 (flipping proj_precise between steps wrote out of bounds)
+        if (self._shape != (B, Lv, Lt) or lib.uvtg_workspace_bytes(C.byref(dims)) > self.ws.numel()
+                or lib.uvtg_wcache_bytes(C.byref(dims)) > self.wcache.numel()):
             self._alloc(B, Lv, Lt, dims)
         st = _stream()
         d = model.hidden_dim
