@@ -237,7 +237,7 @@ def test_trainstep_survives_a_projection_mode_flip_between_steps(dev):
     assert bool((guard == 7).all())
     model2, step2 = fresh(True)
     l_new = step2.step(batch, tgd, optimize=False)
-    assert torch.equal(l_flip, l_new), (l_flip, l_new)
+    assert torch.allclose(l_flip, l_new, rtol=1e-5, atol=1e-6), (l_flip, l_new)      # (not bitwise: a few loss / gradient sums meet through fp32 atomics)
     gg0, gg1 = g_flip.double(), step2.grads.double()
     assert float((gg0 @ gg1) / (gg0.norm() * gg1.norm())) > 0.999999
 
