@@ -565,11 +565,6 @@ def main():
         model.proj_precise = precise
         for i in range(2):
             step.step(*batches[i % 2])
-        # every other BASELINE config that fits one GPU, and the inference call, in the SAME driver-run line
-        if args.config == 2 and not args.no_other_configs:
-            for cid in (3, 4, 5):
-                comp[f"config{cid}"] = companion_config(cid, dev, precise, _lib.load())
-            comp["inference"] = companion_infer(dev)
 
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch, on the launch stream ----
     lib = _lib.load()
@@ -662,6 +657,14 @@ def main():
                     backward_ms=round(sm[3] / k, 3))
     if world > 1:
         torch.distributed.barrier()
+
+    # every other BASELINE config that fits one GPU, and the inference call, in the SAME driver-run line.  LAST on the
+    # device: each builds (and frees) its own model + multi-GB workspace, and the headline's instrumented passes above must not run behind
+    # that allocator traffic (visit r5a: the LayerNorm-forward event pairs of the pass that followed it read 10 ms per step)
+    if rank == 0 and world == 1 and not args.no_companions and args.config == 2 and not args.no_other_configs:
+        for cid in (3, 4, 5):
+            comp[f"config{cid}"] = companion_config(cid, dev, precise, lib)
+        comp["inference"] = companion_infer(dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:

@@ -178,24 +178,12 @@ int uvtg_linear_split(const void* A, const void* W, const float* bias, float* C,
  * batches): K is cut into <= 4 parts, one workgroup each; the parts meet through fp32 partial-tile slabs and one ticket per tile, the part that
  * arrives last sums ALL parts in part order (bit-reproducible) and runs the epilogue.  sk_ws: uvtg_linear_sk_ws_floats() floats, 16-byte
  * aligned; its first 256 words (the tickets) must be ZERO before the first call (the kernel leaves them zero).  Shapes that do not qualify run
- * exactly as uvtg_linear_bf16 / uvtg_linear_split do.  uvtg_debug_nt_splitk(n): at most n parts per tile from now on (0 / 1 = never split,
- * default 4); uvtg_debug_nt_splitk_parts: host arithmetic only, the parts an M x N x K launch (K in staged elements: 2 x real columns for split
- * operands) would get on `cus` compute units (0 = not split). */
+ * exactly as uvtg_linear_bf16 / uvtg_linear_split do.  (Experiment knobs of the split: include/uvtg_dev.h.) */
 long long uvtg_linear_sk_ws_floats(void);
 int uvtg_linear_bf16_sk(const void* A, const void* W, const float* bias, float* C, int M, int N, int K, int act, float* sk_ws,
                         uvtg_stream_t stream);
 int uvtg_linear_split_sk(const void* A, const void* W, const float* bias, float* C, int M, int N, int Kp, int act, float* sk_ws,
                          uvtg_stream_t stream);
-/* Launches of at most one 128 x 256 tile per compute unit run a single-tile variant of the persistent kernel (three-stage staging ring: the K
- * loop of such a launch is a chain of memory round trips, not of MFMAs; results bit-identical).  uvtg_debug_nt_small(0) sends them through the
- * persistent two-stage kernel again (parity tests / A-B measurements), 1 restores the default. */
-int uvtg_debug_nt_small(int on);
-/* Persistent NT kernel, plain row mapping: bit (rows / 64 - 2) of `mask` = the staging pieces of tile height 128 / 192 / 256 are issued by one
- * wave per SIMD for both waves of that SIMD ("loader waves"; default 7; results bit-identical either way -- parity tests / A-B measurements). */
-int uvtg_debug_nt_loader_waves(int mask);
-int uvtg_debug_nt_splitk(int max_parts);
-int uvtg_debug_nt_splitk_parts(int M, int N, int K, int groups, int cus);
-int uvtg_debug_nt_small_tile(int M, int N, int K, int groups, int cus);      /* its tile: 128 = 128 x 128, 256 = 128 x 256, 0 = not a single-tile launch */
 /* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 operands, fp32 atomic accumulate), dbias[N] += colsum(dY) (may be NULL) */
 int uvtg_wgrad_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int splits,
                     uvtg_stream_t stream);
@@ -308,42 +296,6 @@ int uvtg_adamw_clip_step_prenorm(float* params, const float* grads, float* exp_a
 const float* uvtg_backward_gradnorm2(const uvtg_dims* dm, void* workspace);
 
 
-/* ---- measurement hooks (bench.py): HIP events around every launch of the GEMM kernels, recorded on the launch
- * stream.  index 0: gemm_nt bf16 (128-tile), 1: gemm_nt split-operand (fp16 hi / lo images; flops = algorithmic 2 M N K), 2: gemm_tn (wgrad), 3: gemm_nt256 bf16 (256-tile,
- * persistent), 4: attention forward, 5: attention backward (all its kernels; FLOPs counted on the padded S: 4 S^2 hd per
- * (sample, head) forward, 10 S^2 hd backward), 6: LayerNorm forward launches, 7: LayerNorm backward launches (for 6 / 7 the
- * "flops" entry carries the algorithmic BYTES of the row streams: input + every output + the position rows added into the +pos outputs).
- * host arrays [8]. */
-int uvtg_profile_start(void);
-int uvtg_profile_stop(double* total_ms, double* total_flops, long long* launches);
-/* algorithmic bytes of the launches between uvtg_profile_start and _stop, per family (host array [8]; filled for family 3, the persistent
- * NT GEMM: A and W once, every output once, residual / pre-activation / position operands once) */
-int uvtg_profile_bytes(double* bytes);
-/* the empty-event-pair floor (ms) that uvtg_profile_stop measured on the launch stream and subtracted from every launch */
-double uvtg_profile_event_floor_ms(void);
-
-/* Section timing (its own pass, so that the per-launch events above do not sit inside the sections): one event pair on the launch
- * stream around 0: the E encoder layers of uvtg_forward, 1: their backward in uvtg_backward (LayerNorm / dgrad / attention /
- * weight-gradient kernels of the E layers), 2: the whole uvtg_forward, 3: the whole uvtg_backward.  host arrays [4]. */
-int uvtg_profile_sections_start(void);
-int uvtg_profile_sections_stop(double* total_ms, long long* counts);
-
-/* Test knob: force the NT GEMM tile size (0 = automatic choice, 128, 256) so that both kernels can be compared on
- * identical inputs.  Process-wide. */
-int uvtg_debug_force_nt_tile(int tile);
-/* ... and the tile HEIGHT of the persistent 256-wide kernel (0 = automatic per launch, 128, 192, 256, 320; 320 applies to the launches
- * with the plain row mapping, the gather launches run 256 rows then) */
-int uvtg_debug_force_nt_bm(int bm);
-/* Host arithmetic only (no device needed): the tile height the persistent NT GEMM picks for an M x N launch of `groups` groups on `cus`
- * compute units, gather != 0 for launches with row gather / scatter / conv taps / row tables.  Returns 128, 192, 256 or 320. */
-int uvtg_debug_nt_tile_rows(int M, int N, int groups, int gather, int cus);
-/* Host arithmetic only: the launch plan of the persistent NT GEMM for an M x N x K launch -- out3 = {tile rows of the head (or only)
- * launch, rows the head covers (0 = a single launch), tile rows of the tail launch}.  A launch whose last CU round would be sparsely
- * filled is cut into whole rounds of tall tiles + a tail of short ones. */
-int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, int cus, int* out3);
-/* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
- * launches on different streams can run side by side. */
-int uvtg_debug_gemm_cus(int n);
 /* Data-parallel runs: leave k compute units out of every persistent GEMM grid (NT tiles and weight-gradient units are sized for
  * CUs - k), so that RCCL's all-reduce kernels on the communication stream always find free CUs while backward runs (the reference
  * gets this from DDP's bucket hooks running beside cuBLAS kernels that do not fill the chip, main/train_vlp_ddp.py:272-275).

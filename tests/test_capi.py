@@ -23,11 +23,16 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     from univtg_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "uvtg.h")).read()
-    declared = set(re.findall(r"\b(uvtg_[a-z0-9_]+)\s*\(", hdr)) - {"uvtg_stream_t"}
-    assert declared, "no prototypes found"
+    pub = open(os.path.join(ROOT, "include", "uvtg.h")).read()
+    dev = open(os.path.join(ROOT, "include", "uvtg_dev.h")).read()
+    proto = lambda h: set(re.findall(r"\b(uvtg_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", h, flags=re.S))) - {"uvtg_stream_t"}
+    # the public header is what a maintainer binds: no experiment knob or measurement hook in it
+    assert not [n for n in proto(pub) if n.startswith(("uvtg_debug_", "uvtg_profile_"))]
+    assert all(n.startswith(("uvtg_debug_", "uvtg_profile_")) for n in proto(dev)), proto(dev)
+    declared = proto(pub) | proto(dev)
+    assert proto(pub) and proto(dev), "no prototypes found"
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/uvtg.h but not exported by libuvtg.so"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported by libuvtg.so"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.uvtg_version() >= 100
 

@@ -44,7 +44,7 @@ def _stamp(paths):
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "uvtg_common.h"), os.path.join(CSRC, "uvtg_kernels.h"),
-               os.path.join(os.path.dirname(HERE), "include", "uvtg.h")]
+               os.path.join(os.path.dirname(HERE), "include", "uvtg.h"), os.path.join(os.path.dirname(HERE), "include", "uvtg_dev.h")]
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:

@@ -48,6 +48,7 @@ int check_dims(const uvtg_dims* d) {
   if (d->d % 32 || d->F % 8) return -13;
   const int hd = d->d / d->H;
   if (hd * d->H != d->d || (hd != 32 && hd != 64 && hd != 128)) return -14;
+  if (d->precise != 0 && d->precise != 1) return -25;           // (0 / 1 are the two arithmetic modes; nothing else is defined)
   if (d->precise && d->training) return -15;
   if (d->precise && d->F % 32) return -13;       // split operand rows are made of whole 32-column blocks (uvtg_common.h, split_col)
   if (d->Dv <= 0 || d->Dt <= 0) return -16;
@@ -404,11 +405,13 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // public: sizes / tables
 // =================================================================================================
 // 300 (round 4): uvtg_dims gained use_txt_pos / max_q_l (trainable text positions; three more table entries when set) and n_proj accepts
-// 1..3 (the table holds 4 n_proj entries per modality); precise == 2 selects the three-image operand split.
+// 1..3 (the table holds 4 n_proj entries per modality); precise = 1 means fp16 hi + lo operand images (precise takes 0 / 1 only);
+// REMOVED in this step: uvtg_linear_f32x3 (replaced by uvtg_split_f16 + uvtg_linear_split: the kernel-level entry takes pre-split rows).
 // 100: round 1 ABI.  200: uvtg_dims gained struct_size (first field, validated) and loss_only; uvtg_decode_rank_nms / uvtg_postprocess_mr take
 // nms_thd as double; uvtg_debug_force_nt_wn / uvtg_set_dynamic_tiles removed ("ABI history").
 // 301: additive -- uvtg_linear_bf16_sk / uvtg_linear_split_sk / uvtg_linear_sk_ws_floats, uvtg_debug_nt_small / _splitk / _splitk_parts / _small_tile / _loader_waves;
-// uvtg_workspace_bytes grew by the forward's split-K slabs (32 MB) and tickets
+// uvtg_workspace_bytes grew by the forward's split-K slabs (32 MB) and tickets.  (Round 5, still 301: no symbol added or removed; the
+// uvtg_debug_* / uvtg_profile_* PROTOTYPES moved from include/uvtg.h to include/uvtg_dev.h; check_dims rejects precise outside {0, 1}: -25.)
 extern "C" int uvtg_version(void) { return 301; }
 
 extern "C" const char* uvtg_strerror(int code) {
@@ -436,6 +439,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -21: return "force_nt_tile: tile must be 0, 128 or 256";
     case -22: return "backward: ready_events must hold enc_layers + 1 events (or n_events = 0)";
     case -23: return "lens_host: every sample needs 1 <= len_v <= Lv clips and 1 <= len_t <= Lt text tokens";
+    case -25: return "dims: precise must be 0 (bf16 operands) or 1 (fp16 hi + lo operand images)";
     case -24: return "forward: lens_host (packed encoder stream) cannot be combined with the memory output in training mode";
     default: return "invalid argument";
   }
