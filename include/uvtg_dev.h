@@ -63,6 +63,12 @@ int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, int cus, int
 /* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
  * launches on different streams can run side by side. */
 int uvtg_debug_gemm_cus(int n);
+/* Experiment knob (round 5): force the launch plan of the plain-row persistent NT launches of ONE shape -- head of tm1_rows-row tiles over rows
+ * [0, rows1) + tail of tm2_rows-row tiles (rows1 = 0: a single launch at tm1_rows); M <= 0 clears every override.  In-box A/B of the cost model. */
+int uvtg_debug_nt_plan_override(int M, int N, int tm1_rows, int rows1, int tm2_rows);
+/* Experiment knob (round 5): tile order of the wide plain-row launches (>= 8 column tiles): column groups of `tiles_per_group` tiles,
+ * row-block-major inside a group (0 = row-block-major over the whole width).  Same tiles, same K order: bit-identical results. */
+int uvtg_debug_nt_cgw(int tiles_per_group);
 
 #ifdef __cplusplus
 }

@@ -332,6 +332,36 @@ def test_nt_loader_waves_bit_identical(dev):
         lib.uvtg_debug_force_nt_tile(0)
 
 
+def test_nt_column_group_order_and_forced_plans_bit_identical(dev):
+    """Round-5 experiment knobs of the persistent NT GEMM change WHICH workgroup computes a tile and how a launch is cut into head + tail, never
+    the products or the K order: column-group tile order (wide outputs: 12 column tiles walked in groups of 4 / 6 / 5), forced head / tail plans
+    (tails of at most one tile per CU now take the single-tile variant) -- bit for bit against the default plan."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(43)
+    try:
+        for (M, N, K, act) in [(27392, 3072, 256, 0), (9000, 2100, 192, 2)]:
+            a = bf(torch.randn(M, K, generator=g).to(dev))
+            w = bf((torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev))
+            b = torch.randn(N, generator=g).to(dev)
+            _lib.check(lib.uvtg_debug_nt_cgw(0))
+            base = ops.linear_bf16(a, w, b, act)
+            for cgw in (4, 6, 5):
+                _lib.check(lib.uvtg_debug_nt_cgw(cgw))
+                assert torch.equal(ops.linear_bf16(a, w, b, act), base), (M, N, K, cgw)
+            _lib.check(lib.uvtg_debug_nt_cgw(0))
+            for plan in ((320, 320 * (M // 320 - 1), 192), (256, 256 * (M // 256 - 2), 128), (320, 0, 0), (192, 0, 0)):
+                _lib.check(lib.uvtg_debug_nt_plan_override(M, N, *plan))
+                assert torch.equal(ops.linear_bf16(a, w, b, act), base), (M, N, K, plan)
+                _lib.check(lib.uvtg_debug_nt_cgw(6))
+                assert torch.equal(ops.linear_bf16(a, w, b, act), base), (M, N, K, plan, "cgw 6")
+                _lib.check(lib.uvtg_debug_nt_cgw(0))
+            _lib.check(lib.uvtg_debug_nt_plan_override(0, 0, 0, 0, 0))
+    finally:
+        lib.uvtg_debug_nt_cgw(0)
+        lib.uvtg_debug_nt_plan_override(0, 0, 0, 0, 0)
+
+
 def test_nt256_tile_heights_agree(dev):
     """Every tile-height instantiation of the persistent GEMM gives identical results (same products, same K order)."""
     from univtg_amd import _lib, ops

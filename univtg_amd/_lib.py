@@ -74,6 +74,8 @@ SIGNATURES = {
     "uvtg_linear_split_sk": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "uvtg_debug_nt_splitk": (_I, [_I]),
     "uvtg_debug_nt_small": (_I, [_I]),
+    "uvtg_debug_nt_plan_override": (_I, [_I, _I, _I, _I, _I]),
+    "uvtg_debug_nt_cgw": (_I, [_I]),
     "uvtg_debug_nt_loader_waves": (_I, [_I]),
     "uvtg_debug_nt_splitk_parts": (_I, [_I, _I, _I, _I, _I]),
     "uvtg_debug_nt_small_tile": (_I, [_I, _I, _I, _I, _I]),

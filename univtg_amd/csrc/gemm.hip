@@ -384,7 +384,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
     int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     gz = l / per_group; l -= gz * per_group;
-    m0 = p.m_begin + (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
+    if (p.cgw > 0 && p.cgw < tiles_n) {      // column groups of cgw tiles, row-block-major inside a group (the last group may be narrower)
+      const int gsz = tiles_m * p.cgw, cg = l / gsz, rem = l - cg * gsz, w = min(p.cgw, tiles_n - cg * p.cgw);
+      m0 = p.m_begin + (rem / w) * BM; n0 = (cg * p.cgw + rem % w) * TB;
+    } else {
+      m0 = p.m_begin + (l / tiles_n) * BM; n0 = (l % tiles_n) * TB;
+    }
   };
   constexpr int LWF = LW ? 2 : 1;          // staging rows per issuing wave: its own, (LW) and those of wave + 4
   unsigned aofs[LWF * PA], bofs[LWF * PB];   // byte offsets of this lane's staging pieces (1 KB = 8 rows x 128 B each) for the tile being loaded
@@ -1785,8 +1790,32 @@ static double nt256_cost(int M, int N, int groups, int tm, int cus) {
   const double rounds = (double)full + (rem ? 0.84 + 0.16 * (fill > 0.7 ? (fill - 0.7) / 0.3 : 0.0) : 0.0);
   return rounds * (64.0 * tm) * f[tm];
 }
+// Experiment knob (include/uvtg_dev.h): the plan of the plain-row launches of one M x N shape, forced (in-box A/B of the cost model's choice).
+struct NtPlanOverride { int M, N, tm1, rows1, tm2; };
+static NtPlanOverride g_plan_ovr[8]; static int g_plan_novr = 0;
+extern "C" int uvtg_debug_nt_plan_override(int M, int N, int tm1_rows, int rows1, int tm2_rows) {
+  if (M <= 0) { g_plan_novr = 0; return 0; }
+  if (tm1_rows % 64 || tm1_rows < 128 || tm1_rows > 320 || (rows1 && (tm2_rows % 64 || tm2_rows < 128 || tm2_rows > 256 || rows1 % tm1_rows || rows1 >= M))) return -21;
+  for (int i = 0; i < g_plan_novr; i++) if (g_plan_ovr[i].M == M && g_plan_ovr[i].N == N) { g_plan_ovr[i] = NtPlanOverride{M, N, tm1_rows / 64, rows1, tm2_rows / 64}; return 0; }
+  if (g_plan_novr >= 8) return -17;
+  g_plan_ovr[g_plan_novr++] = NtPlanOverride{M, N, tm1_rows / 64, rows1, tm2_rows / 64};
+  return 0;
+}
 static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, int force) {
   static const bool split_off = getenv("UVTG_NT_SPLIT_OFF") != nullptr;      // experiment: single launches only
+  static const bool ovr_env = [] {      // UVTG_NT_PLAN_OVR="M,N,tm1_rows,rows1,tm2_rows;..." = uvtg_debug_nt_plan_override calls (A/B runs of bench.py)
+    const char* e = getenv("UVTG_NT_PLAN_OVR");
+    while (e && *e) {
+      int v[5] = {0, 0, 0, 0, 0}, n = 0;
+      if (sscanf(e, "%d,%d,%d,%d,%d%n", &v[0], &v[1], &v[2], &v[3], &v[4], &n) == 5) uvtg_debug_nt_plan_override(v[0], v[1], v[2], v[3], v[4]);
+      else break;
+      e += n; if (*e == ';') e++;
+    }
+    return true;
+  }();
+  (void)ovr_env;
+  if (!gather && groups == 1 && !force)
+    for (int i = 0; i < g_plan_novr; i++) if (g_plan_ovr[i].M == M && g_plan_ovr[i].N == N) return NtPlan{g_plan_ovr[i].tm1, g_plan_ovr[i].rows1, g_plan_ovr[i].tm2};
   NtPlan pl{nt256_pick_tm(M, N, groups, gather, cus, force), 0, 0};
   if (!pl.tm1 || split_off || force || cus < 1) return pl;
   double best = nt256_cost(M, N, groups, pl.tm1, cus);
@@ -1898,6 +1927,8 @@ template <int TM> static int launch_nt256_small(const GemmArgs& b, int grid, boo
 // chip does besides, and the last arriver folds `parts` slabs of 128 KB alone (~2 us each from L2 / Infinity Cache): K-loop time / parts +
 // fold time x parts has its minimum near 4 at the encoder's K, so: at most g_nt_splitk_max (4) parts, at least 4 K tiles each, never more
 // workgroups than CUs (every part must be resident with the others only for SPEED -- nothing waits).
+static int g_nt_cgw = -1;            // column-group width of the tile order of wide plain-row launches (0 = row-block-major over the whole width)
+extern "C" int uvtg_debug_nt_cgw(int tiles_per_group) { if (tiles_per_group < 0 || tiles_per_group > 64) return -21; g_nt_cgw = tiles_per_group; return 0; }
 static int g_nt_splitk_max = -1;
 static int g_nt_small = -1;          // the single-tile (three-stage ring) variant for launches of at most one tile per CU: 1 on (default), 0 off
 extern "C" int uvtg_debug_nt_small(int on) { if (on < 0 || on > 2) return -21; g_nt_small = on; return 0; }       // (2: 128-row tiles only)
@@ -2019,9 +2050,14 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
     // one per CU, and cut along K too where the caller gave the launch a workspace and the tiles leave half the chip idle and the shorter K
     // loop pays for the fold (nt256_small_plan; b.sk = parts per tile, 0 = the persistent kernel).
     b.sk = 0;
+    {   // column-group tile order for wide outputs (plain row mapping): UVTG_NT_CGW = tiles per group (0 = off), default off until measured
+      static const int cgw_env = getenv("UVTG_NT_CGW") ? atoi(getenv("UVTG_NT_CGW")) : 0;
+      if (g_nt_cgw < 0) g_nt_cgw = cgw_env;
+      b.cgw = (!gather && cdiv(b.N, 256) >= 8) ? g_nt_cgw : 0;
+    }
     int small_tm = 0;
     if (g_nt_small < 0) g_nt_small = getenv("UVTG_NT_SMALL_OFF") ? 0 : (getenv("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
-    if (g_nt_small && !plan.rows1 && best_tm == 2 && tiles <= eff_cus() && !g_force_tile && !g_force_bm && !(b.act >= 100 && b.act <= 103)) {
+    if (g_nt_small && (!plan.rows1 || part == 1) && best_tm == 2 && tiles <= eff_cus() && !g_force_tile && !g_force_bm && !(b.act >= 100 && b.act <= 103)) {
       const SmallPlan sp = nt256_small_plan(rows, b.N, b.groups, b.K / 64, eff_cus(), b.sk_cap_units, b.sk_slab && b.sk_tickets, g_nt_small);
       small_tm = sp.tm; b.sk = sp.parts;
       tiles = nt_small_tiles(rows, b.N, b.groups, small_tm);

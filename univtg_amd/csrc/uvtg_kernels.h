@@ -55,6 +55,10 @@ struct GemmArgs {
   // provides sk_slab (sk_cap_units x 128 x 256 floats) and sk_tickets (sk_cap_units words, ZERO before the launch; the kernel leaves them zero);
   // null = never split.  `sk` is set by the launcher.
   float* sk_slab; unsigned* sk_tickets; int sk_cap_units; int sk;
+  // ---- tile order of the persistent 256-wide kernel (set by its launcher): the column tiles are walked in GROUPS of `cgw` (0 = all of them:
+  // row-block-major over the whole width).  Wide outputs (N = 3 d: 12 column tiles) in groups of cgw keep cgw weight panels -- not all
+  // twelve, 6 MB against a 4 MB L2 -- in front of an XCD while its row blocks stream past them; same tiles, same K order, same results.
+  int cgw;
 };
 constexpr int UVTG_SK_UNITS = 256;                 // capacity the engine's workspace provides
 constexpr int UVTG_SK_TILE_FLOATS = 128 * 256;
