@@ -63,6 +63,9 @@ int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, int cus, int
 /* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
  * launches on different streams can run side by side. */
 int uvtg_debug_gemm_cus(int n);
+/* Host arithmetic only: uvtg_debug_nt_plan with the launch's epilogue class (eop != 0: the launch reads a bf16 residual / pre-activation operand in
+ * its epilogue; uvtg_debug_nt_plan assumes it does) and whether the caller hands the launch a split-K workspace (have_ws). */
+int uvtg_debug_nt_plan2(int M, int N, int K, int groups, int gather, int cus, int eop, int have_ws, int* out3);
 /* Experiment knob (round 5): force the launch plan of the plain-row persistent NT launches of ONE shape -- head of tm1_rows-row tiles over rows
  * [0, rows1) + tail of tm2_rows-row tiles (rows1 = 0: a single launch at tm1_rows); M <= 0 clears every override.  In-box A/B of the cost model. */
 int uvtg_debug_nt_plan_override(int M, int N, int tm1_rows, int rows1, int tm2_rows);

@@ -170,6 +170,7 @@ struct WSpace {
   float *alpha, *cosv, *vnorm, *qnorm, *sal_dq, *sal_dlog;
   // backward scratch
   float *dvm, *gx[2], *dyF, *delta, *dA[2], *tn_scratch; long long tn_scratch_floats;
+  float* ln_part[2 * MAXE]; long long ln_part_floats;      // per-launch dgamma / dbeta partials of the encoder's LayerNorm backward launches (folded by ONE launch)
   float *dpos_txt, *tp_dx;   // use_txt_pos: gradient wrt the text position rows (summed over the layers' q,k operands), and wrt their LayerNorm input
   float* gnorm2;       // sum of squares of the step's gradients, accumulated by uvtg_backward (uvtg_backward_gradnorm2)
   bf16_t *dh2_pad, *dh1_pad, *dyR, *dvmB, *gxb[2], *dOb, *dyP[2], *dhb[2][MAXP];   // dhb[w][b]: gradient wrt the output of projection block b (b < n_proj - 1)
@@ -268,6 +269,8 @@ struct WSpace {
         { const long long grouped = 320LL * 65536 + 64LL * 8 * (2 * (long long)d + (long long)F + 256); if (grouped > need) need = grouped; }   // grouped launches: <= ~1 unit per CU + bias partials
         tn_scratch_floats = need; tn_scratch = a.take<float>((size_t)need);
       }
+      ln_part_floats = ln_bwd_partial_floats(m.M, (int)d);
+      for (size_t l = 0; l < 2 * MAXE; l++) ln_part[l] = l < 2 * E ? a.take<float>((size_t)ln_part_floats) : nullptr;
       dh2_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d); dh1_pad = a.take<bf16_t>((size_t)(m.Rp + 1) * 2 * d);
       dOb = a.take<bf16_t>(M * d);
       for (size_t l = 0; l < E; l++) { dy2L[l] = a.take<bf16_t>(M * d); dy1L[l] = a.take<bf16_t>(M * d); daL[l] = a.take<bf16_t>(M * F); dqkvL[l] = a.take<bf16_t>(M * 3 * d); }
@@ -280,6 +283,8 @@ struct WSpace {
       dpos_txt = tpos ? a.take<float>((size_t)m.Mt * d) : nullptr; tp_dx = tpos ? a.take<float>((size_t)m.Mt * d) : nullptr;
     } else {
       dpos_txt = tp_dx = nullptr;
+      for (int l = 0; l < 2 * MAXE; l++) ln_part[l] = nullptr;
+      ln_part_floats = 0;
       dvm = gx[0] = gx[1] = dyF = delta = nullptr; dyR = dvmB = gxb[0] = gxb[1] = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dOb = nullptr; gnorm2 = nullptr; tnh_slabs = nullptr; tnh_slab_floats = 0; tnh_tickets = nullptr; tnh_n_tickets = 0;
       for (int l = 0; l < MAXE; l++) dy2L[l] = dy1L[l] = daL[l] = dqkvL[l] = nullptr;
       for (int w = 0; w < 2; w++) { dyP[w] = nullptr; dA[w] = nullptr; for (int b = 0; b < MAXP; b++) dhb[w][b] = nullptr; }
@@ -999,6 +1004,19 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // The gradient stream is bf16 (like the activation stream): gin = gradient wrt the layer output; dyB = LayerNorm input
   // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
   const bf16_t* gin = nullptr;                  // null = zero
+  // LayerNorm gamma / beta gradients of the encoder: like the weight gradients, without per-layer readiness events every launch keeps its
+  // per-block partials in its own buffer and ONE launch folds all 2 E of them behind the loop (was: a 5 us reduce launch behind each)
+  static const bool lnred_off = getenv("UVTG_LN_DEFER_OFF") != nullptr;
+  LnReduceMulti lnm; memset(&lnm, 0, sizeof(lnm)); lnm.D = d;
+  int ln_nb = 0;
+  auto ln_partials = [&](LnBwdArgs& lb, int slot) {
+    if (defer && !lnred_off && ws.ln_part[slot]) { lb.partial = ws.ln_part[slot]; lb.partial_floats = ws.ln_part_floats; lb.defer_blocks = &ln_nb; }
+    else { lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats; }
+  };
+  auto ln_deferred = [&](const LnBwdArgs& lb) {
+    if (!lb.defer_blocks || ln_nb <= 0) return;
+    lnm.partial[lnm.count] = lb.partial; lnm.dgamma[lnm.count] = lb.dgamma; lnm.dbeta[lnm.count] = lb.dbeta; lnm.nblocks[lnm.count] = ln_nb; lnm.count++;
+  };
   uvtg_prof_section(1, 0, s);
   if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT || pmode == PACK_HALO, pmode == PACK_HALO, ws.g2p, s));   // conv-head gradient onto the packed rows
   const int* row_sample = packed ? ws.pk.row_sample : nullptr;
@@ -1018,8 +1036,9 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
     lb.dxB = dy2; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S; lb.row_sample = row_sample;
     if (dp_ffn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
-    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
+    ln_partials(lb, 2 * l + 1);
     TRY(launch_ln_bwd(lb, s));
+    ln_deferred(lb);
     GemmArgs g = gemm_base(dy2, d, w.w2T[l], d, M, F, d);             // d h = dy2 W2 ; da = dh * gelu'(a)
     g.gradPre = ws.apre[l]; g.ldgp = F; g.actgrad = 2; g.outB = da; g.ldoB = F;
     TRY(launch_gemm_nt_bf16(g, s));
@@ -1037,8 +1056,9 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.gamma = P[m.lay(l, N1W)]; lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
     lb.dxB = dy1; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S; lb.row_sample = row_sample;
     if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
-    lb.partial = ws.tn_scratch; lb.partial_floats = ws.tn_scratch_floats;
+    ln_partials(lb, 2 * l);
     TRY(launch_ln_bwd(lb, s));
+    ln_deferred(lb);
     g = gemm_base(dy1, d, w.woT[l], d, M, d, d);                       // dO = dy1 Wo
     g.outB = ws.dOb; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
@@ -1068,6 +1088,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
     if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
   }
+  TRY(launch_ln_bwd_reduce_multi(lnm, s));
   TRY(tn_flush());                               // the deferred weight gradients of all encoder layers, inside the encoder section
   uvtg_prof_section(1, 1, s);
   const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]

@@ -1681,7 +1681,7 @@ static int check_nt(const GemmArgs& a, int elem) {
 
 // eligibility of the 256-tile path: whole 64-wide K tiles (also per conv tap), 16-byte rows everywhere the epilogue
 // touches 8 columns at a time, 32-bit byte offsets, and enough work that 256 x 256 tiles do not waste the chip
-static double nt256_cost(int M, int N, int groups, int tm, int cus);
+static double nt256_cost(int M, int N, int groups, int tm, int cus, bool eop = true);
 static int g_num_cu = 0;
 static int g_force_tile = 0;   // 0: automatic, 128 / 256: force that NT tile size where it is legal (parity tests)
 static int g_force_bm = 0;     // 0: automatic, 128 / 192 / 256: force the tile height of the 256-wide persistent kernel
@@ -1747,27 +1747,27 @@ extern "C" int uvtg_set_reserved_cus(int k) {
 #define UVTG_NT_F3 1.07
 #define UVTG_NT_F2 1.20
 #endif
+// 320-row tiles WITHOUT a bf16 epilogue operand (QKV projection, FFN1, out-projection dgrad): their epilogue has no two-piece operand ring to
+// walk, and the factor fitted on the residual launches overprices them -- round 5, in-box (profiles/r05_ab_nt_plans.txt): the N = 3 d launch of
+// the headline (27392 rows) 199 us as 7 rounds of 192-row tiles, 187 as 4.03 rounds of 320-row ones, 177 as 4 rounds + a single-tile tail
+#ifndef UVTG_NT_F5_NOEOP
+#define UVTG_NT_F5_NOEOP 0.90
+#endif
 // Tile height (TM = rows / 64) of a persistent NT launch, pure host arithmetic.  Candidates: 256-wide tiles of 320 / 256 / 192 / 128 rows,
 // one workgroup per CU; cost = rounds x rows of a tile x the per-height factor.  A partly filled last round costs ~0.84 of a full one up to
 // ~70 % fill (fewer active CUs run their K loops faster), then rises to a full round (fitted on the per-height timings of tools/tm5_ab.sh at
 // the step's shapes).  320-row tiles: plain row mapping only -- the gather variants have no registers left for them; a forced 320 falls back
 // to 256 there.  Returns 0 when the forced height is not a candidate.
-static int nt256_pick_tm(int M, int N, int groups, bool gather, int cus, int force) {
-  struct Cand { int tm; double f; };
+static int nt256_pick_tm(int M, int N, int groups, bool gather, int cus, int force, bool eop = true) {
   static const bool tm5_off = getenv("UVTG_NT_TM5_OFF") != nullptr;          // experiment: no 320-row tiles
-  static const Cand cands[] = {{5, UVTG_NT_F5}, {4, UVTG_NT_F4}, {3, UVTG_NT_F3}, {2, UVTG_NT_F2}};
   int best_tm = 0; double best = 1e30;
   const int force_bm = (force == 320 && gather) ? 256 : force;
   if (cus < 1) cus = 1;
-  for (const Cand& c : cands) {
-    if (force_bm && c.tm * 64 != force_bm) continue;
-    if (c.tm == 5 && (gather || (tm5_off && force_bm != 320))) continue;
-    const long long tiles = (long long)cdiv(M, 64 * c.tm) * cdiv(N, 256) * groups;
-    const long long full = tiles / cus, rem = tiles % cus;
-    const double fill = (double)rem / cus;
-    const double rounds = (double)full + (rem ? 0.84 + 0.16 * (fill > 0.7 ? (fill - 0.7) / 0.3 : 0.0) : 0.0);
-    const double cost = rounds * (64.0 * c.tm) * c.f;
-    if (cost < best) { best = cost; best_tm = c.tm; }
+  for (int tm = 5; tm >= 2; tm--) {
+    if (force_bm && tm * 64 != force_bm) continue;
+    if (tm == 5 && (gather || (tm5_off && force_bm != 320))) continue;
+    const double cost = nt256_cost(M, N, groups, tm, cus, eop);
+    if (cost < best) { best = cost; best_tm = tm; }
   }
   return best_tm;
 }
@@ -1782,13 +1782,13 @@ extern "C" int uvtg_debug_nt_tile_rows(int M, int N, int groups, int gather, int
 // ragged batch whose packed row count lands just above 320 x 64 = 20480 pays a 128-row tail instead of a second 320-row round.
 // Same cost model as nt256_pick_tm (units: rows of a tile x per-height factor per round); the tail launch is charged its launch gap.
 struct NtPlan { int tm1, rows1, tm2; };      // rows1 == 0: single launch at tm1
-static double nt256_cost(int M, int N, int groups, int tm, int cus) {
+static double nt256_cost(int M, int N, int groups, int tm, int cus, bool eop) {
   static const double f[6] = {0, 0, UVTG_NT_F2, UVTG_NT_F3, UVTG_NT_F4, UVTG_NT_F5};
   const long long tiles = (long long)cdiv(M, 64 * tm) * cdiv(N, 256) * groups;
   const long long full = tiles / cus, rem = tiles % cus;
   const double fill = (double)rem / cus;
   const double rounds = (double)full + (rem ? 0.84 + 0.16 * (fill > 0.7 ? (fill - 0.7) / 0.3 : 0.0) : 0.0);
-  return rounds * (64.0 * tm) * f[tm];
+  return rounds * (64.0 * tm) * ((tm == 5 && !eop) ? UVTG_NT_F5_NOEOP : f[tm]);
 }
 // Experiment knob (include/uvtg_dev.h): the plan of the plain-row launches of one M x N shape, forced (in-box A/B of the cost model's choice).
 struct NtPlanOverride { int M, N, tm1, rows1, tm2; };
@@ -1801,7 +1801,10 @@ extern "C" int uvtg_debug_nt_plan_override(int M, int N, int tm1_rows, int rows1
   g_plan_ovr[g_plan_novr++] = NtPlanOverride{M, N, tm1_rows / 64, rows1, tm2_rows / 64};
   return 0;
 }
-static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, int force) {
+struct SmallPlan { int tm, parts; double us; };
+static SmallPlan nt256_small_plan(int rows, int N, int groups, int nk, int cus, int cap_units, bool have_ws, int mode);
+static int g_nt_small = -1;          // the single-tile (three-stage ring) variant for launches of at most one tile per CU: 1 on (default), 0 off
+static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, int force, bool eop = true, bool have_ws = false, int cap_units = 0) {
   static const bool split_off = getenv("UVTG_NT_SPLIT_OFF") != nullptr;      // experiment: single launches only
   static const bool ovr_env = [] {      // UVTG_NT_PLAN_OVR="M,N,tm1_rows,rows1,tm2_rows;..." = uvtg_debug_nt_plan_override calls (A/B runs of bench.py)
     const char* e = getenv("UVTG_NT_PLAN_OVR");
@@ -1816,10 +1819,12 @@ static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, 
   (void)ovr_env;
   if (!gather && groups == 1 && !force)
     for (int i = 0; i < g_plan_novr; i++) if (g_plan_ovr[i].M == M && g_plan_ovr[i].N == N) return NtPlan{g_plan_ovr[i].tm1, g_plan_ovr[i].rows1, g_plan_ovr[i].tm2};
-  NtPlan pl{nt256_pick_tm(M, N, groups, gather, cus, force), 0, 0};
+  NtPlan pl{nt256_pick_tm(M, N, groups, gather, cus, force, eop), 0, 0};
   if (!pl.tm1 || split_off || force || cus < 1) return pl;
-  double best = nt256_cost(M, N, groups, pl.tm1, cus);
+  double best = nt256_cost(M, N, groups, pl.tm1, cus, eop);
   const double gap = 24.0 * 1024.0 / (K > 64 ? K : 64);          // ~3 us launch gap in units of one 320-row round at K = 1024 (~326 units ~ 40 us)
+  const double us_per_unit = 0.1227 * (K > 64 ? K : 64) / 1024.0;
+  if (g_nt_small < 0) g_nt_small = getenv("UVTG_NT_SMALL_OFF") ? 0 : (getenv("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
   const int tn_g = cdiv(N, 256) * groups;
   for (int tm1 = gather ? 4 : 5; tm1 >= 3; tm1--) {
     const long long rt_total = cdiv(M, 64 * tm1);
@@ -1828,9 +1833,15 @@ static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, 
     const int rt1 = (int)(full_rounds * cus / tn_g);                // row tiles of the head: the most that fit into whole rounds
     const long long rows1 = (long long)rt1 * 64 * tm1;
     if (rt1 < 1 || rows1 >= M) continue;
-    const double head = nt256_cost((int)rows1, N, groups, tm1, cus);
+    const double head = nt256_cost((int)rows1, N, groups, tm1, cus, eop);
     for (int tm2 = 2; tm2 <= 4; tm2++) {
-      const double c = head + nt256_cost(M - (int)rows1, N, groups, tm2, cus) + gap;
+      double tail = nt256_cost(M - (int)rows1, N, groups, tm2, cus, eop);
+      if (tm2 == 2 && g_nt_small && (long long)cdiv(M - (int)rows1, 128) * cdiv(N, 256) * groups <= cus) {
+        // a tail of at most one 128-row tile per CU runs the single-tile variant (launch_nt256): priced by that variant's own estimate
+        const SmallPlan sp = nt256_small_plan(M - (int)rows1, N, groups, K / 64, cus, cap_units, have_ws, g_nt_small);
+        if (sp.tm) tail = sp.us / us_per_unit;
+      }
+      const double c = head + tail + gap;
       if (c < best * 0.97) { best = c; pl = NtPlan{tm1, (int)rows1, tm2}; }      // (3 % margin: do not split for noise)
     }
   }
@@ -1840,6 +1851,13 @@ static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, 
 extern "C" int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, int cus, int* out3) {
   if (M <= 0 || N <= 0 || K <= 0 || groups <= 0 || cus <= 0 || !out3) return -20;
   const NtPlan pl = nt256_plan(M, N, K, groups, gather != 0, cus, 0);
+  out3[0] = 64 * pl.tm1; out3[1] = pl.rows1; out3[2] = 64 * pl.tm2;
+  return 0;
+}
+// ... with the launch's epilogue class (eop != 0: it reads a bf16 residual / pre-activation operand) and whether the caller provides the split-K workspace
+extern "C" int uvtg_debug_nt_plan2(int M, int N, int K, int groups, int gather, int cus, int eop, int have_ws, int* out3) {
+  if (M <= 0 || N <= 0 || K <= 0 || groups <= 0 || cus <= 0 || !out3) return -20;
+  const NtPlan pl = nt256_plan(M, N, K, groups, gather != 0, cus, 0, eop != 0, have_ws != 0, UVTG_SK_UNITS);
   out3[0] = 64 * pl.tm1; out3[1] = pl.rows1; out3[2] = 64 * pl.tm2;
   return 0;
 }
@@ -1930,7 +1948,6 @@ template <int TM> static int launch_nt256_small(const GemmArgs& b, int grid, boo
 static int g_nt_cgw = -1;            // column-group width of the tile order of wide plain-row launches (0 = row-block-major over the whole width)
 extern "C" int uvtg_debug_nt_cgw(int tiles_per_group) { if (tiles_per_group < 0 || tiles_per_group > 64) return -21; g_nt_cgw = tiles_per_group; return 0; }
 static int g_nt_splitk_max = -1;
-static int g_nt_small = -1;          // the single-tile (three-stage ring) variant for launches of at most one tile per CU: 1 on (default), 0 off
 extern "C" int uvtg_debug_nt_small(int on) { if (on < 0 || on > 2) return -21; g_nt_small = on; return 0; }       // (2: 128-row tiles only)
 extern "C" int uvtg_debug_nt_splitk(int max_parts) { if (max_parts < 0 || max_parts > 4) return -21; g_nt_splitk_max = max_parts; return 0; }
 static int nt256_splitk_parts(long long tiles, int nk, int cus, int cap_units) {
@@ -1954,7 +1971,6 @@ static int nt256_splitk_parts(long long tiles, int nk, int cus, int cap_units) {
 // split: + 3 + 0.7 x parts / + 7 + 1.5 x parts for the part that finishes the tile.  The choice needs to be right only where the candidates
 // differ by more than noise: batch 32 encoder GEMMs (216 narrow tiles, no split: 29 us against 39 for 108 wide ones x 2 parts), batch 32
 // video projection (K = 2880: 76 wide tiles x 3 parts: 52 us against 68 for 152 unsplit narrow ones), batch 1 (8 narrow tiles x 4 parts).
-struct SmallPlan { int tm, parts; };
 #ifndef UVTG_NT_SMALL_TK1
 #define UVTG_NT_SMALL_TK1 0.68
 #endif
@@ -1962,7 +1978,7 @@ static long long nt_small_tiles(int rows, int N, int groups, int tm) {
   return (long long)cdiv(rows, 128) * cdiv(N, tm == 1 ? 128 : 256) * groups;
 }
 static SmallPlan nt256_small_plan(int rows, int N, int groups, int nk, int cus, int cap_units, bool have_ws, int mode) {
-  SmallPlan best{0, 0}; double bc = 1e30;
+  SmallPlan best{0, 0, 0.0}; double bc = 1e30;
   for (int tm = 1; tm <= 2; tm++) {                     // 1: 128 x 128 tiles, 2: 128 x 256
     if (tm == 1 && mode == 2) continue;                 // (experiment switch: 128 x 256 tiles only)
     const long long tiles = nt_small_tiles(rows, N, groups, tm);
@@ -1970,7 +1986,7 @@ static SmallPlan nt256_small_plan(int rows, int N, int groups, int nk, int cus, 
     int parts = have_ws ? nt256_splitk_parts(tiles, nk, cus, cap_units) : 0;
     if (parts < 2) parts = 1;
     const double cost = cdiv(nk, parts) * (tm == 1 ? UVTG_NT_SMALL_TK1 : 1.10) + (tm == 1 ? 4.0 : 7.0) + (parts > 1 ? (tm == 1 ? 3.0 + 0.7 * parts : 7.0 + 1.5 * parts) : 0.0);
-    if (cost < bc) { bc = cost; best = SmallPlan{tm, parts}; }
+    if (cost < bc) { bc = cost; best = SmallPlan{tm, parts, cost}; }
   }
   return best;
 }
@@ -2035,7 +2051,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
     else if (!b.outPre && !b.act && b.actgrad == 2 && eop && !b.residB && !b.rowscale) epi = 3;
   }
   if (!((epi_mask >> epi) & 1)) epi = 0;
-  const NtPlan plan = nt256_plan(b.M, b.N, b.K, b.groups, gather, eff_cus(), g_force_bm);
+  const NtPlan plan = nt256_plan(b.M, b.N, b.K, b.groups, gather, eff_cus(), g_force_bm, eop, b.sk_slab && b.sk_tickets, b.sk_cap_units);
   if (!plan.tm1) return -21;
   const int M_all = b.M;
   int rc = 0;

@@ -548,6 +548,31 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const LnBwdArgs a, i
   }
 }
 
+// The same fold for SEVERAL LayerNorm launches at once (blockIdx.z = launch): the encoder's 2 E backward launches keep their partials in
+// their own buffers and are folded by one launch behind the encoder loop (single-rank steps: nobody waits for a layer's gamma / beta gradient).
+__global__ __launch_bounds__(256) void ln_bwd_reduce_multi_kernel(const LnReduceMulti m) {
+  __shared__ float red2[4][64];
+  const int z = blockIdx.z, il = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + il, n = 2 * m.D, nblocks = m.nblocks[z];
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(b0 + per, nblocks);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < n) {
+    const float* pp = m.partial[z] + c;
+    int b = b0 + bl;
+    for (; b + 12 < b1; b += 16) {
+      s0 += pp[(size_t)b * n]; s1 += pp[(size_t)(b + 4) * n]; s2 += pp[(size_t)(b + 8) * n]; s3 += pp[(size_t)(b + 12) * n];
+    }
+    for (; b < b1; b += 4) s0 += pp[(size_t)b * n];
+  }
+  red2[bl][il] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (bl == 0 && c < n) {
+    const float t = (red2[0][il] + red2[1][il]) + (red2[2][il] + red2[3][il]);
+    atomicAdd(c < m.D ? m.dgamma[z] + c : m.dbeta[z] + (c - m.D), t);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Wide rows (the 2818-wide feature LayerNorm of the video projection, model/univtg.py:91-100).  One wave per row keeps
 // 48 values + gamma/beta in registers per lane (218-450 VGPRs: one or two waves per SIMD); here a whole 256-thread block
@@ -761,32 +786,48 @@ template <int VEC, int NV> int run_fwd(const LnFwdArgs& a, hipStream_t s) {
 #ifndef UVTG_LN_BLOCKS
 #define UVTG_LN_BLOCKS 512
 #endif
+static int ln_bwd_wpb(int D) {       // waves per block: as many as fit 64 KB of per-wave partial slabs (8 at D <= 1024, 2 at D = 2818); ~12 rows per wave
+  int wpb = (int)(65536 / (2 * (size_t)D * sizeof(float)));
+  return wpb >= 8 ? 8 : (wpb >= 4 ? 4 : (wpb >= 2 ? 2 : 1));
+}
+static int ln_bwd_blocks(int rows, int D) { const int wpb = ln_bwd_wpb(D); return min(cdiv(rows, wpb), max(1, (UVTG_LN_BLOCKS) * 8 / wpb)); }
 template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
   const bool bf = a.x == nullptr;
   if (bf ? ((a.g != nullptr) || (a.g2 != nullptr) || !a.xB) : ((a.gB != nullptr) || (a.g2B != nullptr))) return -4;   // streams are all bf16 or all fp32
-  // waves per block: as many as fit 64 KB of per-wave partial slabs (8 at D <= 1024, 2 at D = 2818); ~12 rows per wave
-  int wpb = (int)(65536 / (2 * (size_t)a.D * sizeof(float)));
-  wpb = wpb >= 8 ? 8 : (wpb >= 4 ? 4 : (wpb >= 2 ? 2 : 1));
-  const int blocks = min(cdiv(a.rows, wpb), max(1, (UVTG_LN_BLOCKS) * 8 / wpb));
+  const int wpb = ln_bwd_wpb(a.D);
+  const int blocks = ln_bwd_blocks(a.rows, a.D);
   LnBwdArgs b = a;
   if (!b.dgamma || b.partial_floats < (long long)blocks * 2 * b.D) b.partial = nullptr;
+  const bool defer = b.defer_blocks && b.partial;      // the caller folds the partials (launch_ln_bwd_reduce_multi)
+  if (b.defer_blocks) *b.defer_blocks = defer ? blocks : 0;
   if constexpr (VEC == 8 && NV <= 2) {
     static const bool lean_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
     if (bf && (a.gB || a.g2B) && a.p_drop == 0.f && !a.relu_from_x && !a.gather_x && wpb == 8 && !lean_off) {
       hipLaunchKernelGGL((ln_bwd_lean_kernel<NV>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
-      if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
+      if (b.partial && !defer) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
       UVTG_CHECK_LAUNCH();
       return 0;
     }
   }
   if (bf) hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, true>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   else hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, false>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
-  if (b.partial) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
+  if (b.partial && !defer) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace
+
+long long ln_bwd_partial_floats(int rows, int D) { return (long long)ln_bwd_blocks(rows, D) * 2 * D; }
+int launch_ln_bwd_reduce_multi(const LnReduceMulti& m, hipStream_t s) {
+  if (m.count <= 0) return 0;
+  if (m.count > UVTG_LN_MULTI_MAX) return -17;
+  int mx = 0;
+  for (int i = 0; i < m.count; i++) mx = max(mx, m.nblocks[i]);
+  hipLaunchKernelGGL(ln_bwd_reduce_multi_kernel, dim3(cdiv(2 * m.D, 64), mx >= 128 ? 8 : 1, m.count), dim3(256), 0, s, m);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
 
 #define LN_DISPATCH(FN, ARGS)                                                          \
   const int D = ARGS.D;                                                                 \
@@ -842,6 +883,7 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
 }
 
 static int launch_ln_bwd_impl(const LnBwdArgs& a, hipStream_t s) {
+  if (a.defer_blocks) *a.defer_blocks = 0;      // (set by the row kernels' launcher when it leaves the fold to the caller)
   if (a.rows <= 0) return 0;
   const bool align16 = al(a.x, a.ldx, 4, 16) && al(a.g, a.ldg, 4, 16) && al(a.g2, a.ldg2, 4, 16) && al(a.xB, a.ldxB, 2, 8) &&
                        al(a.gB, a.ldgB, 2, 8) && al(a.g2B, a.ldg2B, 2, 8) && al(a.dxB2, a.lddxB2, 2, 8) &&

@@ -159,8 +159,16 @@ struct LnBwdArgs {
   int relu_from_x;              // 1: dx is masked by (x > 0): x is the output of a ReLU (input projections)
   float* partial; long long partial_floats;   // optional scratch for per-block dgamma / dbeta partials (else atomics)
   const int* src_rows; int gather_x;          // as in LnFwdArgs (generic kernel and the wide dgamma / dbeta kernel)
+  // defer_blocks (host pointer, optional): the launch writes its per-block partials to `partial` and does NOT fold them -- *defer_blocks
+  // receives the number of partial rows; the caller folds several launches' partials with ONE launch_ln_bwd_reduce_multi (round 5: the
+  // encoder's 2 E LayerNorm backward launches were each followed by their own 5 us reduce launch)
+  int* defer_blocks;
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
+long long ln_bwd_partial_floats(int rows, int D);      // floats of `partial` a launch of this shape needs (its per-block dgamma / dbeta rows)
+constexpr int UVTG_LN_MULTI_MAX = 32;      // (2 x the engine's MAXE)
+struct LnReduceMulti { const float* partial[UVTG_LN_MULTI_MAX]; float* dgamma[UVTG_LN_MULTI_MAX]; float* dbeta[UVTG_LN_MULTI_MAX]; int nblocks[UVTG_LN_MULTI_MAX]; int D, count; };
+int launch_ln_bwd_reduce_multi(const LnReduceMulti& m, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // attention
