@@ -63,6 +63,12 @@ int uvtg_debug_nt_plan(int M, int N, int K, int groups, int gather, int cus, int
 /* Experiment knob: the persistent GEMM launches that follow size their grids for at most n CUs (0 = the whole chip), so that two
  * launches on different streams can run side by side. */
 int uvtg_debug_gemm_cus(int n);
+/* LayerNorm (round 5): kernel-level entry of the encoder's bf16 launches -- x bf16 [rows, D] -> y (bf16, optional), y + pos (bf16, optional: row s < Lv
+ * of each S-row sample adds the fp32 row pos[b * Lv + s]; S = 0 / pos = NULL: none), mean / rstd [rows] (optional).  uvtg_debug_ln_fwd_lean(0) sends
+ * these launches through the generic row kernel again (1 = default: the lean kernel with the next row in flight). */
+int uvtg_debug_layernorm_fwd_bf16(const void* xB, const float* gamma, const float* beta, void* yB, void* yU, const float* pos, int S, int Lv,
+                                  float* mean, float* rstd, int rows, int D, uvtg_stream_t stream);
+int uvtg_debug_ln_fwd_lean(int on);
 /* Host arithmetic only: uvtg_debug_nt_plan with the launch's epilogue class (eop != 0: the launch reads a bf16 residual / pre-activation operand in
  * its epilogue; uvtg_debug_nt_plan assumes it does) and whether the caller hands the launch a split-K workspace (have_ws). */
 int uvtg_debug_nt_plan2(int M, int N, int K, int groups, int gather, int cus, int eop, int have_ws, int* out3);

@@ -332,6 +332,51 @@ def test_nt_loader_waves_bit_identical(dev):
         lib.uvtg_debug_force_nt_tile(0)
 
 
+@pytest.mark.parametrize("D", [1024, 512])
+def test_layernorm_fwd_bf16_lean_vs_generic_vs_fp32(dev, D):
+    """The encoder's bf16 LayerNorm forward (round 5: ln_fwd_lean_kernel, next row in flight, gamma / beta in registers) against torch fp32 on the
+    same bf16 rows and against the generic row kernel it replaces: y, y + pos (clip rows only), mean, rstd."""
+    from univtg_amd import _lib
+    from univtg_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7)
+    B, S, Lv = 41, 107, 75
+    rows = B * S
+    x = bf((torch.randn(rows, D, generator=g) * 1.7 + 0.3).to(dev))
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev)
+    pos = torch.randn(B * Lv, D, generator=g).to(dev)
+    res = {}
+    try:
+        for lean in (1, 0):
+            _lib.check(lib.uvtg_debug_ln_fwd_lean(lean))
+            y = torch.empty(rows, D, dtype=torch.bfloat16, device=dev); u = torch.empty_like(y)
+            mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+            _lib.check(lib.uvtg_debug_layernorm_fwd_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(u), _ptr(pos), S, Lv, _ptr(mean), _ptr(rstd), rows, D, _stream()))
+            y1 = torch.empty_like(y)
+            _lib.check(lib.uvtg_debug_layernorm_fwd_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y1), None, None, 0, 0, None, None, rows, D, _stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(y1, y)
+            res[lean] = (y.float(), u.float(), mean, rstd)
+    finally:
+        lib.uvtg_debug_ln_fwd_lean(1)
+    xf = x.float()
+    ref = torch.nn.functional.layer_norm(xf, (D,), gamma, beta, 1e-5)
+    refu = ref.clone().view(B, S, D)
+    refu[:, :Lv] += pos.view(B, Lv, D)
+    refu = refu.view(rows, D)
+    for lean in (1, 0):
+        y, u, mean, rstd = res[lean]
+        assert float((y - ref).abs().max()) < 2.5e-2 and float((u - refu).abs().max()) < 4e-2          # bf16 rounding of |y| <= ~6
+        assert float((y - ref).abs().mean()) < 2e-3
+        assert float((mean - xf.mean(1)).abs().max()) < 1e-5
+        assert float((rstd - 1 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5)).abs().max()) < 1e-5
+    # the two kernels round the same fp32 values: they may differ by one bf16 ulp where a value sits on a rounding boundary, not more
+    d = (res[1][0] - res[0][0]).abs()
+    assert float(d.max()) <= 2 ** -7 * 8 and float((d > 0).float().mean()) < 1e-2
+    assert float((res[1][2] - res[0][2]).abs().max()) < 1e-6
+
+
 def test_nt_column_group_order_and_forced_plans_bit_identical(dev):
     """Round-5 experiment knobs of the persistent NT GEMM change WHICH workgroup computes a tile and how a launch is cut into head + tail, never
     the products or the K order: column-group tile order (wide outputs: 12 column tiles walked in groups of 4 / 6 / 5), forced head / tail plans

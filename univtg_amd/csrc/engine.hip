@@ -1320,6 +1320,16 @@ extern "C" int uvtg_layernorm_fwd(const float* x, const float* gamma, const floa
   a.yF = y; a.ldyF = D; a.Dpad = D;
   return launch_ln_fwd(a, (hipStream_t)st);
 }
+// kernel-level entry of the encoder's bf16 LayerNorm launches (include/uvtg_dev.h; parity tests): x bf16 [rows, D]; y (bf16, optional), y + pos
+// (bf16, optional: row (b, s) with s < Lv of each S-row sample adds pos[b * Lv + s], fp32 [rows / S * Lv, D]; pos may be null), mean / rstd.
+extern "C" int uvtg_debug_layernorm_fwd_bf16(const void* xB, const float* gamma, const float* beta, void* yB, void* yU, const float* pos, int S,
+                                             int Lv, float* mean, float* rstd, int rows, int D, uvtg_stream_t st) {
+  if (!xB || !gamma || !beta) return -20;
+  LnFwdArgs a; memset(&a, 0, sizeof(a));
+  a.xB = (const bf16_t*)xB; a.ldxB = D; a.rows = rows; a.D = D; a.gamma = gamma; a.beta = beta; a.eps = 1e-5f; a.mean = mean; a.rstd = rstd;
+  a.yB = (bf16_t*)yB; a.ldyB = D; a.Dpad = D; a.yU = (bf16_t*)yU; a.ldyU = D; a.pos = pos; a.S = S; a.Lv = Lv;
+  return launch_ln_fwd(a, (hipStream_t)st);
+}
 extern "C" int uvtg_layernorm_bwd(const float* g, const float* x, const float* mean, const float* rstd, const float* gamma,
                                   float* dx, float* dgamma, float* dbeta, int rows, int D, uvtg_stream_t st) {
   if (!g || !x || !mean || !rstd || !gamma) return -20;

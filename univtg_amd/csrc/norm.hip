@@ -222,6 +222,95 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
   }
 }
 
+// The encoder's LayerNorm forward in the bf16 mode (round 5; D = 512 / 1024, bf16 rows in, no dropout): same math as ln_fwd_kernel, built
+// like ln_bwd_lean_kernel for the HBM rate.  The generic kernel takes ONE row per wave through a chain load -> wave sum -> wave sum ->
+// stores with ~20 run-time feature tests in it and re-reads gamma / beta per row (LN1: 112 MB in 31.5 us = 3.6 TB/s).  Here a wave walks
+// its rows with the NEXT row's 16-byte pieces already in flight (still packed: 4 registers per piece), gamma / beta live in registers,
+// and the position row of a clip token (fp32, the y + pos output of LN2) is requested before the two reductions that precede its use.
+// Outputs: y (bf16), y + pos (bf16; clip rows: pos by (S, Lv) arithmetic or by the packed stream's row table), the clip rows' copy into
+// the zero-framed conv layout (last layer), mean / rstd.
+template <int NV>
+__global__ __launch_bounds__(256, 4) void ln_fwd_lean_kernel(const LnFwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int D = a.D;
+  float gm[NV][8], bt[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int c = (i * 64 + lane) * 8;
+    const f32x4 g0 = *(const f32x4*)(a.gamma + c), g1 = *(const f32x4*)(a.gamma + c + 4);
+    const f32x4 b0 = *(const f32x4*)(a.beta + c), b1 = *(const f32x4*)(a.beta + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { gm[i][e] = g0[e]; gm[i][4 + e] = g1[e]; bt[i][e] = b0[e]; bt[i][4 + e] = b1[e]; }
+  }
+  const int stride = gridDim.x * wpb;
+  const float invD = 1.0f / (float)D;
+  u32x4 px[NV];
+  auto fetch = [&](int r) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) px[i] = *(const u32x4*)(a.xB + (size_t)r * a.ldxB + (i * 64 + lane) * 8);
+  };
+  int row = blockIdx.x * wpb + wave;
+  if (row < a.rows) fetch(row);
+  for (; row < a.rows; row += stride) {
+    u32x4 cx[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) cx[i] = px[i];
+    fetch(min(row + stride, a.rows - 1));
+    // row classification (wave-uniform): position row of a clip token, its row in the conv frame
+    int prow = -1; size_t frow = 0; bool is_vid = false;
+    if (a.pos_row) prow = a.pos_row[row];
+    else if (a.S > 0) { const int b = row / a.S, sidx = row - b * a.S; is_vid = sidx < a.Lv; if (is_vid) { prow = b * a.Lv + sidx; frow = (size_t)(b * (a.Lv + 2) + sidx + 1); } }
+    const bool want_u = a.yU != nullptr;
+    const bool have_pos = want_u && a.pos && prow >= 0;
+    f32x4 pv[NV][2];
+    if (have_pos) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const float* pp = a.pos + (size_t)prow * D + (i * 64 + lane) * 8;
+        pv[i][0] = *(const f32x4*)pp; pv[i][1] = *(const f32x4*)(pp + 4);
+      }
+    }
+    float v[NV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        v[i][2 * e] = __uint_as_float(cx[i][e] << 16); v[i][2 * e + 1] = __uint_as_float(cx[i][e] & 0xffff0000u);
+        sum += v[i][2 * e]; sum += v[i][2 * e + 1];
+      }
+    const float mean = wave_sum_dpp(sum) * invD;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float t = v[i][e] - mean; sq += t * t; }
+    const float rstd = rsqrtf(wave_sum_dpp(sq) * invD + a.eps);
+    if (lane == 0) {
+      if (a.mean) a.mean[row] = mean;
+      if (a.rstd) a.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int c = (i * 64 + lane) * 8;
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) y[e] = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+      u32x4 t; t[0] = pack_bf2(y[0], y[1]); t[1] = pack_bf2(y[2], y[3]); t[2] = pack_bf2(y[4], y[5]); t[3] = pack_bf2(y[6], y[7]);
+      if (a.yB) *(u32x4*)(a.yB + (size_t)row * a.ldyB + c) = t;
+      if (is_vid && a.yP) *(u32x4*)(a.yP + frow * a.ldyP + c) = t;
+      if (want_u) {
+        u32x4 u = t;
+        if (have_pos) {
+          u[0] = pack_bf2(y[0] + pv[i][0][0], y[1] + pv[i][0][1]); u[1] = pack_bf2(y[2] + pv[i][0][2], y[3] + pv[i][0][3]);
+          u[2] = pack_bf2(y[4] + pv[i][1][0], y[5] + pv[i][1][1]); u[3] = pack_bf2(y[6] + pv[i][1][2], y[7] + pv[i][1][3]);
+        }
+        *(u32x4*)(a.yU + (size_t)row * a.ldyU + c) = u;
+      }
+    }
+  }
+}
+
 // dx = rstd * (gh - mean(gh) - xhat * mean(gh * xhat)),  gh = g * gamma;  dgamma += g * xhat; dbeta += g
 // RPW rows per wave are in flight together (the row loop is a chain load -> two wave reductions -> store: one row at a time
 // leaves the kernel latency-bound at half the HBM rate).
@@ -856,6 +945,8 @@ static bool al(const void* p, int ld_elems, int bytes_per, int want) {
   return p == nullptr || ((((uintptr_t)p) % want == 0) && ((size_t)ld_elems * bytes_per) % want == 0);
 }
 
+static int g_ln_fwd_lean = -1;       // 1 (default): the encoder's bf16 LayerNorm launches take ln_fwd_lean_kernel; 0: the generic kernel (parity tests / A-B)
+extern "C" int uvtg_debug_ln_fwd_lean(int on) { g_ln_fwd_lean = on ? 1 : 0; return 0; }
 static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
   if (a.addtab && (a.D > 2048 || a.add_L <= 0)) return -4;      // (only the generic kernel adds the table)
@@ -878,6 +969,19 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((ln_fwd_wide_kernel<6>), dim3(min(a.rows, 4096)), dim3(256), 0, s, a);         // block per row (see the kernel)
     UVTG_CHECK_LAUNCH();
     return 0;
+  }
+  {   // the encoder's bf16 LayerNorms (round 5): lean kernel, next row in flight
+    if (g_ln_fwd_lean < 0) g_ln_fwd_lean = getenv("UVTG_LN_FWD_LEAN_OFF") ? 0 : 1;
+    const bool lean_off = g_ln_fwd_lean == 0;
+    const bool plain = a.xB && !a.x && a.p_drop == 0.f && !a.yF && !a.yS && !a.yUS && !a.yPS && !a.yUF && !a.yPF && !a.addtab && !a.src_rows && !a.u_from_x &&
+                       !a.xsum && (a.Dpad <= a.D) && (a.D == 1024 || a.D == 512) && alignv8 && !(a.pos_row && a.yP);
+    if (plain && !lean_off && a.rows >= 1024) {
+      const int blocks = min(cdiv(a.rows, 4), 1024);
+      if (a.D == 1024) hipLaunchKernelGGL((ln_fwd_lean_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((ln_fwd_lean_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+      UVTG_CHECK_LAUNCH();
+      return 0;
+    }
   }
   LN_DISPATCH(run_fwd, a)
 }
