@@ -242,6 +242,39 @@ def test_trainstep_survives_a_projection_mode_flip_between_steps(dev):
     assert float((gg0 @ gg1) / (gg0.norm() * gg1.norm())) > 0.999999
 
 
+@pytest.mark.parametrize("packed", [False, "auto"], ids=["padded", "packed"])
+def test_attention_delta_from_the_dgrad_epilogue_matches_its_own_pass(dev, packed):
+    """Round 5: attention backward's delta = rowsum_head(dO * O) is produced by the out-projection dgrad GEMM's epilogue (EPI 4: O as the epilogue
+    operand, two fp32 atomics per (row, head) at head_dim 128) instead of attn_delta_kernel's pass.  Same rounded dO, same O: the whole train step's
+    gradients must agree with the separate pass to fp32 summation order -- padded rows and the packed (ragged) stream with its row tables."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import _lib
+    from univtg_amd.trainer import TrainStep
+    lib = _lib.load()
+    cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
+    params = O.init_params(cfg, seed=21)
+    inputs, tg = O.make_batch(cfg, 48, 75, 32, seed=22, ragged=True)
+    batch, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    batch["_lens_host"] = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+    res = []
+    try:
+        for fuse in (1, 0):
+            _lib.check(lib.uvtg_debug_delta_fuse(fuse))
+            model, crit = build(cfg, params, dev, "auto", proj_precise=False)
+            model.train(); model.set_seed(9)
+            step = TrainStep(model, crit, grad_clip=0.1, packed=packed)
+            losses = step.step(batch, tgd, optimize=False)
+            torch.cuda.synchronize()
+            res.append((losses.clone(), step.grads.clone()))
+    finally:
+        lib.uvtg_debug_delta_fuse(1)
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-6, atol=1e-7)          # (the forward is the same launch sequence)
+    g1, g0 = res[0][1].double(), res[1][1].double()
+    assert bool(torch.isfinite(g1).all())
+    assert float((g1 @ g0) / (g1.norm() * g0.norm())) > 0.999999
+    assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
+
+
 def test_hl_loss_subset_production_width(dev):
     """dset_type 'hl' / 'vs' (losses = labels + saliency, model/univtg.py:439-440) at d = 1024, E = 4 against the oracle's fp32 autograd:
     every parameter gradient within 1.5 % in norm, cosine >= 0.998; span_embed gets no gradient."""

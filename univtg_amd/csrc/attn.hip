@@ -1121,8 +1121,10 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   if (a.precise) return -6;
   const long long rows = a.row_sample ? (long long)a.total_rows : (long long)a.B * a.S;
   uvtg_prof_begin_launch(5, 10.0 * a.B * a.H * (double)a.S * a.S * a.hd, s);
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
-  UVTG_CHECK_LAUNCH();
+  if (!a.delta_ready) {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+    UVTG_CHECK_LAUNCH();
+  }
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
   static const bool swz_off = getenv("UVTG_ATTN_SWZ_OFF") != nullptr;       // experiment: padded rows instead of the chunk swizzle (head_dim 128)
   const bool swz = a.hd == 128 && !swz_off;

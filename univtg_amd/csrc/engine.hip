@@ -170,6 +170,7 @@ struct WSpace {
   float *alpha, *cosv, *vnorm, *qnorm, *sal_dq, *sal_dlog;
   // backward scratch
   float *dvm, *gx[2], *dyF, *delta, *dA[2], *tn_scratch; long long tn_scratch_floats;
+  float* deltaL[MAXE]; long long delta_floats;      // per-layer attention-backward delta [B, H, S], zeroed with gnorm2 / the tickets (they follow them): filled by the dO GEMM's epilogue
   float* ln_part[2 * MAXE]; long long ln_part_floats;      // per-launch dgamma / dbeta partials of the encoder's LayerNorm backward launches (folded by ONE launch)
   float *dpos_txt, *tp_dx;   // use_txt_pos: gradient wrt the text position rows (summed over the layers' q,k operands), and wrt their LayerNorm input
   float* gnorm2;       // sum of squares of the step's gradients, accumulated by uvtg_backward (uvtg_backward_gradnorm2)
@@ -256,8 +257,11 @@ struct WSpace {
       {   // clipping-norm slots, directly followed by the tickets of the hybrid weight-gradient launch: ONE memset zeroes both
         const int dt = (int)((d + 255) / 256), ft = (int)((F + 255) / 256);
         tnh_n_tickets = (int)E * (2 * dt * ft + 4 * dt * dt);
-        gnorm2 = a.take<float>(UVTG_SQSUM_FLOATS + (size_t)tnh_n_tickets);
+        const size_t dfl = ((size_t)B * m.c.H * m.S + 3) & ~(size_t)3;
+        delta_floats = (long long)(dfl * E);
+        gnorm2 = a.take<float>(UVTG_SQSUM_FLOATS + (size_t)tnh_n_tickets + dfl * E);
         tnh_tickets = (unsigned*)(gnorm2 + UVTG_SQSUM_FLOATS);
+        for (size_t l = 0; l < MAXE; l++) deltaL[l] = l < E ? gnorm2 + UVTG_SQSUM_FLOATS + tnh_n_tickets + dfl * l : nullptr;
         tnh_slab_floats = gemm_tn_multi_slab_floats(tnh_n_tickets, 320);
         tnh_slabs = a.take<float>((size_t)tnh_slab_floats);
       }
@@ -285,6 +289,8 @@ struct WSpace {
       dpos_txt = tp_dx = nullptr;
       for (int l = 0; l < 2 * MAXE; l++) ln_part[l] = nullptr;
       ln_part_floats = 0;
+      for (int l = 0; l < MAXE; l++) deltaL[l] = nullptr;
+      delta_floats = 0;
       dvm = gx[0] = gx[1] = dyF = delta = nullptr; dyR = dvmB = gxb[0] = gxb[1] = nullptr; sal_dq = sal_dlog = nullptr; tn_scratch = nullptr; tn_scratch_floats = 0; dh2_pad = dh1_pad = dOb = nullptr; gnorm2 = nullptr; tnh_slabs = nullptr; tnh_slab_floats = 0; tnh_tickets = nullptr; tnh_n_tickets = 0;
       for (int l = 0; l < MAXE; l++) dy2L[l] = dy1L[l] = daL[l] = dqkvL[l] = nullptr;
       for (int w = 0; w < 2; w++) { dyP[w] = nullptr; dA[w] = nullptr; for (int b = 0; b < MAXP; b++) dhb[w][b] = nullptr; }
@@ -877,7 +883,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       zr.off[zr.count] = off[i]; zr.n[zr.count] = (int)(off[i + 1] - off[i]); zr.count++;
     }
     // (the same launch zeroes the clipping-norm slots and the hybrid weight-gradient launch's tickets: was a memset)
-    TRY(launch_zero_ranges(grads, zr, s, ws.gnorm2, UVTG_SQSUM_FLOATS + ws.tnh_n_tickets));
+    TRY(launch_zero_ranges(grads, zr, s, ws.gnorm2, UVTG_SQSUM_FLOATS + ws.tnh_n_tickets + (int)ws.delta_floats));
     zr_keep = zr;
   }
   const int splits_M = 8, splits_v = 8;
@@ -1061,12 +1067,19 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     ln_deferred(lb);
     g = gemm_base(dy1, d, w.woT[l], d, M, d, d);                       // dO = dy1 Wo
     g.outB = ws.dOb; g.ldoB = d;
+    // ... and delta = rowsum_head(dO * O) in the same epilogue where the launch can carry it (round 5): attn_delta_kernel's pass over dO and O is gone
+    bool delta_fused = false;
+    if (ws.deltaL[l] && gemm_nt_delta_ok(g)) {
+      g.deltaO = (const bf16_t*)ws.o[l]; g.ldDO = d; g.delta = ws.deltaL[l]; g.delta_S = S; g.delta_H = m.c.H; g.delta_hd = m.hd;
+      if (packed) { g.delta_row_sample = ws.pk.row_sample; g.delta_seq_start = ws.pk.seq_start; }
+      delta_fused = true;
+    }
     TRY(launch_gemm_nt_bf16(g, s));
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qkv = ws.qkv[l]; at.ldqkv = 3 * d; at.o = ws.o[l]; at.ldo = d; at.lse = ws.lse[l]; at.kvalid = packed ? ws.pk.kvalid : ws.kvalid;
     if (packed) { at.seq_start = ws.pk.seq_start; at.seq_count = ws.pk.seq_count; at.row_sample = ws.pk.row_sample; at.total_rows = M; }
     at.B = B; at.S = S; at.H = m.c.H; at.hd = m.hd; at.p_drop = m.c.p_attn; at.seed = m.c.seed; at.layer = l;
-    at.dO = ws.dOb; at.lddo = d; at.delta = ws.delta; at.dqkv = dqkv; at.lddqkv = 3 * d; at.qscale = 1.0f / sqrtf((float)m.hd);
+    at.dO = ws.dOb; at.lddo = d; at.delta = delta_fused ? ws.deltaL[l] : ws.delta; at.delta_ready = delta_fused ? 1 : 0; at.dqkv = dqkv; at.lddqkv = 3 * d; at.qscale = 1.0f / sqrtf((float)m.hd);
     TRY(launch_attn_bwd(at, s));
     {   // attention-block weight gradients, one launch: dWo = dy1^T o, dWq|dWk = dqk^T (x + pos), dWv = dv^T x
       GemmTNBatch tb; tb.count = 3;

@@ -318,7 +318,8 @@ __global__ void nt_trace_set_kernel(unsigned long long* ptr) { g_nt_trace_dev = 
 // run-time feature tests and 64-bit address arithmetic of paths the launch does not take), so the step's recurring feature sets get
 // bodies without the rest: 0 = general; 1 = bias, column scale, row factor, bf16 residual (EOP), bf16 out (q,k,v / out-proj / FFN2 /
 // dgrads: 24 of the 40 launches); 2 = bias, pre-activation copy, GELU, bf16 out (FFN1); 3 = GELU' of the bf16 pre-activation (EOP),
-// bf16 out (the activation-gradient GEMM).
+// bf16 out (the activation-gradient GEMM); 4 = bf16 out + attention backward's delta: the epilogue operand is O, every row adds the dot product
+// of its rounded outputs with it into delta[sample][head][row] (the out-projection dgrad; GemmArgs::delta).
 // HALF: split-operand precise mode -- rows of fp16 hi / lo images interleaved in 32-column blocks (uvtg_common.h): staging, LDS image and
 // fragment reads are the bf16 kernel's; the K-tile body issues hi.hi, hi.lo, lo.hi from the four fragment sets (6 MFMA groups instead of 4 per
 // K tile: 2/3 of the LDS and staging traffic per MFMA) on v_mfma_f32_32x32x16_f16; general epilogue only, fp32 residual, exact erf GELU,
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   static_assert(!LW || (ORD == 0 && !SMALL && !HALF), "loader waves: pieces at the head of the K tile, persistent bf16 kernel");
   static_assert(EPI != 2 || !EOP, "FFN1 has no epilogue operand");
   static_assert(EPI != 3 || EOP, "the activation gradient reads its pre-activation");
+  static_assert(EPI != 4 || (EOP && !HALF && !SMALL), "the delta epilogue reads O as its operand");
   static_assert(TM < 5 || ((TM + 4 + 1) / 2 <= TM), "320-row tiles: at most one staging piece per A-fragment group of a k-step");
   constexpr bool SIMPLE = EPI != 0;
   // NARROW (the single-tile variant at TM = 1): 128 x 128 tiles, the eight waves as 4 x 2 (32 x 64 outputs each) -- as many tiles as 64 x 256
@@ -371,6 +373,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
   constexpr int NPF = !EOP ? 0 : (TM >= 4 ? 0 : (TM == 3 || TM == 1 ? 1 : 2));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   __shared__ float s_rs[RT];               // per-row factors (DropPath / frame mask) of the tile in its epilogue
+  // attention-backward delta (GemmArgs::delta): the launches that can carry it are the plain-row bf16 ones with an epilogue operand
+  constexpr bool DELTA = EPI == 4;
+  __shared__ int s_dl[DELTA ? RT : 1];     // per tile row: index of delta[b][0][s]
   __shared__ int s_tab[GATHER ? 3 : 1][RT]; // GATHER: the tile rows' entries of the output-row tables (o_rows, f_rows, pos_map)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = NARROW ? wave >> 1 : wave >> 2, wn = NARROW ? wave & 1 : wave & 3, g = lane >> 5, l31 = lane & 31;
@@ -525,8 +530,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
     asm volatile("" :: "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]));
     // epilogue operand: residual, else the pre-activation of the activation gradient
     const size_t go = (size_t)gz * p.gOut, gp = (size_t)gz * p.gPre;
-    const bf16_t* esrc = !EOP ? nullptr : (p.residB ? p.residB : p.gradPre + gp);
-    const int eld = !EOP ? 0 : (p.residB ? p.ldrB : p.ldgp);
+    const bf16_t* esrc = !EOP ? nullptr : (DELTA ? p.deltaO : (p.residB ? p.residB : p.gradPre + gp));
+    const int eld = !EOP ? 0 : (DELTA ? p.ldDO : (p.residB ? p.ldrB : p.ldgp));
     u32x4 eg[EOP ? TM : 1][4];
     auto fetch_group = [&](int i, int q) {     // one 16-byte piece: rows q * 8 + lane / 8 of 32-row group i
       const int m = min(m0 + wm * (32 * TM) + i * 32 + q * 8 + (lane >> 3), p.M - 1);     // clamped: loaded, not used
@@ -820,6 +825,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
       const int n = n0 + wn * 64 + c8e;
       const bool ncol = n < p.N;
       if (tid < RT) s_rs[tid] = rs_reg;
+      if constexpr (DELTA) {
+        if (tid < RT) {
+          const int mr = min(m0 + tid, p.M - 1);
+          int bb, ss;
+          if (p.delta_row_sample) { bb = p.delta_row_sample[mr]; ss = mr - p.delta_seq_start[bb]; }      // (packed stream: two dependent look-ups per tile row, once per tile)
+          else { bb = mr / p.delta_S; ss = mr - bb * p.delta_S; }
+          s_dl[tid] = bb * p.delta_H * p.delta_S + ss;
+        }
+      }
       if constexpr (GATHER) { if (tid < RT) { s_tab[0][tid] = tab_reg[0]; s_tab[1][tid] = tab_reg[1]; s_tab[2][tid] = tab_reg[2]; } }
       __builtin_amdgcn_s_barrier();          // every wave is done reading that stage (the prefetch is NOT drained)
       float* wbuf = (float*)(smem256 + (SMALL ? 0 : ((it - 1) & 1) * SSTR)) + wave * 2048;    // [32][64] fp32, wave-private
@@ -918,6 +932,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmArgs p) {
             const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
             for (int e = 0; e < 4; e++) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          if constexpr (DELTA) {
+            {      // delta[b][head][s] += sum over this lane's 8 columns of bf16(dO) * O, reduced over the lanes that share (row, head)
+              float dot = 0.f;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const unsigned t = pack_bf2(v[2 * e], v[2 * e + 1]);
+                dot += __uint_as_float(t << 16) * __uint_as_float(eop[e] << 16);
+                dot += __uint_as_float(t & 0xffff0000u) * __uint_as_float(eop[e] & 0xffff0000u);
+              }
+              dot += dpp_mov<0xB1>(dot);          // quad_perm [1,0,3,2]
+              dot += dpp_mov<0x4E>(dot);          // quad_perm [2,3,0,1]
+              const bool wide = p.delta_hd >= 64;
+              const float other = dpp_mov<0x141>(dot);      // row_half_mirror: the other quad of this row's 8 lanes
+              if (wide) dot += other;
+              if ((lane & (wide ? 7 : 3)) == 0)
+                atomicAdd(p.delta + (size_t)s_dl[wm * (32 * TM) + i * 32 + row] + (size_t)(n / p.delta_hd) * p.delta_S, dot);
+            }
           }
           if (EOP && (EPI == 1 || (EPI == 0 && p.residB))) {
 #pragma unroll
@@ -1883,7 +1915,7 @@ template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int gri
 #define NT256_ATTR(G, E, P) if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<G, TM, E, ORD, P>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
   if (!attr) {
     NT256_ATTR(false, false, 0) NT256_ATTR(false, true, 0) NT256_ATTR(false, false, 1) NT256_ATTR(false, true, 1)
-    NT256_ATTR(false, false, 2) NT256_ATTR(false, true, 3)
+    NT256_ATTR(false, false, 2) NT256_ATTR(false, true, 3) NT256_ATTR(false, true, 4)
     if constexpr (TM < 5) { NT256_ATTR(true, false, 0) NT256_ATTR(true, true, 0) }
     attr = true;
   }
@@ -1895,6 +1927,7 @@ template <int TM, int ORD> static int launch_nt256_tm(const GemmArgs& b, int gri
   } else if (epi == 1) { if (eop) NT256_GO(false, true, 1); else NT256_GO(false, false, 1); }
   else if (epi == 2 && !eop) NT256_GO(false, false, 2);
   else if (epi == 3 && eop) NT256_GO(false, true, 3);
+  else if (epi == 4 && eop) NT256_GO(false, true, 4);
   else { if (eop) NT256_GO(false, true, 0); else NT256_GO(false, false, 0); }
 #undef NT256_GO
   return 0;
@@ -1908,7 +1941,7 @@ template <int TM> static int launch_nt256_lw(const GemmArgs& b, int grid, bool e
   static bool attr = false;
 #define NTLW_ATTR(E, P) if (hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, TM, E, 0, P, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return (int)e;
   if (!attr) {
-    NTLW_ATTR(false, 0) NTLW_ATTR(false, 1) NTLW_ATTR(true, 1) NTLW_ATTR(false, 2) NTLW_ATTR(true, 3)
+    NTLW_ATTR(false, 0) NTLW_ATTR(false, 1) NTLW_ATTR(true, 1) NTLW_ATTR(false, 2) NTLW_ATTR(true, 3) NTLW_ATTR(true, 4)
     if constexpr (TM < 4) { NTLW_ATTR(true, 0) }       // (general epilogue + operand at 256 / 320 rows: 16-40 B of scratch with the second set of piece offsets -- not built)
     attr = true;
   }
@@ -1917,6 +1950,7 @@ template <int TM> static int launch_nt256_lw(const GemmArgs& b, int grid, bool e
   if (epi == 1) { if (eop) NTLW_GO(true, 1); else NTLW_GO(false, 1); }
   else if (epi == 2 && !eop) NTLW_GO(false, 2);
   else if (epi == 3 && eop) NTLW_GO(true, 3);
+  else if (epi == 4 && eop) NTLW_GO(true, 4);
   else if (eop) { if constexpr (TM < 4) NTLW_GO(true, 0); else return -100; }
   else NTLW_GO(false, 0);
 #undef NTLW_GO
@@ -1945,6 +1979,8 @@ template <int TM> static int launch_nt256_small(const GemmArgs& b, int grid, boo
 // chip does besides, and the last arriver folds `parts` slabs of 128 KB alone (~2 us each from L2 / Infinity Cache): K-loop time / parts +
 // fold time x parts has its minimum near 4 at the encoder's K, so: at most g_nt_splitk_max (4) parts, at least 4 K tiles each, never more
 // workgroups than CUs (every part must be resident with the others only for SPEED -- nothing waits).
+static int g_delta_fuse = -1;        // 0: attention backward's delta by its own kernel (parity tests / A-B); else fused into the dO GEMM's epilogue where legal
+extern "C" int uvtg_debug_delta_fuse(int on) { g_delta_fuse = on ? 1 : 0; return 0; }
 static int g_nt_cgw = -1;            // column-group width of the tile order of wide plain-row launches (0 = row-block-major over the whole width)
 extern "C" int uvtg_debug_nt_cgw(int tiles_per_group) { if (tiles_per_group < 0 || tiles_per_group > 64) return -21; g_nt_cgw = tiles_per_group; return 0; }
 static int g_nt_splitk_max = -1;
@@ -2041,16 +2077,20 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
   GemmArgs b = a;
   if (b.groups <= 0) b.groups = 1;
   const bool gather = b.a_seg || b.o_seg || b.a_off || b.o_off || b.ktap != b.K || b.groups != 1 || b.o_rows || b.pos_map;
-  const bool eop = b.residB || (b.actgrad && b.gradPre);
+  if (b.deltaO && (gather || half || b.residB || b.gradPre || !b.delta || b.delta_S <= 0 || b.delta_H <= 0 || (b.delta_hd != 32 && b.delta_hd != 64 && b.delta_hd != 128) ||
+                   b.N != b.delta_H * b.delta_hd || b.ldDO % 8)) return -2;
+  const bool eop = b.residB || (b.actgrad && b.gradPre) || b.deltaO;
   static const bool epi_off = getenv("UVTG_NT_EPI_OFF") != nullptr;       // experiment: the general epilogue everywhere
   static const int epi_mask = getenv("UVTG_NT_EPI_MASK") ? atoi(getenv("UVTG_NT_EPI_MASK")) : 14;      // bit e: specialisation e allowed
   int epi = 0;
   if (!epi_off && !gather && b.outB && !b.resid && !b.outF && !b.outU && !b.outUF && !b.pos) {
-    if (!b.outPre && !b.act && !b.actgrad && (!eop || b.residB)) epi = 1;
+    if (b.deltaO) epi = 4;
+    else if (!b.outPre && !b.act && !b.actgrad && (!eop || b.residB)) epi = 1;
     else if (b.outPre && b.act == 2 && !b.actgrad && !eop && !b.rowscale) epi = 2;
     else if (!b.outPre && !b.act && b.actgrad == 2 && eop && !b.residB && !b.rowscale) epi = 3;
   }
-  if (!((epi_mask >> epi) & 1)) epi = 0;
+  if (epi != 4 && !((epi_mask >> epi) & 1)) epi = 0;
+  if (b.deltaO && epi != 4) return -2;       // (gemm_nt_delta_ok() is the contract: plain bf16 out, nothing else in the epilogue)
   const NtPlan plan = nt256_plan(b.M, b.N, b.K, b.groups, gather, eff_cus(), g_force_bm, eop, b.sk_slab && b.sk_tickets, b.sk_cap_units);
   if (!plan.tm1) return -21;
   const int M_all = b.M;
@@ -2073,7 +2113,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
     }
     int small_tm = 0;
     if (g_nt_small < 0) g_nt_small = getenv("UVTG_NT_SMALL_OFF") ? 0 : (getenv("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
-    if (g_nt_small && (!plan.rows1 || part == 1) && best_tm == 2 && tiles <= eff_cus() && !g_force_tile && !g_force_bm && !(b.act >= 100 && b.act <= 103)) {
+    if (g_nt_small && !b.deltaO && (!plan.rows1 || part == 1) && best_tm == 2 && tiles <= eff_cus() && !g_force_tile && !g_force_bm && !(b.act >= 100 && b.act <= 103)) {
       const SmallPlan sp = nt256_small_plan(rows, b.N, b.groups, b.K / 64, eff_cus(), b.sk_cap_units, b.sk_slab && b.sk_tickets, g_nt_small);
       small_tm = sp.tm; b.sk = sp.parts;
       tiles = nt_small_tiles(rows, b.N, b.groups, small_tm);
@@ -2095,7 +2135,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
       const double mn = (double)rows * b.N * b.groups;
       double by = 2.0 * ((double)rows * b.K + (double)b.N * b.K) * b.groups;
       by += mn * ((b.outB ? 2 : 0) + (b.outF ? 4 : 0) + (b.outPre ? 2 : 0) + (b.outU ? 2 : 0) + (b.outUF ? 4 : 0));
-      by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0));
+      by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0) + (b.deltaO ? 2 : 0));
       uvtg_prof_add_bytes(3, by);
     }
     if (g_nt_lw < 0) g_nt_lw = getenv("UVTG_NT_LW") ? atoi(getenv("UVTG_NT_LW")) & 7 : 7;      // bit (TM - 2) = loader waves at that tile height (128 / 192 / 256 rows)
@@ -2114,8 +2154,19 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
   return 0;
 }
 
+// can this launch carry the attention-backward delta in its epilogue?  (the persistent 256-wide kernel with the plain row mapping)
+bool gemm_nt_delta_ok(const GemmArgs& a) {
+  static const bool off = getenv("UVTG_DELTA_FUSE_OFF") != nullptr;       // experiment: attn_delta_kernel's own pass
+  if (off || g_delta_fuse == 0) return false;
+  if (check_nt(a, 2) || ensure_num_cu() || !nt256_ok(a)) return false;
+  const int groups = a.groups > 0 ? a.groups : 1;
+  const bool gather = a.a_seg || a.o_seg || a.a_off || a.o_off || a.ktap != a.K || groups != 1 || a.o_rows || a.pos_map;
+  static const bool epi_off = getenv("UVTG_NT_EPI_OFF") != nullptr;
+  return !epi_off && !gather && !a.residB && !a.gradPre && !a.resid && !a.outF && !a.outU && !a.outUF && !a.pos && a.outB && !a.outPre && !a.act && !a.actgrad && !a.rowscale;
+}
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
   if (int e = check_nt(a, 2)) return e;
+  if (a.deltaO && !nt256_ok(a)) return -2;
   if (nt256_ok(a)) return launch_nt256(a, s);
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, a.groups > 0 ? a.groups : 1);
   uvtg_prof_begin_launch(0, 2.0 * a.M * a.N * a.K * grid.z, s);

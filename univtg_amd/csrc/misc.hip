@@ -74,8 +74,9 @@ __global__ void droppath_kernel(float* scales, int n, int B, float p, unsigned l
 }
 
 __global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const ZeroRanges r, float* extra, int n_extra) {
-  if ((int)blockIdx.x == r.count) {       // one more block: a second buffer (the clipping-norm slots + tickets of uvtg_backward; was a memset)
-    for (int i = threadIdx.x; i < n_extra; i += 256) extra[i] = 0.f;
+  if ((int)blockIdx.x >= r.count) {       // further blocks: a second buffer (clipping-norm slots + tickets + attention deltas of uvtg_backward; was a memset)
+    const int nb = gridDim.x - r.count, j = blockIdx.x - r.count;
+    for (long long i = (long long)j * 256 + threadIdx.x; i < n_extra; i += (long long)nb * 256) extra[i] = 0.f;
     return;
   }
   float* p = base + r.off[blockIdx.x];
@@ -1102,7 +1103,8 @@ int launch_droppath_scales(float* scales, int n, int B, float p, unsigned long l
 }
 int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* extra, int n_extra) {
   if (r.count <= 0 && !extra) return 0;
-  hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count + (extra ? 1 : 0)), dim3(256), 0, s, base, r, extra, n_extra);
+  const int nb_extra = extra ? (n_extra > 65536 ? 256 : 1) : 0;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count + nb_extra), dim3(256), 0, s, base, r, extra, n_extra);
   UVTG_CHECK_LAUNCH();
   return 0;
 }

@@ -976,7 +976,8 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
     const bool plain = a.xB && !a.x && a.p_drop == 0.f && !a.yF && !a.yS && !a.yUS && !a.yPS && !a.yUF && !a.yPF && !a.addtab && !a.src_rows && !a.u_from_x &&
                        !a.xsum && (a.Dpad <= a.D) && (a.D == 1024 || a.D == 512) && alignv8 && !(a.pos_row && a.yP);
     if (plain && !lean_off && a.rows >= 1024) {
-      const int blocks = min(cdiv(a.rows, 4), 1024);
+      static const int blocks_env = getenv("UVTG_LN_FWD_BLOCKS") ? atoi(getenv("UVTG_LN_FWD_BLOCKS")) : 1024;      // (A/B: 512 / 1024 / 2048 measured in round 5)
+      const int blocks = min(cdiv(a.rows, 4), blocks_env > 0 ? blocks_env : 1024);
       if (a.D == 1024) hipLaunchKernelGGL((ln_fwd_lean_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((ln_fwd_lean_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
       UVTG_CHECK_LAUNCH();

@@ -59,7 +59,14 @@ struct GemmArgs {
   // row-block-major over the whole width).  Wide outputs (N = 3 d: 12 column tiles) in groups of cgw keep cgw weight panels -- not all
   // twelve, 6 MB against a 4 MB L2 -- in front of an XCD while its row blocks stream past them; same tiles, same K order, same results.
   int cgw;
+  // ---- attention backward's delta = rowsum_head(dO * O), produced where dO is (round 5; persistent 256-wide kernel, plain row mapping): the
+  // out-projection dgrad launch takes O [M, ldDO] (bf16) as its epilogue operand and adds, per output row m and head, the dot product of the
+  // ROUNDED (bf16) dO values it stores with the O values into delta[(b * delta_H + head) * delta_S + s] -- (b, s) = (m / delta_S, m % delta_S), or
+  // (delta_row_sample[m], m - delta_seq_start[b]) on the packed stream.  delta must be ZERO before the launch (two fp32 atomics per element at
+  // head_dim 128, one below: order-independent).  Replaces attn_delta_kernel's pass over dO and O (gemm_nt_delta_ok() says whether a launch takes it).
+  const bf16_t* deltaO; int ldDO; float* delta; int delta_S, delta_H, delta_hd; const int* delta_row_sample; const int* delta_seq_start;
 };
+bool gemm_nt_delta_ok(const GemmArgs& a);
 constexpr int UVTG_SK_UNITS = 256;                 // capacity the engine's workspace provides
 constexpr int UVTG_SK_TILE_FLOATS = 128 * 256;
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s);
@@ -188,6 +195,7 @@ struct AttnArgs {
   // backward
   const bf16_t* dO; int lddo;   // [B*S, d]
   float* delta;                 // [B, H, S] scratch: rowsum(dO * O)
+  int delta_ready;              // 1: delta was already produced (by the dO GEMM's epilogue, GemmArgs::delta): launch_attn_bwd skips its own pass
   bf16_t* dqkv; int lddqkv;     // [B*S, 3d]
   float qscale;                 // dq is multiplied by the forward q scale
 };
