@@ -72,6 +72,9 @@ int uvtg_debug_ln_fwd_lean(int on);
 /* Attention backward's delta = rowsum_head(dO * O) is produced by the out-projection dgrad GEMM's epilogue where that launch can carry it (round 5);
  * uvtg_debug_delta_fuse(0) restores attn_delta_kernel's own pass (parity tests / A-B), 1 = default. */
 int uvtg_debug_delta_fuse(int on);
+/* Long-sequence attention backward at head_dim 128 (round 5): dK / dV by the role-split kernel (score waves + product waves, two per SIMD; default)
+ * or, 0, by the one-wave-per-SIMD kernel it replaces (parity tests / A-B). */
+int uvtg_debug_attn_ws(int on);
 /* Host arithmetic only: uvtg_debug_nt_plan with the launch's epilogue class (eop != 0: the launch reads a bf16 residual / pre-activation operand in
  * its epilogue; uvtg_debug_nt_plan assumes it does) and whether the caller hands the launch a split-K workspace (have_ws). */
 int uvtg_debug_nt_plan2(int M, int N, int K, int groups, int gather, int cus, int eop, int have_ws, int* out3);

@@ -219,6 +219,38 @@ def test_attention_bwd(dev, B, S, H, hd):
         assert e < 2.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("B,S,H,hd", [(1, 300, 2, 128), (2, 1232, 3, 128), (3, 517, 1, 128)])
+def test_attention_bwd_role_split_dkdv_bit_identical(dev, B, S, H, hd):
+    """Long-sequence attention backward at head_dim 128 (round 5): dK / dV by the role-split kernel (score waves hand P / dS to product waves through
+    LDS; two waves per SIMD) against the one-wave-per-SIMD kernel it replaces -- same products, same accumulation order over the query blocks:
+    bit for bit; and both against fp64 autograd (S = 1232 is BASELINE config 4's sequence)."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(S + 7)
+    d = H * hd
+    qkv = torch.randn(B * S, 3 * d, generator=g)
+    qkv[:, :d] *= hd ** -0.5
+    kv = _kvalid(B, S, g, dev)
+    xb = bf(qkv).to(dev)
+    o, lse = ops.attention_fwd(xb, kv, B, S, H, hd, False)
+    do = bf(torch.randn(B * S, d, generator=g)).to(dev)
+    try:
+        _lib.check(lib.uvtg_debug_attn_ws(0))
+        old = ops.attention_bwd(xb, kv, o, lse, do, 1.0, B, S, H, hd)
+        _lib.check(lib.uvtg_debug_attn_ws(1))
+        new = ops.attention_bwd(xb, kv, o, lse, do, 1.0, B, S, H, hd)
+    finally:
+        lib.uvtg_debug_attn_ws(1)
+    assert torch.equal(old, new)
+    if S <= 600:
+        xr = xb.double().cpu().requires_grad_(True)
+        ref_o, _ = _attn_ref(xr, kv.cpu(), B, S, H, hd)
+        ref_o.backward(do.double().cpu())
+        for name, sl in (("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+            e = relerr(new[:, sl].float().cpu(), xr.grad[:, sl])
+            assert e < 2.5e-2, (name, e)
+
+
 def test_sine_position(dev):
     from oracle import univtg_oracle as O
     from univtg_amd import ops

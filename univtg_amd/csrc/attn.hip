@@ -621,6 +621,184 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward: dK, dV at head_dim 128, ROLE-SPLIT (round 5; BASELINE config 4, S = 1232).  attn_bwd_dkdv_kernel above needs ~360-420 registers at
+// head_dim 128 (128 dK / dV accumulators + 64 K / V fragment registers + scores + fragments in flight): ONE wave per SIMD, so the ~190 VALU
+// operations of a query block's softmax and the 32 MFMAs of the block cannot overlap however they are interleaved in the one instruction stream
+// (in-order issue; the matrix pipe was busy 18-24 % of the time).  Here the work of a 32-key group is cut between TWO waves that meet on the same
+// SIMD: the S-wave keeps the K / V fragments and computes S = Q K^T, dP = dO V^T and the softmax arithmetic of query block t; the P-wave keeps
+// the dK / dV accumulators and computes dV += dO^T P, dK += Q^T dS of block t - 1.  P and dS travel as the packed B operands the P-wave's MFMAs
+// take -- 64 bytes per lane and block, lane-order image in LDS (4 x ds_write_b128 / ds_read_b128, conflict-free by construction), double
+// buffered.  Both roles fit 256 registers: eight waves per workgroup, two per SIMD, and the S-wave's VALU section runs under the P-wave's MFMAs.
+// One barrier per query block, as before; Q / dO tiles: the same three-buffer ring (tile t + 1 staged while t is read by rows and t - 1
+// transposed).  The two roles are two separate loops (not one loop with a role branch): the register allocator then sees that the K / V
+// fragments and the accumulators are never live together.
+// ------------------------------------------------------------------------------------------------
+template <bool DROP, bool SWZ>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs a) {
+  constexpr int HD = 128;
+  using QT = TileRT<HD, SWZ>;
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[3][32 * QT::STR];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[3][32 * QT::STR];
+  __shared__ __attribute__((aligned(16))) float sL[3][32], sD[3][32];     // lse * log2(e) (ROW_OFF beyond S), delta
+  __shared__ __attribute__((aligned(16))) u32x4 sH[2][4][4][64];          // hand-off: [slot][key group][P lo, P hi, dS lo, dS hi][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  const int role = wave >> 2, kg = wave & 3;          // role 0: scores + softmax, role 1: products; both for keys 32 kg .. 32 kg + 31 of the block
+  int kblk, h, b;
+  attn_block_id((a.S + 127) / 128, a.H, kblk, h, b);
+  const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  if (kblk * 128 >= S) return;
+  const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
+  const int key0 = kblk * 128;
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  constexpr int CH = HD / 8;
+  const int key = key0 + kg * 32 + l31;              // this lane's key (lane <-> key in the S, dP tiles and in the dK / dV rows)
+  const bool kin = key < S;
+  [[maybe_unused]] const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
+  // staging: 32 rows x 16 chunks of Q and of dO per query block = one 16-byte piece per thread and operand
+  u32x4 pq, po;
+  float pl = 0.f, pdl = 0.f;
+  auto prefetch = [&](int qb) {
+    const int r = tid / CH, c = tid % CH;
+    const int qi = min(qb * 32 + r, S - 1);            // clamped rows are loaded; their probabilities are exact zeros (ROW_OFF)
+    pq = *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8);
+    po = *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8);
+    if (tid < 32) {          // (raw values: anything computed from them HERE would wait out the whole load latency right behind the request)
+      const int q2 = min(qb * 32 + tid, S - 1);
+      pl = a.lse[((size_t)b * a.H + h) * a.S + q2];
+      pdl = a.delta[((size_t)b * a.H + h) * a.S + q2];
+    }
+  };
+  auto stage = [&](int buf, int qb) {                 // the prefetched rows of block qb -> tile buffer `buf`
+    const int r = tid / CH, c = tid % CH;
+    *(u32x4*)(&sQ[buf][QT::off(r, c * 8)]) = pq;
+    *(u32x4*)(&sO[buf][QT::off(r, c * 8)]) = po;
+    if (tid < 32) { sL[buf][tid] = (qb * 32 + tid < S) ? pl * LOG2E : ROW_OFF; sD[buf][tid] = pdl; }
+  };
+  const int nqb = (S + 31) / 32;
+  prefetch(0);
+  stage(0, 0);
+  if (1 < nqb) prefetch(1);
+  __syncthreads();
+  // iteration t = 0 .. nqb: tile t + 1 is staged and tile t + 2 requested by everybody; the S-waves work on block t, the P-waves on block t - 1
+  if (role == 0) {
+    // ---- S-waves: this lane's K / V row as MFMA B fragments (k-step ks covers head-dim columns 16 ks + 8 g .. + 7) ----
+    s16x8 kf[HD / 16], vf[HD / 16];
+    {
+      const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++) {
+        kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
+        vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+      }
+    }
+    const int qoff = QT::off(l31, 8 * g);                                        // + k-step: QT::step(qoff, 16 ks)
+    for (int t = 0; t <= nqb; t++) {
+      if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
+      if (t + 2 < nqb) prefetch(t + 2);
+      if (t < nqb) {
+        const int buf = t % 3;
+        const bf16_t* bq = sQ[buf];
+        const bf16_t* bo = sO[buf];
+        f32x16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
+        constexpr int KS = HD / 16, AHEAD = 4;
+        s16x8 qf[KS], of[KS];
+#pragma unroll
+        for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+          sc = mfma32(qf[ks], kf[ks], sc);
+          dp = mfma32(of[ks], vf[ks], dp);
+          if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
+        }
+        f32x4 Lq[4], Dq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
+#pragma unroll
+        for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
+        unsigned pw[8], dw[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float pd[2], ds[2];
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int rr = r + u;
+            const float pp = exp2_raw(fmaf(sc[rr], LOG2E, -Lq[rr >> 2][rr & 3]));      // (padded keys: masked at the dK / dV stores)
+            if constexpr (DROP) {
+              const int qi = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+              const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
+              pd[u] = pp * ksc;
+              ds[u] = pp * (dp[rr] * ksc - Dq[rr >> 2][rr & 3]);
+            } else {
+              pd[u] = pp;
+              ds[u] = pp * (dp[rr] - Dq[rr >> 2][rr & 3]);
+            }
+          }
+          pw[r >> 1] = pack_bf2(pd[0], pd[1]);
+          dw[r >> 1] = pack_bf2(ds[0], ds[1]);
+        }
+        u32x4* hs = &sH[t & 1][kg][0][lane];
+        hs[0] = (u32x4){pw[0], pw[1], pw[2], pw[3]};
+        hs[64] = (u32x4){pw[4], pw[5], pw[6], pw[7]};
+        hs[128] = (u32x4){dw[0], dw[1], dw[2], dw[3]};
+        hs[192] = (u32x4){dw[4], dw[5], dw[6], dw[7]};
+      }
+      __syncthreads();
+    }
+  } else {
+    // ---- P-waves: dV^T += dO^T P, dK^T += Q^T dS of the previous block; the accumulators live here ----
+    f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+    for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    const int toff0 = QT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));      // + head-dim block: QT::step(toff, 32 blk); + 16 rows for the
+    const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
+    for (int t = 0; t <= nqb; t++) {
+      if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
+      if (t + 2 < nqb) prefetch(t + 2);
+      if (t >= 1) {
+        const int buf = (t - 1) % 3;
+        const bf16_t* bq = sQ[buf];
+        const bf16_t* bo = sO[buf];
+        const u32x4* hs = &sH[(t - 1) & 1][kg][0][lane];
+        s16x8 pb[2], db[2];
+        pb[0] = __builtin_bit_cast(s16x8, hs[0]); pb[1] = __builtin_bit_cast(s16x8, hs[64]);
+        db[0] = __builtin_bit_cast(s16x8, hs[128]); db[1] = __builtin_bit_cast(s16x8, hs[192]);
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+          for (int blk = 0; blk < HD / 32; blk++) {
+            const int o0 = QT::step(toff0, 32 * blk) + 16 * hf * QT::STR, o1 = QT::step(toff1, 32 * blk) + 16 * hf * QT::STR;
+            const s16x8 ot = cat4(lds_tr16(&bo[o0]), lds_tr16(&bo[o1]));
+            const s16x8 qt = cat4(lds_tr16(&bq[o0]), lds_tr16(&bq[o1]));
+            dv[blk] = mfma32(ot, pb[hf], dv[blk]);
+            dk[blk] = mfma32(qt, db[hf], dk[blk]);
+          }
+      }
+      __syncthreads();
+    }
+    // A lane's key contributes to nobody's sums but its own dK / dV row: the key-padding mask is applied HERE (a padded key's row is zero)
+    if (kin) {
+      const bool kok = a.kvalid[rowbase + key] != 0;
+      const u32x2 z = {0u, 0u};
+#pragma unroll
+      for (int blk = 0; blk < HD / 32; blk++)
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+          const int c = blk * 32 + 8 * rq + 4 * g;
+          bf16_t* base = a.dqkv + (rowbase + key) * a.lddqkv + h * HD + c;
+          u32x2 tt;
+          tt[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); tt[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]);
+          *(u32x2*)(base + d) = kok ? tt : z;
+          tt[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); tt[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]);
+          *(u32x2*)(base + 2 * d) = kok ? tt : z;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: dQ   (one wave = 32 queries, loops over 64-key tiles)
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool DROP, bool SWZ>
@@ -1116,6 +1294,8 @@ int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
   return 0;
 }
 
+static int g_attn_ws = -1;          // head_dim-128 dK / dV: role-split kernel (default) / 0: the one-wave-per-SIMD kernel (parity tests, A-B)
+extern "C" int uvtg_debug_attn_ws(int on) { g_attn_ws = on ? 1 : 0; return 0; }
 int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
   if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
   if (a.precise) return -6;
@@ -1191,9 +1371,11 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     }
   }
 #endif
+  static const bool ws_off = getenv("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);            \
+    if (HD_ == 128 && !ws_off && g_attn_ws != 0) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_>), grid1, dim3(512), 0, s, a); \
+    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);       \
     if (HD_ == 128 && dq_dma) {                                                                   \
       hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DROP_>), grid1, blk, 0, s, a, (unsigned)qkv_bytes); \
     } else hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);       \
