@@ -681,77 +681,96 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
   if (1 < nqb) prefetch(1);
   __syncthreads();
   // iteration t = 0 .. nqb: tile t + 1 is staged and tile t + 2 requested by everybody; the S-waves work on block t, the P-waves on block t - 1
+  // Work split.  DROP (attention dropout; never set by the reference's scripts): the S-wave does scores, dP and the whole softmax section and hands
+  // over the packed P / dS operands.  !DROP (round 5, second step): the S-wave of the first version was the long pole (16 MFMAs + ~190 VALU in
+  // ONE stream against the P-wave's 16 MFMAs) -- now it computes S = Q K^T and p = exp2(s log2e - lse) only (8 MFMAs, ~35 VALU incl. 16 quarter-rate
+  // exponentials) and hands the fp32 probabilities over; the P-wave keeps the V fragments too and computes dP = dO V^T (8 MFMAs), dS = p (dP - delta),
+  // the bf16 packing (~60 VALU) and the 16 product MFMAs.  Same arithmetic on the same values in the same order: bit-identical to the other kernel.
+  const int qoff = QT::off(l31, 8 * g);                                        // Q / dO row fragments: + k-step: QT::step(qoff, 16 ks)
+  constexpr int KS = HD / 16, AHEAD = 4;
   if (role == 0) {
-    // ---- S-waves: this lane's K / V row as MFMA B fragments (k-step ks covers head-dim columns 16 ks + 8 g .. + 7) ----
-    s16x8 kf[HD / 16], vf[HD / 16];
+    // ---- S-waves: this lane's K (DROP: and V) row as MFMA B fragments (k-step ks covers head-dim columns 16 ks + 8 g .. + 7) ----
+    s16x8 kf[KS], vf[DROP ? KS : 1];
     {
       const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
 #pragma unroll
-      for (int ks = 0; ks < HD / 16; ks++) {
+      for (int ks = 0; ks < KS; ks++) {
         kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
-        vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+        if constexpr (DROP) vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
       }
     }
-    const int qoff = QT::off(l31, 8 * g);                                        // + k-step: QT::step(qoff, 16 ks)
     for (int t = 0; t <= nqb; t++) {
       if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
       if (t + 2 < nqb) prefetch(t + 2);
       if (t < nqb) {
         const int buf = t % 3;
         const bf16_t* bq = sQ[buf];
-        const bf16_t* bo = sO[buf];
+        [[maybe_unused]] const bf16_t* bo = sO[buf];
         f32x16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
-        constexpr int KS = HD / 16, AHEAD = 4;
-        s16x8 qf[KS], of[KS];
+        s16x8 qf[KS], of[DROP ? KS : 1];
 #pragma unroll
-        for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+        for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); if constexpr (DROP) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
           sc = mfma32(qf[ks], kf[ks], sc);
-          dp = mfma32(of[ks], vf[ks], dp);
-          if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
+          if constexpr (DROP) dp = mfma32(of[ks], vf[ks], dp);
+          if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); if constexpr (DROP) of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
         }
-        f32x4 Lq[4], Dq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
+        f32x4 Lq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
 #pragma unroll
-        for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
-        unsigned pw[8], dw[8];
+        for (int j = 0; j < 4; j++) Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]);
+        u32x4* hs = &sH[t & 1][kg][0][lane];
+        if constexpr (DROP) {
+          f32x4 Dq[4];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          float pd[2], ds[2];
+          for (int j = 0; j < 4; j++) Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]);
+          unsigned pw[8], dw[8];
 #pragma unroll
-          for (int u = 0; u < 2; u++) {
-            const int rr = r + u;
-            const float pp = exp2_raw(fmaf(sc[rr], LOG2E, -Lq[rr >> 2][rr & 3]));      // (padded keys: masked at the dK / dV stores)
-            if constexpr (DROP) {
+          for (int r = 0; r < 16; r += 2) {
+            float pd[2], ds[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const int rr = r + u;
+              const float pp = exp2_raw(fmaf(sc[rr], LOG2E, -Lq[rr >> 2][rr & 3]));      // (padded keys: masked at the dK / dV stores)
               const int qi = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
               const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
               pd[u] = pp * ksc;
               ds[u] = pp * (dp[rr] * ksc - Dq[rr >> 2][rr & 3]);
-            } else {
-              pd[u] = pp;
-              ds[u] = pp * (dp[rr] - Dq[rr >> 2][rr & 3]);
             }
+            pw[r >> 1] = pack_bf2(pd[0], pd[1]);
+            dw[r >> 1] = pack_bf2(ds[0], ds[1]);
           }
-          pw[r >> 1] = pack_bf2(pd[0], pd[1]);
-          dw[r >> 1] = pack_bf2(ds[0], ds[1]);
+          hs[0] = (u32x4){pw[0], pw[1], pw[2], pw[3]};
+          hs[64] = (u32x4){pw[4], pw[5], pw[6], pw[7]};
+          hs[128] = (u32x4){dw[0], dw[1], dw[2], dw[3]};
+          hs[192] = (u32x4){dw[4], dw[5], dw[6], dw[7]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {       // the fp32 probabilities of accumulator registers 4 j .. 4 j + 3
+            f32x4 pv;
+#pragma unroll
+            for (int e = 0; e < 4; e++) pv[e] = exp2_raw(fmaf(sc[4 * j + e], LOG2E, -Lq[j][e]));
+            hs[64 * j] = __builtin_bit_cast(u32x4, pv);
+          }
         }
-        u32x4* hs = &sH[t & 1][kg][0][lane];
-        hs[0] = (u32x4){pw[0], pw[1], pw[2], pw[3]};
-        hs[64] = (u32x4){pw[4], pw[5], pw[6], pw[7]};
-        hs[128] = (u32x4){dw[0], dw[1], dw[2], dw[3]};
-        hs[192] = (u32x4){dw[4], dw[5], dw[6], dw[7]};
       }
       __syncthreads();
     }
   } else {
-    // ---- P-waves: dV^T += dO^T P, dK^T += Q^T dS of the previous block; the accumulators live here ----
+    // ---- P-waves: dV^T += dO^T P, dK^T += Q^T dS of the previous block (!DROP: and its dP = dO V^T, dS = p (dP - delta)); the accumulators live here ----
     f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
     for (int i = 0; i < HD / 32; i++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    s16x8 vf[DROP ? 1 : KS];
+    if constexpr (!DROP) {
+      const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+    }
     const int toff0 = QT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));      // + head-dim block: QT::step(toff, 32 blk); + 16 rows for the
     const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
     for (int t = 0; t <= nqb; t++) {
@@ -763,8 +782,34 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         const bf16_t* bo = sO[buf];
         const u32x4* hs = &sH[(t - 1) & 1][kg][0][lane];
         s16x8 pb[2], db[2];
-        pb[0] = __builtin_bit_cast(s16x8, hs[0]); pb[1] = __builtin_bit_cast(s16x8, hs[64]);
-        db[0] = __builtin_bit_cast(s16x8, hs[128]); db[1] = __builtin_bit_cast(s16x8, hs[192]);
+        if constexpr (DROP) {
+          pb[0] = __builtin_bit_cast(s16x8, hs[0]); pb[1] = __builtin_bit_cast(s16x8, hs[64]);
+          db[0] = __builtin_bit_cast(s16x8, hs[128]); db[1] = __builtin_bit_cast(s16x8, hs[192]);
+        } else {
+          f32x16 dp;
+#pragma unroll
+          for (int r = 0; r < 16; r++) dp[r] = 0.f;
+          constexpr int AP = 2;             // (the P-wave sits at the 256-register line: two row fragments in flight, statistics fetched at use)
+          s16x8 of[KS];
+#pragma unroll
+          for (int ks = 0; ks < AP; ks++) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]);
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) {
+            dp = mfma32(of[ks], vf[ks], dp);
+            if (ks + AP < KS) of[ks + AP] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AP))]);
+          }
+          unsigned pw[8], dw[8];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {       // accumulator registers 4 j .. 4 j + 3: queries 8 j + 4 g + (0..3)
+            const f32x4 pv = __builtin_bit_cast(f32x4, hs[64 * j]);
+            const f32x4 Dq = *(const f32x4*)(&sD[buf][8 * j + 4 * g]);
+            pw[2 * j] = pack_bf2(pv[0], pv[1]); pw[2 * j + 1] = pack_bf2(pv[2], pv[3]);
+            dw[2 * j] = pack_bf2(pv[0] * (dp[4 * j] - Dq[0]), pv[1] * (dp[4 * j + 1] - Dq[1]));
+            dw[2 * j + 1] = pack_bf2(pv[2] * (dp[4 * j + 2] - Dq[2]), pv[3] * (dp[4 * j + 3] - Dq[3]));
+          }
+          pb[0] = __builtin_bit_cast(s16x8, (u32x4){pw[0], pw[1], pw[2], pw[3]}); pb[1] = __builtin_bit_cast(s16x8, (u32x4){pw[4], pw[5], pw[6], pw[7]});
+          db[0] = __builtin_bit_cast(s16x8, (u32x4){dw[0], dw[1], dw[2], dw[3]}); db[1] = __builtin_bit_cast(s16x8, (u32x4){dw[4], dw[5], dw[6], dw[7]});
+        }
 #pragma unroll
         for (int hf = 0; hf < 2; hf++)
 #pragma unroll
