@@ -633,14 +633,19 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
 // transposed).  The two roles are two separate loops (not one loop with a role branch): the register allocator then sees that the K / V
 // fragments and the accumulators are never live together.
 // ------------------------------------------------------------------------------------------------
-template <bool DROP, bool SWZ>
+template <bool DROP, bool SWZ, int MODE_>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs a) {
   constexpr int HD = 128;
+  // MODE (what the S-wave does beyond S = Q K^T and p = exp2(.)): 0 = dP, dS and the bf16 packing too (hands over the packed operands; always with
+  // DROP); 1 = nothing else (hands over p; the P-wave computes dP, dS, packs); 2 = dP (hands over p and dP; the P-wave computes dS and packs)
+  constexpr int MODE = DROP ? 0 : MODE_;
+  constexpr bool S_DP = MODE != 1;               // the S-wave holds the V fragments and computes dP
+  constexpr int NH = MODE == 2 ? 8 : 4;          // 16-byte hand-off slots per lane and block
   using QT = TileRT<HD, SWZ>;
   __shared__ __attribute__((aligned(16))) bf16_t sQ[3][32 * QT::STR];
   __shared__ __attribute__((aligned(16))) bf16_t sO[3][32 * QT::STR];
   __shared__ __attribute__((aligned(16))) float sL[3][32], sD[3][32];     // lse * log2(e) (ROW_OFF beyond S), delta
-  __shared__ __attribute__((aligned(16))) u32x4 sH[2][4][4][64];          // hand-off: [slot][key group][P lo, P hi, dS lo, dS hi][lane]
+  __shared__ __attribute__((aligned(16))) u32x4 sH[2][4][NH][64];         // hand-off: [slot][key group][MODE 0: P lo, P hi, dS lo, dS hi | 1: p | 2: p, dP][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   const int role = wave >> 2, kg = wave & 3;          // role 0: scores + softmax, role 1: products; both for keys 32 kg .. 32 kg + 31 of the block
@@ -690,13 +695,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
   constexpr int KS = HD / 16, AHEAD = 4;
   if (role == 0) {
     // ---- S-waves: this lane's K (DROP: and V) row as MFMA B fragments (k-step ks covers head-dim columns 16 ks + 8 g .. + 7) ----
-    s16x8 kf[KS], vf[DROP ? KS : 1];
+    s16x8 kf[KS], vf[S_DP ? KS : 1];
     {
       const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) {
         kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
-        if constexpr (DROP) vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+        if constexpr (S_DP) vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
       }
     }
     for (int t = 0; t <= nqb; t++) {
@@ -709,20 +714,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         f32x16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
-        s16x8 qf[KS], of[DROP ? KS : 1];
+        s16x8 qf[KS], of[S_DP ? KS : 1];
 #pragma unroll
-        for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); if constexpr (DROP) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+        for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); if constexpr (S_DP) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
           sc = mfma32(qf[ks], kf[ks], sc);
-          if constexpr (DROP) dp = mfma32(of[ks], vf[ks], dp);
-          if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); if constexpr (DROP) of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
+          if constexpr (S_DP) dp = mfma32(of[ks], vf[ks], dp);
+          if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); if constexpr (S_DP) of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
         }
         f32x4 Lq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
 #pragma unroll
         for (int j = 0; j < 4; j++) Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]);
         u32x4* hs = &sH[t & 1][kg][0][lane];
-        if constexpr (DROP) {
+        if constexpr (MODE == 0) {
           f32x4 Dq[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]);
@@ -734,10 +739,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
             for (int u = 0; u < 2; u++) {
               const int rr = r + u;
               const float pp = exp2_raw(fmaf(sc[rr], LOG2E, -Lq[rr >> 2][rr & 3]));      // (padded keys: masked at the dK / dV stores)
-              const int qi = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
-              const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
-              pd[u] = pp * ksc;
-              ds[u] = pp * (dp[rr] * ksc - Dq[rr >> 2][rr & 3]);
+              if constexpr (DROP) {
+                const int qi = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+                const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
+                pd[u] = pp * ksc;
+                ds[u] = pp * (dp[rr] * ksc - Dq[rr >> 2][rr & 3]);
+              } else {
+                pd[u] = pp;
+                ds[u] = pp * (dp[rr] - Dq[rr >> 2][rr & 3]);
+              }
             }
             pw[r >> 1] = pack_bf2(pd[0], pd[1]);
             dw[r >> 1] = pack_bf2(ds[0], ds[1]);
@@ -753,6 +763,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
 #pragma unroll
             for (int e = 0; e < 4; e++) pv[e] = exp2_raw(fmaf(sc[4 * j + e], LOG2E, -Lq[j][e]));
             hs[64 * j] = __builtin_bit_cast(u32x4, pv);
+            if constexpr (MODE == 2) hs[64 * (4 + j)] = __builtin_bit_cast(u32x4, (f32x4){dp[4 * j], dp[4 * j + 1], dp[4 * j + 2], dp[4 * j + 3]});
           }
         }
       }
@@ -765,8 +776,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
     for (int i = 0; i < HD / 32; i++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-    s16x8 vf[DROP ? 1 : KS];
-    if constexpr (!DROP) {
+    s16x8 vf[MODE == 1 ? KS : 1];
+    if constexpr (MODE == 1) {
       const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
@@ -782,21 +793,31 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         const bf16_t* bo = sO[buf];
         const u32x4* hs = &sH[(t - 1) & 1][kg][0][lane];
         s16x8 pb[2], db[2];
-        if constexpr (DROP) {
+        if constexpr (MODE == 0) {
           pb[0] = __builtin_bit_cast(s16x8, hs[0]); pb[1] = __builtin_bit_cast(s16x8, hs[64]);
           db[0] = __builtin_bit_cast(s16x8, hs[128]); db[1] = __builtin_bit_cast(s16x8, hs[192]);
         } else {
           f32x16 dp;
 #pragma unroll
           for (int r = 0; r < 16; r++) dp[r] = 0.f;
+          if constexpr (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const f32x4 dj = __builtin_bit_cast(f32x4, hs[64 * (4 + j)]);
+#pragma unroll
+              for (int e = 0; e < 4; e++) dp[4 * j + e] = dj[e];
+            }
+          }
           constexpr int AP = 2;             // (the P-wave sits at the 256-register line: two row fragments in flight, statistics fetched at use)
-          s16x8 of[KS];
+          if constexpr (MODE == 1) {
+            s16x8 of[KS];
 #pragma unroll
-          for (int ks = 0; ks < AP; ks++) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]);
+            for (int ks = 0; ks < AP; ks++) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]);
 #pragma unroll
-          for (int ks = 0; ks < KS; ks++) {
-            dp = mfma32(of[ks], vf[ks], dp);
-            if (ks + AP < KS) of[ks + AP] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AP))]);
+            for (int ks = 0; ks < KS; ks++) {
+              dp = mfma32(of[ks], vf[ks], dp);
+              if (ks + AP < KS) of[ks + AP] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AP))]);
+            }
           }
           unsigned pw[8], dw[8];
 #pragma unroll
@@ -1416,10 +1437,15 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     }
   }
 #endif
+  static const int ws_mode = getenv("UVTG_ATTN_WS_MODE") ? atoi(getenv("UVTG_ATTN_WS_MODE")) : 0;      // work split of the role-split kernel (see it): 0 / 1 / 2
   static const bool ws_off = getenv("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
-    if (HD_ == 128 && !ws_off && g_attn_ws != 0) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_>), grid1, dim3(512), 0, s, a); \
+    if (HD_ == 128 && !ws_off && g_attn_ws != 0) {                                                \
+      if (ws_mode == 1) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, 1>), grid1, dim3(512), 0, s, a); \
+      else if (ws_mode == 2) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, 2>), grid1, dim3(512), 0, s, a); \
+      else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, 0>), grid1, dim3(512), 0, s, a); \
+    }                                                                                             \
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);       \
     if (HD_ == 128 && dq_dma) {                                                                   \
       hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DROP_>), grid1, blk, 0, s, a, (unsigned)qkv_bytes); \
