@@ -624,31 +624,34 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
 // backward: dK, dV at head_dim 128, ROLE-SPLIT (round 5; BASELINE config 4, S = 1232).  attn_bwd_dkdv_kernel above needs ~360-420 registers at
 // head_dim 128 (128 dK / dV accumulators + 64 K / V fragment registers + scores + fragments in flight): ONE wave per SIMD, so the ~190 VALU
 // operations of a query block's softmax and the 32 MFMAs of the block cannot overlap however they are interleaved in the one instruction stream
-// (in-order issue; the matrix pipe was busy 18-24 % of the time).  Here the work of a 32-key group is cut between TWO waves that meet on the same
-// SIMD: the S-wave keeps the K / V fragments and computes S = Q K^T, dP = dO V^T and the softmax arithmetic of query block t; the P-wave keeps
-// the dK / dV accumulators and computes dV += dO^T P, dK += Q^T dS of block t - 1.  P and dS travel as the packed B operands the P-wave's MFMAs
-// take -- 64 bytes per lane and block, lane-order image in LDS (4 x ds_write_b128 / ds_read_b128, conflict-free by construction), double
-// buffered.  Both roles fit 256 registers: eight waves per workgroup, two per SIMD, and the S-wave's VALU section runs under the P-wave's MFMAs.
-// One barrier per query block, as before; Q / dO tiles: the same three-buffer ring (tile t + 1 staged while t is read by rows and t - 1
-// transposed).  The two roles are two separate loops (not one loop with a role branch): the register allocator then sees that the K / V
-// fragments and the accumulators are never live together.
+// (in-order issue; the matrix pipe was busy 18-24 % of the time).  Here the work of a 128-key block is cut between two kinds of waves that meet
+// on the same SIMD.  S-wave kg (four of them) keeps the K / V fragments of keys 32 kg .. 32 kg + 31 and computes S = Q K^T, dP = dO V^T and the
+// whole softmax section of query block t: P and dS leave as the packed bf16 B operands the product MFMAs take -- 64 bytes per lane and block,
+// lane-order image in LDS (4 x ds_write_b128, conflict-free by construction), double buffered.  The P-waves keep the dK / dV accumulators
+// and compute dV += dO^T P, dK += Q^T dS of block t - 1.  Both roles fit 256 registers: eight waves per workgroup, two per SIMD, and the S-wave's
+// VALU section runs under the P-wave's MFMAs.  One barrier per query block, as before; Q / dO tiles: the same three-buffer ring (tile t + 1
+// staged while t is read by rows and t - 1 transposed).  The two roles are two separate loops (not one loop with a role branch): the register
+// allocator then sees that the K / V fragments and the accumulators are never live together.
+// Which accumulators a P-wave owns (HDP):
+//   false -- the keys of S-wave kg x all 128 head-dim columns (first version).  Every P-wave then fetches the WHOLE transposed Q / dO tile: 32
+//            ds_read_b64_tr_b16 per wave and block, the slowest LDS read (profiles/r03_lds_conflict_probe.txt), four times over for the same bytes.
+//            In-box (profiles/r05_ab_attn_dkdv_role_split_modes.txt): attention backward of config 4 3.27 -> 2.94 ms; moving dP / dS work from the
+//            S-wave to the P-wave made it SLOWER (3.23 / 3.01): the P-wave, not the S-wave, was the long stream.
+//   true  -- head-dim block w (32 columns) x all 128 keys: 8 transposing reads per wave and block instead of 32, and 16 ds_read_b128 of the
+//            hand-off image (all four key groups) instead of 4.  Same MFMAs on the same operands in the same order per accumulator.
+// Either way the results are bit-identical to attn_bwd_dkdv_kernel's (tests/test_gpu_kernels.py::test_attention_bwd_role_split_dkdv_bit_identical).
 // ------------------------------------------------------------------------------------------------
-template <bool DROP, bool SWZ, int MODE_>
+template <bool DROP, bool SWZ, bool HDP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs a) {
   constexpr int HD = 128;
-  // MODE (what the S-wave does beyond S = Q K^T and p = exp2(.)): 0 = dP, dS and the bf16 packing too (hands over the packed operands; always with
-  // DROP); 1 = nothing else (hands over p; the P-wave computes dP, dS, packs); 2 = dP (hands over p and dP; the P-wave computes dS and packs)
-  constexpr int MODE = DROP ? 0 : MODE_;
-  constexpr bool S_DP = MODE != 1;               // the S-wave holds the V fragments and computes dP
-  constexpr int NH = MODE == 2 ? 8 : 4;          // 16-byte hand-off slots per lane and block
   using QT = TileRT<HD, SWZ>;
   __shared__ __attribute__((aligned(16))) bf16_t sQ[3][32 * QT::STR];
   __shared__ __attribute__((aligned(16))) bf16_t sO[3][32 * QT::STR];
   __shared__ __attribute__((aligned(16))) float sL[3][32], sD[3][32];     // lse * log2(e) (ROW_OFF beyond S), delta
-  __shared__ __attribute__((aligned(16))) u32x4 sH[2][4][NH][64];         // hand-off: [slot][key group][MODE 0: P lo, P hi, dS lo, dS hi | 1: p | 2: p, dP][lane]
+  __shared__ __attribute__((aligned(16))) u32x4 sH[2][4][4][64];          // hand-off: [slot][key group][P q0-15, P q16-31, dS q0-15, dS q16-31][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
-  const int role = wave >> 2, kg = wave & 3;          // role 0: scores + softmax, role 1: products; both for keys 32 kg .. 32 kg + 31 of the block
+  const int role = wave >> 2, kg = wave & 3;          // role 0: S-wave of key group kg; role 1: P-wave (HDP: of head-dim block kg, else of key group kg)
   int kblk, h, b;
   attn_block_id((a.S + 127) / 128, a.H, kblk, h, b);
   const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
@@ -657,8 +660,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
   const int key0 = kblk * 128;
   const bf16_t* qkv = (const bf16_t*)a.qkv;
   constexpr int CH = HD / 8;
-  const int key = key0 + kg * 32 + l31;              // this lane's key (lane <-> key in the S, dP tiles and in the dK / dV rows)
-  const bool kin = key < S;
   [[maybe_unused]] const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
   // staging: 32 rows x 16 chunks of Q and of dO per query block = one 16-byte piece per thread and operand
   u32x4 pq, po;
@@ -686,102 +687,79 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
   if (1 < nqb) prefetch(1);
   __syncthreads();
   // iteration t = 0 .. nqb: tile t + 1 is staged and tile t + 2 requested by everybody; the S-waves work on block t, the P-waves on block t - 1
-  // Work split.  DROP (attention dropout; never set by the reference's scripts): the S-wave does scores, dP and the whole softmax section and hands
-  // over the packed P / dS operands.  !DROP (round 5, second step): the S-wave of the first version was the long pole (16 MFMAs + ~190 VALU in
-  // ONE stream against the P-wave's 16 MFMAs) -- now it computes S = Q K^T and p = exp2(s log2e - lse) only (8 MFMAs, ~35 VALU incl. 16 quarter-rate
-  // exponentials) and hands the fp32 probabilities over; the P-wave keeps the V fragments too and computes dP = dO V^T (8 MFMAs), dS = p (dP - delta),
-  // the bf16 packing (~60 VALU) and the 16 product MFMAs.  Same arithmetic on the same values in the same order: bit-identical to the other kernel.
-  const int qoff = QT::off(l31, 8 * g);                                        // Q / dO row fragments: + k-step: QT::step(qoff, 16 ks)
-  constexpr int KS = HD / 16, AHEAD = 4;
   if (role == 0) {
-    // ---- S-waves: this lane's K (DROP: and V) row as MFMA B fragments (k-step ks covers head-dim columns 16 ks + 8 g .. + 7) ----
-    s16x8 kf[KS], vf[S_DP ? KS : 1];
+    // ---- S-waves: this lane's K / V row as MFMA B fragments (k-step ks covers head-dim columns 16 ks + 8 g .. + 7) ----
+    constexpr int KS = HD / 16, AHEAD = 4;
+    const int key = key0 + kg * 32 + l31;              // this lane's key (lane <-> key in the S, dP tiles)
+    s16x8 kf[KS], vf[KS];
     {
       const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) {
         kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
-        if constexpr (S_DP) vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
+        vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
       }
     }
+    const int qoff = QT::off(l31, 8 * g);                                        // Q / dO row fragments: + k-step: QT::step(qoff, 16 ks)
     for (int t = 0; t <= nqb; t++) {
       if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
       if (t + 2 < nqb) prefetch(t + 2);
       if (t < nqb) {
         const int buf = t % 3;
         const bf16_t* bq = sQ[buf];
-        [[maybe_unused]] const bf16_t* bo = sO[buf];
+        const bf16_t* bo = sO[buf];
         f32x16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
-        s16x8 qf[KS], of[S_DP ? KS : 1];
+        s16x8 qf[KS], of[KS];
 #pragma unroll
-        for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); if constexpr (S_DP) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+        for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
           sc = mfma32(qf[ks], kf[ks], sc);
-          if constexpr (S_DP) dp = mfma32(of[ks], vf[ks], dp);
-          if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); if constexpr (S_DP) of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
+          dp = mfma32(of[ks], vf[ks], dp);
+          if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
         }
-        f32x4 Lq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
+        f32x4 Lq[4], Dq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
 #pragma unroll
-        for (int j = 0; j < 4; j++) Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]);
-        u32x4* hs = &sH[t & 1][kg][0][lane];
-        if constexpr (MODE == 0) {
-          f32x4 Dq[4];
+        for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
+        unsigned pw[8], dw[8];
 #pragma unroll
-          for (int j = 0; j < 4; j++) Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]);
-          unsigned pw[8], dw[8];
+        for (int r = 0; r < 16; r += 2) {
+          float pd[2], ds[2];
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            float pd[2], ds[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const int rr = r + u;
-              const float pp = exp2_raw(fmaf(sc[rr], LOG2E, -Lq[rr >> 2][rr & 3]));      // (padded keys: masked at the dK / dV stores)
-              if constexpr (DROP) {
-                const int qi = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
-                const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
-                pd[u] = pp * ksc;
-                ds[u] = pp * (dp[rr] * ksc - Dq[rr >> 2][rr & 3]);
-              } else {
-                pd[u] = pp;
-                ds[u] = pp * (dp[rr] - Dq[rr >> 2][rr & 3]);
-              }
+          for (int u = 0; u < 2; u++) {
+            const int rr = r + u;
+            const float pp = exp2_raw(fmaf(sc[rr], LOG2E, -Lq[rr >> 2][rr & 3]));      // (padded keys: masked at the dK / dV stores)
+            if constexpr (DROP) {
+              const int qi = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+              const float ksc = keep_scale(a.seed, rng_stream, b * a.H + h, qi, key, a.S, a.p_drop);
+              pd[u] = pp * ksc;
+              ds[u] = pp * (dp[rr] * ksc - Dq[rr >> 2][rr & 3]);
+            } else {
+              pd[u] = pp;
+              ds[u] = pp * (dp[rr] - Dq[rr >> 2][rr & 3]);
             }
-            pw[r >> 1] = pack_bf2(pd[0], pd[1]);
-            dw[r >> 1] = pack_bf2(ds[0], ds[1]);
           }
-          hs[0] = (u32x4){pw[0], pw[1], pw[2], pw[3]};
-          hs[64] = (u32x4){pw[4], pw[5], pw[6], pw[7]};
-          hs[128] = (u32x4){dw[0], dw[1], dw[2], dw[3]};
-          hs[192] = (u32x4){dw[4], dw[5], dw[6], dw[7]};
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {       // the fp32 probabilities of accumulator registers 4 j .. 4 j + 3
-            f32x4 pv;
-#pragma unroll
-            for (int e = 0; e < 4; e++) pv[e] = exp2_raw(fmaf(sc[4 * j + e], LOG2E, -Lq[j][e]));
-            hs[64 * j] = __builtin_bit_cast(u32x4, pv);
-            if constexpr (MODE == 2) hs[64 * (4 + j)] = __builtin_bit_cast(u32x4, (f32x4){dp[4 * j], dp[4 * j + 1], dp[4 * j + 2], dp[4 * j + 3]});
-          }
+          pw[r >> 1] = pack_bf2(pd[0], pd[1]);
+          dw[r >> 1] = pack_bf2(ds[0], ds[1]);
         }
+        u32x4* hs = &sH[t & 1][kg][0][lane];
+        hs[0] = (u32x4){pw[0], pw[1], pw[2], pw[3]};
+        hs[64] = (u32x4){pw[4], pw[5], pw[6], pw[7]};
+        hs[128] = (u32x4){dw[0], dw[1], dw[2], dw[3]};
+        hs[192] = (u32x4){dw[4], dw[5], dw[6], dw[7]};
       }
       __syncthreads();
     }
   } else {
-    // ---- P-waves: dV^T += dO^T P, dK^T += Q^T dS of the previous block (!DROP: and its dP = dO V^T, dS = p (dP - delta)); the accumulators live here ----
-    f32x16 dk[HD / 32], dv[HD / 32];
+    // ---- P-waves: dV^T += dO^T P, dK^T += Q^T dS of the previous block; the accumulators live here ----
+    // accumulator i: !HDP head-dim block i of key group kg; HDP key group i of head-dim block kg
+    f32x16 dk[4], dv[4];
 #pragma unroll
-    for (int i = 0; i < HD / 32; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-    s16x8 vf[MODE == 1 ? KS : 1];
-    if constexpr (MODE == 1) {
-      const bf16_t* kvbase = qkv + (rowbase + min(key, S - 1)) * a.ldqkv + h * HD + 8 * g;
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++) vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
-    }
     const int toff0 = QT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));      // + head-dim block: QT::step(toff, 32 blk); + 16 rows for the
     const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
     for (int t = 0; t <= nqb; t++) {
@@ -791,75 +769,61 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         const int buf = (t - 1) % 3;
         const bf16_t* bq = sQ[buf];
         const bf16_t* bo = sO[buf];
-        const u32x4* hs = &sH[(t - 1) & 1][kg][0][lane];
-        s16x8 pb[2], db[2];
-        if constexpr (MODE == 0) {
+        if constexpr (!HDP) {
+          const u32x4* hs = &sH[(t - 1) & 1][kg][0][lane];
+          s16x8 pb[2], db[2];
           pb[0] = __builtin_bit_cast(s16x8, hs[0]); pb[1] = __builtin_bit_cast(s16x8, hs[64]);
           db[0] = __builtin_bit_cast(s16x8, hs[128]); db[1] = __builtin_bit_cast(s16x8, hs[192]);
-        } else {
-          f32x16 dp;
 #pragma unroll
-          for (int r = 0; r < 16; r++) dp[r] = 0.f;
-          if constexpr (MODE == 2) {
+          for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int blk = 0; blk < HD / 32; blk++) {
+              const int o0 = QT::step(toff0, 32 * blk) + 16 * hf * QT::STR, o1 = QT::step(toff1, 32 * blk) + 16 * hf * QT::STR;
+              const s16x8 ot = cat4(lds_tr16(&bo[o0]), lds_tr16(&bo[o1]));
+              const s16x8 qt = cat4(lds_tr16(&bq[o0]), lds_tr16(&bq[o1]));
+              dv[blk] = mfma32(ot, pb[hf], dv[blk]);
+              dk[blk] = mfma32(qt, db[hf], dk[blk]);
+            }
+        } else {
+          const u32x4* hs = &sH[(t - 1) & 1][0][0][lane];
+          s16x8 ot[2], qt[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {
+            const int o0 = QT::step(toff0, 32 * kg) + 16 * hf * QT::STR, o1 = QT::step(toff1, 32 * kg) + 16 * hf * QT::STR;
+            ot[hf] = cat4(lds_tr16(&bo[o0]), lds_tr16(&bo[o1]));
+            qt[hf] = cat4(lds_tr16(&bq[o0]), lds_tr16(&bq[o1]));
+          }
+          // (hf outermost: eight independent MFMAs between two uses of an accumulator)
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              const f32x4 dj = __builtin_bit_cast(f32x4, hs[64 * (4 + j)]);
-#pragma unroll
-              for (int e = 0; e < 4; e++) dp[4 * j + e] = dj[e];
+              const s16x8 pj = __builtin_bit_cast(s16x8, hs[256 * j + 64 * hf]), dj = __builtin_bit_cast(s16x8, hs[256 * j + 128 + 64 * hf]);
+              dv[j] = mfma32(ot[hf], pj, dv[j]);
+              dk[j] = mfma32(qt[hf], dj, dk[j]);
             }
-          }
-          constexpr int AP = 2;             // (the P-wave sits at the 256-register line: two row fragments in flight, statistics fetched at use)
-          if constexpr (MODE == 1) {
-            s16x8 of[KS];
-#pragma unroll
-            for (int ks = 0; ks < AP; ks++) of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]);
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-              dp = mfma32(of[ks], vf[ks], dp);
-              if (ks + AP < KS) of[ks + AP] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AP))]);
-            }
-          }
-          unsigned pw[8], dw[8];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {       // accumulator registers 4 j .. 4 j + 3: queries 8 j + 4 g + (0..3)
-            const f32x4 pv = __builtin_bit_cast(f32x4, hs[64 * j]);
-            const f32x4 Dq = *(const f32x4*)(&sD[buf][8 * j + 4 * g]);
-            pw[2 * j] = pack_bf2(pv[0], pv[1]); pw[2 * j + 1] = pack_bf2(pv[2], pv[3]);
-            dw[2 * j] = pack_bf2(pv[0] * (dp[4 * j] - Dq[0]), pv[1] * (dp[4 * j + 1] - Dq[1]));
-            dw[2 * j + 1] = pack_bf2(pv[2] * (dp[4 * j + 2] - Dq[2]), pv[3] * (dp[4 * j + 3] - Dq[3]));
-          }
-          pb[0] = __builtin_bit_cast(s16x8, (u32x4){pw[0], pw[1], pw[2], pw[3]}); pb[1] = __builtin_bit_cast(s16x8, (u32x4){pw[4], pw[5], pw[6], pw[7]});
-          db[0] = __builtin_bit_cast(s16x8, (u32x4){dw[0], dw[1], dw[2], dw[3]}); db[1] = __builtin_bit_cast(s16x8, (u32x4){dw[4], dw[5], dw[6], dw[7]});
         }
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++)
-#pragma unroll
-          for (int blk = 0; blk < HD / 32; blk++) {
-            const int o0 = QT::step(toff0, 32 * blk) + 16 * hf * QT::STR, o1 = QT::step(toff1, 32 * blk) + 16 * hf * QT::STR;
-            const s16x8 ot = cat4(lds_tr16(&bo[o0]), lds_tr16(&bo[o1]));
-            const s16x8 qt = cat4(lds_tr16(&bq[o0]), lds_tr16(&bq[o1]));
-            dv[blk] = mfma32(ot, pb[hf], dv[blk]);
-            dk[blk] = mfma32(qt, db[hf], dk[blk]);
-          }
       }
       __syncthreads();
     }
     // A lane's key contributes to nobody's sums but its own dK / dV row: the key-padding mask is applied HERE (a padded key's row is zero)
-    if (kin) {
-      const bool kok = a.kvalid[rowbase + key] != 0;
-      const u32x2 z = {0u, 0u};
 #pragma unroll
-      for (int blk = 0; blk < HD / 32; blk++)
+    for (int i = 0; i < 4; i++) {
+      const int key = key0 + (HDP ? i : kg) * 32 + l31, blk = HDP ? kg : i;
+      if (key < S) {
+        const bool kok = a.kvalid[rowbase + key] != 0;
+        const u32x2 z = {0u, 0u};
 #pragma unroll
         for (int rq = 0; rq < 4; rq++) {
           const int c = blk * 32 + 8 * rq + 4 * g;
           bf16_t* base = a.dqkv + (rowbase + key) * a.lddqkv + h * HD + c;
           u32x2 tt;
-          tt[0] = pack_bf2(dk[blk][4 * rq], dk[blk][4 * rq + 1]); tt[1] = pack_bf2(dk[blk][4 * rq + 2], dk[blk][4 * rq + 3]);
+          tt[0] = pack_bf2(dk[i][4 * rq], dk[i][4 * rq + 1]); tt[1] = pack_bf2(dk[i][4 * rq + 2], dk[i][4 * rq + 3]);
           *(u32x2*)(base + d) = kok ? tt : z;
-          tt[0] = pack_bf2(dv[blk][4 * rq], dv[blk][4 * rq + 1]); tt[1] = pack_bf2(dv[blk][4 * rq + 2], dv[blk][4 * rq + 3]);
+          tt[0] = pack_bf2(dv[i][4 * rq], dv[i][4 * rq + 1]); tt[1] = pack_bf2(dv[i][4 * rq + 2], dv[i][4 * rq + 3]);
           *(u32x2*)(base + 2 * d) = kok ? tt : z;
         }
+      }
     }
   }
 }
@@ -1437,14 +1401,13 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     }
   }
 #endif
-  static const int ws_mode = getenv("UVTG_ATTN_WS_MODE") ? atoi(getenv("UVTG_ATTN_WS_MODE")) : 0;      // work split of the role-split kernel (see it): 0 / 1 / 2
+  static const bool ws_hdp = !getenv("UVTG_ATTN_WS_KEYP");      // product waves own a head-dim block (default) / UVTG_ATTN_WS_KEYP: a key group (first version)
   static const bool ws_off = getenv("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
     if (HD_ == 128 && !ws_off && g_attn_ws != 0) {                                                \
-      if (ws_mode == 1) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, 1>), grid1, dim3(512), 0, s, a); \
-      else if (ws_mode == 2) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, 2>), grid1, dim3(512), 0, s, a); \
-      else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, 0>), grid1, dim3(512), 0, s, a); \
+      if (ws_hdp) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, true>), grid1, dim3(512), 0, s, a); \
+      else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, false>), grid1, dim3(512), 0, s, a); \
     }                                                                                             \
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);       \
     if (HD_ == 128 && dq_dma) {                                                                   \
