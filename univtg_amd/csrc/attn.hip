@@ -687,6 +687,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
   if (1 < nqb) prefetch(1);
   __syncthreads();
   // iteration t = 0 .. nqb: tile t + 1 is staged and tile t + 2 requested by everybody; the S-waves work on block t, the P-waves on block t - 1
+  if (a.ws_prio == 1 + role) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for one role)
   if (role == 0) {
     // ---- S-waves: this lane's K / V row as MFMA B fragments (k-step ks covers head-dim columns 16 ks + 8 g .. + 7) ----
     constexpr int KS = HD / 16, AHEAD = 4;
@@ -701,10 +702,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
       }
     }
     const int qoff = QT::off(l31, 8 * g);                                        // Q / dO row fragments: + k-step: QT::step(qoff, 16 ks)
-    for (int t = 0; t <= nqb; t++) {
+    for (int t = 0; t < nqb; t++) {
       if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
       if (t + 2 < nqb) prefetch(t + 2);
-      if (t < nqb) {
+      {
         const int buf = t % 3;
         const bf16_t* bq = sQ[buf];
         const bf16_t* bo = sO[buf];
@@ -714,12 +715,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         s16x8 qf[KS], of[KS];
 #pragma unroll
         for (int ks = 0; ks < AHEAD; ks++) { qf[ks] = *(const s16x8*)(&bq[QT::step(qoff, 16 * ks)]); of[ks] = *(const s16x8*)(&bo[QT::step(qoff, 16 * ks)]); }
+        if (a.ws_prio == 3) __builtin_amdgcn_s_setprio(1);      // (experiment: the S-wave's MFMAs first, its VALU section under the P-wave's MFMAs)
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
           sc = mfma32(qf[ks], kf[ks], sc);
           dp = mfma32(of[ks], vf[ks], dp);
           if (ks + AHEAD < KS) { qf[ks + AHEAD] = *(const s16x8*)(&bq[QT::step(qoff, 16 * (ks + AHEAD))]); of[ks + AHEAD] = *(const s16x8*)(&bo[QT::step(qoff, 16 * (ks + AHEAD))]); }
         }
+        if (a.ws_prio == 3) __builtin_amdgcn_s_setprio(0);
         f32x4 Lq[4], Dq[4];     // row statistics of this lane's 16 accumulator registers: queries 8 j + 4 g + (0..3), j = 0..3
 #pragma unroll
         for (int j = 0; j < 4; j++) { Lq[j] = *(const f32x4*)(&sL[buf][8 * j + 4 * g]); Dq[j] = *(const f32x4*)(&sD[buf][8 * j + 4 * g]); }
@@ -752,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
       }
       __syncthreads();
     }
+    __syncthreads();       // (iteration nqb: the P-waves multiply the last block)
   } else {
     // ---- P-waves: dV^T += dO^T P, dK^T += Q^T dS of the previous block; the accumulators live here ----
     // accumulator i: !HDP head-dim block i of key group kg; HDP key group i of head-dim block kg
@@ -762,10 +766,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
       for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
     const int toff0 = QT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3));      // + head-dim block: QT::step(toff, 32 blk); + 16 rows for the
     const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
-    for (int t = 0; t <= nqb; t++) {
+    // (iteration 0 peeled: with `if (t >= 1)` around the accumulator updates hipcc kept two copies of the 128 accumulator registers and moved
+    //  them every iteration -- 130 v_mov_b32 per block in the first build)
+    if (1 < nqb) stage(1, 1);
+    if (2 < nqb) prefetch(2);
+    __syncthreads();
+    for (int t = 1; t <= nqb; t++) {
       if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
       if (t + 2 < nqb) prefetch(t + 2);
-      if (t >= 1) {
+      {
         const int buf = (t - 1) % 3;
         const bf16_t* bq = sQ[buf];
         const bf16_t* bo = sO[buf];
@@ -1401,13 +1410,15 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
     }
   }
 #endif
+  static const int ws_prio = getenv("UVTG_ATTN_WS_PRIO") ? atoi(getenv("UVTG_ATTN_WS_PRIO")) : 0;
+  AttnArgs aw = a; aw.ws_prio = ws_prio;
   static const bool ws_hdp = !getenv("UVTG_ATTN_WS_KEYP");      // product waves own a head-dim block (default) / UVTG_ATTN_WS_KEYP: a key group (first version)
   static const bool ws_off = getenv("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
     if (HD_ == 128 && !ws_off && g_attn_ws != 0) {                                                \
-      if (ws_hdp) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, true>), grid1, dim3(512), 0, s, a); \
-      else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, false>), grid1, dim3(512), 0, s, a); \
+      if (ws_hdp) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, true>), grid1, dim3(512), 0, s, aw); \
+      else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, false>), grid1, dim3(512), 0, s, aw); \
     }                                                                                             \
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);       \
     if (HD_ == 128 && dq_dma) {                                                                   \
