@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
 //            hand-off image (all four key groups) instead of 4.  Same MFMAs on the same operands in the same order per accumulator.
 // Either way the results are bit-identical to attn_bwd_dkdv_kernel's (tests/test_gpu_kernels.py::test_attention_bwd_role_split_dkdv_bit_identical).
 // ------------------------------------------------------------------------------------------------
-template <bool DROP, bool SWZ, bool HDP>
+template <bool DROP, bool SWZ, bool HDP, bool PF2>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs a) {
   constexpr int HD = 128;
   using QT = TileRT<HD, SWZ>;
@@ -661,31 +661,43 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
   const bf16_t* qkv = (const bf16_t*)a.qkv;
   constexpr int CH = HD / 8;
   [[maybe_unused]] const unsigned rng_stream = UVTG_RNG_ATTN + a.layer;
-  // staging: 32 rows x 16 chunks of Q and of dO per query block = one 16-byte piece per thread and operand
-  u32x4 pq, po;
-  float pl = 0.f, pdl = 0.f;
-  auto prefetch = [&](int qb) {
-    const int r = tid / CH, c = tid % CH;
-    const int qi = min(qb * 32 + r, S - 1);            // clamped rows are loaded; their probabilities are exact zeros (ROW_OFF)
-    pq = *(const u32x4*)(qkv + (rowbase + qi) * a.ldqkv + h * HD + c * 8);
-    po = *(const u32x4*)(a.dO + (rowbase + qi) * a.lddo + h * HD + c * 8);
-    if (tid < 32) {          // (raw values: anything computed from them HERE would wait out the whole load latency right behind the request)
-      const int q2 = min(qb * 32 + tid, S - 1);
-      pl = a.lse[((size_t)b * a.H + h) * a.S + q2];
-      pdl = a.delta[((size_t)b * a.H + h) * a.S + q2];
-    }
-  };
-  auto stage = [&](int buf, int qb) {                 // the prefetched rows of block qb -> tile buffer `buf`
-    const int r = tid / CH, c = tid % CH;
-    *(u32x4*)(&sQ[buf][QT::off(r, c * 8)]) = pq;
-    *(u32x4*)(&sO[buf][QT::off(r, c * 8)]) = po;
-    if (tid < 32) { sL[buf][tid] = (qb * 32 + tid < S) ? pl * LOG2E : ROW_OFF; sD[buf][tid] = pdl; }
-  };
+  // staging: 32 rows x 16 chunks of Q and of dO per query block = one 16-byte piece per thread and operand.  PF2: TWO register sets -- the rows of
+  // block t + 1 are staged from the set that was requested TWO iterations ago (first build, !PF2: one iteration ago -- an iteration is ~1 us, about
+  // one global load round trip under load, and every iteration opened with a wait for it)
+  u32x4 aq, ao, bq2, bo2;                 // set A / set B
+  float al = 0.f, adl = 0.f, bl = 0.f, bdl = 0.f;
+#define WS_PREFETCH(qb_, Q_, O_, L_, D_) do {                                                                  \
+    const int r_ = tid / CH, c_ = tid % CH;                                                                    \
+    const int qi_ = min((qb_) * 32 + r_, S - 1);      /* clamped rows are loaded; their probabilities are exact zeros (ROW_OFF) */ \
+    Q_ = *(const u32x4*)(qkv + (rowbase + qi_) * a.ldqkv + h * HD + c_ * 8);                                   \
+    O_ = *(const u32x4*)(a.dO + (rowbase + qi_) * a.lddo + h * HD + c_ * 8);                                   \
+    if (tid < 32) {      /* raw values: anything computed from them HERE would wait out the whole load latency right behind the request */ \
+      const int q2_ = min((qb_) * 32 + tid, S - 1);                                                            \
+      L_ = a.lse[((size_t)b * a.H + h) * a.S + q2_];                                                           \
+      D_ = a.delta[((size_t)b * a.H + h) * a.S + q2_];                                                         \
+    }                                                                                                          \
+  } while (0)
+#define WS_STAGE(buf_, qb_, Q_, O_, L_, D_) do {      /* the prefetched rows of block qb_ -> tile buffer buf_ */ \
+    const int r_ = tid / CH, c_ = tid % CH;                                                                    \
+    *(u32x4*)(&sQ[buf_][QT::off(r_, c_ * 8)]) = Q_;                                                            \
+    *(u32x4*)(&sO[buf_][QT::off(r_, c_ * 8)]) = O_;                                                            \
+    if (tid < 32) { sL[buf_][tid] = ((qb_) * 32 + tid < S) ? L_ * LOG2E : ROW_OFF; sD[buf_][tid] = D_; }       \
+  } while (0)
   const int nqb = (S + 31) / 32;
-  prefetch(0);
-  stage(0, 0);
-  if (1 < nqb) prefetch(1);
+  WS_PREFETCH(0, aq, ao, al, adl);
+  WS_STAGE(0, 0, aq, ao, al, adl);
+  if (1 < nqb) WS_PREFETCH(1, aq, ao, al, adl);
+  if (PF2 && 2 < nqb) WS_PREFETCH(2, bq2, bo2, bl, bdl);
   __syncthreads();
+  // top of iteration t: stage tile t + 1 from the set of its parity, then re-fill that set with tile t + 3 (!PF2: one set, tile t + 2)
+  auto advance_a = [&](int t) {      // even t (or !PF2: every t): set A
+    if (t + 1 < nqb) WS_STAGE((t + 1) % 3, t + 1, aq, ao, al, adl);
+    if (t + (PF2 ? 3 : 2) < nqb) WS_PREFETCH(t + (PF2 ? 3 : 2), aq, ao, al, adl);
+  };
+  auto advance_b = [&](int t) {      // odd t with PF2: set B
+    if (t + 1 < nqb) WS_STAGE((t + 1) % 3, t + 1, bq2, bo2, bl, bdl);
+    if (t + 3 < nqb) WS_PREFETCH(t + 3, bq2, bo2, bl, bdl);
+  };
   // iteration t = 0 .. nqb: tile t + 1 is staged and tile t + 2 requested by everybody; the S-waves work on block t, the P-waves on block t - 1
   if (a.ws_prio == 1 + role) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for one role)
   if (role == 0) {
@@ -702,9 +714,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
       }
     }
     const int qoff = QT::off(l31, 8 * g);                                        // Q / dO row fragments: + k-step: QT::step(qoff, 16 ks)
-    for (int t = 0; t < nqb; t++) {
-      if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
-      if (t + 2 < nqb) prefetch(t + 2);
+    auto s_block = [&](int t) {
       {
         const int buf = t % 3;
         const bf16_t* bq = sQ[buf];
@@ -754,6 +764,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         hs[192] = (u32x4){dw[4], dw[5], dw[6], dw[7]};
       }
       __syncthreads();
+    };
+    // (two iterations per trip: which register set an iteration stages from is then a compile-time fact -- selected by `t & 1` inside one loop body
+    //  hipcc kept one set in scratch)
+    for (int t = 0; t < nqb; t += 2) {
+      advance_a(t);
+      s_block(t);
+      if (t + 1 < nqb) {
+        if constexpr (PF2) advance_b(t + 1); else advance_a(t + 1);
+        s_block(t + 1);
+      }
     }
     __syncthreads();       // (iteration nqb: the P-waves multiply the last block)
   } else {
@@ -768,12 +788,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
     const int toff1 = QT::rows8(toff0);                                          // second half of the block (the same chunk permutation)
     // (iteration 0 peeled: with `if (t >= 1)` around the accumulator updates hipcc kept two copies of the 128 accumulator registers and moved
     //  them every iteration -- 130 v_mov_b32 per block in the first build)
-    if (1 < nqb) stage(1, 1);
-    if (2 < nqb) prefetch(2);
-    __syncthreads();
-    for (int t = 1; t <= nqb; t++) {
-      if (t + 1 < nqb) stage((t + 1) % 3, t + 1);
-      if (t + 2 < nqb) prefetch(t + 2);
+    auto p_block = [&](int t) {
       {
         const int buf = (t - 1) % 3;
         const bf16_t* bq = sQ[buf];
@@ -814,6 +829,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         }
       }
       __syncthreads();
+    };
+    advance_a(0);
+    __syncthreads();
+    for (int t = 1; t <= nqb; t += 2) {
+      if constexpr (PF2) advance_b(t); else advance_a(t);
+      p_block(t);
+      if (t + 1 <= nqb) {
+        advance_a(t + 1);
+        p_block(t + 1);
+      }
     }
     // A lane's key contributes to nobody's sums but its own dK / dV row: the key-padding mask is applied HERE (a padded key's row is zero)
 #pragma unroll
@@ -836,6 +861,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
     }
   }
 }
+
+#undef WS_PREFETCH
+#undef WS_STAGE
 
 // ------------------------------------------------------------------------------------------------
 // backward: dQ   (one wave = 32 queries, loops over 64-key tiles)
@@ -1412,13 +1440,15 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t s) {
 #endif
   static const int ws_prio = getenv("UVTG_ATTN_WS_PRIO") ? atoi(getenv("UVTG_ATTN_WS_PRIO")) : 0;
   AttnArgs aw = a; aw.ws_prio = ws_prio;
+  static const bool ws_pf1 = getenv("UVTG_ATTN_WS_PF1") != nullptr;      // experiment: rows requested one iteration ahead (first build) instead of two
   static const bool ws_hdp = !getenv("UVTG_ATTN_WS_KEYP");      // product waves own a head-dim block (default) / UVTG_ATTN_WS_KEYP: a key group (first version)
   static const bool ws_off = getenv("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
     if (HD_ == 128 && !ws_off && g_attn_ws != 0) {                                                \
-      if (ws_hdp) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, true>), grid1, dim3(512), 0, s, aw); \
-      else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, false>), grid1, dim3(512), 0, s, aw); \
+      if (!ws_hdp) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, false, true>), grid1, dim3(512), 0, s, aw); \
+      else if (ws_pf1) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, true, false>), grid1, dim3(512), 0, s, aw); \
+      else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<DROP_, SWZ_, true, true>), grid1, dim3(512), 0, s, aw); \
     }                                                                                             \
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, DROP_, SWZ_>), grid1, blk, 0, s, a);       \
     if (HD_ == 128 && dq_dma) {                                                                   \
