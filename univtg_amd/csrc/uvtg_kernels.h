@@ -195,6 +195,7 @@ struct AttnArgs {
   // backward
   const bf16_t* dO; int lddo;   // [B*S, d]
   float* delta;                 // [B, H, S] scratch: rowsum(dO * O)
+  int sample_major;             // tiled kernels' block decode: 0 = head-major over the (sample, head) pairs (XCD balance on ragged batches), 1 = sample-major (experiment)
   int ws_prio;                  // role-split dK / dV kernel: wave-priority experiment (0 none, 1 S-waves high, 2 P-waves high, 3 S-waves high during their MFMAs only)
   int delta_ready;              // 1: delta was already produced (by the dO GEMM's epilogue, GemmArgs::delta): launch_attn_bwd skips its own pass
   bf16_t* dqkv; int lddqkv;     // [B*S, 3d]
