@@ -25,7 +25,7 @@ template <int HD> struct KSwz {      // swizzle for [rows][HD] bf16 tiles read w
 // `nblk` 128-row blocks of one (sample, head) stream the SAME K / V rows (forward, dQ) or Q / dO rows (dK / dV): with the (block, head, sample)
 // grid their ids were consecutive, i.e. one block per XCD, and every XCD pulled every head's rows into its own L2 (8 x the traffic, S = 1232:
 // 1.3 GB per launch).  Here XCD x takes a contiguous range of the block list, so that the blocks of a head run on ONE XCD, back to back.
-__device__ __forceinline__ void attn_block_id(int nblk, int H, int& blk, int& h, int& b, int sample_major = 0) {
+__device__ __forceinline__ void attn_block_id(int nblk, int H, int B, int& blk, int& h, int& b, int sample_major) {
   const int total = gridDim.x, q = total / 8, r = total % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   blk = v % nblk;
@@ -33,9 +33,8 @@ __device__ __forceinline__ void attn_block_id(int nblk, int H, int& blk, int& h,
   // head-major over the (sample, head) pairs (round 5): an XCD's contiguous share is then ONE head of (nearly) every sample rather than every head of
   // a few samples -- all heads of a sample cost the same, samples of a ragged batch do not (S_b^2: 4x between 600 and 1200 clips), and a launch
   // ends with its slowest XCD.  UVTG_ATTN_SAMPLE_MAJOR (experiment; AttnArgs::sample_major) restores b = bh / H.
-  if (sample_major) { h = bh % H; b = bh / H; return; }
-  const int B = total / (nblk * H);
-  b = bh % B; h = bh / B;
+  const int dv = sample_major ? H : B, lo = bh % dv, hi = bh / dv;
+  h = sample_major ? lo : hi; b = sample_major ? hi : lo;
 }
 
 // Counter = position in the PADDED [B, H, S, S] probability tensor (S = a.S also on the packed stream, whose in-sample row order under
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   int qblk, h, b;
-  attn_block_id((a.S + 127) / 128, a.H, qblk, h, b, a.sample_major);
+  attn_block_id((a.S + 127) / 128, a.H, a.B, qblk, h, b, a.sample_major);
   const int S = a.seq_count ? a.seq_count[b] : a.S;
   if (qblk * 128 >= S) return;
   const int q_raw = qblk * 128 + wave * 32 + l31;
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(256, (HD < 128 && !DROP) ? 2 : 1) void attn_bwd_dkd
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   int kblk, h, b;
-  attn_block_id((a.S + 127) / 128, a.H, kblk, h, b, a.sample_major);
+  attn_block_id((a.S + 127) / 128, a.H, a.B, kblk, h, b, a.sample_major);
   const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
   if (kblk * 128 >= S) return;
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
@@ -658,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   const int role = wave >> 2, kg = wave & 3;          // role 0: S-wave of key group kg; role 1: P-wave (HDP: of head-dim block kg, else of key group kg)
   int kblk, h, b;
-  attn_block_id((a.S + 127) / 128, a.H, kblk, h, b, a.sample_major);
+  attn_block_id((a.S + 127) / 128, a.H, a.B, kblk, h, b, a.sample_major);
   const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
   if (kblk * 128 >= S) return;
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
@@ -883,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   int qblk, h, b;
-  attn_block_id((a.S + 127) / 128, a.H, qblk, h, b, a.sample_major);
+  attn_block_id((a.S + 127) / 128, a.H, a.B, qblk, h, b, a.sample_major);
   const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
   if (qblk * 128 >= S) return;
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
@@ -997,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const AttnArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, l31 = lane & 31;
   const int i16 = lane & 15, qd = (lane >> 4) & 1;
   int qblk, h, b;
-  attn_block_id((a.S + 127) / 128, a.H, qblk, h, b, a.sample_major);
+  attn_block_id((a.S + 127) / 128, a.H, a.B, qblk, h, b, a.sample_major);
   const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
   if (qblk * 128 >= S) return;
   const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
