@@ -716,6 +716,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
         kf[ks] = *(const s16x8*)(kvbase + d + 16 * ks);
         vf[ks] = *(const s16x8*)(kvbase + 2 * d + 16 * ks);
       }
+      // These loads must be WAITED FOR HERE.  Left to hipcc, the waits sit at the fragments' first use -- inside the loop, as a counted
+      // s_waitcnt vmcnt(15) ... vmcnt(0) ladder along the 16 score MFMAs -- and in every later iteration that same ladder drains the rows
+      // the iteration has just requested for two blocks ahead: the S-waves stood still for a global round trip per query block with the P-waves
+      // parked at the barrier (first builds: 3150 cycles per block at 32 % matrix-pipe occupancy; PMC: 39 % of the wave cycles in s_waitcnt).
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) asm volatile("" :: "v"(kf[ks]), "v"(vf[ks]));
     }
     const int qoff = QT::off(l31, 8 * g);                                        // Q / dO row fragments: + k-step: QT::step(qoff, 16 ks)
     auto s_block = [&](int t) {
