@@ -1032,13 +1032,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const AttnArgs 
       attn_dma16(rsrc, src + (unsigned)d * 4u, lds0 + (unsigned)((buf * 2 + 1) * 64 * HD * 2 + p * 1024));
     }
   };
-  auto bias_of = [&](int kt) -> float {                  // tid < 64
-    const int key = kt * 64 + tid;
-    return (key < S && a.kvalid[rowbase + min(key, S - 1)]) ? 0.f : -ROW_OFF;
+  // key-padding byte of key kt * 64 + tid (tid < 64), RAW: the bias is derived from it where it is stored, at the END of the iteration.  Round 5:
+  // computed right behind the request (`nbias = kvalid[..] ? 0 : -ROW_OFF`) hipcc put `s_waitcnt vmcnt(0)` between the tile's LDS-DMA issue and
+  // its own compute in wave 0 -- which drained the DMA it had just issued: wave 0 stood still for a global round trip per key tile and the
+  // other three waited for it at the next barrier.
+  auto valid_of = [&](int kt) -> unsigned char {        // tid < 64
+    return a.kvalid[rowbase + min(kt * 64 + tid, S - 1)];
   };
+  auto bias_from = [&](int kt, unsigned char v) -> float { return (kt * 64 + tid < S && v) ? 0.f : -ROW_OFF; };
   const int ntiles = (S + 63) / 64;
+  unsigned char nvalid = tid < 64 ? valid_of(0) : (unsigned char)0;
   request(0, 0);
-  float nbias = tid < 64 ? bias_of(0) : 0.f;
   s16x8 qf[HD / 16], of[HD / 16];
 #pragma unroll
   for (int ks = 0; ks < HD / 16; ks++) {
@@ -1056,14 +1060,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const AttnArgs 
   // this lane's fragment offsets inside a tile (rows 0..31; + 32 rows for kb = 1, + 16 for hf = 1: the same chunk permutation)
   const int koff = KT::off(l31, 8 * g);
   const int toff0 = KT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3)), toff1 = KT::rows8(toff0);
-  if (tid < 64) sBias[0][tid] = nbias;
+  if (tid < 64) sBias[0][tid] = bias_from(0, nvalid);
   for (int kt = 0; kt < ntiles; kt++) {
     const int buf = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed (and everything older)
     __syncthreads();                                     // ... everybody's; and everybody is done with the other buffer (tile kt - 1)
     if (kt + 1 < ntiles) {
+      if (tid < 64) nvalid = valid_of(kt + 1);          // (requested BEFORE the DMA pieces, consumed behind the tile's compute)
       request(kt + 1, buf ^ 1);
-      if (tid < 64) nbias = bias_of(kt + 1);
     }
     const bf16_t* sK = sKV[buf][0];
     const bf16_t* sV = sKV[buf][1];
@@ -1104,7 +1108,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const AttnArgs 
         }
       }
     }
-    if (kt + 1 < ntiles && tid < 64) sBias[buf ^ 1][tid] = nbias;     // (visible behind the next barrier; its last readers passed this one)
+    if (kt + 1 < ntiles && tid < 64) sBias[buf ^ 1][tid] = bias_from(kt + 1, nvalid);     // (visible behind the next barrier; its last readers passed this one)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
   if (q_raw < S) {
