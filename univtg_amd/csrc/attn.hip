@@ -799,6 +799,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
     // (iteration 0 peeled: with `if (t >= 1)` around the accumulator updates hipcc kept two copies of the 128 accumulator registers and moved
     //  them every iteration -- 130 v_mov_b32 per block in the first build)
     auto p_block = [&](int t) {
+      // (experiment, ws_prio 4 / 5 / 6: the P-wave starts its block 256 / 512 / 768 cycles late -- its MFMAs then run beside the S-wave's VALU
+      //  section instead of beside the S-wave's MFMAs)
+      if (a.ws_prio == 4) __builtin_amdgcn_s_sleep(4);
+      else if (a.ws_prio == 5) __builtin_amdgcn_s_sleep(8);
+      else if (a.ws_prio == 6) __builtin_amdgcn_s_sleep(12);
       {
         const int buf = (t - 1) % 3;
         const bf16_t* bq = sQ[buf];
