@@ -832,14 +832,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_ws_kernel(const AttnArgs
             ot[hf] = cat4(lds_tr16(&bo[o0]), lds_tr16(&bo[o1]));
             qt[hf] = cat4(lds_tr16(&bq[o0]), lds_tr16(&bq[o1]));
           }
+          // ALL sixteen hand-off operands are requested up front and fenced there.  Left alone hipcc read each one into the same four registers
+          // right in front of its MFMA (write-after-read on the previous MFMA's operand + an exposed LDS round trip per pair): the P-wave -- 16 MFMAs --
+          // was the long stream of the iteration (delaying it by 256 / 512 / 768 cycles cost exactly that: profiles/r05_attn_ws_skew.txt).
+          s16x8 pv[4][2], dvv[4][2];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+              pv[j][hf] = __builtin_bit_cast(s16x8, hs[256 * j + 64 * hf]);
+              dvv[j][hf] = __builtin_bit_cast(s16x8, hs[256 * j + 128 + 64 * hf]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
           // (hf outermost: eight independent MFMAs between two uses of an accumulator)
 #pragma unroll
           for (int hf = 0; hf < 2; hf++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              const s16x8 pj = __builtin_bit_cast(s16x8, hs[256 * j + 64 * hf]), dj = __builtin_bit_cast(s16x8, hs[256 * j + 128 + 64 * hf]);
-              dv[j] = mfma32(ot[hf], pj, dv[j]);
-              dk[j] = mfma32(qt[hf], dj, dk[j]);
+              dv[j] = mfma32(ot[hf], pv[j][hf], dv[j]);
+              dk[j] = mfma32(qt[hf], dvv[j][hf], dk[j]);
             }
         }
       }
@@ -1462,7 +1473,7 @@ int launch_attn_bwd(const AttnArgs& a0, hipStream_t s) {
 #endif
   static const int ws_prio = getenv("UVTG_ATTN_WS_PRIO") ? atoi(getenv("UVTG_ATTN_WS_PRIO")) : 0;
   AttnArgs aw = a; aw.ws_prio = ws_prio;
-  static const bool ws_pf1 = getenv("UVTG_ATTN_WS_PF1") != nullptr;      // experiment: rows requested one iteration ahead (first build) instead of two
+  static const bool ws_pf1 = getenv("UVTG_ATTN_WS_PF2") == nullptr;      // rows requested one iteration ahead (default; two ahead measured the same and costs the registers the P-wave's operand block needs: UVTG_ATTN_WS_PF2 = experiment)
   static const bool ws_hdp = !getenv("UVTG_ATTN_WS_KEYP");      // product waves own a head-dim block (default) / UVTG_ATTN_WS_KEYP: a key group (first version)
   static const bool ws_off = getenv("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
