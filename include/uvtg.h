@@ -35,7 +35,11 @@ typedef struct uvtg_dims {
   int d, H, F, E;            /* hidden_dim, nheads, dim_feedforward, enc_layers                    */
   int Dv, Dt;                /* v_feat_dim (incl. TEF), t_feat_dim                                 */
   int n_proj;                /* n_input_proj: 1, 2 or 3 LinearLayer blocks per modality (model/univtg.py:89-100)  */
-  int precise;               /* 0: bf16 MFMA encoder/heads; 1: split-operand fp16 hi+lo images, three products (fp32-class), forward only */
+  int precise;               /* 0: bf16 MFMA encoder/heads; 1: split-operand fp16 hi+lo images, three products (fp32-class), forward only.
+                                OPERAND RANGE of mode 1 (and of proj_precise): an operand x is held as fp16(x s) + fp16(x s - hi), s = 16 for
+                                activations / 64 for weights, clamped at +-65000 -- |activation| > ~4060 (LayerNorm outputs, GELU / ReLU hidden
+                                rows, q, k, v, attention probabilities) or |weight| > ~1015 SATURATES silently instead of being fp32-class.
+                                Trained UniVTG checkpoints are orders of magnitude below both; any other value than 0 / 1 is rejected (-25)  */
   int training;              /* 1: keep activations for backward, apply dropout / DropPath         */
   int proj_precise;          /* 1: input projections on split operands even when precise==0 (keeps the
                                 saliency logits within 1e-4 of the fp32 reference)                 */

@@ -421,9 +421,12 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // 100: round 1 ABI.  200: uvtg_dims gained struct_size (first field, validated) and loss_only; uvtg_decode_rank_nms / uvtg_postprocess_mr take
 // nms_thd as double; uvtg_debug_force_nt_wn / uvtg_set_dynamic_tiles removed ("ABI history").
 // 301: additive -- uvtg_linear_bf16_sk / uvtg_linear_split_sk / uvtg_linear_sk_ws_floats, uvtg_debug_nt_small / _splitk / _splitk_parts / _small_tile / _loader_waves;
-// uvtg_workspace_bytes grew by the forward's split-K slabs (32 MB) and tickets.  (Round 5, still 301: no symbol added or removed; the
-// uvtg_debug_* / uvtg_profile_* PROTOTYPES moved from include/uvtg.h to include/uvtg_dev.h; check_dims rejects precise outside {0, 1}: -25.)
-extern "C" int uvtg_version(void) { return 301; }
+// uvtg_workspace_bytes grew by the forward's split-K slabs (32 MB) and tickets.
+// 302 (round 5): additive -- developer-side symbols only (include/uvtg_dev.h, where the uvtg_debug_* / uvtg_profile_* PROTOTYPES now live):
+// uvtg_debug_nt_plan2 / _nt_plan_override / _nt_cgw / _layernorm_fwd_bf16 / _ln_fwd_lean / _delta_fuse / _attn_ws; uvtg_workspace_bytes grew by the
+// per-layer attention-delta buffers and LayerNorm partial slabs (E x (B H S + 2 x 4 MB)); check_dims rejects precise outside {0, 1}: -25.  Nothing in
+// include/uvtg.h changed.
+extern "C" int uvtg_version(void) { return 302; }
 
 extern "C" const char* uvtg_strerror(int code) {
   if (code == 0) return "ok";
