@@ -9,8 +9,12 @@ synchronises (include/uvtg.h), so the whole call can be captured ONCE per input 
     out = run(src_txt, src_txt_mask, src_vid, src_vid_mask, timestamp, timestamp_mask, durations)
     out["pred_logits"], out["windows"], out["order"], out["keep"], out["n_keep"], out["saliency"]
 
-The returned tensors are the graph's static output buffers: consume (or clone) them before the next call of the same shape.
-There is no fallback: shapes are captured on first use (two eager warm-up calls on a side stream, then the capture).
+The returned tensors are the graph's static output buffers: consume (or clone) them before the next call of the same shape
+(`clone_outputs=True` hands out copies instead).  There is no fallback: shapes are captured on first use (two eager warm-up calls on a side
+stream, then the capture).  Every captured shape keeps its own workspace (incl. the 32 MB split-K slab) inside the graph's memory pool, and the
+reference's evaluation loop pads each batch to its own maximum length: the cache is an LRU of `max_graphs` shapes (default 8; the least
+recently used graph and its pool are dropped), and `bucket=(dv, dt)` rounds L_v / L_t up to multiples of dv / dt with zero-masked padding so
+that the loop's many lengths share a few graphs (the masks already carry the lengths; outputs are cut back to the caller's L_v).
 """
 from __future__ import annotations
 
@@ -24,14 +28,17 @@ __all__ = ["GraphedInference"]
 
 class GraphedInference:
     def __init__(self, model: Model, clip_length: float = 2.0, eval_mode: str = "add", nms_thd: float = 0.7, max_before: int = 1000,
-                 max_after: int = 10):
+                 max_after: int = 10, max_graphs: int = 8, bucket=None, clone_outputs: bool = False):
         if model.training:
             raise RuntimeError("GraphedInference captures the inference call: put the model in eval() mode first")
         if model.packed:
             raise RuntimeError("the packed stream reads the mask sums back to the host (a sync): capture needs Model(packed=False)")
         self.model = model
         self.post = dict(clip_length=clip_length, eval_mode=eval_mode, nms_thd=nms_thd, max_before=max_before, max_after=max_after)
-        self._graphs = {}
+        self._graphs = {}                                   # insertion-ordered: least recently used first
+        self.max_graphs = max(1, int(max_graphs))
+        self.bucket = tuple(int(x) for x in bucket) if bucket else None
+        self.clone_outputs = bool(clone_outputs)
 
     def _call(self, st):
         with torch.no_grad():
@@ -53,6 +60,9 @@ class GraphedInference:
         graph = torch.cuda.CUDAGraph()                      # (a hipGraph on ROCm)
         with torch.cuda.graph(graph):
             outs = self._call(static)
+        self._graphs.pop(key, None)
+        while len(self._graphs) >= self.max_graphs:         # LRU eviction: drop the oldest graph (and with it its memory pool)
+            self._graphs.pop(next(iter(self._graphs)))
         self._graphs[key] = (graph, static, outs, self.model._param_epoch, tuple(p._version for p in self.model._ordered_params()))
         return self._graphs[key]
 
@@ -64,6 +74,15 @@ class GraphedInference:
                 raise RuntimeError(f"{k}: inputs must live on the ROCm device (no CPU fallback)")
             if v.dtype != torch.float32:
                 tensors[k] = v.float()
+        Lv = tensors["src_vid"].shape[1]
+        if self.bucket:                                     # pad L_v / L_t up to the bucket sizes: zero features, zero masks (= padded positions)
+            pad = lambda t, dim, to: t if t.shape[dim] == to else torch.nn.functional.pad(t, (0, 0) * (t.dim() - 1 - dim) + (0, to - t.shape[dim]))
+            up = lambda n, m: (n + m - 1) // m * m
+            Lvb, Ltb = up(Lv, self.bucket[0]), up(tensors["src_txt"].shape[1], self.bucket[1])
+            for k in ("src_vid", "src_vid_mask", "timestamp", "timestamp_mask"):
+                tensors[k] = pad(tensors[k], 1, Lvb)
+            for k in ("src_txt", "src_txt_mask"):
+                tensors[k] = pad(tensors[k], 1, Ltb)
         key = tuple((k, tuple(v.shape)) for k, v in tensors.items())
         ent = self._graphs.get(key)
         sig = (self.model._param_epoch, tuple(p._version for p in self.model._ordered_params()))
@@ -71,8 +90,11 @@ class GraphedInference:
             ent = None
         if ent is None:
             ent = self._capture(key, tensors)
+        self._graphs[key] = self._graphs.pop(key)            # most recently used
         graph, static, outs = ent[:3]
         for k, v in tensors.items():
             static[k].copy_(v, non_blocking=True)
         graph.replay()
-        return outs
+        if self.bucket and outs["pred_logits"].shape[1] != Lv:      # cut the clip dimension back to the caller's L_v (views, or copies below)
+            outs = {k: (v[:, :Lv] if k in ("pred_logits", "pred_spans", "saliency_scores", "saliency") else v) for k, v in outs.items()}
+        return {k: v.clone() for k, v in outs.items()} if self.clone_outputs else outs
