@@ -309,6 +309,22 @@ __global__ void zero_frame_rows_kernel(char* p, int B, int Lv, int row_bytes, co
   const u32x4 z = {0, 0, 0, 0};
   for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) row[i] = z;
 }
+// up to three frame buffers in ONE launch (blockIdx.y = buffer; the forward's heads zero the frames of vm_pad, h1_pad and h2_pad: three 5 us launches)
+struct ZeroFrames { char* p[3]; int row_bytes[3]; const int* fstart[3]; const int* kept[3]; };
+__global__ void zero_frame_rows_multi_kernel(ZeroFrames z, int B, int Lv) {
+  const int which = blockIdx.x, b = which >> 1, k = blockIdx.y;
+  const int* fs = z.fstart[k];
+  const int r = fs ? fs[b] + ((which & 1) ? z.kept[k][b] + 1 : 0) : b * (Lv + 2) + ((which & 1) ? Lv + 1 : 0);
+  u32x4* row = (u32x4*)(z.p[k] + (size_t)r * z.row_bytes[k]);
+  const u32x4 zero = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < z.row_bytes[k] / 16; i += blockDim.x) row[i] = zero;
+}
+int zero_frames(const ZeroFrames& z, int count, int B, int Lv, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(zero_frame_rows_multi_kernel, dim3(2 * B, count), dim3(256), 0, s, z, B, Lv);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
 int zero_frame(void* p, int B, int Lv, int row_bytes, hipStream_t s, const int* fstart = nullptr, const int* kept = nullptr) {
   hipLaunchKernelGGL(zero_frame_rows_kernel, dim3(2 * B), dim3(256), 0, s, (char*)p, B, Lv, row_bytes, fstart, kept);
   UVTG_CHECK_LAUNCH();
@@ -568,7 +584,8 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     if (w.pwB[wm][0] && wm == 1)       // (both modalities' first blocks in one launch)
       TRY(launch_cast_pad2_bf16(P[m.proj(0, 0, PW)], d, m.c.Dv, w.pwB[0][0], m.Kpv, P[m.proj(1, 0, PW)], d, m.c.Dt, w.pwB[1][0], m.Kpt, s));
     if (tr) {
-      if (hipError_t e = hipMemsetAsync(w.pwT[wm][0], 0, (size_t)K0 * d * 2, s)) return (int)e;      // the padding rows [D0, K0) stay zero
+      // the padding rows [D0, K0) of the transposed operand are zero (the transpose below writes rows [0, D0) only); nothing to do where K0 == D0
+      if (K0 > D0) { if (hipError_t e = hipMemsetAsync(w.pwT[wm][0] + (size_t)D0 * d, 0, (size_t)(K0 - D0) * d * 2, s)) return (int)e; }
       transp(W0, d, D0, w.pwT[wm][0], d);
     }
     for (int b = 1; b < m.nproj; b++) {
@@ -751,10 +768,15 @@ struct Fwd {
     const size_t es = fast ? 2 : 4;
     const int* fs = halo ? ws.pk.fstart : nullptr;
     const int* kc = halo ? ws.pk.kept : nullptr;
-    if (!packed) TRY(zero_frame(ws.vm_pad, B, Lv, (int)(d * es), s, fs, kc));      // (packed stream: unpack_vm wrote the frame's zero rows)
-    if (!halo) {
-      TRY(zero_frame(ws.h1_pad, B, Lv, (int)(2 * d * es), s));
-      TRY(zero_frame(ws.h2_pad, B, Lv, (int)(2 * d * es), s));
+    {   // zero rows of the conv frames, one launch (packed stream: unpack_vm wrote vm_pad's; ragged frames: the epilogue's 0/1 row factor re-establishes h1 / h2's)
+      ZeroFrames z; memset(&z, 0, sizeof(z));
+      int n = 0;
+      if (!packed) { z.p[n] = (char*)ws.vm_pad; z.row_bytes[n] = (int)(d * es); z.fstart[n] = fs; z.kept[n] = kc; n++; }
+      if (!halo) {
+        z.p[n] = (char*)ws.h1_pad; z.row_bytes[n] = (int)(2 * d * es); n++;
+        z.p[n] = (char*)ws.h2_pad; z.row_bytes[n] = (int)(2 * d * es); n++;
+      }
+      TRY(zero_frames(z, n, B, Lv, s));
     }
     // Frame addressing of the 3-tap GEMMs.  Uniform frames: output row m = (b, t) reads frame rows b (Lv + 2) + t + tap and lands on
     // frame row b (Lv + 2) + t + 1 (the zero rows are never written).  Ragged frames (loss-only stream): the GEMM runs over ALL frame
