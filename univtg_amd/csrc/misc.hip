@@ -807,8 +807,8 @@ __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFina
   const int fs = h.fstart ? h.fstart[b] : b * (h.Lv + 2);
   const int kept = h.kept ? h.kept[b] : h.Lv;
   const bf16_t* h2 = (const bf16_t*)h.h2;
-  // gridDim.y blocks per sample (round 5: 2): each pools the text tokens itself (identical values; 128 KB of L2 reads) and walks its share of the
-  // clips -- the walk is a per-clip latency chain, 10 clips per wave with one block per sample, 5 with two
+  // gridDim.y blocks per sample (experiment; default 1): each pools the text tokens itself (identical values; 128 KB of L2 reads) and walks its
+  // share of the clips -- the walk is a per-clip latency chain, 10 clips per wave with one block per sample, 5 with two
   const int nw = 8 * gridDim.y, wslot = blockIdx.y * 8 + wave;
   const int per = (a.Lv + nw - 1) / nw, t0 = wslot * per, t1 = min(a.Lv, t0 + per);
   float w0[NPASS][24], w1[NPASS][24], wc[NPASS][24];
@@ -1272,8 +1272,10 @@ int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hi
     if (int e = launch_heads_final_fwd(h, s)) return e;
     return launch_saliency_fwd(a, s);
   }
-  static const int split_env = getenv("UVTG_HEADFUSE_SPLIT") ? atoi(getenv("UVTG_HEADFUSE_SPLIT")) : 2;      // blocks per sample (A/B: 1 = round 4)
-  const int ny = (split_env >= 1 && split_env <= 4) ? split_env : 2;
+  // blocks per sample: 1.  (Round 5 measured 2 and 4 -- each block pooling the text itself, half / a quarter of the clips per wave -- in-box:
+  // 9.150 / 9.178 / 9.220 ms per step, profiles/r05_ab_head_pass_blocks.txt: the second pooling costs what the shorter clip walk saves.)
+  static const int split_env = getenv("UVTG_HEADFUSE_SPLIT") ? atoi(getenv("UVTG_HEADFUSE_SPLIT")) : 1;
+  const int ny = (split_env >= 1 && split_env <= 4) ? split_env : 1;
   if (a.d == 1024) hipLaunchKernelGGL(heads_saliency_fwd_kernel<2>, dim3(a.B, ny), dim3(512), sh, s, h, a);
   else hipLaunchKernelGGL(heads_saliency_fwd_kernel<1>, dim3(a.B, ny), dim3(512), sh, s, h, a);
   UVTG_CHECK_LAUNCH();
