@@ -13,8 +13,9 @@ The returned tensors are the graph's static output buffers: consume (or clone) t
 (`clone_outputs=True` hands out copies instead).  There is no fallback: shapes are captured on first use (two eager warm-up calls on a side
 stream, then the capture).  Every captured shape keeps its own workspace (incl. the 32 MB split-K slab) inside the graph's memory pool, and the
 reference's evaluation loop pads each batch to its own maximum length: the cache is an LRU of `max_graphs` shapes (default 8; the least
-recently used graph and its pool are dropped), and `bucket=(dv, dt)` rounds L_v / L_t up to multiples of dv / dt with zero-masked padding so
-that the loop's many lengths share a few graphs (the masks already carry the lengths; outputs are cut back to the caller's L_v).
+recently used graph and its pool are dropped).  (Padding the lengths up to a few bucket sizes would let shapes share graphs, but it is NOT exact:
+the k = 3 conv heads of a maximum-length sample see encoder outputs of padded clips where the unpadded call sees the zero frame -- measured
+0.23 on `pred_logits` at the last valid clips -- so it is not offered.)
 """
 from __future__ import annotations
 
@@ -28,7 +29,7 @@ __all__ = ["GraphedInference"]
 
 class GraphedInference:
     def __init__(self, model: Model, clip_length: float = 2.0, eval_mode: str = "add", nms_thd: float = 0.7, max_before: int = 1000,
-                 max_after: int = 10, max_graphs: int = 8, bucket=None, clone_outputs: bool = False):
+                 max_after: int = 10, max_graphs: int = 8, clone_outputs: bool = False):
         if model.training:
             raise RuntimeError("GraphedInference captures the inference call: put the model in eval() mode first")
         if model.packed:
@@ -37,7 +38,6 @@ class GraphedInference:
         self.post = dict(clip_length=clip_length, eval_mode=eval_mode, nms_thd=nms_thd, max_before=max_before, max_after=max_after)
         self._graphs = {}                                   # insertion-ordered: least recently used first
         self.max_graphs = max(1, int(max_graphs))
-        self.bucket = tuple(int(x) for x in bucket) if bucket else None
         self.clone_outputs = bool(clone_outputs)
 
     def _call(self, st):
@@ -74,15 +74,6 @@ class GraphedInference:
                 raise RuntimeError(f"{k}: inputs must live on the ROCm device (no CPU fallback)")
             if v.dtype != torch.float32:
                 tensors[k] = v.float()
-        Lv = tensors["src_vid"].shape[1]
-        if self.bucket:                                     # pad L_v / L_t up to the bucket sizes: zero features, zero masks (= padded positions)
-            pad = lambda t, dim, to: t if t.shape[dim] == to else torch.nn.functional.pad(t, (0, 0) * (t.dim() - 1 - dim) + (0, to - t.shape[dim]))
-            up = lambda n, m: (n + m - 1) // m * m
-            Lvb, Ltb = up(Lv, self.bucket[0]), up(tensors["src_txt"].shape[1], self.bucket[1])
-            for k in ("src_vid", "src_vid_mask", "timestamp", "timestamp_mask"):
-                tensors[k] = pad(tensors[k], 1, Lvb)
-            for k in ("src_txt", "src_txt_mask"):
-                tensors[k] = pad(tensors[k], 1, Ltb)
         key = tuple((k, tuple(v.shape)) for k, v in tensors.items())
         ent = self._graphs.get(key)
         sig = (self.model._param_epoch, tuple(p._version for p in self.model._ordered_params()))
@@ -95,6 +86,4 @@ class GraphedInference:
         for k, v in tensors.items():
             static[k].copy_(v, non_blocking=True)
         graph.replay()
-        if self.bucket and outs["pred_logits"].shape[1] != Lv:      # cut the clip dimension back to the caller's L_v (views, or copies below)
-            outs = {k: (v[:, :Lv] if k in ("pred_logits", "pred_spans", "saliency_scores", "saliency") else v) for k, v in outs.items()}
         return {k: v.clone() for k, v in outs.items()} if self.clone_outputs else outs
