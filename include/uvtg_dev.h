@@ -75,6 +75,8 @@ int uvtg_debug_delta_fuse(int on);
 /* Long-sequence attention backward at head_dim 128 (round 5): dK / dV by the role-split kernel (score waves + product waves, two per SIMD; default)
  * or, 0, by the one-wave-per-SIMD kernel it replaces (parity tests / A-B). */
 int uvtg_debug_attn_ws(int on);
+/* ... and the head_dim-128 bf16 FORWARD: K / V tiles by LDS-DMA into a double buffer (default) or, 0, the register-staged kernel (bit-identical). */
+int uvtg_debug_attn_fwd_dma(int on);
 /* Host arithmetic only: uvtg_debug_nt_plan with the launch's epilogue class (eop != 0: the launch reads a bf16 residual / pre-activation operand in
  * its epilogue; uvtg_debug_nt_plan assumes it does) and whether the caller hands the launch a split-K workspace (have_ws). */
 int uvtg_debug_nt_plan2(int M, int N, int K, int groups, int gather, int cus, int eop, int have_ws, int* out3);

@@ -219,6 +219,32 @@ def test_attention_bwd(dev, B, S, H, hd):
         assert e < 2.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("B,S,H,hd", [(2, 107, 4, 128), (1, 300, 2, 128), (2, 1232, 3, 128), (3, 517, 1, 128), (2, 64, 2, 128)])
+def test_attention_fwd_dma_tile_loop_bit_identical(dev, B, S, H, hd):
+    """head_dim-128 bf16 forward (round 5): K / V tiles by LDS-DMA into a double buffer, one barrier per tile (the dQ kernel's tile loop) against the
+    register-staged single-buffer kernel -- same products, same online-softmax order: outputs and lse bit for bit; and against the fp64 reference."""
+    from univtg_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(S + 3 * hd)
+    d = H * hd
+    qkv = torch.randn(B * S, 3 * d, generator=g)
+    qkv[:, :d] *= hd ** -0.5
+    kv = _kvalid(B, S, g, dev)
+    xb = bf(qkv).to(dev)
+    try:
+        _lib.check(lib.uvtg_debug_attn_fwd_dma(0))
+        o0, l0 = ops.attention_fwd(xb, kv, B, S, H, hd, False)
+        _lib.check(lib.uvtg_debug_attn_fwd_dma(1))
+        o1, l1 = ops.attention_fwd(xb, kv, B, S, H, hd, False)
+    finally:
+        lib.uvtg_debug_attn_fwd_dma(1)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    if S <= 600:
+        ref_o, ref_l = _attn_ref(xb.float().cpu(), kv.cpu(), B, S, H, hd)
+        assert float((o1.float().cpu() - ref_o).abs().max()) < 1.5e-2
+        assert float((l1.cpu() - ref_l).abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize("B,S,H,hd", [(1, 300, 2, 128), (2, 1232, 3, 128), (3, 517, 1, 128)])
 def test_attention_bwd_role_split_dkdv_bit_identical(dev, B, S, H, hd):
     """Long-sequence attention backward at head_dim 128 (round 5): dK / dV by the role-split kernel (score waves hand P / dS to product waves through

@@ -73,6 +73,7 @@ SIGNATURES = {
     "uvtg_debug_ln_fwd_lean": (_I, [_I]),
     "uvtg_debug_delta_fuse": (_I, [_I]),
     "uvtg_debug_attn_ws": (_I, [_I]),
+    "uvtg_debug_attn_fwd_dma": (_I, [_I]),
     "uvtg_debug_nt_plan2": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "uvtg_linear_sk_ws_floats": (_LL, []),
     "uvtg_linear_bf16_sk": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

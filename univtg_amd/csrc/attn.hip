@@ -1375,12 +1375,193 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused_kerne
 void uvtg_prof_begin_launch(int family, double flops, hipStream_t s);
 void uvtg_prof_end_launch(int family, hipStream_t s);
 
+// ------------------------------------------------------------------------------------------------
+// forward at head_dim 128, bf16, K / V tiles by LDS-DMA (round 5).  attn_fwd_kernel stages a 64-key tile through registers into ONE LDS buffer:
+// two barriers per tile, the staging stores in front of the compute, the next tile's request behind them -- at S = 1232 it ran 578 TFLOP/s where the
+// dQ kernel, which walks the same K / V tiles with the LDS-DMA double buffer below and ONE barrier per tile, ran 1125 (tools/attn_bench.py).  This is
+// that kernel's tile loop (same requests, same swizzled tile image: K by rows, V transposed through ds_read_b64_tr_b16) around the forward's online
+// softmax and output transposition.  Same products in the same order as attn_fwd_kernel<128, false>: bit-identical outputs and lse.  No attention
+// dropout here (p_drop > 0 takes the other kernel).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs a, unsigned qkv_bytes) {
+  constexpr int HD = 128;
+  using KT = TileRT<HD, true>;
+  __shared__ __attribute__((aligned(1024))) bf16_t sKV[2][2][64 * HD];      // [buffer][K | V][64 keys x 128], swizzled 256-byte rows
+  __shared__ __attribute__((aligned(16))) float sBias[2][64];               // 0 on a real key, NEG_BIG on padding and beyond S (log2 domain)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, l31 = lane & 31;
+  const int i16 = lane & 15, qd = (lane >> 4) & 1;
+  int qblk, h, b;
+  attn_block_id((a.S + 127) / 128, a.H, a.B, qblk, h, b, a.sample_major);
+  const int S = a.seq_count ? a.seq_count[b] : a.S, d = a.H * HD;
+  if (qblk * 128 >= S) return;
+  const size_t rowbase = a.seq_start ? (size_t)a.seq_start[b] : (size_t)b * S;
+  const int q_raw = qblk * 128 + wave * 32 + l31;
+  const int qrow = min(q_raw, S - 1);
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  i32x4_t rsrc;       // buffer resource over the whole qkv matrix (wave-uniform)
+  {
+    const unsigned long long pa = (unsigned long long)(uintptr_t)qkv;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pa);
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu));
+    rsrc[2] = __builtin_amdgcn_readfirstlane((int)qkv_bytes);
+    rsrc[3] = 0x00020000;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)&sKV[0][0][0];
+  // this lane's share of a tile: pieces 4 wave .. 4 wave + 3 of K and of V (a piece = 4 tile rows = 1 KB); lane l supplies physical chunk
+  // l & 15 of row 4 p + (l >> 4), i.e. the logical chunk (l & 15) ^ (4 (l >> 4) + (p & 3))
+  auto request = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int p = wave * 4 + i, row = 4 * p + (lane >> 4);
+      const int chunk = (lane & 15) ^ (((lane >> 4) << 2) | (p & 3));
+      const int key = min(kt * 64 + row, S - 1);          // rows beyond S: clamped duplicates, their probabilities are exact zeros (bias)
+      const unsigned src = (unsigned)(((rowbase + key) * (size_t)a.ldqkv + (size_t)h * HD + (size_t)chunk * 8) * 2);
+      attn_dma16(rsrc, src + (unsigned)d * 2u, lds0 + (unsigned)((buf * 2 + 0) * 64 * HD * 2 + p * 1024));
+      attn_dma16(rsrc, src + (unsigned)d * 4u, lds0 + (unsigned)((buf * 2 + 1) * 64 * HD * 2 + p * 1024));
+    }
+  };
+  // key-padding byte of key kt * 64 + tid (tid < 64), RAW: requested before the tile's DMA pieces, turned into the bias behind the tile's compute
+  auto valid_of = [&](int kt) -> unsigned char { return a.kvalid[rowbase + min(kt * 64 + tid, S - 1)]; };
+  auto bias_from = [&](int kt, unsigned char v) -> float { return (kt * 64 + tid < S && v) ? 0.f : NEG_BIG; };
+  const int ntiles = (S + 63) / 64;
+  unsigned char nvalid = tid < 64 ? valid_of(0) : (unsigned char)0;
+  request(0, 0);
+  // Q fragments (B operand of S^T = K Q^T): lane (query, g) holds q[16 ks + 8 g .. + 7]
+  s16x8 qh[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ks++) qh[ks] = *(const s16x8*)(qkv + (rowbase + qrow) * a.ldqkv + h * HD + 16 * ks + 8 * g);
+  f32x16 oacc[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[i][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  // this lane's fragment offsets inside a tile (rows 0..31; + 32 rows for kb = 1, + 16 for hf = 1: the same chunk permutation)
+  const int koff = KT::off(l31, 8 * g);
+  const int toff0 = KT::off(4 * g + (i16 >> 2), 16 * qd + 4 * (i16 & 3)), toff1 = KT::rows8(toff0);
+  if (tid < 64) sBias[0][tid] = bias_from(0, nvalid);
+  for (int kt = 0; kt < ntiles; kt++) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed (and everything older)
+    __syncthreads();                                     // ... everybody's; and everybody is done with the other buffer (tile kt - 1)
+    if (kt + 1 < ntiles) {
+      if (tid < 64) nvalid = valid_of(kt + 1);
+      request(kt + 1, buf ^ 1);
+    }
+    const bf16_t* sK = sKV[buf][0];
+    const bf16_t* sV = sKV[buf][1];
+    // ---- S^T = K Q^T : sc[kb][r] <-> key kb*32 + (r&3)+8(r>>2)+4g, query l31 ----
+    f32x16 sc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) sc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++)
+        sc[kb] = mfma32(*(const s16x8*)(&sK[KT::step(koff, 16 * ks) + kb * 32 * KT::STR]), qh[ks], sc[kb]);
+    }
+    // online softmax in the log2 domain: t = s log2(e) + bias (the running maximum m_run is a log2-domain value too)
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x4 bk = *(const f32x4*)(&sBias[buf][kb * 32 + 8 * j + 4 * g]);      // keys kb*32 + 8 j + 4 g + (0..3) = registers 4 j .. 4 j + 3
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          sc[kb][4 * j + e] = fmaf(sc[kb][4 * j + e], LOG2E, bk[e]);
+          mx = fmaxf(mx, sc[kb][4 * j + e]);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2_raw(m_run - m_new);
+    const float m_use = fmaxf(m_new, -1e20f);          // nothing but padding so far: t - m_use stays at -1e30, p = 0 (not exp2(0))
+    float rs = 0.f;
+    float pv[2][16];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float p = exp2_raw(sc[kb][r] - m_use);
+        rs += p;
+        pv[kb][r] = p;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {     // (the running maximum settles after the first tiles: HD/2 multiplies saved per tile)
+#pragma unroll
+      for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[i][r] *= alpha;
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const s16x8 pb = pack8(&pv[kb][8 * hf]);
+        const int rowo = (kb * 32 + 16 * hf) * KT::STR;
+#pragma unroll
+        for (int dvb = 0; dvb < HD / 32; dvb++) {
+          const s16x8 vt = cat4(lds_tr16(&sV[KT::step(toff0, 32 * dvb) + rowo]), lds_tr16(&sV[KT::step(toff1, 32 * dvb) + rowo]));
+          oacc[dvb] = mfma32(vt, pb, oacc[dvb]);
+        }
+      }
+    if (kt + 1 < ntiles && tid < 64) sBias[buf ^ 1][tid] = bias_from(kt + 1, nvalid);     // (visible behind the next barrier; its last readers passed this one)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
+  // O^T fragments hold (channel, query): transpose through a wave-private slab in the dead tile buffers, half the channels per pass, and store
+  // 16 B per lane with HD/16 lanes covering one contiguous half row (as attn_fwd_kernel)
+  constexpr int OSTR = HD / 2 + 8, CPR = HD / 16;
+  __syncthreads();                                       // every wave is done reading the tiles
+  bf16_t* slab = &sKV[0][0][0] + wave * 32 * OSTR;
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+    for (int dvh = 0; dvh < HD / 64; dvh++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const int dvb = pass * (HD / 64) + dvh;
+        u32x2 t;
+        t[0] = pack_bf2(oacc[dvb][4 * rq] * inv, oacc[dvb][4 * rq + 1] * inv);
+        t[1] = pack_bf2(oacc[dvb][4 * rq + 2] * inv, oacc[dvb][4 * rq + 3] * inv);
+        *(u32x2*)(slab + l31 * OSTR + dvh * 32 + 8 * rq + 4 * g) = t;
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < (32 * CPR) / 64; i++) {
+      const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR;
+      const int q = qblk * 128 + wave * 32 + row;
+      const u32x4 v = *(const u32x4*)(slab + row * OSTR + ch * 8);
+      if (q < S) *(u32x4*)((bf16_t*)a.o + (rowbase + q) * a.ldo + h * HD + pass * (HD / 2) + ch * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (q_raw < S && a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run * 0.6931471805599453f + __logf(l_run);
+}
+
+static int g_attn_fwd_dma = -1;      // head_dim-128 bf16 forward: LDS-DMA tile loop (default) / 0: the register-staged kernel (parity tests, A-B)
+extern "C" int uvtg_debug_attn_fwd_dma(int on) { g_attn_fwd_dma = on ? 1 : 0; return 0; }
 static const bool g_attn_sample_major = getenv("UVTG_ATTN_SAMPLE_MAJOR") != nullptr;      // experiment: the former (sample, head) order of the tiled kernels' block decode
 int launch_attn_fwd(const AttnArgs& a0, hipStream_t s) {
   AttnArgs a = a0; a.sample_major = g_attn_sample_major ? 1 : 0;
   if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
   dim3 grid(cdiv(a.S, 128) * a.H * a.B), blk(256);      // decoded by attn_block_id
   uvtg_prof_begin_launch(4, 4.0 * a.B * a.H * (double)a.S * a.S * a.hd, s);
+  {   // head_dim 128, bf16, no attention dropout: K / V tiles by LDS-DMA (round 5); the buffer descriptor addresses qkv with 32-bit byte offsets
+    static const bool dma_off = getenv("UVTG_ATTN_FWD_DMA_OFF") != nullptr;
+    const long long rows_ = a.row_sample ? (long long)a.total_rows : (long long)a.B * a.S;
+    const unsigned long long qkv_bytes = (unsigned long long)rows_ * a.ldqkv * 2ull;
+    if (a.hd == 128 && !a.precise && a.p_drop <= 0.f && !dma_off && g_attn_fwd_dma != 0 && qkv_bytes < (1ull << 32)) {
+      hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, blk, 0, s, a, (unsigned)qkv_bytes);
+      uvtg_prof_end_launch(4, s);
+      UVTG_CHECK_LAUNCH();
+      return 0;
+    }
+  }
 #define FWD(HD_)                                                                                  \
   if (a.hd == HD_) {                                                                              \
     if (a.precise) hipLaunchKernelGGL((attn_fwd_kernel<HD_, true>), grid, blk, 0, s, a);          \
