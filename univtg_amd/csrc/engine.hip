@@ -439,7 +439,7 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // 301: additive -- uvtg_linear_bf16_sk / uvtg_linear_split_sk / uvtg_linear_sk_ws_floats, uvtg_debug_nt_small / _splitk / _splitk_parts / _small_tile / _loader_waves;
 // uvtg_workspace_bytes grew by the forward's split-K slabs (32 MB) and tickets.
 // 302 (round 5): additive -- developer-side symbols only (include/uvtg_dev.h, where the uvtg_debug_* / uvtg_profile_* PROTOTYPES now live):
-// uvtg_debug_nt_plan2 / _nt_plan_override / _nt_cgw / _layernorm_fwd_bf16 / _ln_fwd_lean / _delta_fuse / _attn_ws; uvtg_workspace_bytes grew by the
+// uvtg_debug_nt_plan2 / _nt_plan_override / _nt_cgw / _layernorm_fwd_bf16 / _ln_fwd_lean / _delta_fuse / _attn_ws / _attn_fwd_dma; uvtg_workspace_bytes grew by the
 // per-layer attention-delta buffers and LayerNorm partial slabs (E x (B H S + 2 x 4 MB)); check_dims rejects precise outside {0, 1}: -25.  Nothing in
 // include/uvtg.h changed.
 extern "C" int uvtg_version(void) { return 302; }
