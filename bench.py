@@ -317,13 +317,16 @@ def timed_steps(step, batches, n, barrier=None):
 
 def encoder_flops(lens, B, Lv, Lt, packed_halo):
     """(algorithmic, executed) encoder fwd+bwd FLOPs per step: SURVEY 8d's 3*E*B*(8Sd^2+4SdF+4S^2d) with padded positions counted, and
-    the same sum over the rows the packed loss-only stream really runs (kept clips = valid + 3-clip conv halo, valid text tokens)."""
+    the same sum over the rows the step really runs (packed loss-only stream: kept clips = valid + 3-clip conv halo, valid text tokens;
+    every stream: no text rows in the last layer's FFN)."""
     S, d, F_, E = Lv + Lt, MODEL["d"], MODEL["F"], MODEL["E"]
     alg = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)
+    # the LAST layer's FFN runs on the clip rows only (engine.hip, last_layer_clip): its text rows' 3 x 4 d F are not executed
+    clip = 0 if os.environ.get("UVTG_LAST_CLIP_OFF") else 3 * 4 * d * F_
     if not packed_halo:
-        return alg, alg
+        return alg, alg - clip * B * Lt
     per = [[min(Lv, x + 3) + y for x, y in zip(a, b)] for a, b in lens]
-    exe = sum(3 * E * sum(r * (8 * d * d + 4 * d * F_) + 4 * r * r * d for r in rows) for rows in per) / len(per)
+    exe = sum(3 * E * sum(r * (8 * d * d + 4 * d * F_) + 4 * r * r * d for r in rows) - clip * sum(b) for rows, (a, b) in zip(per, lens)) / len(per)
     return alg, exe
 
 

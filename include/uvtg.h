@@ -105,7 +105,10 @@ int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* params, void* 
  *          layout: the rows of the other padded clips are copies of the representative's row (first variant: bit-identical to
  *          computing them) or zeros (loss-only variant: saliency at those positions is the masked constant + 0).
  *          The choice is a function of (dims, lens_host != NULL) only, so uvtg_backward -- which must get the same array -- makes the
- *          same one.  With memory != NULL: ignored in eval calls, error -24 in training calls. */
+ *          same one.  With memory != NULL: ignored in eval calls, error -24 in training calls.
+ * memory: in the bf16 mode the LAST encoder layer computes its FFN half for the clip rows only (the text rows of the encoder output are read by
+ *          nobody, model/univtg.py:127): an eval call that passes memory != NULL runs every row instead, a TRAINING call that does is refused
+ *          with -24 (uvtg_backward, which re-derives the row layout from dims alone, could not know). */
 int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                  const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                  const float* dim_t,

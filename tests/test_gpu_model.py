@@ -276,6 +276,78 @@ def test_attention_delta_from_the_dgrad_epilogue_matches_its_own_pass(dev, packe
     assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
 
 
+@pytest.mark.parametrize("variant", ["droppath_attn_dropout", "txt_pos_512", "packed_halo", "packed_all_clips"])
+def test_last_layer_ffn_half_on_clip_rows_matches_every_row(dev, variant):
+    """Round 5: nobody reads the text rows of the encoder output (`vid_mem = memory[:, :L_v]`, model/univtg.py:127), so the LAST layer's
+    LayerNorm 1 -> linear1 -> GELU -> linear2 -> LayerNorm 2 -- and their gradients -- run on the B Lv clip rows only (engine.hip,
+    last_layer_clip; LayerNorm 1's backward scatters into the token-major gradient stream whose text rows are zero).  Against the same step
+    with every row computed (uvtg_debug_last_layer_clip(0)): the same predictions for the kept rows (row-wise work; a split-K tail tile may sum in another order),
+    losses and gradients to fp32 summation order (the weight gradients reduce over fewer, differently grouped rows).  Also the eval call
+    with the `memory` output (runs every row) and the refusal of a training call that asks for it."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import _lib
+    from univtg_amd.trainer import TrainStep
+    lib = _lib.load()
+    packed = "auto" if variant.startswith("packed") else False      # the packed (ragged) stream reads / scatters the clip rows through its row tables
+    if variant == "txt_pos_512":
+        cfg = O.make_cfg(hidden_dim=512, dim_feedforward=1024, enc_layers=2, input_dropout=0.5, dropout=0.0, droppath=0.0, use_txt_pos=True)
+        B = 40
+    elif variant == "packed_halo":                                  # loss-only stream: valid clips + 3-clip halo + valid text
+        cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
+        B = 48
+    else:                                                           # attention dropout: every clip row (+ valid text when packed)
+        cfg = O.make_cfg(input_dropout=0.5, dropout=0.1, droppath=0.1)
+        B = 48
+    params = O.init_params(cfg, seed=61)
+    inputs, tg = O.make_batch(cfg, B, 75, 32, seed=62, ragged=True)
+    batch, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    batch["_lens_host"] = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+    res, preds = [], []
+    try:
+        for clip in (1, 0):
+            _lib.check(lib.uvtg_debug_last_layer_clip(clip))
+            model, crit = build(cfg, params, dev, "auto", proj_precise=False)
+            model.train(); model.set_seed(9)
+            step = TrainStep(model, crit, grad_clip=0.1, packed=packed)
+            losses = step.step(batch, tgd, optimize=False)
+            torch.cuda.synchronize()
+            res.append((losses.clone(), step.grads.clone()))
+            preds.append({"pred_logits": step.pred_logits.clone(), "pred_spans": step.pred_spans.clone(), "saliency_scores": step.sal.clone()})
+        # the bf16 inference call: clip rows only / every row / every row because `memory` is asked for
+        model, _ = build(cfg, params, dev, "bf16")
+        model.eval()
+        model.packed = bool(packed) and not cfg.use_txt_pos              # (eval: valid clips + one representative padded clip + valid text)
+        ebatch = {k: v for k, v in batch.items() if not k.startswith("_")}
+        outs = []
+        with torch.no_grad():
+            for clip, mem in ((1, False), (0, False), (1, True)):
+                _lib.check(lib.uvtg_debug_last_layer_clip(clip))
+                model.return_memory = mem
+                out = model(**ebatch)
+                outs.append({k: out[k].clone() for k in out if torch.is_tensor(out[k])})
+        assert outs[2]["memory"].shape == (B, 75 + 32, cfg.hidden_dim) and bool(torch.isfinite(outs[2]["memory"]).all())
+        model.train()                                   # a training call cannot have the text rows of `memory`: refused, not silently wrong
+        with pytest.raises(RuntimeError, match="memory output"):
+            model(**ebatch)["pred_logits"].sum().backward()
+    finally:
+        lib.uvtg_debug_last_layer_clip(1)
+    valid = inputs["src_vid_mask"].bool().to(dev)
+
+    def close(a, b, what, tol=5e-3):      # the kept rows run the same row-wise arithmetic; only a split-K tail tile may sum in another order
+        a, b = a.reshape(B, 75, -1)[valid].float(), b.reshape(B, 75, -1)[valid].float()
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6, (what, float((a - b).abs().max()), float(b.abs().max()))
+
+    for k in preds[0]:
+        close(preds[0][k], preds[1][k], "train " + k)
+        close(outs[0][k], outs[1][k], "eval " + k)
+        close(outs[2][k], outs[1][k], "eval+memory " + k, tol=2e-2)      # (the fp32 `memory` output takes the last LayerNorm off the lean kernel: bf16 rounding of another kernel)
+    assert torch.allclose(res[0][0], res[1][0], rtol=2e-4, atol=1e-6), (res[0][0], res[1][0])
+    g1, g0 = res[0][1].double(), res[1][1].double()
+    assert bool(torch.isfinite(g1).all())
+    assert float((g1 @ g0) / (g1.norm() * g0.norm())) > 0.99999
+    assert float((g1 - g0).abs().max()) <= 4e-3 * float(g0.abs().max())
+
+
 def test_hl_loss_subset_production_width(dev):
     """dset_type 'hl' / 'vs' (losses = labels + saliency, model/univtg.py:439-440) at d = 1024, E = 4 against the oracle's fp32 autograd:
     every parameter gradient within 1.5 % in norm, cosine >= 0.998; span_embed gets no gradient."""

@@ -1,11 +1,12 @@
 #!/bin/bash
-# in-box A/B on alternating bench runs (headline workload): tools/ab5.sh <rounds> "<label>|<ENV=val ENV2=val ...>" ...   (empty env = defaults)
+# in-box A/B on alternating bench runs (headline workload): tools/ab5.sh <rounds> "<label>|<ENV=val ENV2=val ...>[|<extra bench.py arguments>]" ...   (empty env = defaults)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 ROUNDS=$1; shift
 for round in $(seq 1 $ROUNDS); do
   for spec in "$@"; do
-    L="${spec%%|*}"; E="${spec#*|}"
-    env X_AB=1 $E timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-companions $AB_ARGS 2>/dev/null | tail -1 > /tmp/b.json
+    L="${spec%%|*}"; E="${spec#*|}"; X=""
+    case "$E" in *"|"*) X="${E#*|}"; E="${E%%|*}";; esac
+    env X_AB=1 $E timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-companions $AB_ARGS $X 2>/dev/null | tail -1 > /tmp/b.json
     python - "$L" <<'PY'
 import json, sys
 d = json.loads(open('/tmp/b.json').read())

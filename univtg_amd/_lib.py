@@ -23,7 +23,7 @@ class Dims(C.Structure):
         self.struct_size = C.sizeof(Dims)
 
 
-ABI_VERSION = 302          # uvtg_version() this binding was written against
+ABI_VERSION = 303          # uvtg_version() this binding was written against
 
 
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -74,6 +74,7 @@ SIGNATURES = {
     "uvtg_debug_delta_fuse": (_I, [_I]),
     "uvtg_debug_attn_ws": (_I, [_I]),
     "uvtg_debug_attn_fwd_dma": (_I, [_I]),
+    "uvtg_debug_last_layer_clip": (_I, [_I]),
     "uvtg_debug_nt_plan2": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "uvtg_linear_sk_ws_floats": (_LL, []),
     "uvtg_linear_bf16_sk": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

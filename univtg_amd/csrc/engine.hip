@@ -201,7 +201,7 @@ struct WSpace {
     pk.pad2pack = a.take<int>(M); pk.grad_map = a.take<int>(M); pk.kvalid = a.take<unsigned char>(M);
     pk.fstart = a.take<int>(B); pk.kept = a.take<int>(B); pk.frame_valid = a.take<float>((size_t)m.Rp + 1);
     pk.vin_src = a.take<int>(m.Mv); pk.vin_dst = a.take<int>(m.Mv); pk.vin_x0 = a.take<int>(m.Mv); pk.vin_of = a.take<int>(m.Mv);
-    pk.tin_dst = a.take<int>(m.Mt); pk.vin_cnt = a.take<int>(B);
+    pk.tin_dst = a.take<int>(m.Mt); pk.vin_cnt = a.take<int>(B); pk.vin_sample = a.take<int>(m.Mv);
     xb0p = fast ? a.take<bf16_t>(M * d) : nullptr; ub0p = fast ? a.take<bf16_t>(M * d) : nullptr;
     g2p = (fast && tr) ? a.take<bf16_t>(M * d) : nullptr;
     for (int w = 0; w < 2; w++)
@@ -330,6 +330,37 @@ int zero_frame(void* p, int B, int Lv, int row_bytes, hipStream_t s, const int* 
   UVTG_CHECK_LAUNCH();
   return 0;
 }
+// rows [off, off + seg) of every sample's S-row block of up to two bf16 [B * S, d] buffers (blockIdx.z = buffer): the text rows of the last encoder
+// layer's LayerNorm-1 gradient, which the clip-row launches below never write
+__global__ void zero_row_segments_kernel(char* p0, char* p1, long long off_bytes, long long seg_bytes, long long stride_bytes) {
+  char* p = (blockIdx.z ? p1 : p0) + (size_t)blockIdx.x * stride_bytes + off_bytes;
+  const u32x4 zero = {0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < seg_bytes / 16; i += (long long)gridDim.y * blockDim.x) ((u32x4*)p)[i] = zero;
+}
+// ... and on the packed stream, where a sample's text rows follow its clip rows wherever they start: the rows rows[i] >= 0 of the table
+__global__ void zero_table_rows_kernel(char* p0, char* p1, const int* rows, int n, int row_bytes) {
+  const int i = blockIdx.x, r = i < n ? rows[i] : -1;
+  if (r < 0) return;
+  u32x4* row = (u32x4*)((blockIdx.y ? p1 : p0) + (size_t)r * row_bytes);
+  const u32x4 zero = {0, 0, 0, 0};
+  for (int c = threadIdx.x; c < row_bytes / 16; c += blockDim.x) row[c] = zero;
+}
+// ---- the LAST encoder layer's FFN half on the clip rows only (round 5) ------------------------------------------------------------------------
+// The text rows of the encoder output are read by nobody (`vid_mem = memory[:, :L_v]`, model/univtg.py:127; the saliency branch reads the
+// PROJECTED text rows x0).  In the last layer everything behind the attention block's LayerNorm is row-wise, so LayerNorm 1 reads the clip
+// rows out of the token-major stream (LnFwdArgs::x_seg) and writes them compact; linear1 / GELU / linear2 / LayerNorm 2 -- and in the backward
+// their gradients -- run on B Lv instead of B (Lv + Lt) rows; LayerNorm 1's backward scatters its input gradient back into the token-major
+// stream, whose text rows are zero (their only gradient arrives through the attention as keys / values).  On the packed (ragged) stream the
+// clip rows are the compact rows of the video input projection (PackTables::vin_dst: valid clips + representative / halo clips), read and
+// scattered through that table.  Exact: the dropped rows' values never reach an output, and their gradient contributions are exact zeros.  A
+// function of dims only, so uvtg_backward makes the same choice; a training call that asks for `memory` is refused (-24), an eval call with
+// `memory` runs all rows.
+static int g_last_clip = -1;
+extern "C" int uvtg_debug_last_layer_clip(int on) { g_last_clip = on ? 1 : 0; return 0; }
+static bool last_layer_clip(const Dm& m) {
+  if (g_last_clip < 0) g_last_clip = getenv("UVTG_LAST_CLIP_OFF") ? 0 : 1;
+  return g_last_clip == 1 && !m.c.precise && m.c.Lt > 0 && ln_clip_rows_ok(m.c.d);
+}
 __global__ void concat2_kernel(const float* a, const float* b, float* dst, const float* a2, const float* b2, float* dst2, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;       // two concatenations per launch (the merged conv biases of both conv layers)
   if (i < n) { dst[i] = a[i]; dst[n + i] = b[i]; dst2[i] = a2[i]; dst2[n + i] = b2[i]; }
@@ -442,7 +473,9 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // uvtg_debug_nt_plan2 / _nt_plan_override / _nt_cgw / _layernorm_fwd_bf16 / _ln_fwd_lean / _delta_fuse / _attn_ws / _attn_fwd_dma; uvtg_workspace_bytes grew by the
 // per-layer attention-delta buffers and LayerNorm partial slabs (E x (B H S + 2 x 4 MB)); check_dims rejects precise outside {0, 1}: -25.  Nothing in
 // include/uvtg.h changed.
-extern "C" int uvtg_version(void) { return 302; }
+// 303 (round 5): the last encoder layer's FFN half runs on the clip rows only (last_layer_clip below); a bf16 training call with memory != NULL is
+// refused (-24) on the unpacked stream as it already was on the packed one; developer switch uvtg_debug_last_layer_clip.
+extern "C" int uvtg_version(void) { return 303; }
 
 extern "C" const char* uvtg_strerror(int code) {
   if (code == 0) return "ok";
@@ -470,7 +503,7 @@ extern "C" const char* uvtg_strerror(int code) {
     case -22: return "backward: ready_events must hold enc_layers + 1 events (or n_events = 0)";
     case -23: return "lens_host: every sample needs 1 <= len_v <= Lv clips and 1 <= len_t <= Lt text tokens";
     case -25: return "dims: precise must be 0 (bf16 operands) or 1 (fp16 hi + lo operand images)";
-    case -24: return "forward: lens_host (packed encoder stream) cannot be combined with the memory output in training mode";
+    case -24: return "forward: the memory output cannot be requested in a bf16 training call (neither the packed stream nor the last layer's clip-row tail computes its text rows)";
     default: return "invalid argument";
   }
 }
@@ -612,6 +645,7 @@ struct Fwd {
   bool packed = false; int Mrows = 0;     // packed (ragged) encoder stream: Mrows <= B * S rows (see misc.hip)
   bool halo = false; int Rf = 0;          // loss-only stream: ragged conv-head frames of Rf rows in all (else B * (Lv + 2))
   int Rv = 0;                             // packed: clip rows of the compact video input projection (pk.vin_*)
+  bool clip = false;                      // last layer's FFN half on the clip rows only (last_layer_clip)
   // x3: split-operand launch.  The callers describe the operands in REAL columns; a split row holds two elements per real column (hi / lo
   // images interleaved in 32-column blocks, uvtg_common.h), so every K-side size and offset doubles.
   int run_gemm(GemmArgs& g, bool x3) {
@@ -721,29 +755,34 @@ struct Fwd {
     else { g.resid = ws.xin[l]; g.ldr = d; g.outF = ws.y1[l]; g.ldoF = d; }
     if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l) * m.c.B; g.rs_seg = S; if (packed) g.row_sample = ws.pk.row_sample; }
     TRY(run_gemm(g, !fast));
+    // (last layer, clip mode: from here on the rows are the B Lv clip rows, compact -- see last_layer_clip)
+    const bool cl = last && clip;
+    const int Mf = cl ? (packed ? Rv : m.Mv) : M, Sf = cl ? m.c.Lv : S;
     LnFwdArgs ln; memset(&ln, 0, sizeof(ln));
-    ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
+    ln.rows = Mf; ln.D = d; ln.gamma = P[m.lay(l, N1W)]; ln.beta = P[m.lay(l, N1B)]; ln.eps = 1e-5f;
     ln.mean = ws.mean1[l]; ln.rstd = ws.rstd1[l]; ln.Dpad = d;
+    if (cl) { if (packed) ln.x_rows = ws.pk.vin_dst; else { ln.x_seg = m.c.Lv; ln.x_seg_stride = S; } }
     if (fast) { ln.xB = ws.y1b[l]; ln.ldxB = d; ln.yB = (bf16_t*)ws.x1b[l]; ln.ldyB = d; }
     else { ln.x = ws.y1[l]; ln.ldx = d; ln.yF = ws.x1; ln.ldyF = d; ln.yS = (unsigned short*)ws.x1b[l]; ln.ldyS = 2 * d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     TRY(launch_ln_fwd(ln, s));
     // FFN: linear1 + GELU, linear2 + DropPath + residual -> y2 ; LN2
-    g = gemm_base(ws.x1b[l], d, fast ? (const void*)w.w1[l] : (const void*)w.w1S[l], d, M, F, d);
+    g = gemm_base(ws.x1b[l], d, fast ? (const void*)w.w1[l] : (const void*)w.w1S[l], d, Mf, F, d);
     g.bias = P[m.lay(l, L1B)]; g.act = 2;
     if (tr) { g.outPre = ws.apre[l]; g.ldpre_out = F; }
     if (fast) set_out(g, ws.h[l], F); else set_split(g, ws.h[l], F);
     TRY(run_gemm(g, !fast));
-    g = gemm_base(ws.h[l], F, fast ? (const void*)w.w2[l] : (const void*)w.w2S[l], F, M, d, F);
+    g = gemm_base(ws.h[l], F, fast ? (const void*)w.w2[l] : (const void*)w.w2S[l], F, Mf, d, F);
     g.bias = P[m.lay(l, L2B)];
     if (fast) { g.residB = (const bf16_t*)ws.x1b[l]; g.ldrB = d; g.outB = ws.y2b[l]; g.ldoB = d; }
     else { g.resid = ws.x1; g.ldr = d; g.outF = ws.y2[l]; g.ldoF = d; }
-    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l + 1) * m.c.B; g.rs_seg = S; if (packed) g.row_sample = ws.pk.row_sample; }
+    if (tr && m.c.p_path > 0.f) { g.rowscale = ws.dps + (size_t)(2 * l + 1) * m.c.B; g.rs_seg = Sf; if (packed) g.row_sample = cl ? ws.pk.vin_sample : ws.pk.row_sample; }
     TRY(run_gemm(g, !fast));
     memset(&ln, 0, sizeof(ln));
-    ln.rows = M; ln.D = d; ln.gamma = P[m.lay(l, N2W)]; ln.beta = P[m.lay(l, N2B)]; ln.eps = 1e-5f;
-    ln.mean = ws.mean2[l]; ln.rstd = ws.rstd2[l]; ln.Dpad = d; ln.S = S; ln.Lv = m.c.Lv;
+    ln.rows = Mf; ln.D = d; ln.gamma = P[m.lay(l, N2W)]; ln.beta = P[m.lay(l, N2B)]; ln.eps = 1e-5f;
+    ln.mean = ws.mean2[l]; ln.rstd = ws.rstd2[l]; ln.Dpad = d; ln.S = Sf; ln.Lv = m.c.Lv;
     if (fast) { ln.xB = ws.y2b[l]; ln.ldxB = d; } else { ln.x = ws.y2[l]; ln.ldx = d; }
-    if (packed) ln.pos_row = ws.pk.row_pos;
+    if (packed && cl) { ln.S = 0; ln.yB_rows = ws.pk.vin_dst; }      // (compact clip rows in, the packed stream's rows out: launch_unpack_vm below)
+    else if (packed) ln.pos_row = ws.pk.row_pos;
     else if (m.c.use_txt_pos && !last) ln.pos_row = ws.pos_row_all;      // text rows add their trainable positions too (the last layer has no next q,k operand)
     if (!fast) { ln.ldyS = 2 * d; ln.sscale = UVTG_SPLIT_A_SCALE; }
     if (!last) {
@@ -833,6 +872,11 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
   if (pmode != PACK_NONE && memory) {           // the packed stream has no [B, S, d] encoder output to hand out
     if (m.c.training) return -24;               // (uvtg_backward could not know: refuse instead of silently diverging from it)
     pmode = PACK_NONE;
+  }
+  f.clip = last_layer_clip(m);
+  if (f.clip && memory) {                       // the clip-row tail of the last layer has no text rows of the encoder output to hand out either
+    if (m.c.training) return -24;
+    f.clip = false;
   }
   if (pmode != PACK_NONE) {                     // packed (ragged) encoder stream
     int mp = 0;
@@ -955,6 +999,8 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
         if (mu.count >= UVTG_TNH_MAX_GROUPS) { fits = false; break; }
         mu.g[mu.count++] = deferred[i].g[j];
       }
+    // (the clip-row groups of the last layer reduce over fewer rows: their tiles end early; moving them behind the others -- among the split tiles --
+    // measured the same, profiles/r05_ab_last_layer_clip_rows.txt)
     if (fits && gemm_tn_multi_ok(mu)) return launch_gemm_tn_multi(mu, s);
     for (int i = 0; i < n_deferred; i++) TRY(tn_batch(deferred[i]));            // shapes the hybrid launch does not take: the split + reduce path
     return 0;
@@ -1051,6 +1097,8 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   uvtg_prof_section(1, 0, s);
   if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT || pmode == PACK_HALO, pmode == PACK_HALO, ws.g2p, s));   // conv-head gradient onto the packed rows
   const int* row_sample = packed ? ws.pk.row_sample : nullptr;
+  const bool clip = last_layer_clip(m);              // the forward's choice (a function of dims only)
+  const int Rv_clip = packed ? compact_clip_rows(m, lens_host, pmode) : m.Mv;
   for (int l = E - 1; l >= 0; l--) {
     const bf16_t* xb_in = (packed && l == 0) ? ws.xb0p : (const bf16_t*)ws.xb[l];
     const bf16_t* ub_in = (packed && l == 0) ? ws.ub0p : (const bf16_t*)ws.ub[l];
@@ -1059,34 +1107,51 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     const float* dp_ffn = (m.c.p_path > 0.f) ? ws.dps + (size_t)(2 * l + 1) * B : nullptr;
     bf16_t* const dy2 = ws.dy2L[l]; bf16_t* const dy1 = ws.dy1L[l]; bf16_t* const da = ws.daL[l]; bf16_t* const dqkv = ws.dqkvL[l];
     const bf16_t* dyRes = dp_ffn ? ws.dyR : dy2;
+    // (last layer, clip mode: the FFN half of the layer holds the B Lv clip rows, compact -- see last_layer_clip)
+    const bool cl = last && clip;
+    const int Mf = cl ? Rv_clip : M, Sf = cl ? Lv : S;
+    const int* rsamp = cl ? (packed ? ws.pk.vin_sample : nullptr) : row_sample;
     LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
     lb.gB = gin; lb.ldgB = d;
-    if (last && packed) { lb.g2B = ws.g2p; lb.ldg2B = d; }
+    if (cl && packed) { lb.g2B = ws.g2p; lb.ldg2B = d; lb.g2_rows = ws.pk.vin_dst; }      // the conv-head gradient of the packed rows, gathered
+    else if (cl) { lb.gB = ws.dvmB; lb.ldgB = d; }          // the heads' gradient IS the layer-output gradient, row for row
+    else if (last && packed) { lb.g2B = ws.g2p; lb.ldg2B = d; }
     else if (last) { lb.g2B = ws.dvmB; lb.ldg2B = d; lb.g2_S = S; lb.g2_Lv = Lv; }
     lb.xB = ws.y2b[l]; lb.ldxB = d; lb.mean = ws.mean2[l]; lb.rstd = ws.rstd2[l]; lb.gamma = P[m.lay(l, N2W)];
-    lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
-    lb.dxB = dy2; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = S; lb.row_sample = row_sample;
+    lb.rows = Mf; lb.D = d; lb.dgamma = G(m.lay(l, N2W)); lb.dbeta = G(m.lay(l, N2B));
+    lb.dxB = dy2; lb.lddxB = d; lb.rowscale = dp_ffn; lb.rs_seg = Sf; lb.row_sample = rsamp;
     if (dp_ffn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     ln_partials(lb, 2 * l + 1);
     TRY(launch_ln_bwd(lb, s));
     ln_deferred(lb);
-    GemmArgs g = gemm_base(dy2, d, w.w2T[l], d, M, F, d);             // d h = dy2 W2 ; da = dh * gelu'(a)
+    GemmArgs g = gemm_base(dy2, d, w.w2T[l], d, Mf, F, d);            // d h = dy2 W2 ; da = dh * gelu'(a)
     g.gradPre = ws.apre[l]; g.ldgp = F; g.actgrad = 2; g.outB = da; g.ldoB = F;
     TRY(launch_gemm_nt_bf16(g, s));
     {   // FFN weight gradients, one launch: dW2 = dy2^T h, dW1 = da^T x1
       GemmTNBatch tb; tb.count = 2;
-      tb.g[0] = tn_group(dy2, d, (const bf16_t*)ws.h[l], F, M, d, F, G(m.lay(l, L2W)), F, G(m.lay(l, L2B)));
-      tb.g[1] = tn_group(da, F, (const bf16_t*)ws.x1b[l], d, M, F, d, G(m.lay(l, L1W)), d, G(m.lay(l, L1B)));
+      tb.g[0] = tn_group(dy2, d, (const bf16_t*)ws.h[l], F, Mf, d, F, G(m.lay(l, L2W)), F, G(m.lay(l, L2B)));
+      tb.g[1] = tn_group(da, F, (const bf16_t*)ws.x1b[l], d, Mf, F, d, G(m.lay(l, L1W)), d, G(m.lay(l, L1B)));
       TRY(tn_encoder(tb));
     }
-    g = gemm_base(da, F, w.w1T[l], F, M, d, F);                        // dx1 = da W1 + dy2
+    g = gemm_base(da, F, w.w1T[l], F, Mf, d, F);                       // dx1 = da W1 + dy2
     g.residB = dyRes; g.ldrB = d; g.outB = ws.gxb[0]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
     memset(&lb, 0, sizeof(lb));
     lb.gB = ws.gxb[0]; lb.ldgB = d; lb.xB = ws.y1b[l]; lb.ldxB = d; lb.mean = ws.mean1[l]; lb.rstd = ws.rstd1[l];
-    lb.gamma = P[m.lay(l, N1W)]; lb.rows = M; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
-    lb.dxB = dy1; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = S; lb.row_sample = row_sample;
+    lb.gamma = P[m.lay(l, N1W)]; lb.rows = Mf; lb.D = d; lb.dgamma = G(m.lay(l, N1W)); lb.dbeta = G(m.lay(l, N1B));
+    lb.dxB = dy1; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = Sf; lb.row_sample = rsamp;
     if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
+    if (cl) {      // back into the token-major stream: the clip rows scatter, the text rows (no gradient behind the attention block) are zero
+      if (packed) {
+        lb.x_rows = ws.pk.vin_dst;
+        hipLaunchKernelGGL(zero_table_rows_kernel, dim3(m.Mt, dp_attn ? 2 : 1), dim3(128), 0, s, (char*)dy1, (char*)ws.dyR, ws.pk.tin_dst, m.Mt, d * 2);
+      } else {
+        lb.x_seg = Lv; lb.x_seg_stride = S;
+        hipLaunchKernelGGL(zero_row_segments_kernel, dim3(B, 8, dp_attn ? 2 : 1), dim3(256), 0, s, (char*)dy1, (char*)ws.dyR,
+                           (long long)Lv * d * 2, (long long)m.c.Lt * d * 2, (long long)S * d * 2);
+      }
+      UVTG_CHECK_LAUNCH();
+    }
     ln_partials(lb, 2 * l);
     TRY(launch_ln_bwd(lb, s));
     ln_deferred(lb);

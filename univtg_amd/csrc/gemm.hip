@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
 // Restrictions (the launcher falls back to the slab + reduce path otherwise): N, K multiples of 256, contiguous outputs, no conv taps.
 // ------------------------------------------------------------------------------------------------
 constexpr int TNH_SLAB = 65536 + 256;            // floats per part: the 256 x 256 partial tile + 256 bias-gradient partials
-struct TNHGroup { const bf16_t* P; const bf16_t* Q; float* out; float* dbias; int ldp, ldq, ldo, tiles_k, tile_base; unsigned bytes_p, bytes_q; };
+struct TNHGroup { const bf16_t* P; const bf16_t* Q; float* out; float* dbias; int ldp, ldq, ldo, tiles_k, tile_base, steps_total; unsigned bytes_p, bytes_q; };
 struct TNHPlan {
   TNHGroup g[UVTG_TNH_MAX_GROUPS];
   int count, M, steps_total, total_tiles, full_tiles, nsplit, steps_per;
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
     const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * 256, k0 = tile_k * 256;
     const int st0 = part < 0 ? 0 : part * plan.steps_per;
-    const int st1 = part < 0 ? plan.steps_total : min(plan.steps_total, st0 + plan.steps_per);
+    const int st1 = part < 0 ? p.steps_total : min(p.steps_total, st0 + plan.steps_per);      // (a group may reduce over fewer rows than the launch's longest: its late parts are short or empty)
     const i32x4 rp = tn_rsrc(p.P, p.bytes_p), rq = tn_rsrc(p.Q, p.bytes_q);
     unsigned vp[4], vq[4];
 #pragma unroll
@@ -2315,24 +2315,28 @@ long long gemm_tn_multi_slab_floats(int total_tiles, int cus_hint) {
   const long long by_tiles = (long long)total_tiles * 3, by_cus = cus_hint > 0 ? cus_hint : 320;
   return (by_tiles < by_cus ? by_tiles : by_cus) * TNH_SLAB;
 }
+// (round 5: the groups of a launch may reduce over different row counts -- the last encoder layer's FFN runs on the clip rows only; the plan is
+// laid out for the longest, a shorter group's tiles end early)
+static int tnh_max_rows(const GemmTNMulti& b) { int m = 0; for (int i = 0; i < b.count; i++) m = b.g[i].M > m ? b.g[i].M : m; return m; }
+static int tnh_min_rows(const GemmTNMulti& b) { int m = b.g[0].M; for (int i = 1; i < b.count; i++) m = b.g[i].M < m ? b.g[i].M : m; return m; }
 bool gemm_tn_multi_ok(const GemmTNMulti& b) {
   if (g_force_tile == 128 || b.count < 1 || b.count > UVTG_TNH_MAX_GROUPS || !b.slabs || !b.tickets) return false;
   static const bool off = getenv("UVTG_TN_HYBRID_OFF") != nullptr;       // experiment: always the slab + reduce path
   if (off) return false;
   for (int i = 0; i < b.count; i++) {
     const GemmTNArgs& a = b.g[i];
-    if (!tn256_group_ok(a) || a.M != b.g[0].M || a.ktap != 0 || a.col_stride != 1 || !a.assign || a.q_row_off != 0 || a.Mq != a.M) return false;
+    if (!tn256_group_ok(a) || a.ktap != 0 || a.col_stride != 1 || !a.assign || a.q_row_off != 0 || a.Mq != a.M) return false;
     if (a.N % 256 || a.K % 256 || a.ldo % 4 || ((uintptr_t)a.out & 15)) return false;
   }
   if (((uintptr_t)b.slabs & 15)) return false;
   const int tiles = tnh_total_tiles(b);
   int full, nsplit, per;
-  tnh_plan_counts(b.g[0].M, tiles, tnh_cus(), full, nsplit, per);
+  tnh_plan_counts(tnh_max_rows(b), tiles, tnh_cus(), full, nsplit, per);
   if (g_tnh_max_split < 0) g_tnh_max_split = getenv("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(getenv("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
   if (nsplit > g_tnh_max_split) return false;                       // the last arriver of a tile folds nsplit - 1 slabs alone: only short folds pay
   if (full == 0 && nsplit == 0) return false;
   if ((long long)(tiles - full) * nsplit * TNH_SLAB > b.slab_floats || tiles - full > b.n_tickets) return false;
-  return b.g[0].M >= 2048;
+  return tnh_min_rows(b) >= 2048;
 }
 int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s) {
   static bool attr = false;
@@ -2345,14 +2349,14 @@ int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s) {
   if (!gemm_tn_multi_ok(b)) return -2;
   TNHPlan pl;
   memset(&pl, 0, sizeof(pl));
-  pl.count = b.count; pl.M = b.g[0].M; pl.steps_total = cdiv(pl.M, 64);
+  pl.count = b.count; pl.M = tnh_max_rows(b); pl.steps_total = cdiv(pl.M, 64);
   int tiles = 0;
   double flops = 0;
   for (int i = 0; i < b.count; i++) {
     const GemmTNArgs& a = b.g[i];
     TNHGroup& g = pl.g[i];
     g.P = a.P; g.Q = a.Q; g.out = a.out; g.dbias = a.dbias; g.ldp = a.ldp; g.ldq = a.ldq; g.ldo = a.ldo;
-    g.tiles_k = a.K / 256; g.tile_base = tiles;
+    g.tiles_k = a.K / 256; g.tile_base = tiles; g.steps_total = cdiv(a.M, 64);
     g.bytes_p = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
     g.bytes_q = (unsigned)((((long long)a.M - 1) * a.ldq + a.K) * 2);
     tiles += (a.N / 256) * (a.K / 256);

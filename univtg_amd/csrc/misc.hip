@@ -367,7 +367,7 @@ __global__ __launch_bounds__(128) void pack_tables_kernel(const int* lens, int B
   for (int i = threadIdx.x; i < Lv; i += blockDim.x) {
     const bool in = i < lv + rep;
     t.vin_of[b * Lv + i] = in ? s_vstart + i : -1;
-    if (in) { t.vin_src[s_vstart + i] = b * Lv + i; t.vin_dst[s_vstart + i] = st + i; t.vin_x0[s_vstart + i] = b * S + i; }
+    if (in) { t.vin_src[s_vstart + i] = b * Lv + i; t.vin_dst[s_vstart + i] = st + i; t.vin_x0[s_vstart + i] = b * S + i; t.vin_sample[s_vstart + i] = b; }
   }
   if (threadIdx.x == 0) t.vin_cnt[b] = lv + rep;
   for (int i = threadIdx.x; i < Lt; i += blockDim.x) t.tin_dst[b * Lt + i] = i < lt ? st + lv + rep + i : -1;

@@ -246,8 +246,9 @@ __global__ __launch_bounds__(256, 4) void ln_fwd_lean_kernel(const LnFwdArgs a) 
   const float invD = 1.0f / (float)D;
   u32x4 px[NV];
   auto fetch = [&](int r) {
+    const size_t rin = a.x_rows ? (size_t)a.x_rows[r] : (a.x_seg ? (size_t)(r / a.x_seg) * a.x_seg_stride + (size_t)(r % a.x_seg) : (size_t)r);      // (last layer: the clip rows of the stream)
 #pragma unroll
-    for (int i = 0; i < NV; i++) px[i] = *(const u32x4*)(a.xB + (size_t)r * a.ldxB + (i * 64 + lane) * 8);
+    for (int i = 0; i < NV; i++) px[i] = *(const u32x4*)(a.xB + rin * a.ldxB + (i * 64 + lane) * 8);
   };
   int row = blockIdx.x * wpb + wave;
   if (row < a.rows) fetch(row);
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256, 4) void ln_fwd_lean_kernel(const LnFwdArgs a) 
     else if (a.S > 0) { const int b = row / a.S, sidx = row - b * a.S; is_vid = sidx < a.Lv; if (is_vid) { prow = b * a.Lv + sidx; frow = (size_t)(b * (a.Lv + 2) + sidx + 1); } }
     const bool want_u = a.yU != nullptr;
     const bool have_pos = want_u && a.pos && prow >= 0;
+    const size_t yrow = a.yB_rows ? (size_t)a.yB_rows[row] : (size_t)row;
     f32x4 pv[NV][2];
     if (have_pos) {
 #pragma unroll
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256, 4) void ln_fwd_lean_kernel(const LnFwdArgs a) 
 #pragma unroll
       for (int e = 0; e < 8; e++) y[e] = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
       u32x4 t; t[0] = pack_bf2(y[0], y[1]); t[1] = pack_bf2(y[2], y[3]); t[2] = pack_bf2(y[4], y[5]); t[3] = pack_bf2(y[6], y[7]);
-      if (a.yB) *(u32x4*)(a.yB + (size_t)row * a.ldyB + c) = t;
+      if (a.yB) *(u32x4*)(a.yB + yrow * a.ldyB + c) = t;
       if (is_vid && a.yP) *(u32x4*)(a.yP + frow * a.ldyP + c) = t;
       if (want_u) {
         u32x4 u = t;
@@ -511,22 +513,24 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
   const bool have_g2 = a.g2B != nullptr;
   u32x4 px[NV], pg[NV], pg2[NV];
   float pmean = 0.f, prstd = 0.f;
+  auto xrow_of = [&](int r) -> size_t { return a.x_rows ? (size_t)a.x_rows[r] : (a.x_seg ? (size_t)(r / a.x_seg) * a.x_seg_stride + (size_t)(r % a.x_seg) : (size_t)r); };
   auto fetch = [&](int r) {            // r is clamped by the caller: always a legal row
-    const size_t row = (size_t)r;
+    const size_t row = (size_t)r, xrow = xrow_of(r);
     pmean = a.mean[row]; prstd = a.rstd[row];
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * 8;
       px[i] = (u32x4){0, 0, 0, 0}; pg[i] = (u32x4){0, 0, 0, 0}; pg2[i] = (u32x4){0, 0, 0, 0};
       if (c < D) {
-        px[i] = *(const u32x4*)(a.xB + row * a.ldxB + c);
+        px[i] = *(const u32x4*)(a.xB + xrow * a.ldxB + c);
         if (a.gB) pg[i] = *(const u32x4*)(a.gB + row * a.ldgB + c);       // (the top layer has only the heads' gradient: g2)
       }
     }
     if (have_g2) {
       size_t r2 = row;
       bool on = true;
-      if (a.g2_S > 0) {
+      if (a.g2_rows) r2 = (size_t)a.g2_rows[r];
+      else if (a.g2_S > 0) {
         const int b = r / a.g2_S, sidx = r - b * a.g2_S;
         on = sidx < a.g2_Lv;
         r2 = (size_t)(b * a.g2_Lv + sidx);
@@ -583,6 +587,7 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
     }
     const float c1 = wave_sum_dpp(s1) / (float)D, c2 = wave_sum_dpp(s2) / (float)D;
     const float rs = a.rowscale ? a.rowscale[a.row_sample ? a.row_sample[row] : row / a.rs_seg] : 1.0f;
+    const size_t orow = xrow_of(row);
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * 8;
@@ -590,12 +595,12 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
         float dx[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) dx[e] = rstd * (gh[i][e] - c1 - xh[i][e] * c2);
-        if (a.dxF) storev<8>(a.dxF + (size_t)row * a.lddxF + c, dx);
-        if (a.dxB2) storeb<8>(a.dxB2 + (size_t)row * a.lddxB2 + c, dx);
+        if (a.dxF) storev<8>(a.dxF + orow * a.lddxF + c, dx);
+        if (a.dxB2) storeb<8>(a.dxB2 + orow * a.lddxB2 + c, dx);
         if (a.dxB) {
 #pragma unroll
           for (int e = 0; e < 8; e++) dx[e] *= rs;
-          storeb<8>(a.dxB + (size_t)row * a.lddxB + c, dx);
+          storeb<8>(a.dxB + orow * a.lddxB + c, dx);
         }
       }
     }
@@ -898,6 +903,7 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
       return 0;
     }
   }
+  if (a.x_seg || a.x_rows || a.g2_rows) return -4;         // (the clip-row maps exist in the lean kernel only: the engine asks ln_clip_rows_ok first)
   if (bf) hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, true>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   else hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, false>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   if (b.partial && !defer) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
@@ -975,7 +981,7 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
     const bool lean_off = g_ln_fwd_lean == 0;
     const bool plain = a.xB && !a.x && a.p_drop == 0.f && !a.yF && !a.yS && !a.yUS && !a.yPS && !a.yUF && !a.yPF && !a.addtab && !a.src_rows && !a.u_from_x &&
                        !a.xsum && (a.Dpad <= a.D) && (a.D == 1024 || a.D == 512) && alignv8 && !(a.pos_row && a.yP);
-    if (plain && !lean_off && a.rows >= 1024) {
+    if (plain && !lean_off && (a.rows >= 1024 || a.x_seg || a.x_rows || a.yB_rows)) {
       static const int blocks_env = getenv("UVTG_LN_FWD_BLOCKS") ? atoi(getenv("UVTG_LN_FWD_BLOCKS")) : 1024;      // (A/B: 512 / 1024 / 2048 measured in round 5)
       const int blocks = min(cdiv(a.rows, 4), blocks_env > 0 ? blocks_env : 1024);
       if (a.D == 1024) hipLaunchKernelGGL((ln_fwd_lean_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
@@ -984,7 +990,14 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
       return 0;
     }
   }
+  if (a.x_seg || a.x_rows || a.yB_rows) return -4;         // (the clip-row maps exist in the lean kernel only)
   LN_DISPATCH(run_fwd, a)
+}
+// the clip-row launches of the last encoder layer need BOTH lean kernels (bf16 streams, D = 512 / 1024, neither switched off)
+bool ln_clip_rows_ok(int D) {
+  if (g_ln_fwd_lean < 0) g_ln_fwd_lean = getenv("UVTG_LN_FWD_LEAN_OFF") ? 0 : 1;
+  static const bool bwd_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;
+  return (D == 512 || D == 1024) && g_ln_fwd_lean == 1 && !bwd_off;
 }
 
 static int launch_ln_bwd_impl(const LnBwdArgs& a, hipStream_t s) {

@@ -143,6 +143,10 @@ struct LnFwdArgs {
   // xsum (optional, fp32 [rows, D]) receives that sum (saved for backward); with u_from_x the yU / yUF output is y + x (the row as it was
   // read, without the table) written at row src_rows[row] -- the text rows' q,k operand x + pos of layer 0
   const float* addtab; int add_L; float* xsum; int u_from_x;
+  // clip-row stream of the LAST encoder layer (lean kernel only, else -4): row r READS input row x_rows[r] (packed stream: the clip rows'
+  // table) or (r / x_seg) * x_seg_stride + r % x_seg (the clip rows of the token-major stream); mean, rstd and every output stay indexed by
+  // r, except yB with yB_rows: row yB_rows[r] (the packed stream's encoder output, which launch_unpack_vm expands)
+  int x_seg, x_seg_stride; const int* x_rows; const int* yB_rows;
 };
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
 
@@ -170,8 +174,13 @@ struct LnBwdArgs {
   // receives the number of partial rows; the caller folds several launches' partials with ONE launch_ln_bwd_reduce_multi (round 5: the
   // encoder's 2 E LayerNorm backward launches were each followed by their own 5 us reduce launch)
   int* defer_blocks;
+  // clip-row stream of the LAST encoder layer (lean kernel only, else -4): g / mean / rstd / rowscale are indexed by the compact row r; the
+  // rows of xB and of every dx output are x_rows[r] (packed stream) or (r / x_seg) * x_seg_stride + r % x_seg (token-major stream) -- the
+  // caller zeroes the rows in between; g2_rows: g2B is read at row g2_rows[r] (the packed stream's conv-head gradient)
+  int x_seg, x_seg_stride; const int* x_rows; const int* g2_rows;
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
+bool ln_clip_rows_ok(int D);     // x_seg launches (forward and backward) will be taken at this width
 long long ln_bwd_partial_floats(int rows, int D);      // floats of `partial` a launch of this shape needs (its per-block dgamma / dbeta rows)
 constexpr int UVTG_LN_MULTI_MAX = 32;      // (2 x the engine's MAXE)
 struct LnReduceMulti { const float* partial[UVTG_LN_MULTI_MAX]; float* dgamma[UVTG_LN_MULTI_MAX]; float* dbeta[UVTG_LN_MULTI_MAX]; int nblocks[UVTG_LN_MULTI_MAX]; int D, count; };
@@ -222,6 +231,7 @@ struct PackTables {
   // vin_of [B*Lv] = compact row of a clip or -1; tin_dst [B*Lt] = packed-stream row of a text token or -1 (padded)
   int* vin_src; int* vin_dst; int* vin_x0; int* vin_of; int* tin_dst;
   int* vin_cnt;                       // [B] clips of the sample that have a packed row (a prefix of its clips)
+  int* vin_sample;                    // [Rv] sample of a compact clip row (DropPath factor of the last layer's clip-row launches)
 };
 // keep_pad < 0: valid clips + ONE representative padded clip per sample; keep_pad >= 0: valid clips + the first keep_pad padded clips,
 // each its own row (keep_pad >= Lv: every clip row), no representative; padded clips beyond that are dropped (pad2pack = -1)
