@@ -323,10 +323,14 @@ def encoder_flops(lens, B, Lv, Lt, packed_halo):
     alg = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)
     # the LAST layer's FFN runs on the clip rows only (engine.hip, last_layer_clip): its text rows' 3 x 4 d F are not executed
     clip = 0 if os.environ.get("UVTG_LAST_CLIP_OFF") else 3 * 4 * d * F_
+    # the encoder SECTION also holds the four conv-head weight gradients (2 R_f d 3d each over the zero-framed rows): on a single rank they
+    # ride in the section's deferred weight-gradient launch (engine.hip, tn_flush) -- counted as executed work of the section, not as encoder FLOPs
+    conv = 0 if (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF") or int(os.environ.get("WORLD_SIZE", "1")) > 1) else 4 * 2 * d * 3 * d
     if not packed_halo:
-        return alg, alg - clip * B * Lt
+        return alg, alg - clip * B * Lt + conv * B * (Lv + 2)
     per = [[min(Lv, x + 3) + y for x, y in zip(a, b)] for a, b in lens]
-    exe = sum(3 * E * sum(r * (8 * d * d + 4 * d * F_) + 4 * r * r * d for r in rows) - clip * sum(b) for rows, (a, b) in zip(per, lens)) / len(per)
+    exe = sum(3 * E * sum(r * (8 * d * d + 4 * d * F_) + 4 * r * r * d for r in rows) - clip * sum(b) + conv * sum(min(Lv, x + 3) + 2 for x in a)
+              for rows, (a, b) in zip(per, lens)) / len(per)
     return alg, exe
 
 
@@ -706,7 +710,9 @@ def main():
                    roofline_encoder=dict(achieved=round(exe_flops / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(exe_flops / t_enc / 2.5e15, 4),
                                          executed_tflop_per_step=round(exe_flops / 1e12, 3), target_frac=0.40,
                                          note="FLOPs of the rows the encoder EXECUTES (3*E*sum_b(8 S_b d^2 + 4 S_b d F + 4 S_b^2 d); in variant A that is SURVEY 8d's "
-                                              "3*E*B*(8Sd^2+4SdF+4S^2d) exactly) / (encoder fwd + bwd section time, HIP events on the launch stream, incl. the "
+                                              "3*E*B*(8Sd^2+4SdF+4S^2d) minus the text rows of the last layer's FFN, which no longer run) + the four conv-head weight "
+                                              "gradients that ride in the section's deferred weight-gradient launch on a single rank (0.50 TFLOP at config 2) "
+                                              "/ (encoder fwd + bwd section time, HIP events on the launch stream, incl. the "
                                               "deferred weight-gradient launch) / 2.5 PFLOP/s"),
                    encoder_rows_fraction=round(sum(sum(min(Lv, x + 3) for x in a) + sum(b) for a, b in lens_a) / (len(lens_a) * B * (Lv + Lt)), 4) if halo else 1.0,
                    companions=comp or None,

@@ -80,6 +80,9 @@ int uvtg_debug_attn_fwd_dma(int on);
 /* The last encoder layer's FFN half on the B Lv clip rows only (default, bf16 mode, unpacked stream, d = 512 / 1024: the text rows of the encoder
  * output are read by nobody, model/univtg.py:127) or, 0, on every row.  uvtg_forward and the uvtg_backward that follows it must see the same setting. */
 int uvtg_debug_last_layer_clip(int on);
+/* The four conv-head weight gradients inside the encoder's deferred weight-gradient launch (default: conv taps and the (d, d, 3) weight layout in the
+ * hybrid kernel's epilogue, no slab + reduce pass) or, 0, as their own slab + reduce launch. */
+int uvtg_debug_tn_conv_defer(int on);
 /* Host arithmetic only: uvtg_debug_nt_plan with the launch's epilogue class (eop != 0: the launch reads a bf16 residual / pre-activation operand in
  * its epilogue; uvtg_debug_nt_plan assumes it does) and whether the caller hands the launch a split-K workspace (have_ws). */
 int uvtg_debug_nt_plan2(int M, int N, int K, int groups, int gather, int cus, int eop, int have_ws, int* out3);

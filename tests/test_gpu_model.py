@@ -348,6 +348,41 @@ def test_last_layer_ffn_half_on_clip_rows_matches_every_row(dev, variant):
     assert float((g1 - g0).abs().max()) <= 4e-3 * float(g0.abs().max())
 
 
+@pytest.mark.parametrize("packed", [False, "auto"], ids=["padded", "packed_halo"])
+def test_conv_head_weight_gradients_inside_the_hybrid_launch_match_their_own_launch(dev, packed):
+    """Round 5: the four Conv1d(k=3) weight gradients of the heads (dW[n][c][tap] = sum_rows dY[row][n] X[row + tap - 1][c] over the zero-framed
+    rows, model/univtg.py:375-382) join the encoder's deferred weight-gradient launch: the hybrid kernel reads tap t's rows shifted by t - 1 and
+    stores its tiles with the (d, d, 3) layout's stride -- no partial slabs, no reduce pass.  Against the slab + reduce launch
+    (uvtg_debug_tn_conv_defer(0)): same operands, so every gradient agrees to fp32 summation order; uniform frames (padded stream) and the ragged
+    frames of the loss-only stream."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import _lib
+    from univtg_amd.trainer import TrainStep
+    lib = _lib.load()
+    cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
+    params = O.init_params(cfg, seed=71)
+    inputs, tg = O.make_batch(cfg, 48, 75, 32, seed=72, ragged=True)
+    batch, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+    batch["_lens_host"] = (inputs["src_vid_mask"].sum(1).int().tolist(), inputs["src_txt_mask"].sum(1).int().tolist())
+    res = []
+    try:
+        for on in (1, 0):
+            _lib.check(lib.uvtg_debug_tn_conv_defer(on))
+            model, crit = build(cfg, params, dev, "auto", proj_precise=False)
+            model.train(); model.set_seed(9)
+            step = TrainStep(model, crit, grad_clip=0.1, packed=packed)
+            losses = step.step(batch, tgd, optimize=False)
+            torch.cuda.synchronize()
+            res.append((losses.clone(), step.grads.clone()))
+    finally:
+        lib.uvtg_debug_tn_conv_defer(1)
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-7)      # (the forward is the same launch sequence; a few loss sums meet in fp32 atomics)
+    g1, g0 = res[0][1].double(), res[1][1].double()
+    assert bool(torch.isfinite(g1).all())
+    assert float((g1 - g0).abs().max()) <= 1e-4 * float(g0.abs().max()), float((g1 - g0).abs().max())
+    assert float((g1 @ g0) / (g1.norm() * g0.norm())) > 0.9999999
+
+
 def test_hl_loss_subset_production_width(dev):
     """dset_type 'hl' / 'vs' (losses = labels + saliency, model/univtg.py:439-440) at d = 1024, E = 4 against the oracle's fp32 autograd:
     every parameter gradient within 1.5 % in norm, cosine >= 0.998; span_embed gets no gradient."""

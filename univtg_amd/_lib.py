@@ -75,6 +75,7 @@ SIGNATURES = {
     "uvtg_debug_attn_ws": (_I, [_I]),
     "uvtg_debug_attn_fwd_dma": (_I, [_I]),
     "uvtg_debug_last_layer_clip": (_I, [_I]),
+    "uvtg_debug_tn_conv_defer": (_I, [_I]),
     "uvtg_debug_nt_plan2": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "uvtg_linear_sk_ws_floats": (_LL, []),
     "uvtg_linear_bf16_sk": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

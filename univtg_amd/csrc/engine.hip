@@ -256,7 +256,7 @@ struct WSpace {
       sal_dq = a.take<float>(B * d); sal_dlog = a.take<float>(B * (size_t)m.c.Lt);
       {   // clipping-norm slots, directly followed by the tickets of the hybrid weight-gradient launch: ONE memset zeroes both
         const int dt = (int)((d + 255) / 256), ft = (int)((F + 255) / 256);
-        tnh_n_tickets = (int)E * (2 * dt * ft + 4 * dt * dt);
+        tnh_n_tickets = (int)E * (2 * dt * ft + 4 * dt * dt) + 12 * dt * dt;      // (+ the four conv-head weight gradients' tap tiles, round 5)
         const size_t dfl = ((size_t)B * m.c.H * m.S + 3) & ~(size_t)3;
         delta_floats = (long long)(dfl * E);
         gnorm2 = a.take<float>(UVTG_SQSUM_FLOATS + (size_t)tnh_n_tickets + dfl * E);
@@ -355,6 +355,8 @@ __global__ void zero_table_rows_kernel(char* p0, char* p1, const int* rows, int 
 // scattered through that table.  Exact: the dropped rows' values never reach an output, and their gradient contributions are exact zeros.  A
 // function of dims only, so uvtg_backward makes the same choice; a training call that asks for `memory` is refused (-24), an eval call with
 // `memory` runs all rows.
+static int g_conv_defer = -1;
+extern "C" int uvtg_debug_tn_conv_defer(int on) { g_conv_defer = on ? 1 : 0; return 0; }
 static int g_last_clip = -1;
 extern "C" int uvtg_debug_last_layer_clip(int on) { g_last_clip = on ? 1 : 0; return 0; }
 static bool last_layer_clip(const Dm& m) {
@@ -474,7 +476,7 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // per-layer attention-delta buffers and LayerNorm partial slabs (E x (B H S + 2 x 4 MB)); check_dims rejects precise outside {0, 1}: -25.  Nothing in
 // include/uvtg.h changed.
 // 303 (round 5): the last encoder layer's FFN half runs on the clip rows only (last_layer_clip below); a bf16 training call with memory != NULL is
-// refused (-24) on the unpacked stream as it already was on the packed one; developer switch uvtg_debug_last_layer_clip.
+// refused (-24) on the unpacked stream as it already was on the packed one; developer switches uvtg_debug_last_layer_clip, uvtg_debug_tn_conv_defer.
 extern "C" int uvtg_version(void) { return 303; }
 
 extern "C" const char* uvtg_strerror(int code) {
@@ -984,7 +986,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // With events (data-parallel overlap) each layer's two batches run in place, as before, and their gradients are final at the event.
   static const bool defer_off = getenv("UVTG_TN_DEFER_OFF") != nullptr;
   const bool defer = n_events == 0 && !defer_off;
-  GemmTNBatch deferred[2 * MAXE]; int n_deferred = 0;
+  GemmTNBatch deferred[2 * MAXE + 1]; int n_deferred = 0;
   auto tn_encoder = [&](const GemmTNBatch& b) -> int {
     if (!defer) return tn_batch(b);
     deferred[n_deferred++] = b;
@@ -1001,6 +1003,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       }
     // (the clip-row groups of the last layer reduce over fewer rows: their tiles end early; moving them behind the others -- among the split tiles --
     // measured the same, profiles/r05_ab_last_layer_clip_rows.txt)
+    if (fits) {      // groups over fewer rows first (stable): their tiles land on the workgroups that also carry a split part (gemm.hip, hybrid plan)
+      for (int i = 1; i < mu.count; i++) {
+        const GemmTNArgs t = mu.g[i]; int j = i - 1;
+        while (j >= 0 && mu.g[j].M > t.M) { mu.g[j + 1] = mu.g[j]; j--; }
+        mu.g[j + 1] = t;
+      }
+    }
     if (fits && gemm_tn_multi_ok(mu)) return launch_gemm_tn_multi(mu, s);
     for (int i = 0; i < n_deferred; i++) TRY(tn_batch(deferred[i]));            // shapes the hybrid launch does not take: the split + reduce path
     return 0;
@@ -1067,7 +1076,11 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       cb.g[cb.count++] = t;
     }
     static const bool cbatch_off = getenv("UVTG_TN_CONVBATCH_OFF") != nullptr;
-    if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) TRY(launch_gemm_tn_batch(cb, s));
+    // round 5: without readiness events they join the encoder's deferred launch (the hybrid kernel takes conv taps and the stride-3 weight
+    // layout now: no slab + reduce pass, 1160 instead of 850 TFLOP/s) -- UVTG_TN_CONV_DEFER_OFF / uvtg_debug_tn_conv_defer(0): their own launch, as before
+    if (g_conv_defer < 0) g_conv_defer = getenv("UVTG_TN_CONV_DEFER_OFF") ? 0 : 1;
+    if (all_ok && !cbatch_off && defer && g_conv_defer == 1 && gemm_tn_batch_ok(cb)) TRY(tn_encoder(cb));
+    else if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) TRY(launch_gemm_tn_batch(cb, s));
     else for (auto& c : cw) TRY(conv_wgrad(c.dY, c.ldp, c.X, c.ldq, G(m.tail(c.w)), G(m.tail(c.b)), Rf));
   }
   {                                             // conv layer 0 dgrad -> dvm (bf16; clip rows [B * Lv], or frame rows on the loss-only stream)

@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TNPlan plan) 
 // Restrictions (the launcher falls back to the slab + reduce path otherwise): N, K multiples of 256, contiguous outputs, no conv taps.
 // ------------------------------------------------------------------------------------------------
 constexpr int TNH_SLAB = 65536 + 256;            // floats per part: the 256 x 256 partial tile + 256 bias-gradient partials
-struct TNHGroup { const bf16_t* P; const bf16_t* Q; float* out; float* dbias; int ldp, ldq, ldo, tiles_k, tile_base, steps_total; unsigned bytes_p, bytes_q; };
+struct TNHGroup { const bf16_t* P; const bf16_t* Q; float* out; float* dbias; int ldp, ldq, ldo, tiles_k, tile_base, steps_total, ktap, q_row_off, col_stride; unsigned bytes_p, bytes_q; };
 struct TNHPlan {
   TNHGroup g[UVTG_TNH_MAX_GROUPS];
   int count, M, steps_total, total_tiles, full_tiles, nsplit, steps_per;
@@ -1478,13 +1478,15 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
     const int st0 = part < 0 ? 0 : part * plan.steps_per;
     const int st1 = part < 0 ? p.steps_total : min(p.steps_total, st0 + plan.steps_per);      // (a group may reduce over fewer rows than the launch's longest: its late parts are short or empty)
     const i32x4 rp = tn_rsrc(p.P, p.bytes_p), rq = tn_rsrc(p.Q, p.bytes_q);
+    // conv tap of this k tile (Conv1d weight gradients, round 5: K = taps x ktap columns; tap t reads the rows shifted by t + q_row_off)
+    const int q_tap = p.ktap > 0 ? k0 / p.ktap : 0, kq0 = k0 - q_tap * p.ktap;
     unsigned vp[4], vq[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int rr = (wave * 4 + i) * 2 + g;
       const int cs = (l31 ^ ((rr & 3) << 2)) * 8;
       vp[i] = (unsigned)(((st0 * 64 + rr) * p.ldp + n0 + cs) * 2);
-      vq[i] = (unsigned)(((st0 * 64 + rr) * p.ldq + k0 + cs) * 2);
+      vq[i] = (unsigned)(((st0 * 64 + rr + p.q_row_off + q_tap) * p.ldq + kq0 + cs) * 2);      // negative rows wrap to out-of-range: zeros
     }
     const unsigned dp = (unsigned)(64 * p.ldp * 2), dq = (unsigned)(64 * p.ldq * 2);
     f32x16 acc[4][2];
@@ -1626,9 +1628,11 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
       }
     }
     if (last) {
-      float* out = p.out + (size_t)n0 * p.ldo + k0;
+      // (conv weights: element (n, tap, c) lives at out[n ldo + c col_stride + tap])
+      float* out = p.out + (size_t)n0 * p.ldo + (size_t)kq0 * p.col_stride + q_tap;
       const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7ffffff0, 0x00020000);
-      const unsigned vo_out = (unsigned)(((lane >> 3) * p.ldo + tcol) * 4);
+      const unsigned vo_out = (unsigned)(((lane >> 3) * p.ldo + tcol * p.col_stride) * 4);
+      const bool strided = p.col_stride != 1;
       const int row_bytes = p.ldo * 4;
       float sq = 0.f;
 #pragma unroll
@@ -1653,8 +1657,17 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
               v0 += __builtin_bit_cast(f32x4, t0); v1 += __builtin_bit_cast(f32x4, t1);
             }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), ro, vo_out, trow0 * row_bytes, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), ro, vo_out + 16, trow0 * row_bytes, 0);
+          if (!strided) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), ro, vo_out, trow0 * row_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), ro, vo_out + 16, trow0 * row_bytes, 0);
+          } else {
+            const unsigned cb = (unsigned)p.col_stride * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0[e]), ro, vo_out + e * cb, trow0 * row_bytes, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1[e]), ro, vo_out + (4 + e) * cb, trow0 * row_bytes, 0);
+            }
+          }
           sq += (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]) + (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
         }
       }
@@ -2295,6 +2308,8 @@ static void tnh_plan_counts(int M, int total_tiles, int cus, int& full_tiles, in
   const int rem = total_tiles % cus;
   full_tiles = total_tiles - rem;
   nsplit = rem ? cus / rem : 0;
+  if (g_tnh_max_split < 0) g_tnh_max_split = getenv("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(getenv("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
+  if (nsplit > g_tnh_max_split && total_tiles > cus) nsplit = g_tnh_max_split;      // (launches of more than one round: fewer, longer parts instead of the fallback)
   if (nsplit > steps_total / 8) nsplit = steps_total / 8;          // (a part needs a real reduction)
   if (nsplit <= 1) { full_tiles = total_tiles; nsplit = 0; steps_per = steps_total; return; }
   steps_per = cdiv(steps_total, nsplit);
@@ -2325,8 +2340,9 @@ bool gemm_tn_multi_ok(const GemmTNMulti& b) {
   if (off) return false;
   for (int i = 0; i < b.count; i++) {
     const GemmTNArgs& a = b.g[i];
-    if (!tn256_group_ok(a) || a.ktap != 0 || a.col_stride != 1 || !a.assign || a.q_row_off != 0 || a.Mq != a.M) return false;
-    if (a.N % 256 || a.K % 256 || a.ldo % 4 || ((uintptr_t)a.out & 15)) return false;
+    if (!tn256_group_ok(a) || !a.assign || a.Mq != a.M || a.col_stride < 1) return false;
+    if (a.ktap ? (a.ktap % 256 || a.K % a.ktap) : (a.q_row_off != 0)) return false;                 // conv taps: whole k tiles per tap
+    if (a.N % 256 || a.K % 256 || ((uintptr_t)a.out & 15) || (a.col_stride == 1 && a.ldo % 4)) return false;
   }
   if (((uintptr_t)b.slabs & 15)) return false;
   const int tiles = tnh_total_tiles(b);
@@ -2357,8 +2373,9 @@ int launch_gemm_tn_multi(const GemmTNMulti& b, hipStream_t s) {
     TNHGroup& g = pl.g[i];
     g.P = a.P; g.Q = a.Q; g.out = a.out; g.dbias = a.dbias; g.ldp = a.ldp; g.ldq = a.ldq; g.ldo = a.ldo;
     g.tiles_k = a.K / 256; g.tile_base = tiles; g.steps_total = cdiv(a.M, 64);
+    g.ktap = a.ktap; g.q_row_off = a.q_row_off; g.col_stride = a.col_stride;
     g.bytes_p = (unsigned)((((long long)a.M - 1) * a.ldp + a.N) * 2);
-    g.bytes_q = (unsigned)((((long long)a.M - 1) * a.ldq + a.K) * 2);
+    g.bytes_q = (unsigned)((((long long)a.Mq - 1) * a.ldq + (a.ktap > 0 ? a.ktap : a.K)) * 2);
     tiles += (a.N / 256) * (a.K / 256);
     flops += 2.0 * a.M * a.N * a.K;
   }

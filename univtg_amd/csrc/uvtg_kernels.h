@@ -103,7 +103,7 @@ int launch_gemm_tn_batch(const GemmTNBatch& b, hipStream_t s);
 // the same WITHOUT a reduce pass ("hybrid" plan, gemm.hip: gemm_tn256h_kernel): whole tiles per workgroup + the remainder cut into <= 3 row
 // ranges whose parts meet through write-through slabs and a ticket per tile.  Contiguous assigned outputs, N and K multiples of 256, no taps.
 // slabs: gemm_tn_multi_slab_floats(total 256 x 256 tiles) floats (16-byte aligned); tickets: one zeroed unsigned per tile.
-constexpr int UVTG_TNH_MAX_GROUPS = 24;
+constexpr int UVTG_TNH_MAX_GROUPS = 32;
 struct GemmTNMulti { GemmTNArgs g[UVTG_TNH_MAX_GROUPS]; int count; float* slabs; long long slab_floats; unsigned* tickets; int n_tickets; };
 bool gemm_tn_multi_ok(const GemmTNMulti& b);
 long long gemm_tn_multi_slab_floats(int total_tiles, int cus_hint);
