@@ -1381,8 +1381,12 @@ void uvtg_prof_end_launch(int family, hipStream_t s);
 // dQ kernel, which walks the same K / V tiles with the LDS-DMA double buffer below and ONE barrier per tile, ran 1125 (tools/attn_bench.py).  This is
 // that kernel's tile loop (same requests, same swizzled tile image: K by rows, V transposed through ds_read_b64_tr_b16) around the forward's online
 // softmax and output transposition.  Same products in the same order as attn_fwd_kernel<128, false>: bit-identical outputs and lse.  No attention
-// dropout here (p_drop > 0 takes the other kernel).
+// dropout here (p_drop > 0 takes the other kernel).  Measured (profiles/r05_attn_bench_fwd_dma.txt): 340 -> 317 us per layer at S = 1232
+// (628 TFLOP/s) -- the tile delivery was NOT what held the forward: per 64-key tile a wave issues 32 MFMAs (1024 matrix-pipe cycles) against
+// ~240 VALU instructions of online softmax, 33 of them quarter-rate v_exp_f32 (~1350 cycles): two waves per SIMD are VALU-bound at ~75 % of the
+// matrix rate before any dependency stall.
 // ------------------------------------------------------------------------------------------------
+namespace {
 __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs a, unsigned qkv_bytes) {
   constexpr int HD = 128;
   using KT = TileRT<HD, true>;
@@ -1542,6 +1546,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs a, 
   }
   if (q_raw < S && a.lse && g == 0) a.lse[((size_t)b * a.H + h) * a.S + q_raw] = m_run * 0.6931471805599453f + __logf(l_run);
 }
+}  // namespace
 
 static int g_attn_fwd_dma = -1;      // head_dim-128 bf16 forward: LDS-DMA tile loop (default) / 0: the register-staged kernel (parity tests, A-B)
 extern "C" int uvtg_debug_attn_fwd_dma(int on) { g_attn_fwd_dma = on ? 1 : 0; return 0; }
