@@ -300,15 +300,6 @@ struct WSpace {
 };
 
 // ---- tiny helper kernels ----------------------------------------------------------------------
-__global__ void zero_frame_rows_kernel(char* p, int B, int Lv, int row_bytes, const int* fstart, const int* kept) {
-  // rows b*(Lv+2) and b*(Lv+2)+Lv+1 of a zero-framed [B*(Lv+2), *] buffer (ragged frames: fstart[b] and fstart[b] + kept[b] + 1)
-  const int which = blockIdx.x;                    // 2*B rows
-  const int b = which >> 1;
-  const int r = fstart ? fstart[b] + ((which & 1) ? kept[b] + 1 : 0) : b * (Lv + 2) + ((which & 1) ? Lv + 1 : 0);
-  u32x4* row = (u32x4*)(p + (size_t)r * row_bytes);
-  const u32x4 z = {0, 0, 0, 0};
-  for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) row[i] = z;
-}
 // up to three frame buffers in ONE launch (blockIdx.y = buffer; the forward's heads zero the frames of vm_pad, h1_pad and h2_pad: three 5 us launches)
 struct ZeroFrames { char* p[3]; int row_bytes[3]; const int* fstart[3]; const int* kept[3]; };
 __global__ void zero_frame_rows_multi_kernel(ZeroFrames z, int B, int Lv) {
@@ -324,26 +315,6 @@ int zero_frames(const ZeroFrames& z, int count, int B, int Lv, hipStream_t s) {
   hipLaunchKernelGGL(zero_frame_rows_multi_kernel, dim3(2 * B, count), dim3(256), 0, s, z, B, Lv);
   UVTG_CHECK_LAUNCH();
   return 0;
-}
-int zero_frame(void* p, int B, int Lv, int row_bytes, hipStream_t s, const int* fstart = nullptr, const int* kept = nullptr) {
-  hipLaunchKernelGGL(zero_frame_rows_kernel, dim3(2 * B), dim3(256), 0, s, (char*)p, B, Lv, row_bytes, fstart, kept);
-  UVTG_CHECK_LAUNCH();
-  return 0;
-}
-// rows [off, off + seg) of every sample's S-row block of up to two bf16 [B * S, d] buffers (blockIdx.z = buffer): the text rows of the last encoder
-// layer's LayerNorm-1 gradient, which the clip-row launches below never write
-__global__ void zero_row_segments_kernel(char* p0, char* p1, long long off_bytes, long long seg_bytes, long long stride_bytes) {
-  char* p = (blockIdx.z ? p1 : p0) + (size_t)blockIdx.x * stride_bytes + off_bytes;
-  const u32x4 zero = {0, 0, 0, 0};
-  for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < seg_bytes / 16; i += (long long)gridDim.y * blockDim.x) ((u32x4*)p)[i] = zero;
-}
-// ... and on the packed stream, where a sample's text rows follow its clip rows wherever they start: the rows rows[i] >= 0 of the table
-__global__ void zero_table_rows_kernel(char* p0, char* p1, const int* rows, int n, int row_bytes) {
-  const int i = blockIdx.x, r = i < n ? rows[i] : -1;
-  if (r < 0) return;
-  u32x4* row = (u32x4*)((blockIdx.y ? p1 : p0) + (size_t)r * row_bytes);
-  const u32x4 zero = {0, 0, 0, 0};
-  for (int c = threadIdx.x; c < row_bytes / 16; c += blockDim.x) row[c] = zero;
 }
 // ---- the LAST encoder layer's FFN half on the clip rows only (round 5) ------------------------------------------------------------------------
 // The text rows of the encoder output are read by nobody (`vid_mem = memory[:, :L_v]`, model/univtg.py:127; the saliency branch reads the
@@ -561,8 +532,9 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     so.src[so.count] = src; so.dst[so.count] = dst; so.rows[so.count] = rows; so.cols[so.count] = cols; so.kp[so.count] = kp; so.conv[so.count] = conv; so.count++;
   };
   auto cast = [&](const float* src, bf16_t* dst, long long n) { co.src[co.count] = src; co.dst[co.count] = dst; co.n[co.count] = n; co.count++; };
-  auto transp = [&](const float* src, int rows, int cols, bf16_t* dst, int ld, bf16_t* plain = nullptr) {
-    to.src[to.count] = src; to.dst[to.count] = dst; to.plain[to.count] = plain; to.rows[to.count] = rows; to.cols[to.count] = cols; to.ld[to.count] = ld; to.count++;
+  auto transp = [&](const float* src, int rows, int cols, bf16_t* dst, int ld, bf16_t* plain = nullptr, int cols_pad = 0) {
+    to.src[to.count] = src; to.dst[to.count] = dst; to.plain[to.count] = plain; to.rows[to.count] = rows; to.cols[to.count] = cols; to.ld[to.count] = ld;
+    to.cols_pad[to.count] = cols_pad; to.count++;
   };
   auto convw = [&](const float* wsrc, bf16_t* dst, int ld, int ntot, int n_off, int kind) {
     cv.w[cv.count] = wsrc; cv.dst[cv.count] = dst; cv.ld[cv.count] = ld; cv.ntot[cv.count] = ntot; cv.n_off[cv.count] = n_off; cv.kind[cv.count] = kind; cv.count++;
@@ -619,9 +591,8 @@ extern "C" int uvtg_prepare_weights(const uvtg_dims* dm, const float* const* P, 
     if (w.pwB[wm][0] && wm == 1)       // (both modalities' first blocks in one launch)
       TRY(launch_cast_pad2_bf16(P[m.proj(0, 0, PW)], d, m.c.Dv, w.pwB[0][0], m.Kpv, P[m.proj(1, 0, PW)], d, m.c.Dt, w.pwB[1][0], m.Kpt, s));
     if (tr) {
-      // the padding rows [D0, K0) of the transposed operand are zero (the transpose below writes rows [0, D0) only); nothing to do where K0 == D0
-      if (K0 > D0) { if (hipError_t e = hipMemsetAsync(w.pwT[wm][0] + (size_t)D0 * d, 0, (size_t)(K0 - D0) * d * 2, s)) return (int)e; }
-      transp(W0, d, D0, w.pwT[wm][0], d);
+      // the padding rows [D0, K0) of the transposed operand are zero: written by the transpose launch itself (cols_pad)
+      transp(W0, d, D0, w.pwT[wm][0], d, nullptr, K0);
     }
     for (int b = 1; b < m.nproj; b++) {
       const float* Wb = P[m.proj(wm, b, PW)];
@@ -954,7 +925,9 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       zr.off[zr.count] = off[i]; zr.n[zr.count] = (int)(off[i + 1] - off[i]); zr.count++;
     }
     // (the same launch zeroes the clipping-norm slots and the hybrid weight-gradient launch's tickets: was a memset)
-    TRY(launch_zero_ranges(grads, zr, s, ws.gnorm2, UVTG_SQSUM_FLOATS + ws.tnh_n_tickets + (int)ws.delta_floats));
+    // (... and, on uniform conv-head frames, dh1_pad's zero rows: was a launch of its own)
+    const bool uf = pmode != PACK_HALO;
+    TRY(launch_zero_ranges(grads, zr, s, ws.gnorm2, UVTG_SQSUM_FLOATS + ws.tnh_n_tickets + (int)ws.delta_floats, uf ? ws.dh1_pad : nullptr, B, Lv, 2 * d * 2));
     zr_keep = zr;
   }
   const int splits_M = 8, splits_v = 8;
@@ -1043,7 +1016,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       if (scatter_out) { g.o_seg = Lv; g.o_seg_stride = Lv + 2; g.o_off = 1; }
     }
   };
-  if (!halo) TRY(zero_frame(ws.dh1_pad, B, Lv, 2 * d * 2, s));      // (dh2_pad's frame rows are zeroed by heads_final_bwd_dh itself)
+  // (dh1_pad's frame rows were zeroed by the zero-ranges launch above, dh2_pad's are by heads_final_bwd_dh itself)
   HeadsFinalArgs hf; memset(&hf, 0, sizeof(hf));
   hf.h2 = ws.h2_pad; hf.ldh = 2 * d; hf.w_span = P[m.tail(SP2W)]; hf.b_span = P[m.tail(SP2B)];
   hf.w_cls = P[m.tail(CL2W)]; hf.b_cls = P[m.tail(CL2B)]; hf.B = B; hf.Lv = Lv; hf.d = d; hf.fstart = fs; hf.kept = kc;
@@ -1155,15 +1128,10 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     lb.dxB = dy1; lb.lddxB = d; lb.rowscale = dp_attn; lb.rs_seg = Sf; lb.row_sample = rsamp;
     if (dp_attn) { lb.dxB2 = ws.dyR; lb.lddxB2 = d; }
     if (cl) {      // back into the token-major stream: the clip rows scatter, the text rows (no gradient behind the attention block) are zero
-      if (packed) {
-        lb.x_rows = ws.pk.vin_dst;
-        hipLaunchKernelGGL(zero_table_rows_kernel, dim3(m.Mt, dp_attn ? 2 : 1), dim3(128), 0, s, (char*)dy1, (char*)ws.dyR, ws.pk.tin_dst, m.Mt, d * 2);
-      } else {
-        lb.x_seg = Lv; lb.x_seg_stride = S;
-        hipLaunchKernelGGL(zero_row_segments_kernel, dim3(B, 8, dp_attn ? 2 : 1), dim3(256), 0, s, (char*)dy1, (char*)ws.dyR,
-                           (long long)Lv * d * 2, (long long)m.c.Lt * d * 2, (long long)S * d * 2);
-      }
-      UVTG_CHECK_LAUNCH();
+      // (the text rows are zeroed by the same launch: LnBwdArgs::zero_*)
+      lb.zero_n = m.Mt;
+      if (packed) { lb.x_rows = ws.pk.vin_dst; lb.zero_tab = ws.pk.tin_dst; }
+      else { lb.x_seg = Lv; lb.x_seg_stride = S; lb.zero_seg = m.c.Lt; lb.zero_stride = S; lb.zero_off = Lv; }
     }
     ln_partials(lb, 2 * l);
     TRY(launch_ln_bwd(lb, s));

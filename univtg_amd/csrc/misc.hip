@@ -73,9 +73,16 @@ __global__ void droppath_kernel(float* scales, int n, int B, float p, unsigned l
   scales[i] = floorf(keep + u01(r[0])) / keep;     // drop_path(): mask = floor(keep + U[0,1)), x / keep * mask
 }
 
-__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const ZeroRanges r, float* extra, int n_extra) {
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const ZeroRanges r, float* extra, int n_extra, int nb_extra, char* frame, int fLv, int frow_bytes) {
+  if ((int)blockIdx.x >= r.count + nb_extra) {      // last 2 B blocks: the zero rows b (Lv + 2) and b (Lv + 2) + Lv + 1 of a zero-framed buffer (was its own launch)
+    const int which = blockIdx.x - r.count - nb_extra, b = which >> 1;
+    u32x4* row = (u32x4*)(frame + (size_t)(b * (fLv + 2) + ((which & 1) ? fLv + 1 : 0)) * frow_bytes);
+    const u32x4 z = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < frow_bytes / 16; i += 256) row[i] = z;
+    return;
+  }
   if ((int)blockIdx.x >= r.count) {       // further blocks: a second buffer (clipping-norm slots + tickets + attention deltas of uvtg_backward; was a memset)
-    const int nb = gridDim.x - r.count, j = blockIdx.x - r.count;
+    const int nb = nb_extra, j = blockIdx.x - r.count;
     for (long long i = (long long)j * 256 + threadIdx.x; i < n_extra; i += (long long)nb * 256) extra[i] = 0.f;
     return;
   }
@@ -199,9 +206,9 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastOps ops)
 __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const TransposeOps ops) {
   __shared__ float t[64][65];
   const int op = blockIdx.z, tid = threadIdx.x;
-  const int rows = ops.rows[op], cols = ops.cols[op], ld = ops.ld[op];
+  const int rows = ops.rows[op], cols = ops.cols[op], ld = ops.ld[op], colsP = ops.cols_pad[op] > cols ? ops.cols_pad[op] : cols;
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-  if (c0 >= cols || r0 >= rows) return;
+  if (c0 >= colsP || r0 >= rows) return;
   const float* src = ops.src[op];
   bf16_t* dst = ops.dst[op];
   bf16_t* plain = ops.plain[op];
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const Transpo
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int cl = (tid >> 4) + 16 * k, rl = (tid & 15) * 4, c = c0 + cl, r = r0 + rl;
-      if (c >= cols || r >= rows) continue;
+      if (c >= colsP || r >= rows) continue;                 // (columns [cols, colsP) hold the zeros the guarded reads left in the tile)
       if (r + 3 < rows) {
         u32x2 o; o[0] = pack_bf2(t[rl][cl], t[rl + 1][cl]); o[1] = pack_bf2(t[rl + 2][cl], t[rl + 3][cl]);
         *(u32x2*)(dst + (size_t)c * ld + r) = o;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const Transpo
     __syncthreads();
     for (int i = tid; i < 64 * 64; i += 256) {
       const int cl = i >> 6, rl = i & 63, r = r0 + rl, c = c0 + cl;
-      if (c < cols && r < rows) dst[(size_t)c * ld + r] = f2bf(t[rl][cl]);
+      if (c < colsP && r < rows) dst[(size_t)c * ld + r] = f2bf(t[rl][cl]);
     }
   }
 }
@@ -1104,10 +1111,10 @@ int launch_droppath_scales(float* scales, int n, int B, float p, unsigned long l
   UVTG_CHECK_LAUNCH();
   return 0;
 }
-int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* extra, int n_extra) {
-  if (r.count <= 0 && !extra) return 0;
+int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* extra, int n_extra, void* frame, int fB, int fLv, int frow_bytes) {
+  if (r.count <= 0 && !extra && !frame) return 0;
   const int nb_extra = extra ? (n_extra > 65536 ? 256 : 1) : 0;
-  hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count + nb_extra), dim3(256), 0, s, base, r, extra, n_extra);
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(r.count + nb_extra + (frame ? 2 * fB : 0)), dim3(256), 0, s, base, r, extra, n_extra, nb_extra, (char*)frame, fLv, frow_bytes);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
@@ -1201,7 +1208,7 @@ int launch_cast_bf16_multi(const CastOps& ops, hipStream_t s) {
 int launch_transpose_bf16_multi(const TransposeOps& ops, hipStream_t s) {
   if (ops.count <= 0) return 0;
   int mr = 0, mc = 0;
-  for (int i = 0; i < ops.count; i++) { mr = ops.rows[i] > mr ? ops.rows[i] : mr; mc = ops.cols[i] > mc ? ops.cols[i] : mc; }
+  for (int i = 0; i < ops.count; i++) { mr = ops.rows[i] > mr ? ops.rows[i] : mr; mc = ops.cols[i] > mc ? ops.cols[i] : mc; mc = ops.cols_pad[i] > mc ? ops.cols_pad[i] : mc; }
   hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3(cdiv(mc, 64), cdiv(mr, 64), ops.count), dim3(256), 0, s, ops);
   UVTG_CHECK_LAUNCH();
   return 0;

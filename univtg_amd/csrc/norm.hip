@@ -605,6 +605,20 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
       }
     }
   }
+  // clip-row launch of the last encoder layer: the rows of the gradient stream that have no clip row behind them (text rows) are zero
+  for (int i = blockIdx.x * wpb + wave; i < a.zero_n; i += stride) {
+    const long long zr = a.zero_tab ? (long long)a.zero_tab[i] : (long long)(i / a.zero_seg) * a.zero_stride + a.zero_off + i % a.zero_seg;
+    if (zr < 0) continue;
+    const u32x4 z = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int c = (k * 64 + lane) * 8;
+      if (c < D) {
+        if (a.dxB) *(u32x4*)(a.dxB + (size_t)zr * a.lddxB + c) = z;
+        if (a.dxB2) *(u32x4*)(a.dxB2 + (size_t)zr * a.lddxB2 + c) = z;
+      }
+    }
+  }
   if (a.dgamma) {
     __syncthreads();
     for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
@@ -903,7 +917,7 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
       return 0;
     }
   }
-  if (a.x_seg || a.x_rows || a.g2_rows) return -4;         // (the clip-row maps exist in the lean kernel only: the engine asks ln_clip_rows_ok first)
+  if (a.x_seg || a.x_rows || a.g2_rows || a.zero_n) return -4;      // (the clip-row maps exist in the lean kernel only: the engine asks ln_clip_rows_ok first)
   if (bf) hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, true>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   else hipLaunchKernelGGL((ln_bwd_kernel<VEC, NV, false>), dim3(blocks), dim3(64 * wpb), (size_t)wpb * 2 * a.D * sizeof(float), s, b);
   if (b.partial && !defer) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);

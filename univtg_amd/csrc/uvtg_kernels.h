@@ -175,9 +175,12 @@ struct LnBwdArgs {
   // encoder's 2 E LayerNorm backward launches were each followed by their own 5 us reduce launch)
   int* defer_blocks;
   // clip-row stream of the LAST encoder layer (lean kernel only, else -4): g / mean / rstd / rowscale are indexed by the compact row r; the
-  // rows of xB and of every dx output are x_rows[r] (packed stream) or (r / x_seg) * x_seg_stride + r % x_seg (token-major stream) -- the
-  // caller zeroes the rows in between; g2_rows: g2B is read at row g2_rows[r] (the packed stream's conv-head gradient)
+  // rows of xB and of every dx output are x_rows[r] (packed stream) or (r / x_seg) * x_seg_stride + r % x_seg (token-major stream);
+  // g2_rows: g2B is read at row g2_rows[r] (the packed stream's conv-head gradient)
   int x_seg, x_seg_stride; const int* x_rows; const int* g2_rows;
+  // ... and the rows in between, zeroed by the same launch: zero_n rows of every dx output, row i = zero_tab[i] (< 0: none) or
+  // (i / zero_seg) * zero_stride + zero_off + i % zero_seg
+  int zero_n, zero_seg, zero_stride, zero_off; const int* zero_tab;
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
 bool ln_clip_rows_ok(int D);     // x_seg launches (forward and backward) will be taken at this width
@@ -257,7 +260,8 @@ int launch_cast_f32(const bf16_t* src, float* dst, long long n, hipStream_t s);
 // zero the float ranges [off[i], off[i] + n[i]) of base (the gradients no weight-gradient launch assigns)
 constexpr int UVTG_MAX_ZERO_RANGES = 224;
 struct ZeroRanges { long long off[UVTG_MAX_ZERO_RANGES]; int n[UVTG_MAX_ZERO_RANGES]; int count; };
-int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* extra = nullptr, int n_extra = 0);   // extra: one more float buffer zeroed by the same launch
+// extra: one more float buffer zeroed by the same launch; frame: the two zero rows per sample of a zero-framed [fB (fLv + 2), frow_bytes] buffer too
+int launch_zero_ranges(float* base, const ZeroRanges& r, hipStream_t s, float* extra = nullptr, int n_extra = 0, void* frame = nullptr, int fB = 0, int fLv = 0, int frow_bytes = 0);
 constexpr int UVTG_SQSUM_FLOATS = 32 + 64 * 32;
 int launch_sqsum_ranges(const float* base, const ZeroRanges& r, float* sqsum, hipStream_t s);     // sqsum[0] += sum of squares over the ranges + the 64 slots
 int launch_sqsum(const float* x, long long n, float* sqsum, hipStream_t s);
@@ -270,7 +274,8 @@ constexpr int UVTG_MAX_PREP_OPS = 80;
 struct CastOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; long long n[UVTG_MAX_PREP_OPS]; int count; };
 // dst[c][r] = bf16(src[r][c]) (leading dimension ld); plain (optional) additionally receives the untransposed bf16 copy [rows, cols]:
 // one read of the fp32 master feeds both GEMM operands (the forward's W and the dgrad's W^T)
-struct TransposeOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; bf16_t* plain[UVTG_MAX_PREP_OPS]; int rows[UVTG_MAX_PREP_OPS], cols[UVTG_MAX_PREP_OPS], ld[UVTG_MAX_PREP_OPS]; int count; };
+// (cols_pad >= cols: rows [cols, cols_pad) of the transposed copy are written as zeros -- the zero padding of a K-padded dgrad operand, round 5: was a memset)
+struct TransposeOps { const float* src[UVTG_MAX_PREP_OPS]; bf16_t* dst[UVTG_MAX_PREP_OPS]; bf16_t* plain[UVTG_MAX_PREP_OPS]; int rows[UVTG_MAX_PREP_OPS], cols[UVTG_MAX_PREP_OPS], ld[UVTG_MAX_PREP_OPS], cols_pad[UVTG_MAX_PREP_OPS]; int count; };
 struct ConvWOps {     // kind 0: forward operand (dst[n][tap*C + c]), 1: dgrad operand (dst[c][tap'*Ntot + n_off + n] = w[n][c][2 - tap'])
   const float* w[16]; bf16_t* dst[16]; int ld[16], ntot[16], n_off[16], kind[16]; int N, C, count;
 };
