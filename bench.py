@@ -325,7 +325,8 @@ def encoder_flops(lens, B, Lv, Lt, packed_halo):
     clip = 0 if os.environ.get("UVTG_LAST_CLIP_OFF") else 3 * 4 * d * F_
     # the encoder SECTION also holds the four conv-head weight gradients (2 R_f d 3d each over the zero-framed rows): on a single rank they
     # ride in the section's deferred weight-gradient launch (engine.hip, tn_flush) -- counted as executed work of the section, not as encoder FLOPs
-    conv = 0 if (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF") or int(os.environ.get("WORLD_SIZE", "1")) > 1) else 4 * 2 * d * 3 * d
+    conv = 0 if (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF") or int(os.environ.get("WORLD_SIZE", "1")) > 1
+                 or "force" in sys.argv) else 4 * 2 * d * 3 * d
     if not packed_halo:
         return alg, alg - clip * B * Lt + conv * B * (Lv + 2)
     per = [[min(Lv, x + 3) + y for x, y in zip(a, b)] for a, b in lens]
@@ -443,6 +444,9 @@ def main():
                          "reference, the north_star tolerance; default), bf16 = plain bf16 operands (3e-2)")
     ap.add_argument("--mode", default="train", choices=["train", "infer"], help="train = the headline metric; infer = forward + post-processing")
     ap.add_argument("--grad-comm-dtype", default=os.environ.get("UVTG_GRAD_COMM_DTYPE", "fp32"), choices=["fp32", "bf16"], help="wire dtype of the gradient buckets (N > 1)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "force"],
+                    help="force = run the N > 1 step (per-layer readiness events, bucketed side-stream exchange, clipping-norm pass) on ONE rank: what the "
+                         "data-parallel step costs in compute against the timed single-rank step (dev)")
     ap.add_argument("--comm-cus", type=int, default=int(os.environ.get("UVTG_COMM_CUS", "0")), help="CUs kept out of the persistent GEMM grids for RCCL's kernels (N > 1)")
     args = ap.parse_args()
     if args.variant is None:
@@ -469,6 +473,10 @@ def main():
         else:
             torch.distributed.init_process_group(backend=backend)
         comm_size = torch.distributed.get_world_size()
+    elif args.overlap == "force":                # the N > 1 step on one rank: a one-rank RCCL group carries the (no-op) range all-reduces
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     if comm_size != max(world, 1) or (args.gpus > 1 and comm_size != args.gpus):
         print(f"bench.py: --gpus {args.gpus} but the process group has {comm_size} ranks (WORLD_SIZE={world})", file=sys.stderr)
         sys.exit(2)
@@ -492,7 +500,7 @@ def main():
     model.set_seed(2018 + rank)
     packed = False if args.packed == "off" else "auto"
     step = TrainStep(model, crit, lr=1e-4, weight_decay=1e-4, grad_clip=0.1, packed=packed, grad_comm_dtype=args.grad_comm_dtype,
-                     comm_cus=args.comm_cus, time_comm=world > 1)
+                     comm_cus=args.comm_cus, time_comm=world > 1, overlap_comm="force" if args.overlap == "force" else True)
     full = args.variant == "A"
 
     def make_batches(full_, n=2):

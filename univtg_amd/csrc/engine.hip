@@ -958,7 +958,11 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // rows at config 2, whole tiles per workgroup + half tiles for the remainder, no partial-slab reduce pass (gemm.hip, gemm_tn256h_kernel).
   // With events (data-parallel overlap) each layer's two batches run in place, as before, and their gradients are final at the event.
   static const bool defer_off = getenv("UVTG_TN_DEFER_OFF") != nullptr;
-  const bool defer = n_events == 0 && !defer_off;
+  // UVTG_TN_DEFER_EVENTS=1 (opt-in, N > 1): keep the deferred launch under readiness events too -- every encoder layer's event is then recorded
+  // behind it, i.e. the encoder gradients' all-reduce overlaps only what follows the encoder (saliency branch + input projections).  Which of the
+  // two wins depends on the node's all-reduce time; the compute side is measured (bench.py --overlap force).
+  static const bool defer_events = getenv("UVTG_TN_DEFER_EVENTS") != nullptr;
+  const bool defer = (n_events == 0 || defer_events) && !defer_off;
   GemmTNBatch deferred[2 * MAXE + 1]; int n_deferred = 0;
   auto tn_encoder = [&](const GemmTNBatch& b) -> int {
     if (!defer) return tn_batch(b);
@@ -1052,7 +1056,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     // round 5: without readiness events they join the encoder's deferred launch (the hybrid kernel takes conv taps and the stride-3 weight
     // layout now: no slab + reduce pass, 1160 instead of 850 TFLOP/s) -- UVTG_TN_CONV_DEFER_OFF / uvtg_debug_tn_conv_defer(0): their own launch, as before
     if (g_conv_defer < 0) g_conv_defer = getenv("UVTG_TN_CONV_DEFER_OFF") ? 0 : 1;
-    if (all_ok && !cbatch_off && defer && g_conv_defer == 1 && gemm_tn_batch_ok(cb)) TRY(tn_encoder(cb));
+    if (all_ok && !cbatch_off && defer && n_events == 0 && g_conv_defer == 1 && gemm_tn_batch_ok(cb)) TRY(tn_encoder(cb));      // (under events their own launch: ready_events[0] is recorded right below)
     else if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) TRY(launch_gemm_tn_batch(cb, s));
     else for (auto& c : cw) TRY(conv_wgrad(c.dY, c.ldp, c.X, c.ldq, G(m.tail(c.w)), G(m.tail(c.b)), Rf));
   }
@@ -1170,10 +1174,12 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       TRY(launch_gemm_nt_bf16(g, s));
     }
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
-    if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
+    if (n_events && !defer) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
   }
   TRY(launch_ln_bwd_reduce_multi(lnm, s));
   TRY(tn_flush());                               // the deferred weight gradients of all encoder layers, inside the encoder section
+  if (n_events && defer)                         // (UVTG_TN_DEFER_EVENTS) every layer's gradients are final here
+    for (int l = 0; l < E; l++) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + l], s)) return (int)e; }
   uvtg_prof_section(1, 1, s);
   const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]
   // ---------------- trainable text positions ----------------
