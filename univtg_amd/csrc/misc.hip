@@ -941,7 +941,11 @@ __global__ __launch_bounds__(1024) void saliency_dlog_kernel(const SaliencyArgs 
 }
 // one block per (sample, SAL_CHUNK-row chunk); 4 waves, each walks rows chunk*SAL_CHUNK + wave, +4, ...; lane owns columns 4*lane + 256*k
 // (16-row chunks: twice the blocks of the 32-row version, all still resident at once -- the kernel is a per-row latency chain)
-constexpr int SAL_CHUNK = 16;
+#ifndef UVTG_SAL_CHUNK
+#define UVTG_SAL_CHUNK 16
+#define UVTG_SAL_TXT_CHUNK 16     // text rows per block (0: all text rows of a sample in ONE block = one set of pooling-weight atomics per sample, but an 8-row chain per wave: the launch's tail -- 71.9 vs 65.4 us at config 2, round 5)
+#endif
+constexpr int SAL_CHUNK = UVTG_SAL_CHUNK, SAL_TXT = UVTG_SAL_TXT_CHUNK;
 template <int KC>    // d = 256 * KC
 __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a) {
   __shared__ float s_dw[4][256 * KC];
@@ -954,11 +958,11 @@ __global__ __launch_bounds__(256) void saliency_rows_kernel(const SaliencyArgs a
 #pragma unroll
     for (int e = 0; e < 4; e++) dw[k][e] = 0.f;
   bool any_txt = false;
-  // clip chunks of SAL_CHUNK rows, then ONE chunk with all the text rows of the sample (the pooling-weight gradient leaves as one set of
-  // atomics per sample instead of one per 16-row chunk that happens to contain text rows)
+  // clip chunks of SAL_CHUNK rows, then the text rows of the sample in their own chunks of SAL_TXT rows (the pooling-weight gradient leaves
+  // as one set of atomics per text chunk, none from the clip chunks)
   const int nvc = (a.Lv + SAL_CHUNK - 1) / SAL_CHUNK;
-  const int s_begin = chunk < nvc ? chunk * SAL_CHUNK : a.Lv;
-  const int s_end = chunk < nvc ? min(a.Lv, chunk * SAL_CHUNK + SAL_CHUNK) : a.S;
+  const int s_begin = chunk < nvc ? chunk * SAL_CHUNK : a.Lv + (SAL_TXT ? (chunk - nvc) * SAL_TXT : 0);
+  const int s_end = chunk < nvc ? min(a.Lv, chunk * SAL_CHUNK + SAL_CHUNK) : (SAL_TXT ? min(a.S, s_begin + SAL_TXT) : a.S);
   for (int srow = s_begin + wave; srow < s_end; srow += 4) {
     const size_t row = (size_t)b * a.S + srow;
     const float* x = a.x0 + row * d;
@@ -1291,7 +1295,7 @@ int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hi
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 64)), dim3(256), (3 * a.Lv + 256) * sizeof(float), s, a);
   hipLaunchKernelGGL(saliency_dlog_kernel, dim3(a.B), dim3(1024), a.Lt * sizeof(float), s, a);
-  const dim3 grid(a.B, cdiv(a.Lv, SAL_CHUNK) + 1);
+  const dim3 grid(a.B, cdiv(a.Lv, SAL_CHUNK) + (SAL_TXT ? cdiv(a.Lt, SAL_TXT) : 1));
   if (a.d == 1024) hipLaunchKernelGGL(saliency_rows_kernel<4>, grid, dim3(256), 0, s, a);
   else if (a.d == 512) hipLaunchKernelGGL(saliency_rows_kernel<2>, grid, dim3(256), 0, s, a);
   else if (a.d == 256) hipLaunchKernelGGL(saliency_rows_kernel<1>, grid, dim3(256), 0, s, a);
