@@ -117,17 +117,76 @@ def synth_batch(B, Lv, Lt, Dv, Dt, seed, dev, lens_v=None, full=False):
     return inputs, targets
 
 
-def cpu_baseline(batch, steps=2):
+def reference_parity(batch, dev, ref_eval_npz, run_job, tmp):
+    """The reference's own eval-mode outputs (child process, oracle/ref_runner.py) beside the HIP path on THIS box at the headline batch
+    (VERDICT r5 item 1c): the default drop-in model (precision 'auto' -> fp32x3 under no_grad) with the same oracle-seeded weights through
+    load_state_dict(strict=True); then the REFERENCE's round_multiple + temporal_nms on the HIP outputs against uvtg_postprocess_mr, and the
+    end-to-end ranking + post-NMS keep-set (reference forward + reference tail vs HIP forward + device tail)."""
+    import numpy as np
+    from oracle import univtg_oracle as O
+    from univtg_amd import ops
+    from univtg_amd.model import build_model
+    inputs, tg = batch
+    B, Lv = inputs["src_vid"].shape[:2]
+    cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
+    params = O.init_params(cfg, seed=0)
+    model, _ = build_model(model_args(max_v_l=Lv, precision="auto", packed=False))
+    model.load_state_dict(params, strict=True)
+    model.to(dev).eval()
+    with torch.no_grad():
+        out = model(**{k: v for k, v in inputs.items() if not k.startswith("_")})
+    ref = {k: torch.from_numpy(v) for k, v in np.load(ref_eval_npz).items()}
+    valid = inputs["src_vid_mask"].bool().cpu()
+    rep = dict(saliency_max_err=float((out["saliency_scores"].cpu() - ref["saliency_scores"])[valid].abs().max()),
+               pred_logits_max_err=float((out["pred_logits"].cpu() - ref["pred_logits"]).abs().max()),
+               pred_spans_max_err=float((out["pred_spans"].cpu() - ref["pred_spans"]).abs().max()),
+               tolerances=dict(saliency=1e-4, pred=2e-5))
+    durations = (inputs["src_vid_mask"].sum(1) * 2.0).float().contiguous()
+    common = dict(timestamp=tg["timestamp"].cpu().numpy(), timestamp_mask=tg["timestamp_mask"].cpu().numpy(), durations=durations.cpu().numpy())
+    tails = {}
+    for tag, o in (("hip", out), ("ref", ref)):
+        pin, pj = os.path.join(tmp, tag + "_out.npz"), os.path.join(tmp, tag + "_tail.json")
+        np.savez(pin, pred_logits=o["pred_logits"].cpu().numpy(), pred_spans=o["pred_spans"].cpu().numpy(), **common)
+        run_job(dict(task="postproc", outputs_npz=pin, result_json=pj, clip_lengths=[0.0, 2.0]))
+        with open(pj) as f:
+            tails[tag] = json.load(f)
+    same_inputs, end_to_end, excused = {}, {}, {}
+    for cl in (0.0, 2.0):
+        win, order, keep, nk, _ = ops.postprocess_mr(out["pred_logits"], out["pred_spans"], None, tg["timestamp"], tg["timestamp_mask"], durations, clip_length=cl)
+        win, order, keep, nk = win.cpu().numpy(), order.cpu().tolist(), keep.cpu().tolist(), nk.cpu().tolist()
+        th, tr = tails["hip"][str(cl)], tails["ref"][str(cl)]
+        same_inputs[str(cl)] = sum(win[b].tolist() == th["pre"][b] and [win[b, i].tolist() for i in keep[b][: nk[b]]] == th["nms"][b] for b in range(B))
+        diff = [b for b in range(B) if not (order[b] == tr["order"][b] and keep[b][: nk[b]] == tr["keep"][b])]
+        end_to_end[str(cl)], excused[str(cl)] = B - len(diff), diff
+    rep.update(samples=B, post_nms_identical=min(end_to_end.values()), post_nms_excused=max(len(v) for v in excused.values()),
+               post_nms_identical_by_clip_length=end_to_end, differing_samples=excused, device_tail_equals_reference_tail_on_same_inputs=same_inputs,
+               what="the reference itself (child process, eval mode, fp32, weights = oracle seed 0) vs the default drop-in model under no_grad on the headline "
+                    "batch; post_nms_identical = samples whose ranked clip indices AND post-NMS keep-set (nms_thd 0.7, max 10; raw and round_multiple 2 s) "
+                    "equal the reference forward + the reference's own temporal_nms / PostProcessorDETR; a differing sample is a near-tie the fp32 "
+                    "reference does not resolve itself (tests/test_gpu_parity_full.py::_reference_is_ambiguous); "
+                    "device_tail_equals_reference_tail_on_same_inputs = uvtg_postprocess_mr vs the reference's tail, both fed the HIP outputs")
+    del model
+    return rep
+
+
+def cpu_baseline(batch, dev, steps=2):
     """CPU baseline (reported, not optimised against; SURVEY 8d, north_star: "the reference's own PyTorch CPU forward is timed on the host
     cores of the same box in the same run").  kind = "reference": the REAL showlab/UniVTG model path -- build_model() -> Model.forward +
     SetCriterion + backward (model/univtg.py:105-155,195-351,409-450), imported from oracle/_ref/uvtg_reference_model.zip, the archive
     __graft_entry__.build() packs from /root/reference where that tree exists (oracle/build_ref.py; git-ignored, ships with the built tree
-    like the .so) -- fp32, TRAIN mode, the GPU run's own synthetic batch at the full B: 1 warm-up + `steps` timed steps.  The port
-    (oracle/nn_baseline.py: the same torch.nn modules composed the same way + the oracle's criterion) is timed once beside it so that the
-    ratio of the two is on the same box; it is the fallback (kind = "port") only when the archive is absent."""
+    like the .so; the reference's LICENSE inside) -- in a CHILD process (oracle/ref_runner.py: the archive's generic `model` / `utils` / `eval`
+    packages never enter this process, and the child refuses modules that did not come out of the archive) -- fp32, TRAIN mode, the GPU run's
+    own synthetic batch at the full B: 1 warm-up + `steps` timed steps.  The same child then runs ONE eval-mode forward whose outputs are
+    compared with the HIP path here (`reference_parity`).  The port (oracle/nn_baseline.py: the same torch.nn modules composed the same way +
+    the oracle's criterion) is timed once beside it so that the ratio of the two is on the same box; it is the fallback (kind = "port") only
+    when the archive is absent."""
+    import shutil
+    import tempfile
+    import numpy as np
     from oracle import univtg_oracle as O
     from oracle.nn_baseline import NNBaseline
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))          # more threads than this only adds contention on the 2-socket host
+    threads = min(os.cpu_count() or 1, 32)                       # more threads than this only adds contention on the 2-socket host
+    torch.set_num_threads(threads)
     inputs, tg = batch
     cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
     params = O.init_params(cfg, seed=0)
@@ -135,35 +194,25 @@ def cpu_baseline(batch, steps=2):
     cpu_tg = {k: v.cpu() for k, v in tg.items() if torch.is_tensor(v) and not k.startswith("_")}
     B, Lv = cpu_in["src_vid"].shape[:2]
 
-    def timed(one, n):
-        one()                                                    # warm-up
-        ts = [one() for _ in range(n)]
-        return ts
-
-    ref_times, ref_fwd, ref_note, manifest = None, None, None, None
+    ref, ref_note, parity = None, None, None
+    tmp = tempfile.mkdtemp(prefix="uvtg_ref_")
     try:
-        from oracle.build_ref import import_ref_model
-        from oracle.make_golden import ref_args
-        ref_univtg, manifest = import_ref_model()
-        rmodel, rcrit = ref_univtg.build_model(ref_args(cfg))
-        rmodel.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
-        rmodel.train(); rcrit.train()
-        fwd = []
-
-        def ref_one():
-            rmodel.zero_grad(set_to_none=True)
-            t0 = time.perf_counter()
-            out = rmodel(**cpu_in)
-            t1 = time.perf_counter()
-            ld = rcrit(out, cpu_tg)
-            sum(ld[k] * rcrit.weight_dict[k] for k in ld if k in rcrit.weight_dict).backward()
-            fwd.append(t1 - t0)
-            return time.perf_counter() - t0
-        ref_times = timed(ref_one, steps)
-        ref_fwd = fwd[1:]
-        del rmodel, rcrit
-    except ImportError as e:
+        from oracle.build_ref import ARCHIVE
+        from oracle.ref_runner import run_job
+        if not os.path.exists(ARCHIVE):
+            raise ImportError("oracle/_ref/uvtg_reference_model.zip is absent (built by __graft_entry__.build() where /root/reference exists)")
+        bn, ev = os.path.join(tmp, "batch.npz"), os.path.join(tmp, "ref_eval.npz")
+        np.savez(bn, **{"in/" + k: v.numpy() for k, v in cpu_in.items()}, **{"tg/" + k: v.numpy() for k, v in cpu_tg.items()})
+        ref = run_job(dict(task="model", threads=threads, cfg=dict(input_dropout=0.5, dropout=0.0, droppath=0.1), param_seed=0, batch_npz=bn,
+                           train_steps=steps, eval_out=ev))
+        try:
+            parity = reference_parity(batch, dev, ev, run_job, tmp)
+        except Exception as e:                                   # the baseline number must not die with the comparison
+            parity = dict(error=f"{type(e).__name__}: {e}")
+    except (ImportError, RuntimeError) as e:
         ref_note = f"reference archive not usable: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
     port = NNBaseline(cfg)
     port.load_state_dict(params, strict=True)
@@ -175,21 +224,24 @@ def cpu_baseline(batch, steps=2):
         out = port(**cpu_in)
         O.total_loss(O.criterion(out, cpu_tg, cfg), cfg).backward()
         return time.perf_counter() - t0
-    port_times = timed(port_one, 1 if ref_times else max(steps, 3))
+    port_one()                                                   # warm-up
+    port_times = [port_one() for _ in range(1 if ref else max(steps, 3))]
     port_rate = len(port_times) * B * Lv / sum(port_times)
     common = dict(unit="clips/s", cores=torch.get_num_threads(), torch=torch.__version__, host_cpus=os.cpu_count())
     port_line = dict(value=round(port_rate, 1), step_s=[round(t, 2) for t in port_times], flavour="port-nn-modules",
                      what="oracle/nn_baseline.py (the reference's module composition rebuilt from torch.nn, pinned to the oracle) + the oracle's criterion, same batch, same threads")
-    if ref_times:
+    if ref:
+        ref_times, ref_fwd = ref["train_step_s"], ref["train_forward_s"]
         t = sum(ref_times)
         rate = len(ref_times) * B * Lv / t
-        return dict(value=rate, kind="reference", **common,
+        return dict(value=rate, kind="reference", **dict(common, cores=ref["threads"]), process="child (oracle/ref_runner.py)",
                     forward_only_clips_per_sec=round(len(ref_fwd) * B * Lv / sum(ref_fwd), 1),
-                    reference_archive_sha256=manifest["members"], port_beside_it=port_line, port_over_reference=round(port_rate / rate, 3),
+                    reference_archive_sha256=ref["manifest"], port_beside_it=port_line, port_over_reference=round(port_rate / rate, 3),
+                    reference_parity=parity,
                     sample=f"the reference itself (showlab/UniVTG model/univtg.py build_model -> Model.forward + SetCriterion + backward, imported unmodified from "
-                           f"oracle/_ref/uvtg_reference_model.zip): fp32, TRAIN mode (input dropout 0.5 + DropPath 0.1), the GPU run's own synthetic batch at the full "
-                           f"B={B} (L_v={Lv}, all-ones masks): {len(ref_times)} timed steps after 1 warm-up ({t:.2f} s total, {t / len(ref_times):.2f} s per step, "
-                           f"min {min(ref_times):.2f} s; forward alone {sum(ref_fwd) / len(ref_fwd):.2f} s)")
+                           f"oracle/_ref/uvtg_reference_model.zip in a child process): fp32, TRAIN mode (input dropout 0.5 + DropPath 0.1), the GPU run's own synthetic "
+                           f"batch at the full B={B} (L_v={Lv}, all-ones masks): {len(ref_times)} timed steps after 1 warm-up ({t:.2f} s total, "
+                           f"{t / len(ref_times):.2f} s per step, min {min(ref_times):.2f} s; forward alone {sum(ref_fwd) / len(ref_fwd):.2f} s)")
     t = sum(port_times)
     return dict(value=port_rate, kind="port", flavour="port-nn-modules", **common, fallback_reason=ref_note,
                 sample=f"FALLBACK (no reference archive in this tree): the reference's module composition rebuilt from torch.nn (oracle/nn_baseline.py, pinned to the "
@@ -335,6 +387,34 @@ def encoder_flops(lens, B, Lv, Lt, packed_halo):
     return alg, exe
 
 
+def encoder_roofline(alg_flops, exe_flops, t_enc, B, Lv, halo, lens, roof):
+    """north_star's number AND the executed one.  `frac_survey` = SURVEY 8d's "Target translation": the ALGORITHMIC encoder
+    fwd+bwd FLOPs 3*E*B*(8Sd^2+4SdF+4S^2d) (padded positions counted as the reference computes them; 4.280 TFLOP at config 2) / t_encoder /
+    2.5 PFLOP/s -- t_encoder as measured, i.e. INCLUDING the four conv-head weight gradients that ride in the section's deferred
+    weight-gradient launch on a single rank (they cannot be bracketed by events: one launch).  `frac_executed` divides the FLOPs the section
+    really runs.  `frac_survey_conv_wgrads_priced_out` removes the conv gradients' share of the section time at the weight-gradient family's
+    own measured rate (derived, not an event pair)."""
+    d = MODEL["d"]
+    conv_on = not (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF") or int(os.environ.get("WORLD_SIZE", "1")) > 1 or "force" in sys.argv)
+    rows_f = (sum(sum(min(Lv, x + 3) + 2 for x in a) for a, _ in lens) / len(lens)) if halo else B * (Lv + 2)
+    conv_flops = 4 * 2 * d * 3 * d * rows_f if conv_on else 0.0
+    tn = ((roof or {}).get("all_gemm_kernels") or {}).get("gemm_tn_kernel") or {}
+    t_conv = conv_flops / (tn["tflops"] * 1e12) if tn.get("tflops") else 0.0
+    out = dict(achieved=round(exe_flops / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s",
+               frac=round(exe_flops / t_enc / 2.5e15, 4), frac_executed=round(exe_flops / t_enc / 2.5e15, 4),
+               frac_survey=round(alg_flops / t_enc / 2.5e15, 4), algorithmic_tflop_per_step=round(alg_flops / 1e12, 3),
+               executed_tflop_per_step=round(exe_flops / 1e12, 3), target_frac=0.40,
+               conv_head_wgrads_in_section_tflop=round(conv_flops / 1e12, 3),
+               frac_survey_conv_wgrads_priced_out=(round(alg_flops / max(t_enc - t_conv, 1e-9) / 2.5e15, 4) if t_conv else None),
+               note="frac_survey = SURVEY 8d's algorithmic encoder FLOPs (3*E*B*(8Sd^2+4SdF+4S^2d), padded positions counted) / t_encoder / 2.5 PFLOP/s: the "
+                    "number north_star's >= 40 % target is written against; t_encoder (HIP events on the launch stream around the E layers forward + "
+                    "their backward incl. the deferred weight-gradient launch) INCLUDES the four conv-head weight gradients that ride in that launch on "
+                    "a single rank.  frac_executed = FLOPs of the rows the section really runs (algorithmic - the last layer's FFN on text rows, which no "
+                    "longer run, + those conv-head weight gradients; packed streams: the kept rows only) / the same time.  "
+                    "frac_survey_conv_wgrads_priced_out = algorithmic / (t_encoder - conv-gradient FLOPs at the weight-gradient family's measured rate): derived")
+    return out
+
+
 def quick_roofline(lib, step, batches, B, Lv, Lt, halo, k=3):
     """Dominant-GEMM and encoder-section rooflines of `step` on `batches` (k instrumented steps each; single rank): the same event-pair
     measurements the headline's `roofline` / `roofline_encoder` objects come from, for the companion variant."""
@@ -354,11 +434,14 @@ def quick_roofline(lib, step, batches, B, Lv, Lt, halo, k=3):
     _lib.check(lib.uvtg_profile_sections_stop(sm, sn), "uvtg_profile_sections_stop")
     t_enc = max((sm[0] + sm[1]) / k * 1e-3, 1e-9)
     lens = [bt[0]["_lens_host"] for bt in batches]
-    _, exe = encoder_flops(lens, B, Lv, Lt, halo)
+    alg, exe = encoder_flops(lens, B, Lv, Lt, halo)
     return dict(roofline=dict(kernel="gemm_nt256_kernel", achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                               launches_per_step=int(n[3] // k), avg_launch_us=round(raw * 1e3 / max(1, n[3]), 2)),
                 t_encoder_ms=round(t_enc * 1e3, 3),
-                roofline_encoder=dict(achieved=round(exe / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(exe / t_enc / 2.5e15, 4)))
+                roofline_encoder=dict(achieved=round(exe / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(exe / t_enc / 2.5e15, 4),
+                                      frac_executed=round(exe / t_enc / 2.5e15, 4), frac_survey=round(alg / t_enc / 2.5e15, 4),
+                                      frac_survey_note="SURVEY 8d algorithmic FLOPs of the PADDED shape / t_encoder: on a packed (ragged) stream the padded "
+                                                       "positions are counted but not executed"))
 
 
 def companion_config(cid, dev, precise, lib, k_prof=2, steps=10):
@@ -390,6 +473,61 @@ def companion_config(cid, dev, precise, lib, k_prof=2, steps=10):
     del step, model, crit, bt
     torch.cuda.empty_cache()
     return out
+
+
+def companion_drop_in(dev, batches, precise, Lv, steps=30):
+    """What INTEGRATION.md section 1 gives a maintainer who keeps the reference's loop: the body of
+    main/train_vlp_ddp.py:56-68 -- model(**model_inputs) -> criterion -> weighted sum -> optimizer.zero_grad() -> losses.backward() ->
+    clip_grad_norm_(model.parameters(), 0.1) -> optimizer.step() -- on the drop-in model (autograd path: one C call forward, one backward,
+    dense criterion gradients), on the headline batches.  Twice: with the reference's own torch.optim.AdamW (main/config.py:349-350) and with
+    univtg_amd.optim.FusedAdamWClip swapped in for that one constructor (clip fused into the step, the clip line dropped)."""
+    from univtg_amd.model import build_model
+    from univtg_amd.optim import FusedAdamWClip
+    res = {}
+    for name in ("torch_adamw_and_clip_grad_norm", "fused_adamw_clip"):
+        torch.manual_seed(2018)
+        model, crit = build_model(model_args(max_v_l=Lv, proj_precise=precise))
+        model.to(dev).train()
+        crit.to(dev).train()
+        model.set_seed(2018)
+        group = [{"params": [p for n, p in model.named_parameters() if p.requires_grad]}]
+        fused = name == "fused_adamw_clip"
+        opt = FusedAdamWClip(group, lr=1e-4, weight_decay=1e-4, max_grad_norm=0.1, model=model) if fused else torch.optim.AdamW(group, lr=1e-4, weight_decay=1e-4)
+
+        def one(i):
+            inputs, targets = batches[i % len(batches)]
+            model_inputs = {k: v for k, v in inputs.items() if not k.startswith("_")}
+            outputs = model(**model_inputs)
+            loss_dict = crit(outputs, targets)
+            weight_dict = crit.weight_dict
+            losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+            opt.zero_grad()
+            losses.backward()
+            if not fused:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+            opt.step()
+            return losses
+        for i in range(4):
+            one(i)
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(steps):
+            last = one(i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        res[name] = dict(ms_per_step=round(el / steps * 1e3, 3), ms_per_step_event_median=round(per[steps // 2], 3), loss=round(float(last), 5),
+                         grads_read_in_place=(opt.in_place_steps == steps + 4) if fused else None)
+        del model, crit, opt
+        torch.cuda.empty_cache()
+    res["what"] = ("the loop body of main/train_vlp_ddp.py:56-68 on the drop-in model (univtg_amd.model.build_model, autograd path), the headline batches, "
+                   "host wall clock per step incl. Python; torch_adamw_and_clip_grad_norm = the reference's optimizer lines unchanged; fused_adamw_clip = "
+                   "univtg_amd.optim.FusedAdamWClip(param_dicts, lr, weight_decay, max_grad_norm=opt.grad_clip, model=model) in place of "
+                   "torch.optim.AdamW(...) and the clip_grad_norm_ line dropped")
+    return res
 
 
 def companion_infer(dev, n=20):
@@ -676,6 +814,8 @@ def main():
     # every other BASELINE config that fits one GPU, and the inference call, in the SAME driver-run line.  LAST on the
     # device: each builds (and frees) its own model + multi-GB workspace, and the headline's instrumented passes above must not run behind
     # that allocator traffic (visit r5a: the LayerNorm-forward event pairs of the pass that followed it read 10 ms per step)
+    if rank == 0 and world == 1 and not args.no_companions and args.config == 2:
+        comp["drop_in_autograd"] = companion_drop_in(dev, batches, precise, Lv)
     if rank == 0 and world == 1 and not args.no_companions and args.config == 2 and not args.no_other_configs:
         for cid in (3, 4, 5):
             comp[f"config{cid}"] = companion_config(cid, dev, precise, lib)
@@ -683,7 +823,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
-        cpu = cpu_baseline(batches[0])
+        cpu = cpu_baseline(batches[0], dev)
 
     if rank == 0:
         valid_clips = sum(sum(a) for a, _ in lens_a) / len(lens_a)
@@ -715,13 +855,7 @@ def main():
                    exposed_comm_ms_per_step=(round(exposed[len(exposed) // 2], 3) if exposed else None), exposed_comm_samples=len(exposed),
                    world_size=world, comm_backend=(backend if world > 1 else None), comm_world_size=comm_size, replicas=replicas,
                    t_encoder_ms=round(t_enc * 1e3, 3), sections=sect,
-                   roofline_encoder=dict(achieved=round(exe_flops / t_enc / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(exe_flops / t_enc / 2.5e15, 4),
-                                         executed_tflop_per_step=round(exe_flops / 1e12, 3), target_frac=0.40,
-                                         note="FLOPs of the rows the encoder EXECUTES (3*E*sum_b(8 S_b d^2 + 4 S_b d F + 4 S_b^2 d); in variant A that is SURVEY 8d's "
-                                              "3*E*B*(8Sd^2+4SdF+4S^2d) minus the text rows of the last layer's FFN, which no longer run) + the four conv-head weight "
-                                              "gradients that ride in the section's deferred weight-gradient launch on a single rank (0.50 TFLOP at config 2) "
-                                              "/ (encoder fwd + bwd section time, HIP events on the launch stream, incl. the "
-                                              "deferred weight-gradient launch) / 2.5 PFLOP/s"),
+                   roofline_encoder=encoder_roofline(alg_flops, exe_flops, t_enc, B, Lv, halo, lens_a, roof),
                    encoder_rows_fraction=round(sum(sum(min(Lv, x + 3) for x in a) + sum(b) for a, b in lens_a) / (len(lens_a) * B * (Lv + Lt)), 4) if halo else 1.0,
                    companions=comp or None,
                    numerics=("forward input projections on fp32-class split operands: saliency_scores of the timed train-mode step within 1e-4 of the fp32 "

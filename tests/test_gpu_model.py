@@ -348,6 +348,36 @@ def test_last_layer_ffn_half_on_clip_rows_matches_every_row(dev, variant):
     assert float((g1 - g0).abs().max()) <= 4e-3 * float(g0.abs().max())
 
 
+def test_backward_reads_the_last_layer_rows_the_way_its_forward_wrote_them(dev):
+    """the clip-row layout of the last layer's FFN half depends on developer knobs, so uvtg_backward must not re-derive it --
+    uvtg_forward records its choice per workspace.  A knob flipped BETWEEN a training forward and its backward (both directions) must leave the
+    gradients bit-identical to the undisturbed call's."""
+    from oracle import univtg_oracle as O
+    from univtg_amd import _lib
+    lib = _lib.load()
+    cfg = O.make_cfg(input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=71)
+    inputs, tg = O.make_batch(cfg, 24, 75, 32, seed=72, ragged=True)
+    batch, tgd = to_dev(inputs, dev), to_dev(tg, dev)
+
+    def grads(fwd_knob, bwd_knob):
+        model, crit = build(cfg, params, dev, "bf16", proj_precise=False)
+        model.train()
+        _lib.check(lib.uvtg_debug_last_layer_clip(fwd_knob))
+        out = model(**batch)
+        ld = crit(out, tgd)
+        _lib.check(lib.uvtg_debug_last_layer_clip(bwd_knob))
+        sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.flatten() for _, p in sorted(model.named_parameters()) if p.grad is not None])
+    try:
+        for knob in (1, 0):
+            want, got = grads(knob, knob), grads(knob, 1 - knob)
+            assert bool(torch.isfinite(got).all()) and torch.equal(want, got), knob
+    finally:
+        lib.uvtg_debug_last_layer_clip(1)
+
+
 @pytest.mark.parametrize("packed", [False, "auto"], ids=["padded", "packed_halo"])
 def test_conv_head_weight_gradients_inside_the_hybrid_launch_match_their_own_launch(dev, packed):
     """Round 5: the four Conv1d(k=3) weight gradients of the heads (dW[n][c][tap] = sum_rows dY[row][n] X[row + tap - 1][c] over the zero-framed
@@ -747,6 +777,60 @@ def test_native_train_step_matches_autograd_path(dev):
     opt = torch.optim.AdamW([p_ref], lr=1e-4, weight_decay=1e-4)
     opt.step()
     assert float((p_ref.detach() - step.flat).abs().max()) < 1e-6
+
+
+def test_fused_adamw_clip_in_the_reference_training_loop(dev):
+    """univtg_amd.optim.FusedAdamWClip swapped into the reference's loop body (main/train_vlp_ddp.py:56-68: model(**inputs) -> criterion ->
+    weighted sum -> zero_grad -> backward -> clip_grad_norm_ -> optimizer.step) against torch.optim.AdamW + clip_grad_norm_ on a twin model:
+    the same parameters after three steps, autograd's flat gradient buffer read in place (no gather), and a state_dict that
+    torch.optim.AdamW loads (the reference's checkpoint layout, main/train_vlp_ddp.py:157-195) and that loads back."""
+    from oracle import univtg_oracle as O
+    from univtg_amd.optim import FusedAdamWClip
+    cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
+                     input_dropout=0.0, dropout=0.0, droppath=0.0)
+    params = O.init_params(cfg, seed=19)
+    batches = [O.make_batch(cfg, 6, 30, 10, seed=20 + i, ragged=True) for i in range(3)]
+
+    def loop(make_opt, clip_line):
+        model, crit = build(cfg, params, dev, "bf16", proj_precise=False)
+        model.train()
+        group = [{"params": [p for n, p in model.named_parameters() if p.requires_grad]}]       # main/config.py:349
+        opt = make_opt(group, model)
+        for inputs, tg in batches:
+            out = model(**to_dev(inputs, dev))
+            ld = crit(out, to_dev(tg, dev))
+            losses = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+            opt.zero_grad()
+            losses.backward()
+            if clip_line:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+            opt.step()
+        torch.cuda.synchronize()
+        return model, opt
+
+    m_ref, o_ref = loop(lambda g, m: torch.optim.AdamW(g, lr=1e-3, weight_decay=1e-4), True)
+    m_fus, o_fus = loop(lambda g, m: FusedAdamWClip(g, lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1, model=m), False)
+    m_both, o_both = loop(lambda g, m: FusedAdamWClip(g, lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1, model=m), True)      # the clip line left in
+    assert o_fus.in_place_steps == 3, o_fus.in_place_steps          # autograd's flat buffer was read in place, never gathered
+    ref = dict(m_ref.named_parameters())
+    moved = 0.0
+    for k, p in m_fus.named_parameters():
+        moved = max(moved, float((p - params[k].to(dev)).abs().max()))
+        assert float((p - ref[k]).abs().max()) < 2e-5, k            # three lr = 1e-3 steps move a weight by ~3e-3
+        assert float((dict(m_both.named_parameters())[k] - p).abs().max()) < 2e-5, k
+    assert moved > 1e-3
+    # checkpoint layout: torch.optim.AdamW loads the fused optimizer's state, and the fused optimizer loads AdamW's
+    sd = o_fus.state_dict()
+    assert sd["param_groups"][0]["params"] == o_ref.state_dict()["param_groups"][0]["params"]
+    twin = torch.optim.AdamW([{"params": [p for n, p in m_fus.named_parameters() if p.requires_grad]}], lr=1e-3, weight_decay=1e-4)
+    twin.load_state_dict(sd)
+    rs = o_ref.state_dict()["state"]
+    for i, ent in twin.state_dict()["state"].items():
+        assert float(ent["step"]) == 3.0 and float((ent["exp_avg"] - rs[i]["exp_avg"]).abs().max()) < 1e-5 * max(1.0, float(rs[i]["exp_avg"].abs().max()))
+    o_fus2 = FusedAdamWClip([{"params": [p for n, p in m_fus.named_parameters() if p.requires_grad]}], lr=1e-3, weight_decay=1e-4,
+                            max_grad_norm=0.1, model=m_fus)
+    o_fus2.load_state_dict(o_ref.state_dict())
+    assert o_fus2.t == 3 and float((o_fus2.m - o_fus.m).abs().max()) < 1e-5 * float(o_fus.m.abs().max())
 
 
 def test_nt256_engine_path_matches_nt128(dev):

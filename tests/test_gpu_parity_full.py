@@ -117,12 +117,98 @@ def test_config2_full_size_fp32x3_forward_and_post_nms_indices(dev, config2):
         # ambiguous: the fp32 and the fp64 oracle disagree on it, or the deciding margin is below the fp32 oracle's own deviation from fp64
         if diff:       # (i) does the reference agree with ITSELF on these samples?  (second fp32 GEMM backend of the same torch)
             alt_order, alt_keep = _reference_alt_backend(cfg, params, inputs, tg, durations, clip_length)
+        reasons = {}
         for b in diff:
             if alt_order[b] != ref_order[b] or alt_keep[b] != ref_keep[b]:
                 print(f"   sample {b}: the fp32 reference on torch's other CPU GEMM backend (mkldnn off) ranks / keeps differently too")
+                reasons[b] = "the fp32 reference with mkldnn off differs too"
                 continue
             assert _reference_is_ambiguous(cfg, params, inputs, tg, durations, b, clip_length, ref_order[b], ref_keep[b], order[b]), (clip_length, b)
-        assert len(diff) <= 3, diff         # (measured: 1, 0, 0, 1 over the four weight / batch draws of this file)
+            reasons[b] = "fp64 margin <= the fp32 reference's own deviation from fp64, or fp64 oracle differs from fp32 oracle"
+        _record_index_clause((101, 102), clip_length, diff, reasons)
+
+
+# ---- the index clause's excused samples, pinned (VERDICT r5 item 1d / ADVICE r4) ----
+# (weights seed, batch seed, clip_length) -> samples of the 256 whose ranking / keep-set differs from the fp32 reference algorithm's AND that the
+# reference does not resolve itself (see _reference_is_ambiguous).  Every other sample is bit-identical.  A build that excuses any OTHER sample
+# fails, even if that sample is ambiguous too: the set only changes together with this table and profiles/r06_index_clause.txt.
+KNOWN_EXCUSED = {
+    (101, 102, 0.0): [], (101, 102, 2.0): [],
+    (201, 202, 0.0): [], (201, 202, 2.0): [],
+    (301, 302, 0.0): [], (301, 302, 2.0): [],
+    (401, 402, 0.0): [], (401, 402, 2.0): [],
+}
+
+
+def _record_index_clause(seeds, clip_length, diff, reasons):
+    """Append one line per (draw, clip_length) to gpurun_out/index_clause.txt (copied to profiles/ by the visit script) and hold the excused
+    set to KNOWN_EXCUSED."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "index_clause.txt"), "a") as f:
+            f.write(f"weights seed {seeds[0]} batch seed {seeds[1]} clip_length {clip_length}: identical ranking + post-NMS keep-set "
+                    f"{256 - len(diff)}/256; excused samples {diff} {reasons if diff else ''}\n")
+    except OSError:
+        pass
+    if not os.environ.get("UVTG_INDEX_CLAUSE_RECORD"):          # (set only to take the table above from a new build)
+        assert diff == KNOWN_EXCUSED[(seeds[0], seeds[1], clip_length)], (seeds, clip_length, diff, reasons)
+
+
+def test_real_reference_beside_the_hip_path_at_config2_width(dev, config2, tmp_path):
+    """The REFERENCE ITSELF (showlab/UniVTG, unmodified, from oracle/_ref, in a child process on the host cores -- oracle/ref_runner.py) and
+    the HIP path on ONE box at production width: build_model at config 2 (d = 1024, E = 4, D_v = 2818), the oracle-seeded
+    weights through load_state_dict(strict=True) on both sides, eval mode, B = 256 ragged.
+    (a) the reference's outputs vs the default drop-in model under no_grad: saliency <= 1e-4 (north_star), pred_* <= 2e-5
+        (model/univtg.py:105-155);
+    (b) the reference's OWN inference tail -- PostProcessorDETR round_multiple (eval/postprocessing.py:46-51) + temporal_nms
+        (utils/temporal_nms.py:25-74) behind the compose glue of main/inference_mr.py:111-163 -- run on the HIP outputs, vs
+        uvtg_postprocess_mr on the same outputs: identical ranked rows and identical post-NMS rows for 256/256 samples, raw and rounded;
+    (c) the restated oracle against the reference at this width (the fixtures pin it at d = 64 / 128 only): <= 2e-5."""
+    import json
+    from oracle.build_ref import ARCHIVE
+    from oracle.ref_runner import run_job
+    from univtg_amd import ops
+    if not os.path.exists(ARCHIVE):
+        pytest.skip("no oracle/_ref archive in this tree (built by __graft_entry__.build() where /root/reference exists)")
+    cfg, params, inputs, tg, _, oracle_out, _ = config2
+    B, Lv = inputs["src_vid"].shape[:2]
+    threads = min(os.cpu_count() or 1, 32)
+    ev = str(tmp_path / "ref_eval.npz")
+    r = run_job(dict(task="model", threads=threads, cfg=dict(input_dropout=0.0, droppath=0.0, dropout=0.0), param_seed=101,
+                     batch=dict(B=256, Lv=75, Lt=32, seed=102, ragged=True), eval_out=ev))
+    assert ".zip" in r["module_file"] and len(r["manifest"]) >= 11
+    ref = {k: torch.from_numpy(v) for k, v in np.load(ev).items()}
+    model, _ = build(cfg, params, dev, "auto", proj_precise="auto")         # what INTEGRATION section 1 gives a maintainer
+    model.eval()
+    with torch.no_grad():
+        out = model(**to_dev(inputs, dev))
+    valid = inputs["src_vid_mask"].bool()
+    err = dict(saliency=float((out["saliency_scores"].cpu() - ref["saliency_scores"])[valid].abs().max()),
+               pred_logits=float((out["pred_logits"].cpu() - ref["pred_logits"]).abs().max()),
+               pred_spans=float((out["pred_spans"].cpu() - ref["pred_spans"]).abs().max()))
+    oerr = {k: float((oracle_out[k] - ref[k])[valid if k == "saliency_scores" else slice(None)].abs().max()) for k in ("saliency_scores", "pred_logits", "pred_spans")}
+    print(f"\n[real reference vs HIP, config 2 width] {err}   [oracle vs real reference] {oerr}")
+    assert err["saliency"] <= 1e-4 and err["pred_logits"] <= 2e-5 and err["pred_spans"] <= 2e-5, err
+    assert max(oerr.values()) <= 2e-5, oerr
+    # ---- (b) the reference's own tail on the HIP outputs ----
+    durations = torch.tensor([float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(B)])
+    pin = str(tmp_path / "hip_out.npz")
+    np.savez(pin, pred_logits=out["pred_logits"].cpu().numpy(), pred_spans=out["pred_spans"].cpu().numpy(), timestamp=tg["timestamp"].numpy(),
+             timestamp_mask=tg["timestamp_mask"].numpy(), durations=durations.numpy())
+    pj = str(tmp_path / "ref_tail.json")
+    r2 = run_job(dict(task="postproc", outputs_npz=pin, result_json=pj, clip_lengths=[0.0, 2.0]))
+    assert all(".zip" in f for f in r2["module_files"])
+    with open(pj) as f:
+        tail = json.load(f)
+    tsd, tmd, dud = tg["timestamp"].to(dev), tg["timestamp_mask"].to(dev), durations.to(dev)
+    for clip_length in (0.0, 2.0):
+        win, order, keep, nk, _ = ops.postprocess_mr(out["pred_logits"], out["pred_spans"], None, tsd, tmd, dud, clip_length=clip_length)
+        win, keep, nk = win.cpu().numpy(), keep.cpu().tolist(), nk.cpu().tolist()
+        want = tail[str(clip_length)]
+        same = sum(win[b].tolist() == want["pre"][b] and [win[b, i].tolist() for i in keep[b][: nk[b]]] == want["nms"][b] for b in range(B))
+        print(f"[reference's own round_multiple + temporal_nms on the HIP outputs, clip_length={clip_length}] identical rows {same}/{B}")
+        assert same == B, (clip_length, same)
 
 
 def _oracle_tail(pl, ps, ts, tm, durations, clip_length):
@@ -214,12 +300,15 @@ def test_post_nms_indices_identical_for_every_sample_three_seeds(dev, seeds):
         print(f"[seeds {seeds}, clip_length={clip_length}] identical ranking + keep-set: {B - len(diff)}/{B}")
         if diff:       # (i) does the reference agree with ITSELF on these samples?  (second fp32 GEMM backend of the same torch)
             alt_order, alt_keep = _reference_alt_backend(cfg, params, inputs, tg, durations, clip_length)
+        reasons = {}
         for b in diff:
             if alt_order[b] != ref_order[b] or alt_keep[b] != ref_keep[b]:
                 print(f"   sample {b}: the fp32 reference on torch's other CPU GEMM backend (mkldnn off) ranks / keeps differently too")
+                reasons[b] = "the fp32 reference with mkldnn off differs too"
                 continue
             assert _reference_is_ambiguous(cfg, params, inputs, tg, durations, b, clip_length, ref_order[b], ref_keep[b], order[b]), (clip_length, b)
-        assert len(diff) <= 3, diff         # (measured: 1, 0, 0, 1 over the four weight / batch draws of this file)
+            reasons[b] = "fp64 margin <= the fp32 reference's own deviation from fp64, or fp64 oracle differs from fp32 oracle"
+        _record_index_clause(seeds, clip_length, diff, reasons)
 
 
 def test_config2_full_size_bf16_losses_gradients_and_index_agreement(dev, config2):

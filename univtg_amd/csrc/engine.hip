@@ -3,6 +3,7 @@
 // caller's HIP stream (graph-capturable: no allocation, no host sync, all state in caller-owned buffers).
 // Token-major layout: row (b*S + s) of every [M, *] activation, s < Lv video clips then Lt text tokens.
 #include "uvtg_kernels.h"
+#include <mutex>
 #include <cstdlib>
 #include "../../include/uvtg.h"
 #include <cmath>
@@ -323,8 +324,8 @@ int zero_frames(const ZeroFrames& z, int count, int B, int Lv, hipStream_t s) {
 // their gradients -- run on B Lv instead of B (Lv + Lt) rows; LayerNorm 1's backward scatters its input gradient back into the token-major
 // stream, whose text rows are zero (their only gradient arrives through the attention as keys / values).  On the packed (ragged) stream the
 // clip rows are the compact rows of the video input projection (PackTables::vin_dst: valid clips + representative / halo clips), read and
-// scattered through that table.  Exact: the dropped rows' values never reach an output, and their gradient contributions are exact zeros.  A
-// function of dims only, so uvtg_backward makes the same choice; a training call that asks for `memory` is refused (-24), an eval call with
+// scattered through that table.  Exact: the dropped rows' values never reach an output, and their gradient contributions are exact zeros.  
+// uvtg_backward reads the rows the way the forward on the same workspace wrote them (clip_record below); a training call that asks for `memory` is refused (-24), an eval call with
 // `memory` runs all rows.
 static int g_conv_defer = -1;
 extern "C" int uvtg_debug_tn_conv_defer(int on) { g_conv_defer = on ? 1 : 0; return 0; }
@@ -334,6 +335,26 @@ static bool last_layer_clip(const Dm& m) {
   if (g_last_clip < 0) g_last_clip = getenv("UVTG_LAST_CLIP_OFF") ? 0 : 1;
   return g_last_clip == 1 && !m.c.precise && m.c.Lt > 0 && ln_clip_rows_ok(m.c.d);
 }
+// The choice depends on developer knobs (uvtg_debug_last_layer_clip, uvtg_debug_ln_fwd_lean), so uvtg_backward must not re-derive it: a knob
+// flipped between a training forward and its backward would make it read compact clip-row buffers as full ones.  uvtg_forward
+// remembers what it did per workspace (host side, a handful of entries: one per live workspace) and uvtg_backward reads the buffers that way.
+namespace {
+struct ClipRecord { const void* ws; int clip; };
+ClipRecord g_clip_rec[64];
+int g_clip_rec_n = 0, g_clip_rec_next = 0;
+std::mutex g_clip_rec_mu;
+void clip_record(const void* ws, bool clip) {
+  std::lock_guard<std::mutex> lk(g_clip_rec_mu);
+  for (int i = 0; i < g_clip_rec_n; i++) if (g_clip_rec[i].ws == ws) { g_clip_rec[i].clip = clip; return; }
+  const int slot = g_clip_rec_n < 64 ? g_clip_rec_n++ : (g_clip_rec_next++ & 63);
+  g_clip_rec[slot] = {ws, clip ? 1 : 0};
+}
+int clip_recorded(const void* ws) {        // -1: this workspace has seen no forward
+  std::lock_guard<std::mutex> lk(g_clip_rec_mu);
+  for (int i = 0; i < g_clip_rec_n; i++) if (g_clip_rec[i].ws == ws) return g_clip_rec[i].clip;
+  return -1;
+}
+}  // namespace
 __global__ void concat2_kernel(const float* a, const float* b, float* dst, const float* a2, const float* b2, float* dst2, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;       // two concatenations per launch (the merged conv biases of both conv layers)
   if (i < n) { dst[i] = a[i]; dst[n + i] = b[i]; dst2[i] = a2[i]; dst2[n + i] = b2[i]; }
@@ -851,6 +872,7 @@ extern "C" int uvtg_forward(const uvtg_dims* dm, const float* const* P, const vo
     if (m.c.training) return -24;
     f.clip = false;
   }
+  if (m.c.training) clip_record(workspace, f.clip);
   if (pmode != PACK_NONE) {                     // packed (ragged) encoder stream
     int mp = 0;
     TRY(packed_rows(m, lens_host, pmode, &mp));
@@ -1087,7 +1109,8 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   uvtg_prof_section(1, 0, s);
   if (packed) TRY(launch_pack_reduce_dvm(ws.dvmB, ws.pk, B, S, Lv, M, d, pmode == PACK_TEXT || pmode == PACK_HALO, pmode == PACK_HALO, ws.g2p, s));   // conv-head gradient onto the packed rows
   const int* row_sample = packed ? ws.pk.row_sample : nullptr;
-  const bool clip = last_layer_clip(m);              // the forward's choice (a function of dims only)
+  const int clip_rec = clip_recorded(workspace);     // the forward's choice, as the forward on THIS workspace recorded it
+  const bool clip = clip_rec >= 0 ? clip_rec == 1 : last_layer_clip(m);
   const int Rv_clip = packed ? compact_clip_rows(m, lens_host, pmode) : m.Mv;
   for (int l = E - 1; l >= 0; l--) {
     const bf16_t* xb_in = (packed && l == 0) ? ws.xb0p : (const bf16_t*)ws.xb[l];

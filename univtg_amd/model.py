@@ -150,6 +150,9 @@ class _UniVTGFunction(torch.autograd.Function):
         ptrs = model._param_ptrs(params)
         offs = model._offsets(dims)
         grads = torch.empty(offs[-1], device=x0.device)
+        gaps = model._offset_gaps(offs, params, x0.device)
+        if gaps is not None:                           # alignment gaps between the parameters' ranges: FusedAdamWClip reads the buffer whole
+            grads.index_fill_(0, gaps, 0.0)
         g = [None if t is None else _f32c(t) for t in (g_logits, g_spans, g_sal, g_txt, g_x0)]
         S, d = x0.shape[1], x0.shape[2]
         _lib.check(lib.uvtg_backward(C.byref(dims), ptrs, _ptr(ctx.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
@@ -276,6 +279,14 @@ class Model(nn.Module):
             buf = (C.c_longlong * (n + 1))()
             _lib.check(lib.uvtg_param_offsets(C.byref(dims), buf), "uvtg_param_offsets")
             self._off_cache[key] = list(buf)
+        return self._off_cache[key]
+
+    def _offset_gaps(self, offs, params, dev):
+        """int64 indices of the flat layout's alignment gaps (every parameter starts at a multiple of 4 elements), or None."""
+        key = ("gaps", tuple(offs), str(dev))
+        if key not in self._off_cache:
+            idx = [j for i, p in enumerate(params) for j in range(offs[i] + p.numel(), offs[i + 1])]
+            self._off_cache[key] = torch.tensor(idx, dtype=torch.long, device=dev) if idx else None
         return self._off_cache[key]
 
     def _prepare(self, dims, ptrs, params):
