@@ -372,8 +372,12 @@ def test_backward_reads_the_last_layer_rows_the_way_its_forward_wrote_them(dev):
         return torch.cat([p.grad.flatten() for _, p in sorted(model.named_parameters()) if p.grad is not None])
     try:
         for knob in (1, 0):
-            want, got = grads(knob, knob), grads(knob, 1 - knob)
-            assert bool(torch.isfinite(got).all()) and torch.equal(want, got), knob
+            want, got = grads(knob, knob).double(), grads(knob, 1 - knob).double()
+            # (two runs of one build agree to the fp32 atomics' summation order; a backward that read compact clip-row buffers as full ones --
+            # or the reverse -- reads stale rows of other tensors: errors of the gradients' own magnitude)
+            assert bool(torch.isfinite(got).all()), knob
+            assert float((want - got).abs().max()) <= 1e-4 * float(want.abs().max()), (knob, float((want - got).abs().max()), float(want.abs().max()))
+            assert float((want @ got) / (want.norm() * got.norm())) > 0.9999999, knob
     finally:
         lib.uvtg_debug_last_layer_clip(1)
 
@@ -781,9 +785,11 @@ def test_native_train_step_matches_autograd_path(dev):
 
 def test_fused_adamw_clip_in_the_reference_training_loop(dev):
     """univtg_amd.optim.FusedAdamWClip swapped into the reference's loop body (main/train_vlp_ddp.py:56-68: model(**inputs) -> criterion ->
-    weighted sum -> zero_grad -> backward -> clip_grad_norm_ -> optimizer.step) against torch.optim.AdamW + clip_grad_norm_ on a twin model:
-    the same parameters after three steps, autograd's flat gradient buffer read in place (no gather), and a state_dict that
-    torch.optim.AdamW loads (the reference's checkpoint layout, main/train_vlp_ddp.py:157-195) and that loads back."""
+    weighted sum -> zero_grad -> backward -> [clip_grad_norm_] -> optimizer.step): after every backward the SAME gradients also go through
+    clip_grad_norm_(0.1) + torch.optim.AdamW on shadow parameters (Adam is ill-conditioned across two separately computed backward passes: an
+    element whose gradient is rounding noise moves by +-lr on its sign) -- three steps, then the same parameters; autograd's flat gradient
+    buffer read in place (no gather), the clip line left in the loop changes nothing, and a state_dict that torch.optim.AdamW loads (the
+    reference's checkpoint layout, main/train_vlp_ddp.py:157-195) and that loads back."""
     from oracle import univtg_oracle as O
     from univtg_amd.optim import FusedAdamWClip
     cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=2, v_feat_dim=514, t_feat_dim=512,
@@ -791,46 +797,52 @@ def test_fused_adamw_clip_in_the_reference_training_loop(dev):
     params = O.init_params(cfg, seed=19)
     batches = [O.make_batch(cfg, 6, 30, 10, seed=20 + i, ragged=True) for i in range(3)]
 
-    def loop(make_opt, clip_line):
+    def loop(clip_line):
         model, crit = build(cfg, params, dev, "bf16", proj_precise=False)
         model.train()
-        group = [{"params": [p for n, p in model.named_parameters() if p.requires_grad]}]       # main/config.py:349
-        opt = make_opt(group, model)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        opt = FusedAdamWClip([{"params": [p for _, p in named]}], lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1, model=model)     # main/config.py:349
+        shadow = [p.detach().clone().requires_grad_(True) for _, p in named]
+        sopt = torch.optim.AdamW([{"params": shadow}], lr=1e-3, weight_decay=1e-4)
         for inputs, tg in batches:
             out = model(**to_dev(inputs, dev))
             ld = crit(out, to_dev(tg, dev))
             losses = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
             opt.zero_grad()
             losses.backward()
+            for (_, p), sp in zip(named, shadow):
+                sp.grad = None if p.grad is None else p.grad.detach().clone()
+            torch.nn.utils.clip_grad_norm_(shadow, 0.1)
+            sopt.step()
             if clip_line:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
             opt.step()
         torch.cuda.synchronize()
-        return model, opt
+        return model, opt, named, shadow, sopt
 
-    m_ref, o_ref = loop(lambda g, m: torch.optim.AdamW(g, lr=1e-3, weight_decay=1e-4), True)
-    m_fus, o_fus = loop(lambda g, m: FusedAdamWClip(g, lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1, model=m), False)
-    m_both, o_both = loop(lambda g, m: FusedAdamWClip(g, lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1, model=m), True)      # the clip line left in
-    assert o_fus.in_place_steps == 3, o_fus.in_place_steps          # autograd's flat buffer was read in place, never gathered
-    ref = dict(m_ref.named_parameters())
-    moved = 0.0
-    for k, p in m_fus.named_parameters():
-        moved = max(moved, float((p - params[k].to(dev)).abs().max()))
-        assert float((p - ref[k]).abs().max()) < 2e-5, k            # three lr = 1e-3 steps move a weight by ~3e-3
-        assert float((dict(m_both.named_parameters())[k] - p).abs().max()) < 2e-5, k
-    assert moved > 1e-3
+    for clip_line in (False, True):
+        model, opt, named, shadow, sopt = loop(clip_line)
+        # in place unless the clip line rescaled p.grad in place first (it still IS the flat buffer then)
+        assert opt.in_place_steps == 3, opt.in_place_steps
+        moved = 0.0
+        for (k, p), sp in zip(named, shadow):
+            moved = max(moved, float((p - params[k].to(dev)).abs().max()))
+            # (the clip line left in: the second clip is the identity up to one rounding of the norm)
+            assert float((p - sp).abs().max()) < (2e-6 if not clip_line else 2e-5), (k, clip_line, float((p - sp).abs().max()))
+        assert moved > 1e-3                                         # three lr = 1e-3 steps move a weight by ~3e-3
     # checkpoint layout: torch.optim.AdamW loads the fused optimizer's state, and the fused optimizer loads AdamW's
-    sd = o_fus.state_dict()
-    assert sd["param_groups"][0]["params"] == o_ref.state_dict()["param_groups"][0]["params"]
-    twin = torch.optim.AdamW([{"params": [p for n, p in m_fus.named_parameters() if p.requires_grad]}], lr=1e-3, weight_decay=1e-4)
+    sd = opt.state_dict()
+    ssd = sopt.state_dict()
+    assert sd["param_groups"][0]["params"] == ssd["param_groups"][0]["params"]
+    twin = torch.optim.AdamW([{"params": [p for _, p in named]}], lr=1e-3, weight_decay=1e-4)
     twin.load_state_dict(sd)
-    rs = o_ref.state_dict()["state"]
     for i, ent in twin.state_dict()["state"].items():
-        assert float(ent["step"]) == 3.0 and float((ent["exp_avg"] - rs[i]["exp_avg"]).abs().max()) < 1e-5 * max(1.0, float(rs[i]["exp_avg"].abs().max()))
-    o_fus2 = FusedAdamWClip([{"params": [p for n, p in m_fus.named_parameters() if p.requires_grad]}], lr=1e-3, weight_decay=1e-4,
-                            max_grad_norm=0.1, model=m_fus)
-    o_fus2.load_state_dict(o_ref.state_dict())
-    assert o_fus2.t == 3 and float((o_fus2.m - o_fus.m).abs().max()) < 1e-5 * float(o_fus.m.abs().max())
+        want = ssd["state"][i]
+        assert float(ent["step"]) == 3.0
+        assert float((ent["exp_avg_sq"] - want["exp_avg_sq"]).abs().max()) <= 1e-4 * float(want["exp_avg_sq"].abs().max()) + 1e-12
+    opt2 = FusedAdamWClip([{"params": [p for _, p in named]}], lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1, model=model)
+    opt2.load_state_dict(ssd)
+    assert opt2.t == 3 and float((opt2.v - opt.v).abs().max()) <= 1e-4 * float(opt.v.abs().max())
 
 
 def test_nt256_engine_path_matches_nt128(dev):

@@ -1648,13 +1648,18 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
           f32x4 v0 = *(const f32x4*)(wbuf + row * 64 + c8), v1 = *(const f32x4*)(wbuf + row * 64 + c8 + 4);
           const int trow0 = wm * 128 + i * 32 + q * 8;                     // wave-uniform
           if (part >= 0) {
+            // the parts are summed in PART order, this part's registers at its own position: the gradient does not depend on which part
+            // arrived last (round 6: with three parts "own + others" gave (a2 + a0) + a1 or (a0 + a1) + a2 from run to run)
+            const f32x4 own0 = v0, own1 = v1;
             for (int o = 0; o < plan.nsplit; o++) {
-              if (o == part) continue;
-              const float* os = plan.slabs + (size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB;
-              const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)os, 0, TNH_SLAB * 4, 0x00020000);
-              const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab, trow0 * 1024, 0);
-              const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab + 16, trow0 * 1024, 0);
-              v0 += __builtin_bit_cast(f32x4, t0); v1 += __builtin_bit_cast(f32x4, t1);
+              f32x4 t0 = own0, t1 = own1;
+              if (o != part) {
+                const float* os = plan.slabs + (size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB;
+                const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)os, 0, TNH_SLAB * 4, 0x00020000);
+                t0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab, trow0 * 1024, 0));
+                t1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rso, vo_slab + 16, trow0 * 1024, 0));
+              }
+              if (o == 0) { v0 = t0; v1 = t1; } else { v0 += t0; v1 += t1; }
             }
           }
           if (!strided) {
@@ -1678,9 +1683,13 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
           float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
           const int nn = wm * 128 + i * 32 + l31;
           if (g == 0) {
-            if (part >= 0)
-              for (int o = 0; o < plan.nsplit; o++)
-                if (o != part) t += plan.slabs[(size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB + 65536 + nn];
+            if (part >= 0) {                                    // (part order, like the tile above)
+              const float own = t;
+              for (int o = 0; o < plan.nsplit; o++) {
+                const float x = o == part ? own : plan.slabs[(size_t)((tile_g - plan.full_tiles) * plan.nsplit + o) * TNH_SLAB + 65536 + nn];
+                t = o == 0 ? x : t + x;
+              }
+            }
             p.dbias[n0 + nn] += t;                              // (one tile column block per bias entry: single writer)
           }
         }
