@@ -384,10 +384,11 @@ def encoder_flops(lens, B, Lv, Lt, packed_halo):
     alg = 3 * E * B * (8 * S * d * d + 4 * S * d * F_ + 4 * S * S * d)
     # the LAST layer's FFN runs on the clip rows only (engine.hip, last_layer_clip): its text rows' 3 x 4 d F are not executed
     clip = 0 if os.environ.get("UVTG_LAST_CLIP_OFF") else 3 * 4 * d * F_
-    # the encoder SECTION also holds the four conv-head weight gradients (2 R_f d 3d each over the zero-framed rows): on a single rank they
-    # ride in the section's deferred weight-gradient launch (engine.hip, tn_flush) -- counted as executed work of the section, not as encoder FLOPs
-    conv = 0 if (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF") or int(os.environ.get("WORLD_SIZE", "1")) > 1
-                 or "force" in sys.argv) else 4 * 2 * d * 3 * d
+    # the encoder SECTION also holds the four conv-head weight gradients (2 R_f d 3d each over the zero-framed rows): they ride in the section's
+    # deferred weight-gradient launch (engine.hip, tn_flush; N > 1: in the group behind layer 1) -- counted as executed work of the section, not as
+    # encoder FLOPs; only the per-layer-event mode of rounds 2-5 (UVTG_TN_EVENTS_PER_LAYER) keeps them outside
+    conv = 0 if (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF")
+                 or ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or "force" in sys.argv) and os.environ.get("UVTG_TN_EVENTS_PER_LAYER"))) else 4 * 2 * d * 3 * d
     if not packed_halo:
         return alg, alg - clip * B * Lt + conv * B * (Lv + 2)
     per = [[min(Lv, x + 3) + y for x, y in zip(a, b)] for a, b in lens]
@@ -404,7 +405,8 @@ def encoder_roofline(alg_flops, exe_flops, t_enc, B, Lv, halo, lens, roof):
     really runs.  `frac_survey_conv_wgrads_priced_out` removes the conv gradients' share of the section time at the weight-gradient family's
     own measured rate (derived, not an event pair)."""
     d = MODEL["d"]
-    conv_on = not (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF") or int(os.environ.get("WORLD_SIZE", "1")) > 1 or "force" in sys.argv)
+    conv_on = not (os.environ.get("UVTG_TN_CONV_DEFER_OFF") or os.environ.get("UVTG_TN_DEFER_OFF")
+                   or ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or "force" in sys.argv) and os.environ.get("UVTG_TN_EVENTS_PER_LAYER")))
     rows_f = (sum(sum(min(Lv, x + 3) + 2 for x in a) for a, _ in lens) / len(lens)) if halo else B * (Lv + 2)
     conv_flops = 4 * 2 * d * 3 * d * rows_f if conv_on else 0.0
     tn = ((roof or {}).get("all_gemm_kernels") or {}).get("gemm_tn_kernel") or {}

@@ -125,7 +125,9 @@ int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wc
  * on row pos_idx[b] of vid_mem_proj -- the compact form uvtg_criterion_bwd emits instead of a dense g_vid.  grads: flat fp32 buffer (uvtg_param_offsets), overwritten.
  * ready_events (optional, for overlapping the data-parallel gradient exchange with the rest of backward): event 0 is recorded
  * on `stream` once the span_embed / class_embed gradients (table entries 12E+1 .. 12E+12) are final, event 1 + i once those of
- * encoder layer E-1-i are; everything else is final when the call's work completes. */
+ * encoder layer E-1-i are; everything else is final when the call's work completes.  An event is recorded no earlier than its range is
+ * final and in index order, but several may be recorded at the same point of the stream: by default the weight gradients of the heads and of
+ * layers E-1 .. 1 leave in ONE deferred launch behind layer 1's input gradient (events 0 .. E-1 there), layer 0's behind the loop. */
 int uvtg_backward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                   const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                   const float* x0, const float* pred_logits, const float* pred_spans, const float* txt_mem_proj,

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(monkeypatch, env):
-    for k in ("UVTG_LAST_CLIP_OFF", "UVTG_TN_CONV_DEFER_OFF", "UVTG_TN_DEFER_OFF", "WORLD_SIZE"):
+    for k in ("UVTG_LAST_CLIP_OFF", "UVTG_TN_CONV_DEFER_OFF", "UVTG_TN_DEFER_OFF", "WORLD_SIZE", "UVTG_TN_EVENTS_PER_LAYER"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -34,7 +34,9 @@ def test_encoder_section_flops_follow_the_launches(monkeypatch):
     monkeypatch.setenv("UVTG_TN_CONV_DEFER_OFF", "1")
     assert bench.encoder_flops(None, B, Lv, Lt, False)[1] == alg
     monkeypatch.delenv("UVTG_LAST_CLIP_OFF"); monkeypatch.delenv("UVTG_TN_CONV_DEFER_OFF")
-    monkeypatch.setenv("WORLD_SIZE", "8")              # N > 1: readiness events, the conv gradients keep their own launch
+    monkeypatch.setenv("WORLD_SIZE", "8")              # N > 1 (round 6): grouped deferral under the readiness events, the conv gradients ride along
+    assert bench.encoder_flops(None, B, Lv, Lt, False)[1] == alg - clip + conv
+    monkeypatch.setenv("UVTG_TN_EVENTS_PER_LAYER", "1")   # the per-layer-event mode of rounds 2-5: the conv gradients keep their own launch
     assert bench.encoder_flops(None, B, Lv, Lt, False)[1] == alg - clip
 
 

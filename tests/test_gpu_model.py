@@ -920,9 +920,13 @@ def test_auto_projection_mode_training(dev, golden_dir, name):
     assert not bad, bad
 
 
-def test_overlapped_gradient_exchange_single_rank(dev):
+@pytest.mark.parametrize("shape", ["toy_width", "production_width_grouped_deferral"])
+def test_overlapped_gradient_exchange_single_rank(dev, shape):
     """The bucketed side-stream exchange (ready events recorded inside uvtg_backward, RCCL all-reduce per range on a comm
-    stream) at world size 1: must leave exactly the gradients / parameters of the plain path."""
+    stream) at world size 1: must leave exactly the gradients / parameters of the plain path.  production_width_grouped_deferral: the round-6
+    default under events -- heads + layers E-1 .. 1 in one hybrid weight-gradient launch behind layer 1, layer 0 in a second one -- at
+    d = 1024, E = 4 (the toy width falls back to the per-batch launches).  (UVTG_TN_EVENTS_PER_LAYER=1 in the environment runs the same
+    test on the per-layer-event mode of rounds 2-5.)"""
     import torch.distributed as dist
     from oracle import univtg_oracle as O
     from univtg_amd.trainer import TrainStep
@@ -933,10 +937,15 @@ def test_overlapped_gradient_exchange_single_rank(dev):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         created = True
     try:
-        cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=3, v_feat_dim=514, t_feat_dim=512,
-                         input_dropout=0.0, dropout=0.0, droppath=0.0)
+        if shape == "toy_width":
+            cfg = O.make_cfg(hidden_dim=256, nheads=4, dim_feedforward=256, enc_layers=3, v_feat_dim=514, t_feat_dim=512,
+                             input_dropout=0.0, dropout=0.0, droppath=0.0)
+            B, Lv, Lt = 8, 30, 10
+        else:
+            cfg = O.make_cfg(input_dropout=0.0, dropout=0.0, droppath=0.0)
+            B, Lv, Lt = 64, 75, 32
         params = O.init_params(cfg, seed=31)
-        inputs, tg = O.make_batch(cfg, 8, 30, 10, seed=32, ragged=True)
+        inputs, tg = O.make_batch(cfg, B, Lv, Lt, seed=32, ragged=True)
         ind, tgd = to_dev(inputs, dev), to_dev(tg, dev)
         res = []
         for mode in (False, "force"):

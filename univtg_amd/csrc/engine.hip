@@ -984,7 +984,16 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // behind it, i.e. the encoder gradients' all-reduce overlaps only what follows the encoder (saliency branch + input projections).  Which of the
   // two wins depends on the node's all-reduce time; the compute side is measured (bench.py --overlap force).
   static const bool defer_events = getenv("UVTG_TN_DEFER_EVENTS") != nullptr;
-  const bool defer = (n_events == 0 || defer_events) && !defer_off;
+  // Round 6 (default under events): the deferral stays, in TWO groups -- the conv heads and layers E-1 .. 1 go out as ONE hybrid launch (and
+  // one LayerNorm fold) right behind layer 1's dgrad, their E events recorded together there, while layer 0 (a quarter of the tiles), the
+  // saliency branch and the input projections are still to run: the all-reduce of (E - 1) / E of the encoder gradients and of the heads
+  // overlaps them; layer 0's own group follows the loop.  The step then runs the kernels of the single-rank step plus one small hybrid launch
+  // (bench.py --overlap force).  UVTG_TN_EVENTS_PER_LAYER=1: the per-layer slab + reduce batches of rounds 2-5 (every layer's event behind
+  // its own gradients); UVTG_TN_DEFER_EVENTS=1: one launch behind the whole loop, every event there.
+  static const bool events_per_layer = getenv("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
+  const bool defer = (n_events == 0 || !events_per_layer) && !defer_off;
+  const int flush_layer = (n_events && defer && !defer_events && E >= 2) ? 1 : -1;      // events: group A is flushed behind this layer
+  int events_done = 0;                           // ready_events[0 .. events_done) are recorded
   GemmTNBatch deferred[2 * MAXE + 1]; int n_deferred = 0;
   auto tn_encoder = [&](const GemmTNBatch& b) -> int {
     if (!defer) return tn_batch(b);
@@ -1013,6 +1022,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     for (int i = 0; i < n_deferred; i++) TRY(tn_batch(deferred[i]));            // shapes the hybrid launch does not take: the split + reduce path
     return 0;
   };
+  auto tn_flush_group = [&]() -> int { const int r = tn_flush(); n_deferred = 0; return r; };
   // (The conv-head and input-projection gradients stay on the batched slab + reduce launches.  A stream-K generalisation of the hybrid kernel
   // -- tiles of all groups end to end, equal pieces per workgroup, conv taps and ragged K in its epilogue -- was built and measured in round 3:
   // correct, and SLOWER on both launches (encoder 1.27 vs 0.89 ms, tail 0.71 vs 0.61 ms): cutting every third tile breaks up the sets of tiles
@@ -1059,6 +1069,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     g.outB = ws.dh1_pad; g.ldoB = 2 * d;
     TRY(launch_gemm_nt_bf16(g, s));
   }
+  bool conv_deferred = false;
   {   // weight gradients of the four d -> d convolutions (layer 1 and layer 0 of both heads): the same frame rows, ONE launch over 4 x 12
       // tap tiles (5 row splits instead of 4 launches of 12 tiles x 21 splits each) + one reduce pass; their operands all exist by now
     GemmTNBatch cb; cb.count = 0;
@@ -1078,7 +1089,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     // round 5: without readiness events they join the encoder's deferred launch (the hybrid kernel takes conv taps and the stride-3 weight
     // layout now: no slab + reduce pass, 1160 instead of 850 TFLOP/s) -- UVTG_TN_CONV_DEFER_OFF / uvtg_debug_tn_conv_defer(0): their own launch, as before
     if (g_conv_defer < 0) g_conv_defer = getenv("UVTG_TN_CONV_DEFER_OFF") ? 0 : 1;
-    if (all_ok && !cbatch_off && defer && n_events == 0 && g_conv_defer == 1 && gemm_tn_batch_ok(cb)) TRY(tn_encoder(cb));      // (under events their own launch: ready_events[0] is recorded right below)
+    if (all_ok && !cbatch_off && defer && g_conv_defer == 1 && gemm_tn_batch_ok(cb)) { TRY(tn_encoder(cb)); conv_deferred = true; }      // (under events: ready_events[0] is recorded behind the group's launch)
     else if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) TRY(launch_gemm_tn_batch(cb, s));
     else for (auto& c : cw) TRY(conv_wgrad(c.dY, c.ldp, c.X, c.ldq, G(m.tail(c.w)), G(m.tail(c.b)), Rf));
   }
@@ -1088,7 +1099,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     g.outB = ws.dvmB; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
   }
-  if (n_events) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[0], s)) return (int)e; }   // span_embed / class_embed gradients final
+  if (n_events && !conv_deferred) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[0], s)) return (int)e; events_done = 1; }   // span_embed / class_embed gradients final
   // ---------------- encoder ----------------
   // The gradient stream is bf16 (like the activation stream): gin = gradient wrt the layer output; dyB = LayerNorm input
   // gradient scaled by the DropPath factor (operand of the branch GEMMs), dyR = the same unscaled (residual branch).
@@ -1197,12 +1208,17 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       TRY(launch_gemm_nt_bf16(g, s));
     }
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
-    if (n_events && !defer) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; }   // layer l gradients final
+    if (n_events && !defer) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; events_done = 2 + (E - 1 - l); }   // layer l gradients final
+    if (l == flush_layer) {                      // group A: the heads + layers E-1 .. l, one LayerNorm fold + one hybrid launch, their events together
+      TRY(launch_ln_bwd_reduce_multi(lnm, s));
+      lnm.count = 0;
+      TRY(tn_flush_group());
+      for (; events_done < 1 + (E - l); events_done++) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[events_done], s)) return (int)e; }
+    }
   }
   TRY(launch_ln_bwd_reduce_multi(lnm, s));
-  TRY(tn_flush());                               // the deferred weight gradients of all encoder layers, inside the encoder section
-  if (n_events && defer)                         // (UVTG_TN_DEFER_EVENTS) every layer's gradients are final here
-    for (int l = 0; l < E; l++) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + l], s)) return (int)e; }
+  TRY(tn_flush_group());                         // the deferred weight gradients of the (remaining) encoder layers, inside the encoder section
+  for (; n_events && events_done < n_events; events_done++) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[events_done], s)) return (int)e; }
   uvtg_prof_section(1, 1, s);
   const bf16_t* dx0 = ws.gxb[1];                 // d loss / d x0 from the encoder, bf16 [M, d]
   // ---------------- trainable text positions ----------------

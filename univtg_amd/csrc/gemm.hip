@@ -1623,7 +1623,12 @@ __global__ __launch_bounds__(512) void gemm_tn256h_kernel(const TNHPlan plan) {
       __syncthreads();
       last = s_ticket == (unsigned)(plan.nsplit - 1);
       if (last) {
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines of the other parts' slabs
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines of the other parts' slabs
+          // the ticket is left zero for the NEXT launch (round 6: a backward may issue two hybrid launches -- the group behind layer 1 and
+          // layer 0's -- between two zero fills of the ticket array)
+          __hip_atomic_store(plan.tickets + (tile_g - plan.full_tiles), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
       }
     }
