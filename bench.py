@@ -541,6 +541,65 @@ def companion_drop_in(dev, batches, precise, Lv, steps=30):
     return res
 
 
+def companion_input_pipeline(dev, step, batches, steps=30):
+    """One measured step that STARTS ON THE HOST (main/dataset.py:1037-1100, utils/tensor_utils.py:5-53): the
+    headline batches as `PackedHostBatch`es in pinned host memory (what DataLoader workers with collate_fn=pack_batch_host hand over), uploaded by
+    `DevicePrefetcher` (depth 2: batch n + 1's H2D copies + uvtg_ragged_to_padded on a side stream under batch n's step), fp32 and bf16 wire, the
+    SAME TrainStep as the headline.  `resident` = the same loop over the batches already in HBM, for the in-run ratio."""
+    import itertools
+    from univtg_amd.pipeline import DevicePrefetcher, pack_batch_host
+
+    def samples_of(batch):
+        inputs, tg = batch
+        lv, lt = inputs["_lens_host"]
+        cpu = {k: v.cpu() for k, v in {**{k: v for k, v in inputs.items() if torch.is_tensor(v)}, **{k: v for k, v in tg.items() if torch.is_tensor(v)}}.items()}
+        return [dict(meta=dict(qid=b), model_inputs=dict(
+            query_feat=cpu["src_txt"][b, :lt[b]], video_feat=cpu["src_vid"][b, :lv[b]], timestamp=cpu["timestamp"][b, :lv[b]],
+            timestamp_window=cpu["timestamp_window"][b, :lv[b]], span_labels_nn=cpu["span_labels_nn"][b, :lv[b]],
+            saliency_scores=cpu["saliency_scores"][b, :lv[b]], saliency_pos_labels=[int(cpu["saliency_pos_labels"][b, 0])])) for b in range(len(lv))]
+
+    def run(feed, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for inputs, targets in feed(n):
+            step.step(inputs, targets)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    res = {}
+    for i in range(3):
+        step.step(*batches[i % 2])
+    res["resident"] = dict(ms_per_step=round(run(lambda n: (batches[i % 2] for i in range(n)), steps), 3))
+    sam = [samples_of(b) for b in batches]
+    for name, wire in (("fp32_wire", torch.float32), ("bf16_wire", torch.bfloat16)):
+        t0 = time.perf_counter()
+        pbs = [pack_batch_host(x, feature_dtype=wire) for x in sam]
+        t_pack = (time.perf_counter() - t0) / len(pbs) * 1e3
+        mb = sum(blk.numel() * blk.element_size() for pb in pbs[:1] for blk, _, _, _ in pb.padded.values()) / 1e6
+        pf = DevicePrefetcher(itertools.islice(itertools.cycle(pbs), steps + 3), dev, depth=2, timing=True)
+
+        it = iter(pf)
+        for _ in range(3):                                  # warm-up batches through the same prefetcher
+            _, mi, tg = next(it)
+            step.step(mi, tg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, mi, tg = next(it)
+            step.step(mi, tg)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        next(it, None)                                      # exhausted: the prefetcher folds its side-stream event pairs into stats
+        res[name] = dict(ms_per_step=round(ms, 3), over_resident=round(ms / res["resident"]["ms_per_step"], 4), wire_mb_per_batch=round(mb, 1),
+                         upload_ms_per_batch_side_stream=round(pf.stats["upload_ms"] / max(1, pf.stats["batches"]), 3),
+                         host_enqueue_ms_per_batch=round(pf.stats["host_collate_s"] / max(1, pf.stats["batches"]) * 1e3, 3),
+                         pack_ms_per_batch_one_host_process=round(t_pack, 1))
+    res["what"] = ("the headline TrainStep fed from PINNED HOST memory: PackedHostBatch (univtg_amd.pipeline.pack_batch_host, the collate_fn of the loader's "
+                   "workers; its one-process cost is pack_ms_per_batch_one_host_process, outside the timed loop) -> DevicePrefetcher depth 2 (H2D copies + "
+                   "uvtg_ragged_to_padded on a side stream) -> step; ms_per_step = host wall clock per step over the timed steps; resident = the same loop "
+                   "over batches already in HBM; upload_ms_per_batch_side_stream = device time of one batch's copies + padding kernels (hidden when < the step)")
+    return res
+
+
 def companion_infer(dev, n=20):
     """The inference call (model(...) under no_grad at the default precision + uvtg_postprocess_mr; main/inference_mr.py:88-193) at the
     reference's eval batch 32 and at batch 1 with CLIP-only features (BASELINE config 1's shape), inside the driver-run line."""
@@ -826,6 +885,7 @@ def main():
     # device: each builds (and frees) its own model + multi-GB workspace, and the headline's instrumented passes above must not run behind
     # that allocator traffic (visit r5a: the LayerNorm-forward event pairs of the pass that followed it read 10 ms per step)
     if rank == 0 and world == 1 and not args.no_companions and args.config == 2:
+        comp["with_input_pipeline"] = companion_input_pipeline(dev, step, batches)
         comp["drop_in_autograd"] = companion_drop_in(dev, batches, precise, Lv)
     if rank == 0 and world == 1 and not args.no_companions and args.config == 2 and not args.no_other_configs:
         for cid in (3, 4, 5):

@@ -12,6 +12,18 @@
 extern "C" {
 #endif
 
+/* ---- developer configuration (round 6) -------------------------------------------------------------------------------------------
+ * The library's experiment switches (the UVTG_*_OFF / UVTG_* names quoted in DESIGN.md and profiles/) live in ONE process-wide name -> value
+ * table that starts EMPTY: every switch at its shipped default.  No entry point of libuvtg.so reads the process environment on its own -- a
+ * caller that binds include/uvtg.h cannot be steered by a stray variable.  The developer tools opt in:
+ *   uvtg_dev_config_from_env()      copies every UVTG_* variable of the environment into the table (returns how many); the Python binding
+ *                                   calls it at load time only when UVTG_DEV_ENV=1 is set (tools/ab5.sh and friends set it);
+ *   uvtg_dev_config_set(name, v)    sets (v != NULL) or clears one switch.
+ * A switch is looked up when its launch path first runs and most sites cache the answer: configure before the first launch.  The
+ * uvtg_debug_* setters below are the test suite's run-time toggles for the switches that parity tests flip inside one process. */
+int uvtg_dev_config_from_env(void);
+int uvtg_dev_config_set(const char* name, const char* value);
+
 /* ---- experiment / parity-test knobs of the persistent NT GEMM ----------------------------------------------------------------- */
 /* uvtg_debug_nt_splitk(n): at most n K parts per tile from now on (0 / 1 = never split, default 4); uvtg_debug_nt_splitk_parts: host
  * arithmetic only, the parts an M x N x K launch (K in staged elements: 2 x real columns for split operands) would get on `cus` compute

@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -27,14 +28,36 @@ def test_every_declared_symbol_is_exported(lib):
     dev = open(os.path.join(ROOT, "include", "uvtg_dev.h")).read()
     proto = lambda h: set(re.findall(r"\b(uvtg_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", h, flags=re.S))) - {"uvtg_stream_t"}
     # the public header is what a maintainer binds: no experiment knob or measurement hook in it
-    assert not [n for n in proto(pub) if n.startswith(("uvtg_debug_", "uvtg_profile_"))]
-    assert all(n.startswith(("uvtg_debug_", "uvtg_profile_")) for n in proto(dev)), proto(dev)
+    assert not [n for n in proto(pub) if n.startswith(("uvtg_debug_", "uvtg_profile_", "uvtg_dev_"))]
+    assert all(n.startswith(("uvtg_debug_", "uvtg_profile_", "uvtg_dev_config_")) for n in proto(dev)), proto(dev)
     declared = proto(pub) | proto(dev)
     assert proto(pub) and proto(dev), "no prototypes found"
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/*.h but not exported by libuvtg.so"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.uvtg_version() >= 100
+
+
+def test_library_reads_no_environment_on_its_own():
+    """include/uvtg_dev.h (round 6): the experiment switches live in a table that is empty until a developer entry point fills it -- the
+    only getenv left in the sources is none, and a switch set in the environment changes a launch plan only after
+    uvtg_dev_config_from_env() (host arithmetic: the 320-row tiles of the persistent NT GEMM, UVTG_NT_TM5_OFF)."""
+    import subprocess
+    for f in os.listdir(os.path.join(ROOT, "univtg_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(ROOT, "univtg_amd", "csrc", f)).read()
+            assert not re.search(r"(?<![_a-z])getenv\(", src), f"{f} reads the process environment"
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from univtg_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "if sys.argv[1] == 'explicit': lib.uvtg_dev_config_from_env()\n"
+            "print(lib.uvtg_debug_nt_tile_rows(20158, 1024, 1, 0, 256))\n") % ROOT
+    run = lambda mode, env: subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=300,
+                                           env=dict({k: v for k, v in os.environ.items() if not k.startswith("UVTG_")}, **env))
+    assert run("plain", {}).stdout.split()[-1] == "320"
+    assert run("plain", {"UVTG_NT_TM5_OFF": "1"}).stdout.split()[-1] == "320"                         # a stray variable steers nothing
+    assert run("explicit", {"UVTG_NT_TM5_OFF": "1"}).stdout.split()[-1] != "320"                      # the developer entry point does
+    assert run("plain", {"UVTG_NT_TM5_OFF": "1", "UVTG_DEV_ENV": "1"}).stdout.split()[-1] != "320"    # ... and the binding's opt-in
 
 
 def test_size_queries_and_param_table(lib):

@@ -1112,6 +1112,21 @@ def test_pipeline_collate_upload_matches_reference(dev, golden_dir):
             assert np.array_equal(v.cpu().numpy(), ref) and v.cpu().numpy().dtype == ref.dtype, k
     lv, lt = model_inputs["_lens_host"]
     assert lv == [int(x) for x in z["in/src_vid_mask"].sum(1)] and lt == [int(x) for x in z["in/src_txt_mask"].sum(1)]
+    # the same split at the PCIe boundary (round 6): pack_batch_host in a loader worker -> upload_packed_batch in the training process,
+    # through the prefetcher's side stream
+    from univtg_amd.pipeline import DevicePrefetcher, pack_batch_host
+    for wire in (torch.float32, torch.bfloat16):
+        want = collate_upload_mr(batch, dev, feature_dtype=wire)
+        (got,) = list(DevicePrefetcher([pack_batch_host(batch, feature_dtype=wire)], dev))
+        torch.cuda.synchronize()
+        assert [m["qid"] for m in got[0]] == [m["qid"] for m in want[0]] and got[1]["_lens_host"] == want[1]["_lens_host"]
+        for a, b in ((got[1], want[1]), (got[2], want[2])):
+            assert a.keys() == b.keys()
+            for k in a:
+                if torch.is_tensor(a[k]):
+                    assert torch.equal(a[k], b[k]) and a[k].dtype == b[k].dtype, k
+                elif k == "span_labels":
+                    assert all(torch.equal(x["spans"], y["spans"]) for x, y in zip(a[k], b[k]))
     # bf16 wire format: features rounded to bf16, everything else unchanged
     _, mi16, _ = collate_upload_mr(batch, dev, feature_dtype=torch.bfloat16)
     ref16 = torch.from_numpy(z["in/src_vid"]).to(torch.bfloat16).float().numpy()

@@ -6,7 +6,7 @@ for round in $(seq 1 $ROUNDS); do
   for spec in "$@"; do
     L="${spec%%|*}"; E="${spec#*|}"; X=""
     case "$E" in *"|"*) X="${E#*|}"; E="${E%%|*}";; esac
-    env X_AB=1 $E timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-companions $AB_ARGS $X 2>/dev/null | grep "^{\"metric\"" | tail -1 > /tmp/b.json
+    env UVTG_DEV_ENV=1 $E timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-companions $AB_ARGS $X 2>/dev/null | grep "^{\"metric\"" | tail -1 > /tmp/b.json
     python - "$L" <<'PY'
 import json, sys
 d = json.loads(open('/tmp/b.json').read())

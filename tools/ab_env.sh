@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 A="$1"; B="$2"; shift 2
 for round in 1 2; do
 for E in "$A" "$B"; do
-  env $E timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-padded-compare "$@" 2>/dev/null | tail -1 > /tmp/b.json
+  env UVTG_DEV_ENV=1 $E timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-padded-compare "$@" 2>/dev/null | tail -1 > /tmp/b.json
   python - "${E:-default}" <<'PY'
 import json, sys
 d = json.loads(open('/tmp/b.json').read())

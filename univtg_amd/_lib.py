@@ -31,6 +31,8 @@ _DP = C.POINTER(Dims)
 # name -> (restype, argtypes); the authoritative prototypes are in include/uvtg.h
 SIGNATURES = {
     "uvtg_version": (_I, []),
+    "uvtg_dev_config_from_env": (_I, []),
+    "uvtg_dev_config_set": (_I, [C.c_char_p, C.c_char_p]),
     "uvtg_strerror": (C.c_char_p, [_I]),
     "uvtg_param_count": (_I, [_DP]),
     "uvtg_param_numel": (_I, [_DP, _I, C.POINTER(_LL)]),
@@ -125,6 +127,9 @@ def load():
     if lib.uvtg_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: uvtg_version() = {lib.uvtg_version()}, this binding expects {ABI_VERSION}; rebuild with "
                            "`python -m univtg_amd.build --force`")
+    # developer switches (include/uvtg_dev.h): the library never reads the environment on its own; the tools opt in with UVTG_DEV_ENV=1
+    if os.environ.get("UVTG_DEV_ENV") == "1":
+        lib.uvtg_dev_config_from_env()
     _lib = lib
     return lib
 

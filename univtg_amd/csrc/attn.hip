@@ -1550,14 +1550,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs a, 
 
 static int g_attn_fwd_dma = -1;      // head_dim-128 bf16 forward: LDS-DMA tile loop (default) / 0: the register-staged kernel (parity tests, A-B)
 extern "C" int uvtg_debug_attn_fwd_dma(int on) { g_attn_fwd_dma = on ? 1 : 0; return 0; }
-static const bool g_attn_sample_major = getenv("UVTG_ATTN_SAMPLE_MAJOR") != nullptr;      // experiment: the former (sample, head) order of the tiled kernels' block decode
+static const bool g_attn_sample_major = uvtg_dev_env("UVTG_ATTN_SAMPLE_MAJOR") != nullptr;      // experiment: the former (sample, head) order of the tiled kernels' block decode
 int launch_attn_fwd(const AttnArgs& a0, hipStream_t s) {
   AttnArgs a = a0; a.sample_major = g_attn_sample_major ? 1 : 0;
   if (a.hd != 32 && a.hd != 64 && a.hd != 128) return -5;
   dim3 grid(cdiv(a.S, 128) * a.H * a.B), blk(256);      // decoded by attn_block_id
   uvtg_prof_begin_launch(4, 4.0 * a.B * a.H * (double)a.S * a.S * a.hd, s);
   {   // head_dim 128, bf16, no attention dropout: K / V tiles by LDS-DMA (round 5); the buffer descriptor addresses qkv with 32-bit byte offsets
-    static const bool dma_off = getenv("UVTG_ATTN_FWD_DMA_OFF") != nullptr;
+    static const bool dma_off = uvtg_dev_env("UVTG_ATTN_FWD_DMA_OFF") != nullptr;
     const long long rows_ = a.row_sample ? (long long)a.total_rows : (long long)a.B * a.S;
     const unsigned long long qkv_bytes = (unsigned long long)rows_ * a.ldqkv * 2ull;
     if (a.hd == 128 && !a.precise && a.p_drop <= 0.f && !dma_off && g_attn_fwd_dma != 0 && qkv_bytes < (1ull << 32)) {
@@ -1592,11 +1592,11 @@ int launch_attn_bwd(const AttnArgs& a0, hipStream_t s) {
     UVTG_CHECK_LAUNCH();
   }
   dim3 grid(cdiv(a.S, 128), a.H, a.B), blk(256);
-  static const bool swz_off = getenv("UVTG_ATTN_SWZ_OFF") != nullptr;       // experiment: padded rows instead of the chunk swizzle (head_dim 128)
+  static const bool swz_off = uvtg_dev_env("UVTG_ATTN_SWZ_OFF") != nullptr;       // experiment: padded rows instead of the chunk swizzle (head_dim 128)
   const bool swz = a.hd == 128 && !swz_off;
 #ifdef UVTG_ATTN_ABLATE
   {
-    static const int fabl = getenv("UVTG_ATTN_FABL") ? atoi(getenv("UVTG_ATTN_FABL")) : 0;
+    static const int fabl = uvtg_dev_env("UVTG_ATTN_FABL") ? atoi(uvtg_dev_env("UVTG_ATTN_FABL")) : 0;
     if (fabl > 0 && a.S <= 128 && a.hd == 128 && a.p_drop <= 0.f) {
       switch (fabl) {
         case 1: hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false, 1>), grid, blk, 0, s, a); break;
@@ -1616,7 +1616,7 @@ int launch_attn_bwd(const AttnArgs& a0, hipStream_t s) {
   if (a.S <= 128 && a.p_drop <= 0.f) {   // whole (sample, head) problem in one workgroup: one pass over q, k, v, dO
     // (4-wave kernel: padded rows -- 0.370 vs 0.390 ms per step at config 2: three or four query blocks per workgroup, the XORs and the 16 bytes
     //  of scratch cost more than the transposing reads gain; the 8-wave kernel and the split kernels gain 5 - 8 % from the swizzle)
-    static const bool swz4_on = getenv("UVTG_ATTN_SWZ4_ON") != nullptr;
+    static const bool swz4_on = uvtg_dev_env("UVTG_ATTN_SWZ4_ON") != nullptr;
     if (a.hd == 128) { if (swz && swz4_on) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, true>), grid, blk, 0, s, a); else hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, false>), grid, blk, 0, s, a); }
     else if (a.hd == 64) hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 4, false>), grid, blk, 0, s, a);
     else hipLaunchKernelGGL((attn_bwd_fused_kernel<32, 4, false>), grid, blk, 0, s, a);
@@ -1624,7 +1624,7 @@ int launch_attn_bwd(const AttnArgs& a0, hipStream_t s) {
     UVTG_CHECK_LAUNCH();
     return 0;
   }
-  static const bool fused8_off = getenv("UVTG_ATTN_FUSED8_OFF") != nullptr;      // experiment: the split kernels for 128 < S <= 256
+  static const bool fused8_off = uvtg_dev_env("UVTG_ATTN_FUSED8_OFF") != nullptr;      // experiment: the split kernels for 128 < S <= 256
   if (a.S <= 256 && a.p_drop <= 0.f && !fused8_off) {   // the same with 8 waves / 256 keys (one workgroup per CU)
     const dim3 g8(1, a.H, a.B), b8(512);
     if (a.hd == 128) { if (swz) hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 8, true>), g8, b8, 0, s, a); else hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 8, false>), g8, b8, 0, s, a); }
@@ -1636,12 +1636,12 @@ int launch_attn_bwd(const AttnArgs& a0, hipStream_t s) {
   }
   const dim3 grid1(cdiv(a.S, 128) * a.H * a.B);          // decoded by attn_block_id
   // dQ by LDS-DMA (head_dim 128): the buffer descriptor addresses the qkv matrix with 32-bit byte offsets
-  static const bool dq_dma_off = getenv("UVTG_ATTN_DQ_DMA_OFF") != nullptr;
+  static const bool dq_dma_off = uvtg_dev_env("UVTG_ATTN_DQ_DMA_OFF") != nullptr;
   const unsigned long long qkv_bytes = (unsigned long long)rows * a.ldqkv * 2ull;
   const bool dq_dma = !dq_dma_off && qkv_bytes < (1ull << 32);
 #ifdef UVTG_ATTN_ABLATE
   {
-    static const int abl = getenv("UVTG_ATTN_ABL") ? atoi(getenv("UVTG_ATTN_ABL")) : 0;
+    static const int abl = uvtg_dev_env("UVTG_ATTN_ABL") ? atoi(uvtg_dev_env("UVTG_ATTN_ABL")) : 0;
     if (a.hd == 128 && swz && a.p_drop <= 0.f && abl > 0) {
       switch (abl) {
         case 1: hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, true, 1>), grid1, blk, 0, s, a); break;
@@ -1657,11 +1657,11 @@ int launch_attn_bwd(const AttnArgs& a0, hipStream_t s) {
     }
   }
 #endif
-  static const int ws_prio = getenv("UVTG_ATTN_WS_PRIO") ? atoi(getenv("UVTG_ATTN_WS_PRIO")) : 0;
+  static const int ws_prio = uvtg_dev_env("UVTG_ATTN_WS_PRIO") ? atoi(uvtg_dev_env("UVTG_ATTN_WS_PRIO")) : 0;
   AttnArgs aw = a; aw.ws_prio = ws_prio;
-  static const bool ws_pf1 = getenv("UVTG_ATTN_WS_PF2") == nullptr;      // rows requested one iteration ahead (default; two ahead measured the same and costs the registers the P-wave's operand block needs: UVTG_ATTN_WS_PF2 = experiment)
-  static const bool ws_hdp = !getenv("UVTG_ATTN_WS_KEYP");      // product waves own a head-dim block (default) / UVTG_ATTN_WS_KEYP: a key group (first version)
-  static const bool ws_off = getenv("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
+  static const bool ws_pf1 = uvtg_dev_env("UVTG_ATTN_WS_PF2") == nullptr;      // rows requested one iteration ahead (default; two ahead measured the same and costs the registers the P-wave's operand block needs: UVTG_ATTN_WS_PF2 = experiment)
+  static const bool ws_hdp = !uvtg_dev_env("UVTG_ATTN_WS_KEYP");      // product waves own a head-dim block (default) / UVTG_ATTN_WS_KEYP: a key group (first version)
+  static const bool ws_off = uvtg_dev_env("UVTG_ATTN_WS_OFF") != nullptr;       // experiment: the one-wave-per-SIMD dK / dV kernel at head_dim 128
 #define BWD(HD_, DROP_, SWZ_)                                                                     \
   {                                                                                               \
     if (HD_ == 128 && !ws_off && g_attn_ws != 0) {                                                \

@@ -4,12 +4,45 @@
 // Token-major layout: row (b*S + s) of every [M, *] activation, s < Lv video clips then Lt text tokens.
 #include "uvtg_kernels.h"
 #include <mutex>
+#include <map>
+#include <string>
 #include <cstdlib>
 #include "../../include/uvtg.h"
 #include <cmath>
 #include <cstring>
 
 void uvtg_prof_section(int section, int end, hipStream_t s);   // optim.hip: section timing hooks (bench.py)
+
+// ---- developer configuration (include/uvtg_dev.h) --------------------------------------------------------------------------------
+// name -> value table behind uvtg_dev_env(); empty unless the developer entry points below fill it
+namespace {
+std::mutex g_dev_cfg_mu;
+std::map<std::string, std::string>& dev_cfg_table() { static std::map<std::string, std::string> t; return t; }
+}  // namespace
+const char* uvtg_dev_env(const char* name) {
+  std::lock_guard<std::mutex> lk(g_dev_cfg_mu);
+  auto& t = dev_cfg_table();
+  auto it = t.find(name);
+  return it == t.end() ? nullptr : it->second.c_str();       // (entries are never erased while a caller may hold the pointer: set replaces the value in place)
+}
+extern "C" int uvtg_dev_config_set(const char* name, const char* value) {
+  if (!name || strncmp(name, "UVTG_", 5) != 0) return -20;
+  std::lock_guard<std::mutex> lk(g_dev_cfg_mu);
+  if (value) dev_cfg_table()[name] = value; else dev_cfg_table().erase(name);
+  return 0;
+}
+extern char** environ;
+extern "C" int uvtg_dev_config_from_env(void) {      // copies every UVTG_* variable of the process environment into the table; returns how many
+  int n = 0;
+  for (char** e = environ; e && *e; e++) {
+    if (strncmp(*e, "UVTG_", 5) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    if (!eq) continue;
+    uvtg_dev_config_set(std::string(*e, eq - *e).c_str(), eq + 1);
+    n++;
+  }
+  return n;
+}
 
 namespace {
 
@@ -332,7 +365,7 @@ extern "C" int uvtg_debug_tn_conv_defer(int on) { g_conv_defer = on ? 1 : 0; ret
 static int g_last_clip = -1;
 extern "C" int uvtg_debug_last_layer_clip(int on) { g_last_clip = on ? 1 : 0; return 0; }
 static bool last_layer_clip(const Dm& m) {
-  if (g_last_clip < 0) g_last_clip = getenv("UVTG_LAST_CLIP_OFF") ? 0 : 1;
+  if (g_last_clip < 0) g_last_clip = uvtg_dev_env("UVTG_LAST_CLIP_OFF") ? 0 : 1;
   return g_last_clip == 1 && !m.c.precise && m.c.Lt > 0 && ln_clip_rows_ok(m.c.d);
 }
 // The choice depends on developer knobs (uvtg_debug_last_layer_clip, uvtg_debug_ln_fwd_lean), so uvtg_backward must not re-derive it: a knob
@@ -979,18 +1012,18 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // layer's operands stay in their own buffers and all 5 E gradients go out as ONE launch behind the encoder loop -- 384 tiles over the same
   // rows at config 2, whole tiles per workgroup + half tiles for the remainder, no partial-slab reduce pass (gemm.hip, gemm_tn256h_kernel).
   // With events (data-parallel overlap) each layer's two batches run in place, as before, and their gradients are final at the event.
-  static const bool defer_off = getenv("UVTG_TN_DEFER_OFF") != nullptr;
+  static const bool defer_off = uvtg_dev_env("UVTG_TN_DEFER_OFF") != nullptr;
   // UVTG_TN_DEFER_EVENTS=1 (opt-in, N > 1): keep the deferred launch under readiness events too -- every encoder layer's event is then recorded
   // behind it, i.e. the encoder gradients' all-reduce overlaps only what follows the encoder (saliency branch + input projections).  Which of the
   // two wins depends on the node's all-reduce time; the compute side is measured (bench.py --overlap force).
-  static const bool defer_events = getenv("UVTG_TN_DEFER_EVENTS") != nullptr;
+  static const bool defer_events = uvtg_dev_env("UVTG_TN_DEFER_EVENTS") != nullptr;
   // Round 6 (default under events): the deferral stays, in TWO groups -- the conv heads and layers E-1 .. 1 go out as ONE hybrid launch (and
   // one LayerNorm fold) right behind layer 1's dgrad, their E events recorded together there, while layer 0 (a quarter of the tiles), the
   // saliency branch and the input projections are still to run: the all-reduce of (E - 1) / E of the encoder gradients and of the heads
   // overlaps them; layer 0's own group follows the loop.  The step then runs the kernels of the single-rank step plus one small hybrid launch
   // (bench.py --overlap force).  UVTG_TN_EVENTS_PER_LAYER=1: the per-layer slab + reduce batches of rounds 2-5 (every layer's event behind
   // its own gradients); UVTG_TN_DEFER_EVENTS=1: one launch behind the whole loop, every event there.
-  static const bool events_per_layer = getenv("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
+  static const bool events_per_layer = uvtg_dev_env("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
   const bool defer = (n_events == 0 || !events_per_layer) && !defer_off;
   const int flush_layer = (n_events && defer && !defer_events && E >= 2) ? 1 : -1;      // events: group A is flushed behind this layer
   int events_done = 0;                           // ready_events[0 .. events_done) are recorded
@@ -1085,10 +1118,10 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       all_ok = all_ok && gemm_tn_taps_ok(t);
       cb.g[cb.count++] = t;
     }
-    static const bool cbatch_off = getenv("UVTG_TN_CONVBATCH_OFF") != nullptr;
+    static const bool cbatch_off = uvtg_dev_env("UVTG_TN_CONVBATCH_OFF") != nullptr;
     // round 5: without readiness events they join the encoder's deferred launch (the hybrid kernel takes conv taps and the stride-3 weight
     // layout now: no slab + reduce pass, 1160 instead of 850 TFLOP/s) -- UVTG_TN_CONV_DEFER_OFF / uvtg_debug_tn_conv_defer(0): their own launch, as before
-    if (g_conv_defer < 0) g_conv_defer = getenv("UVTG_TN_CONV_DEFER_OFF") ? 0 : 1;
+    if (g_conv_defer < 0) g_conv_defer = uvtg_dev_env("UVTG_TN_CONV_DEFER_OFF") ? 0 : 1;
     if (all_ok && !cbatch_off && defer && g_conv_defer == 1 && gemm_tn_batch_ok(cb)) { TRY(tn_encoder(cb)); conv_deferred = true; }      // (under events: ready_events[0] is recorded behind the group's launch)
     else if (all_ok && !cbatch_off && gemm_tn_batch_ok(cb)) TRY(launch_gemm_tn_batch(cb, s));
     else for (auto& c : cw) TRY(conv_wgrad(c.dY, c.ldp, c.X, c.ldq, G(m.tail(c.w)), G(m.tail(c.b)), Rf));
@@ -1106,7 +1139,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   const bf16_t* gin = nullptr;                  // null = zero
   // LayerNorm gamma / beta gradients of the encoder: like the weight gradients, without per-layer readiness events every launch keeps its
   // per-block partials in its own buffer and ONE launch folds all 2 E of them behind the loop (was: a 5 us reduce launch behind each)
-  static const bool lnred_off = getenv("UVTG_LN_DEFER_OFF") != nullptr;
+  static const bool lnred_off = uvtg_dev_env("UVTG_LN_DEFER_OFF") != nullptr;
   LnReduceMulti lnm; memset(&lnm, 0, sizeof(lnm)); lnm.D = d;
   int ln_nb = 0;
   auto ln_partials = [&](LnBwdArgs& lb, int slot) {
@@ -1273,7 +1306,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       pb.g[b] = tn_group(gout[b], d, ab, m.kp(which, b), R, d, m.din(which, b), G(m.proj(which, b, PW)), m.din(which, b), G(m.proj(which, b, PB)));
       pb.g[b].splits = splits_v;
     }
-    static const bool pbatch_off = getenv("UVTG_TN_PROJBATCH_OFF") != nullptr;
+    static const bool pbatch_off = uvtg_dev_env("UVTG_TN_PROJBATCH_OFF") != nullptr;
     if (!pbatch_off && nb > 1 && R >= 2048 && gemm_tn_batch_ok(pb)) TRY(launch_gemm_tn_batch(pb, s));
     else for (int b = 0; b < nb; b++) TRY(launch_gemm_tn_bf16(pb.g[b], s));
   }

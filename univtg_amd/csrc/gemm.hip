@@ -1783,7 +1783,7 @@ static bool nt256_ok(const GemmArgs& a) {
     const int cus = ensure_num_cu() ? 256 : eff_cus();
     double c256 = 1e30;
     for (int tm = gather_ ? 4 : 5; tm >= 2; tm--) { const double c = nt256_cost(a.M, a.N, groups, tm, cus); if (c < c256) c256 = c; }
-    static const bool old_choice = getenv("UVTG_NT_OLD_128_CHOICE") != nullptr;
+    static const bool old_choice = uvtg_dev_env("UVTG_NT_OLD_128_CHOICE") != nullptr;
     if (old_choice) {
       const long long t256 = (long long)cdiv(a.M, 256) * cdiv(a.N, 256) * groups;
       const double e256 = (double)t256 / (double)((t256 + 255) / 256 * 256) * 950.0, e128 = (double)t128 / (double)((t128 + 511) / 512 * 512) * 620.0;
@@ -1818,7 +1818,7 @@ extern "C" int uvtg_set_reserved_cus(int k) {
 // the step's shapes).  320-row tiles: plain row mapping only -- the gather variants have no registers left for them; a forced 320 falls back
 // to 256 there.  Returns 0 when the forced height is not a candidate.
 static int nt256_pick_tm(int M, int N, int groups, bool gather, int cus, int force, bool eop = true) {
-  static const bool tm5_off = getenv("UVTG_NT_TM5_OFF") != nullptr;          // experiment: no 320-row tiles
+  static const bool tm5_off = uvtg_dev_env("UVTG_NT_TM5_OFF") != nullptr;          // experiment: no 320-row tiles
   int best_tm = 0; double best = 1e30;
   const int force_bm = (force == 320 && gather) ? 256 : force;
   if (cus < 1) cus = 1;
@@ -1864,9 +1864,9 @@ struct SmallPlan { int tm, parts; double us; };
 static SmallPlan nt256_small_plan(int rows, int N, int groups, int nk, int cus, int cap_units, bool have_ws, int mode);
 static int g_nt_small = -1;          // the single-tile (three-stage ring) variant for launches of at most one tile per CU: 1 on (default), 0 off
 static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, int force, bool eop = true, bool have_ws = false, int cap_units = 0) {
-  static const bool split_off = getenv("UVTG_NT_SPLIT_OFF") != nullptr;      // experiment: single launches only
+  static const bool split_off = uvtg_dev_env("UVTG_NT_SPLIT_OFF") != nullptr;      // experiment: single launches only
   static const bool ovr_env = [] {      // UVTG_NT_PLAN_OVR="M,N,tm1_rows,rows1,tm2_rows;..." = uvtg_debug_nt_plan_override calls (A/B runs of bench.py)
-    const char* e = getenv("UVTG_NT_PLAN_OVR");
+    const char* e = uvtg_dev_env("UVTG_NT_PLAN_OVR");
     while (e && *e) {
       int v[5] = {0, 0, 0, 0, 0}, n = 0;
       if (sscanf(e, "%d,%d,%d,%d,%d%n", &v[0], &v[1], &v[2], &v[3], &v[4], &n) == 5) uvtg_debug_nt_plan_override(v[0], v[1], v[2], v[3], v[4]);
@@ -1883,7 +1883,7 @@ static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, 
   double best = nt256_cost(M, N, groups, pl.tm1, cus, eop);
   const double gap = 24.0 * 1024.0 / (K > 64 ? K : 64);          // ~3 us launch gap in units of one 320-row round at K = 1024 (~326 units ~ 40 us)
   const double us_per_unit = 0.1227 * (K > 64 ? K : 64) / 1024.0;
-  if (g_nt_small < 0) g_nt_small = getenv("UVTG_NT_SMALL_OFF") ? 0 : (getenv("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
+  if (g_nt_small < 0) g_nt_small = uvtg_dev_env("UVTG_NT_SMALL_OFF") ? 0 : (uvtg_dev_env("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
   const int tn_g = cdiv(N, 256) * groups;
   for (int tm1 = gather ? 4 : 5; tm1 >= 3; tm1--) {
     const long long rt_total = cdiv(M, 64 * tm1);
@@ -2014,8 +2014,8 @@ static int g_nt_splitk_max = -1;
 extern "C" int uvtg_debug_nt_small(int on) { if (on < 0 || on > 2) return -21; g_nt_small = on; return 0; }       // (2: 128-row tiles only)
 extern "C" int uvtg_debug_nt_splitk(int max_parts) { if (max_parts < 0 || max_parts > 4) return -21; g_nt_splitk_max = max_parts; return 0; }
 static int nt256_splitk_parts(long long tiles, int nk, int cus, int cap_units) {
-  if (g_nt_splitk_max < 0) g_nt_splitk_max = getenv("UVTG_NT_SPLITK_MAX") ? atoi(getenv("UVTG_NT_SPLITK_MAX")) : 4;
-  static const int max_tiles = getenv("UVTG_NT_SPLITK_MAX_TILES") ? atoi(getenv("UVTG_NT_SPLITK_MAX_TILES")) : 1 << 30;      // experiment: no split above this many tiles
+  if (g_nt_splitk_max < 0) g_nt_splitk_max = uvtg_dev_env("UVTG_NT_SPLITK_MAX") ? atoi(uvtg_dev_env("UVTG_NT_SPLITK_MAX")) : 4;
+  static const int max_tiles = uvtg_dev_env("UVTG_NT_SPLITK_MAX_TILES") ? atoi(uvtg_dev_env("UVTG_NT_SPLITK_MAX_TILES")) : 1 << 30;      // experiment: no split above this many tiles
   if (g_nt_splitk_max < 2 || tiles < 1 || tiles * 2 > cus || tiles > cap_units || tiles > max_tiles) return 0;
   long long parts = cus / tiles;
   if (parts > g_nt_splitk_max) parts = g_nt_splitk_max;
@@ -2070,7 +2070,7 @@ static int nt_order(int tm) {
   static int ord[4] = {-1, -1, -1, -1};
   if (ord[0] < 0) {
     static const int dflt[4] = {0, 0, 1, 1};
-    const char* e = getenv("UVTG_NT_ORD");
+    const char* e = uvtg_dev_env("UVTG_NT_ORD");
     for (int i = 0; i < 4; i++) ord[i] = (e && strlen(e) >= 3 && (int)strlen(e) > i && (e[i] == '0' || e[i] == '1')) ? e[i] - '0' : dflt[i];
   }
   return ord[tm - 2];
@@ -2107,8 +2107,8 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
   if (b.deltaO && (gather || half || b.residB || b.gradPre || !b.delta || b.delta_S <= 0 || b.delta_H <= 0 || (b.delta_hd != 32 && b.delta_hd != 64 && b.delta_hd != 128) ||
                    b.N != b.delta_H * b.delta_hd || b.ldDO % 8)) return -2;
   const bool eop = b.residB || (b.actgrad && b.gradPre) || b.deltaO;
-  static const bool epi_off = getenv("UVTG_NT_EPI_OFF") != nullptr;       // experiment: the general epilogue everywhere
-  static const int epi_mask = getenv("UVTG_NT_EPI_MASK") ? atoi(getenv("UVTG_NT_EPI_MASK")) : 14;      // bit e: specialisation e allowed
+  static const bool epi_off = uvtg_dev_env("UVTG_NT_EPI_OFF") != nullptr;       // experiment: the general epilogue everywhere
+  static const int epi_mask = uvtg_dev_env("UVTG_NT_EPI_MASK") ? atoi(uvtg_dev_env("UVTG_NT_EPI_MASK")) : 14;      // bit e: specialisation e allowed
   int epi = 0;
   if (!epi_off && !gather && b.outB && !b.resid && !b.outF && !b.outU && !b.outUF && !b.pos) {
     if (b.deltaO) epi = 4;
@@ -2134,12 +2134,12 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
     // loop pays for the fold (nt256_small_plan; b.sk = parts per tile, 0 = the persistent kernel).
     b.sk = 0;
     {   // column-group tile order for wide outputs (plain row mapping): UVTG_NT_CGW = tiles per group (0 = off), default off until measured
-      static const int cgw_env = getenv("UVTG_NT_CGW") ? atoi(getenv("UVTG_NT_CGW")) : 0;
+      static const int cgw_env = uvtg_dev_env("UVTG_NT_CGW") ? atoi(uvtg_dev_env("UVTG_NT_CGW")) : 0;
       if (g_nt_cgw < 0) g_nt_cgw = cgw_env;
       b.cgw = (!gather && cdiv(b.N, 256) >= 8) ? g_nt_cgw : 0;
     }
     int small_tm = 0;
-    if (g_nt_small < 0) g_nt_small = getenv("UVTG_NT_SMALL_OFF") ? 0 : (getenv("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
+    if (g_nt_small < 0) g_nt_small = uvtg_dev_env("UVTG_NT_SMALL_OFF") ? 0 : (uvtg_dev_env("UVTG_NT_SMALL_TM1_OFF") ? 2 : 1);
     if (g_nt_small && !b.deltaO && (!plan.rows1 || part == 1) && best_tm == 2 && tiles <= eff_cus() && !g_force_tile && !g_force_bm && !(b.act >= 100 && b.act <= 103)) {
       const SmallPlan sp = nt256_small_plan(rows, b.N, b.groups, b.K / 64, eff_cus(), b.sk_cap_units, b.sk_slab && b.sk_tickets, g_nt_small);
       small_tm = sp.tm; b.sk = sp.parts;
@@ -2165,7 +2165,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
       by += mn * ((b.residB ? 2 : 0) + (b.resid ? 4 : 0) + ((b.actgrad && b.gradPre) ? 2 : 0) + (b.pos ? 4 : 0) + (b.deltaO ? 2 : 0));
       uvtg_prof_add_bytes(3, by);
     }
-    if (g_nt_lw < 0) g_nt_lw = getenv("UVTG_NT_LW") ? atoi(getenv("UVTG_NT_LW")) & 7 : 7;      // bit (TM - 2) = loader waves at that tile height (128 / 192 / 256 rows)
+    if (g_nt_lw < 0) g_nt_lw = uvtg_dev_env("UVTG_NT_LW") ? atoi(uvtg_dev_env("UVTG_NT_LW")) & 7 : 7;      // bit (TM - 2) = loader waves at that tile height (128 / 192 / 256 rows)
     const int lw_mask = g_nt_lw;
     if (small_tm) rc = small_tm == 1 ? launch_nt256_small<1>(b, grid, gather, eop, false, s) : launch_nt256_small<2>(b, grid, gather, eop, false, s);
     else if (!gather && best_tm <= 4 && ((lw_mask >> (best_tm - 2)) & 1) && !(eop && epi == 0 && best_tm >= 4))
@@ -2183,12 +2183,12 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
 
 // can this launch carry the attention-backward delta in its epilogue?  (the persistent 256-wide kernel with the plain row mapping)
 bool gemm_nt_delta_ok(const GemmArgs& a) {
-  static const bool off = getenv("UVTG_DELTA_FUSE_OFF") != nullptr;       // experiment: attn_delta_kernel's own pass
+  static const bool off = uvtg_dev_env("UVTG_DELTA_FUSE_OFF") != nullptr;       // experiment: attn_delta_kernel's own pass
   if (off || g_delta_fuse == 0) return false;
   if (check_nt(a, 2) || ensure_num_cu() || !nt256_ok(a)) return false;
   const int groups = a.groups > 0 ? a.groups : 1;
   const bool gather = a.a_seg || a.o_seg || a.a_off || a.o_off || a.ktap != a.K || groups != 1 || a.o_rows || a.pos_map;
-  static const bool epi_off = getenv("UVTG_NT_EPI_OFF") != nullptr;
+  static const bool epi_off = uvtg_dev_env("UVTG_NT_EPI_OFF") != nullptr;
   return !epi_off && !gather && !a.residB && !a.gradPre && !a.resid && !a.outF && !a.outU && !a.outUF && !a.pos && a.outB && !a.outPre && !a.act && !a.actgrad && !a.rowscale;
 }
 int launch_gemm_nt_bf16(const GemmArgs& a, hipStream_t s) {
@@ -2322,7 +2322,7 @@ static void tnh_plan_counts(int M, int total_tiles, int cus, int& full_tiles, in
   const int rem = total_tiles % cus;
   full_tiles = total_tiles - rem;
   nsplit = rem ? cus / rem : 0;
-  if (g_tnh_max_split < 0) g_tnh_max_split = getenv("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(getenv("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
+  if (g_tnh_max_split < 0) g_tnh_max_split = uvtg_dev_env("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(uvtg_dev_env("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
   if (nsplit > g_tnh_max_split && total_tiles > cus) nsplit = g_tnh_max_split;      // (launches of more than one round: fewer, longer parts instead of the fallback)
   if (nsplit > steps_total / 8) nsplit = steps_total / 8;          // (a part needs a real reduction)
   if (nsplit <= 1) { full_tiles = total_tiles; nsplit = 0; steps_per = steps_total; return; }
@@ -2350,7 +2350,7 @@ static int tnh_max_rows(const GemmTNMulti& b) { int m = 0; for (int i = 0; i < b
 static int tnh_min_rows(const GemmTNMulti& b) { int m = b.g[0].M; for (int i = 1; i < b.count; i++) m = b.g[i].M < m ? b.g[i].M : m; return m; }
 bool gemm_tn_multi_ok(const GemmTNMulti& b) {
   if (g_force_tile == 128 || b.count < 1 || b.count > UVTG_TNH_MAX_GROUPS || !b.slabs || !b.tickets) return false;
-  static const bool off = getenv("UVTG_TN_HYBRID_OFF") != nullptr;       // experiment: always the slab + reduce path
+  static const bool off = uvtg_dev_env("UVTG_TN_HYBRID_OFF") != nullptr;       // experiment: always the slab + reduce path
   if (off) return false;
   for (int i = 0; i < b.count; i++) {
     const GemmTNArgs& a = b.g[i];
@@ -2362,7 +2362,7 @@ bool gemm_tn_multi_ok(const GemmTNMulti& b) {
   const int tiles = tnh_total_tiles(b);
   int full, nsplit, per;
   tnh_plan_counts(tnh_max_rows(b), tiles, tnh_cus(), full, nsplit, per);
-  if (g_tnh_max_split < 0) g_tnh_max_split = getenv("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(getenv("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
+  if (g_tnh_max_split < 0) g_tnh_max_split = uvtg_dev_env("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(uvtg_dev_env("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
   if (nsplit > g_tnh_max_split) return false;                       // the last arriver of a tile folds nsplit - 1 slabs alone: only short folds pay
   if (full == 0 && nsplit == 0) return false;
   if ((long long)(tiles - full) * nsplit * TNH_SLAB > b.slab_floats || tiles - full > b.n_tickets) return false;

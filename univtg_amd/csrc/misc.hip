@@ -1277,7 +1277,7 @@ int launch_saliency_fwd(const SaliencyArgs& a, hipStream_t s) {
 }
 // heads' last layer + activations + text pooling + cosine saliency: ONE launch when every CU gets a sample, else the three per-stage launches
 int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hipStream_t s) {
-  static const bool off = getenv("UVTG_HEADFUSE_OFF") != nullptr;      // experiment: always the separate launches
+  static const bool off = uvtg_dev_env("UVTG_HEADFUSE_OFF") != nullptr;      // experiment: always the separate launches
   const size_t sh = ((size_t)((a.Lt + 3) & ~3) + a.d + 16) * sizeof(float);
   if (off || h.precise || a.B < 128 || (a.d != 512 && a.d != 1024) || sh > 60 * 1024) {
     if (int e = launch_heads_final_fwd(h, s)) return e;
@@ -1285,7 +1285,7 @@ int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hi
   }
   // blocks per sample: 1.  (Round 5 measured 2 and 4 -- each block pooling the text itself, half / a quarter of the clips per wave -- in-box:
   // 9.150 / 9.178 / 9.220 ms per step, profiles/r05_ab_head_pass_blocks.txt: the second pooling costs what the shorter clip walk saves.)
-  static const int split_env = getenv("UVTG_HEADFUSE_SPLIT") ? atoi(getenv("UVTG_HEADFUSE_SPLIT")) : 1;
+  static const int split_env = uvtg_dev_env("UVTG_HEADFUSE_SPLIT") ? atoi(uvtg_dev_env("UVTG_HEADFUSE_SPLIT")) : 1;
   const int ny = (split_env >= 1 && split_env <= 4) ? split_env : 1;
   if (a.d == 1024) hipLaunchKernelGGL(heads_saliency_fwd_kernel<2>, dim3(a.B, ny), dim3(512), sh, s, h, a);
   else hipLaunchKernelGGL(heads_saliency_fwd_kernel<1>, dim3(a.B, ny), dim3(512), sh, s, h, a);

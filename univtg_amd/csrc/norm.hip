@@ -909,7 +909,7 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
   const bool defer = b.defer_blocks && b.partial;      // the caller folds the partials (launch_ln_bwd_reduce_multi)
   if (b.defer_blocks) *b.defer_blocks = defer ? blocks : 0;
   if constexpr (VEC == 8 && NV <= 2) {
-    static const bool lean_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
+    static const bool lean_off = uvtg_dev_env("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
     if (bf && (a.gB || a.g2B) && a.p_drop == 0.f && !a.relu_from_x && !a.gather_x && wpb == 8 && !lean_off) {
       hipLaunchKernelGGL((ln_bwd_lean_kernel<NV>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
       if (b.partial && !defer) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
@@ -981,7 +981,7 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
   const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.yB, a.ldyB, 2, 16) && al(a.yU, a.ldyU, 2, 16) && al(a.yP, a.ldyP, 2, 16) &&
                        al(a.yS, a.ldyS, 2, 16) && al(a.yUS, a.ldyS, 2, 16) && al(a.yPS, a.ldyS, 2, 16);
   if (a.D > 2048 && a.D <= 3072 && a.D % 2 == 0 && align8 && a.x && !a.yF && !a.pos && !a.pos_row && !a.yU && !a.yUF && !a.yP && !a.yPF && !a.addtab && !a.yUS && !a.yPS) {
-    static const bool wave_off = getenv("UVTG_LN_WIDE_WAVE_OFF") != nullptr;     // experiment: the block-per-row kernel
+    static const bool wave_off = uvtg_dev_env("UVTG_LN_WIDE_WAVE_OFF") != nullptr;     // experiment: the block-per-row kernel
     const int dmax = a.Dpad > a.D ? a.Dpad : a.D;
     if (!wave_off && dmax <= 3072 && (a.ldx % 2 == 0) && (!a.yB || a.ldyB % 4 == 0) && (!a.yS || a.ldyS % 4 == 0) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16))
       hipLaunchKernelGGL((ln_fwd_wide_wave_kernel<12>), dim3(cdiv(a.rows, 4)), dim3(256), 0, s, a);     // wave per row
@@ -991,12 +991,12 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
     return 0;
   }
   {   // the encoder's bf16 LayerNorms (round 5): lean kernel, next row in flight
-    if (g_ln_fwd_lean < 0) g_ln_fwd_lean = getenv("UVTG_LN_FWD_LEAN_OFF") ? 0 : 1;
+    if (g_ln_fwd_lean < 0) g_ln_fwd_lean = uvtg_dev_env("UVTG_LN_FWD_LEAN_OFF") ? 0 : 1;
     const bool lean_off = g_ln_fwd_lean == 0;
     const bool plain = a.xB && !a.x && a.p_drop == 0.f && !a.yF && !a.yS && !a.yUS && !a.yPS && !a.yUF && !a.yPF && !a.addtab && !a.src_rows && !a.u_from_x &&
                        !a.xsum && (a.Dpad <= a.D) && (a.D == 1024 || a.D == 512) && alignv8 && !(a.pos_row && a.yP);
     if (plain && !lean_off && (a.rows >= 1024 || a.x_seg || a.x_rows || a.yB_rows)) {
-      static const int blocks_env = getenv("UVTG_LN_FWD_BLOCKS") ? atoi(getenv("UVTG_LN_FWD_BLOCKS")) : 1024;      // (A/B: 512 / 1024 / 2048 measured in round 5)
+      static const int blocks_env = uvtg_dev_env("UVTG_LN_FWD_BLOCKS") ? atoi(uvtg_dev_env("UVTG_LN_FWD_BLOCKS")) : 1024;      // (A/B: 512 / 1024 / 2048 measured in round 5)
       const int blocks = min(cdiv(a.rows, 4), blocks_env > 0 ? blocks_env : 1024);
       if (a.D == 1024) hipLaunchKernelGGL((ln_fwd_lean_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((ln_fwd_lean_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
@@ -1009,8 +1009,8 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
 }
 // the clip-row launches of the last encoder layer need BOTH lean kernels (bf16 streams, D = 512 / 1024, neither switched off)
 bool ln_clip_rows_ok(int D) {
-  if (g_ln_fwd_lean < 0) g_ln_fwd_lean = getenv("UVTG_LN_FWD_LEAN_OFF") ? 0 : 1;
-  static const bool bwd_off = getenv("UVTG_LN_LEAN_OFF") != nullptr;
+  if (g_ln_fwd_lean < 0) g_ln_fwd_lean = uvtg_dev_env("UVTG_LN_FWD_LEAN_OFF") ? 0 : 1;
+  static const bool bwd_off = uvtg_dev_env("UVTG_LN_LEAN_OFF") != nullptr;
   return (D == 512 || D == 1024) && g_ln_fwd_lean == 1 && !bwd_off;
 }
 

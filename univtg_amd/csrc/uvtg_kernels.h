@@ -183,6 +183,10 @@ struct LnBwdArgs {
   int zero_n, zero_seg, zero_stride, zero_off; const int* zero_tab;
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
+// Developer configuration (include/uvtg_dev.h): the experiment switches the launch heuristics consult by name.  The table is EMPTY -- every
+// switch at its shipped default -- until uvtg_dev_config_set / uvtg_dev_config_from_env is called: no entry point of the library reads the
+// process environment on its own.  (A switch is looked up on first use and most call sites cache the answer: configure before the first launch.)
+const char* uvtg_dev_env(const char* name);
 bool ln_clip_rows_ok(int D);     // x_seg launches (forward and backward) will be taken at this width
 long long ln_bwd_partial_floats(int rows, int D);      // floats of `partial` a launch of this shape needs (its per-block dgamma / dbeta rows)
 constexpr int UVTG_LN_MULTI_MAX = 32;      // (2 x the engine's MAXE)
