@@ -276,7 +276,7 @@ def test_attention_delta_from_the_dgrad_epilogue_matches_its_own_pass(dev, packe
     assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
 
 
-@pytest.mark.parametrize("variant", ["droppath_attn_dropout", "txt_pos_512", "packed_halo", "packed_all_clips"])
+@pytest.mark.parametrize("variant", ["droppath_attn_dropout", "txt_pos_512", "packed_halo", "packed_all_clips", "mid_batch_short_clip_groups"])
 def test_last_layer_ffn_half_on_clip_rows_matches_every_row(dev, variant):
     """Round 5: nobody reads the text rows of the encoder output (`vid_mem = memory[:, :L_v]`, model/univtg.py:127), so the LAST layer's
     LayerNorm 1 -> linear1 -> GELU -> linear2 -> LayerNorm 2 -- and their gradients -- run on the B Lv clip rows only (engine.hip,
@@ -295,6 +295,9 @@ def test_last_layer_ffn_half_on_clip_rows_matches_every_row(dev, variant):
     elif variant == "packed_halo":                                  # loss-only stream: valid clips + 3-clip halo + valid text
         cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)
         B = 48
+    elif variant == "mid_batch_short_clip_groups":                  # B Lv = 1800 < 2048 <= B S: the clip-row FFN groups are below the hybrid
+        cfg = O.make_cfg(input_dropout=0.5, dropout=0.0, droppath=0.1)      # weight-gradient kernel's row floor and leave on their own launches,
+        B = 24                                                              # the other 18 groups keep the hybrid launch
     else:                                                           # attention dropout: every clip row (+ valid text when packed)
         cfg = O.make_cfg(input_dropout=0.5, dropout=0.1, droppath=0.1)
         B = 48
@@ -1253,6 +1256,11 @@ def test_hip_graph_inference_replays_the_eager_call(dev):
         bb = batch(B, Lv, Lt, 10 + i)
         same(small(bb[0]["src_txt"], bb[0]["src_txt_mask"], bb[0]["src_vid"], bb[0]["src_vid_mask"], *bb[1:]), eager(*bb))
         assert len(small._graphs) <= 2
+    # four calls over three shapes through two slots: the first shape was evicted before it came back -- four captures, two evictions, no hit
+    assert small.stats == dict(hits=0, captures=4, evictions=2, recaptures_after_parameter_update=0), small.stats
+    bb = batch(4, 20, 8, 13)
+    small(bb[0]["src_txt"], bb[0]["src_txt_mask"], bb[0]["src_vid"], bb[0]["src_vid_mask"], *bb[1:])
+    assert small.stats["hits"] == 1
 
 
 def test_bench_two_rank_control_flow(dev):

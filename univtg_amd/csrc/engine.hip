@@ -1052,6 +1052,20 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       }
     }
     if (fits && gemm_tn_multi_ok(mu)) return launch_gemm_tn_multi(mu, s);
+    if (fits) {
+      // groups over too few rows for the hybrid kernel (mid-size batches: B Lv < 2048 <= B S puts the last layer's clip-row FFN groups and the
+      // conv-head groups below its row floor) leave on their own launches; the long groups keep the hybrid launch
+      GemmTNMulti lng = mu; lng.count = 0;
+      GemmTNArgs shrt[UVTG_TNH_MAX_GROUPS]; int n_short = 0;
+      for (int i = 0; i < mu.count; i++) { if (mu.g[i].M >= 2048) lng.g[lng.count++] = mu.g[i]; else shrt[n_short++] = mu.g[i]; }
+      bool short_ok = true;       // (a conv-tap group below the 256-tile kernel's row floor has no single launch: the whole set then takes the fallback below)
+      for (int i = 0; i < n_short; i++) short_ok = short_ok && (shrt[i].ktap == 0 || gemm_tn_taps_ok(shrt[i]));
+      if (n_short && lng.count && short_ok && gemm_tn_multi_ok(lng)) {
+        TRY(launch_gemm_tn_multi(lng, s));
+        for (int i = 0; i < n_short; i++) TRY(launch_gemm_tn_bf16(shrt[i], s));
+        return 0;
+      }
+    }
     for (int i = 0; i < n_deferred; i++) TRY(tn_batch(deferred[i]));            // shapes the hybrid launch does not take: the split + reduce path
     return 0;
   };

@@ -1863,7 +1863,7 @@ extern "C" int uvtg_debug_nt_plan_override(int M, int N, int tm1_rows, int rows1
 struct SmallPlan { int tm, parts; double us; };
 static SmallPlan nt256_small_plan(int rows, int N, int groups, int nk, int cus, int cap_units, bool have_ws, int mode);
 static int g_nt_small = -1;          // the single-tile (three-stage ring) variant for launches of at most one tile per CU: 1 on (default), 0 off
-static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, int force, bool eop = true, bool have_ws = false, int cap_units = 0) {
+static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, int force, bool eop = true, bool have_ws = false, int cap_units = 0, bool can_small = true) {
   static const bool split_off = uvtg_dev_env("UVTG_NT_SPLIT_OFF") != nullptr;      // experiment: single launches only
   static const bool ovr_env = [] {      // UVTG_NT_PLAN_OVR="M,N,tm1_rows,rows1,tm2_rows;..." = uvtg_debug_nt_plan_override calls (A/B runs of bench.py)
     const char* e = uvtg_dev_env("UVTG_NT_PLAN_OVR");
@@ -1895,7 +1895,7 @@ static NtPlan nt256_plan(int M, int N, int K, int groups, bool gather, int cus, 
     const double head = nt256_cost((int)rows1, N, groups, tm1, cus, eop);
     for (int tm2 = 2; tm2 <= 4; tm2++) {
       double tail = nt256_cost(M - (int)rows1, N, groups, tm2, cus, eop);
-      if (tm2 == 2 && g_nt_small && (long long)cdiv(M - (int)rows1, 128) * cdiv(N, 256) * groups <= cus) {
+      if (tm2 == 2 && g_nt_small && can_small && (long long)cdiv(M - (int)rows1, 128) * cdiv(N, 256) * groups <= cus) {      // (can_small: launch_nt256 keeps delta-carrying launches off the single-tile variant -- ADVICE r5)
         // a tail of at most one 128-row tile per CU runs the single-tile variant (launch_nt256): priced by that variant's own estimate
         const SmallPlan sp = nt256_small_plan(M - (int)rows1, N, groups, K / 64, cus, cap_units, have_ws, g_nt_small);
         if (sp.tm) tail = sp.us / us_per_unit;
@@ -2118,7 +2118,7 @@ static int launch_nt256(const GemmArgs& a, hipStream_t s, bool half = false) {
   }
   if (epi != 4 && !((epi_mask >> epi) & 1)) epi = 0;
   if (b.deltaO && epi != 4) return -2;       // (gemm_nt_delta_ok() is the contract: plain bf16 out, nothing else in the epilogue)
-  const NtPlan plan = nt256_plan(b.M, b.N, b.K, b.groups, gather, eff_cus(), g_force_bm, eop, b.sk_slab && b.sk_tickets, b.sk_cap_units);
+  const NtPlan plan = nt256_plan(b.M, b.N, b.K, b.groups, gather, eff_cus(), g_force_bm, eop, b.sk_slab && b.sk_tickets, b.sk_cap_units, !b.deltaO);
   if (!plan.tm1) return -21;
   const int M_all = b.M;
   int rc = 0;

@@ -499,9 +499,7 @@ __global__ __launch_bounds__(NV * VEC > 32 ? 128 : 512, (NV * VEC <= 16) ? UVTG_
 //  * the next row's x / g (/ g2) are fetched, still PACKED (4 registers per 16 bytes), before the current row's math;
 //  * dgamma / dbeta accumulate in the wave's LDS slab and gamma is read from LDS: 48 fewer live registers than ln_bwd_kernel,
 //    which spilled 20 dwords inside the row loop at its 128-register (4 waves per SIMD) budget.
-// Round 6: a wave keeps RA row SLOTS (packed registers): while slot u is worked on the other slots' rows are in flight, and slot u is refilled
-// right behind its last use -- with <= 16 waves per CU (the LDS slabs) the single prefetched row of rounds 4-5 left the kernel at 3.9 TB/s.
-template <int NV, int RA = 2>
+template <int NV>
 __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) {
   extern __shared__ float red[];       // [waves][2][D] dgamma / dbeta partials, then gamma [D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -513,19 +511,19 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
   __syncthreads();
   const int stride = gridDim.x * wpb;
   const bool have_g2 = a.g2B != nullptr;
-  u32x4 px[RA][NV], pg[RA][NV], pg2[RA][NV];
-  float pmean[RA], prstd[RA];
+  u32x4 px[NV], pg[NV], pg2[NV];
+  float pmean = 0.f, prstd = 0.f;
   auto xrow_of = [&](int r) -> size_t { return a.x_rows ? (size_t)a.x_rows[r] : (a.x_seg ? (size_t)(r / a.x_seg) * a.x_seg_stride + (size_t)(r % a.x_seg) : (size_t)r); };
-  auto fetch = [&](int u, int r) {            // r is clamped by the caller: always a legal row
+  auto fetch = [&](int r) {            // r is clamped by the caller: always a legal row
     const size_t row = (size_t)r, xrow = xrow_of(r);
-    pmean[u] = a.mean[row]; prstd[u] = a.rstd[row];
+    pmean = a.mean[row]; prstd = a.rstd[row];
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = (i * 64 + lane) * 8;
-      px[u][i] = (u32x4){0, 0, 0, 0}; pg[u][i] = (u32x4){0, 0, 0, 0}; pg2[u][i] = (u32x4){0, 0, 0, 0};
+      px[i] = (u32x4){0, 0, 0, 0}; pg[i] = (u32x4){0, 0, 0, 0}; pg2[i] = (u32x4){0, 0, 0, 0};
       if (c < D) {
-        px[u][i] = *(const u32x4*)(a.xB + xrow * a.ldxB + c);
-        if (a.gB) pg[u][i] = *(const u32x4*)(a.gB + row * a.ldgB + c);       // (the top layer has only the heads' gradient: g2)
+        px[i] = *(const u32x4*)(a.xB + xrow * a.ldxB + c);
+        if (a.gB) pg[i] = *(const u32x4*)(a.gB + row * a.ldgB + c);       // (the top layer has only the heads' gradient: g2)
       }
     }
     if (have_g2) {
@@ -541,23 +539,19 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
 #pragma unroll
         for (int i = 0; i < NV; i++) {
           const int c = (i * 64 + lane) * 8;
-          if (c < D) pg2[u][i] = *(const u32x4*)(a.g2B + r2 * a.ldg2B + c);
+          if (c < D) pg2[i] = *(const u32x4*)(a.g2B + r2 * a.ldg2B + c);
         }
       }
     }
   };
-  int row0 = blockIdx.x * wpb + wave;
-  if (row0 < a.rows) {
+  int row = blockIdx.x * wpb + wave;
+  if (row < a.rows) fetch(row);
+  for (; row < a.rows; row += stride) {
+    u32x4 cx[NV], cg[NV], cg2[NV];
 #pragma unroll
-    for (int u = 0; u < RA; u++) fetch(u, min(row0 + u * stride, a.rows - 1));
-  }
-  // RA slots, no copies: slot u is worked on while the other slots' rows are in flight, and is refilled (row + RA * stride) right behind its last use
-  for (; row0 < a.rows; row0 += RA * stride) {
-#pragma unroll
-    for (int u = 0; u < RA; u++) {
-    const int row = row0 + u * stride;
-    if (row >= a.rows) break;                  // (wave-uniform)
-    const float mean = pmean[u], rstd = prstd[u];
+    for (int i = 0; i < NV; i++) { cx[i] = px[i]; cg[i] = pg[i]; cg2[i] = pg2[i]; }
+    const float mean = pmean, rstd = prstd;
+    fetch(min(row + stride, a.rows - 1));
     float xh[NV][8], gh[NV][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -567,10 +561,10 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
         float g[8];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          xh[i][2 * e] = (__uint_as_float(px[u][i][e] << 16) - mean) * rstd;
-          xh[i][2 * e + 1] = (__uint_as_float(px[u][i][e] & 0xffff0000u) - mean) * rstd;
-          g[2 * e] = __uint_as_float(pg[u][i][e] << 16) + __uint_as_float(pg2[u][i][e] << 16);
-          g[2 * e + 1] = __uint_as_float(pg[u][i][e] & 0xffff0000u) + __uint_as_float(pg2[u][i][e] & 0xffff0000u);
+          xh[i][2 * e] = (__uint_as_float(cx[i][e] << 16) - mean) * rstd;
+          xh[i][2 * e + 1] = (__uint_as_float(cx[i][e] & 0xffff0000u) - mean) * rstd;
+          g[2 * e] = __uint_as_float(cg[i][e] << 16) + __uint_as_float(cg2[i][e] << 16);
+          g[2 * e + 1] = __uint_as_float(cg[i][e] & 0xffff0000u) + __uint_as_float(cg2[i][e] & 0xffff0000u);
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -591,7 +585,6 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
         for (int e = 0; e < 8; e++) { xh[i][e] = 0.f; gh[i][e] = 0.f; }
       }
     }
-    fetch(u, min(row + RA * stride, a.rows - 1));          // the slot's packed registers are free: its next row goes out now
     const float c1 = wave_sum_dpp(s1) / (float)D, c2 = wave_sum_dpp(s2) / (float)D;
     const float rs = a.rowscale ? a.rowscale[a.row_sample ? a.row_sample[row] : row / a.rs_seg] : 1.0f;
     const size_t orow = xrow_of(row);
@@ -610,7 +603,6 @@ __global__ __launch_bounds__(512, 4) void ln_bwd_lean_kernel(const LnBwdArgs a) 
           storeb<8>(a.dxB + orow * a.lddxB + c, dx);
         }
       }
-    }
     }
   }
   // clip-row launch of the last encoder layer: the rows of the gradient stream that have no clip row behind them (text rows) are zero
@@ -919,11 +911,7 @@ template <int VEC, int NV> int run_bwd(const LnBwdArgs& a, hipStream_t s) {
   if constexpr (VEC == 8 && NV <= 2) {
     static const bool lean_off = uvtg_dev_env("UVTG_LN_LEAN_OFF") != nullptr;       // experiment: the generic kernel
     if (bf && (a.gB || a.g2B) && a.p_drop == 0.f && !a.relu_from_x && !a.gather_x && wpb == 8 && !lean_off) {
-      static const bool ra1 = uvtg_dev_env("UVTG_LN_BWD_RA1") != nullptr;       // experiment: one row per wave in flight (rounds 4-5)
-      static const int ra = uvtg_dev_env("UVTG_LN_BWD_SLOTS") ? atoi(uvtg_dev_env("UVTG_LN_BWD_SLOTS")) : 2;       // experiment: row slots per wave (3 spills at D = 1024)
-      if (ra <= 1) hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, 1>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
-      else if (ra == 2) hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, 2>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
-      else hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, 3>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
+      hipLaunchKernelGGL((ln_bwd_lean_kernel<NV>), dim3(blocks), dim3(512), (size_t)(wpb * 2 + 1) * a.D * sizeof(float), s, b);
       if (b.partial && !defer) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * b.D, 64), blocks >= 128 ? 8 : 1), dim3(256), 0, s, b, blocks);
       UVTG_CHECK_LAUNCH();
       return 0;

@@ -13,7 +13,10 @@ The returned tensors are the graph's static output buffers: consume (or clone) t
 (`clone_outputs=True` hands out copies instead).  There is no fallback: shapes are captured on first use (two eager warm-up calls on a side
 stream, then the capture).  Every captured shape keeps its own workspace (incl. the 32 MB split-K slab) inside the graph's memory pool, and the
 reference's evaluation loop pads each batch to its own maximum length: the cache is an LRU of `max_graphs` shapes (default 8; the least
-recently used graph and its pool are dropped).  (Padding the lengths up to a few bucket sizes would let shapes share graphs, but it is NOT exact:
+recently used graph and its pool are dropped -- unless the caller still holds the static output tensors handed out for that shape
+(`clone_outputs=False`): those keep the evicted pool's blocks alive until they are released; `stats` counts hits, captures and evictions,
+and a loader that cycles through more than `max_graphs` distinct shapes re-captures on every miss (2 eager warm-up calls + a device
+synchronisation + the capture): size `max_graphs` for the shapes of one evaluation pass or call the model eagerly).  (Padding the lengths up to a few bucket sizes would let shapes share graphs, but it is NOT exact:
 the k = 3 conv heads of a maximum-length sample see encoder outputs of padded clips where the unpadded call sees the zero frame -- measured
 0.23 on `pred_logits` at the last valid clips -- so it is not offered.)
 """
@@ -39,6 +42,7 @@ class GraphedInference:
         self._graphs = {}                                   # insertion-ordered: least recently used first
         self.max_graphs = max(1, int(max_graphs))
         self.clone_outputs = bool(clone_outputs)
+        self.stats = dict(hits=0, captures=0, evictions=0, recaptures_after_parameter_update=0)
 
     def _call(self, st):
         with torch.no_grad():
@@ -63,6 +67,8 @@ class GraphedInference:
         self._graphs.pop(key, None)
         while len(self._graphs) >= self.max_graphs:         # LRU eviction: drop the oldest graph (and with it its memory pool)
             self._graphs.pop(next(iter(self._graphs)))
+            self.stats["evictions"] += 1
+        self.stats["captures"] += 1
         self._graphs[key] = (graph, static, outs, self.model._param_epoch, tuple(p._version for p in self.model._ordered_params()))
         return self._graphs[key]
 
@@ -79,8 +85,11 @@ class GraphedInference:
         sig = (self.model._param_epoch, tuple(p._version for p in self.model._ordered_params()))
         if ent is not None and (ent[3], ent[4]) != sig:     # parameters changed: the captured call holds the old bf16 / split operands
             ent = None
+            self.stats["recaptures_after_parameter_update"] += 1
         if ent is None:
             ent = self._capture(key, tensors)
+        else:
+            self.stats["hits"] += 1
         self._graphs[key] = self._graphs.pop(key)            # most recently used
         graph, static, outs = ent[:3]
         for k, v in tensors.items():

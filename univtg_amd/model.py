@@ -138,12 +138,17 @@ class _UniVTGFunction(torch.autograd.Function):
         if training:
             ctx.model, ctx.dims, ctx.ws, ctx.wcache, ctx.lens = model, dims, ws, wcache, lens
             ctx.save_for_backward(src_txt, src_txt_mask, src_vid, src_vid_mask, x0, pred_logits, pred_spans, txt_mem, *params)
-        ctx.mark_non_differentiable(*([memory] if memory is not None else []))
-        outs = (x0, pred_logits, pred_spans, txt_mem, sal)
+        # vid_mem_proj = x0[:, :Lv] leaves as an output of its own (a view): its gradient then arrives as the [B, Lv, d] tensor the criterion
+        # wrote, not as a zero-filled [B, S, d] copy made by the slice's backward (190 MB of traffic per step at config 2); x0 itself is not
+        # differentiable (nothing but that view is handed out), and absent upstream gradients stay None instead of materialised zeros
+        vid_mem = x0[:, :Lv]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(x0, *([memory] if memory is not None else []))
+        outs = (x0, pred_logits, pred_spans, txt_mem, sal, vid_mem)
         return outs + ((memory,) if memory is not None else ())
 
     @staticmethod
-    def backward(ctx, g_x0, g_logits, g_spans, g_txt, g_sal, *unused):
+    def backward(ctx, g_x0, g_logits, g_spans, g_txt, g_sal, g_vid, *unused):
         lib = _lib.load()
         model, dims = ctx.model, ctx.dims
         src_txt, src_txt_mask, src_vid, src_vid_mask, x0, pred_logits, pred_spans, txt_mem, *params = ctx.saved_tensors
@@ -153,11 +158,11 @@ class _UniVTGFunction(torch.autograd.Function):
         gaps = model._offset_gaps(offs, params, x0.device)
         if gaps is not None:                           # alignment gaps between the parameters' ranges: FusedAdamWClip reads the buffer whole
             grads.index_fill_(0, gaps, 0.0)
-        g = [None if t is None else _f32c(t) for t in (g_logits, g_spans, g_sal, g_txt, g_x0)]
-        S, d = x0.shape[1], x0.shape[2]
+        g = [None if t is None else _f32c(t) for t in (g_logits, g_spans, g_sal, g_txt, g_vid)]
+        Lv, d = pred_logits.shape[1], x0.shape[2]
         _lib.check(lib.uvtg_backward(C.byref(dims), ptrs, _ptr(ctx.wcache), _ptr(src_txt), _ptr(src_txt_mask), _ptr(src_vid),
                                      _ptr(src_vid_mask), _ptr(x0), _ptr(pred_logits), _ptr(pred_spans), _ptr(txt_mem),
-                                     _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), S * d, d, None, None,
+                                     _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), Lv * d, d, None, None,
                                      _ptr(grads), _ptr(ctx.ws), _stream(), None, 0, ctx.lens), "uvtg_backward")
         ctx.ws = None
         out = [None] * 6
@@ -328,12 +333,11 @@ class Model(nn.Module):
         args = [_f32c(t) for t in (src_txt, src_txt_mask, src_vid, src_vid_mask)]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         res = _UniVTGFunction.apply(self, need_grad, *args, *params)
-        x0, pred_logits, pred_spans, txt_mem, sal = res[:5]
-        Lv = src_vid.shape[1]
+        x0, pred_logits, pred_spans, txt_mem, sal, vid_mem = res[:6]
         out = {"pred_logits": pred_logits, "pred_spans": pred_spans, "src_vid_mask": src_vid_mask,
-               "vid_mem_proj": x0[:, :Lv], "txt_mem_proj": txt_mem, "saliency_scores": sal}
+               "vid_mem_proj": vid_mem, "txt_mem_proj": txt_mem, "saliency_scores": sal}
         if self.return_memory:
-            out["memory"] = res[5]
+            out["memory"] = res[6]
         return out
 
 
