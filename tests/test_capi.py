@@ -134,7 +134,7 @@ def test_plain_c_consumer_links_and_runs(lib, tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "version 303 params 78 " in out.stdout and "n_proj=3 use_txt_pos=1 params 89" in out.stdout and "bad struct_size -> -18" in out.stdout
+    assert "version 304 params 78 " in out.stdout and "n_proj=3 use_txt_pos=1 params 89" in out.stdout and "bad struct_size -> -18" in out.stdout
 
 
 def test_no_cpu_fallback(golden_dir):

@@ -23,7 +23,7 @@ class Dims(C.Structure):
         self.struct_size = C.sizeof(Dims)
 
 
-ABI_VERSION = 303          # uvtg_version() this binding was written against
+ABI_VERSION = 304          # uvtg_version() this binding was written against
 
 
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
