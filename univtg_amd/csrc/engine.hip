@@ -1029,10 +1029,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   static const bool events_per_layer = uvtg_dev_env("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
   const bool defer = (n_events == 0 || !events_per_layer) && !defer_off;
   const int flush_layer = (n_events && defer && !defer_events && E >= 2) ? 1 : -1;      // events: group A is flushed behind this layer
-  // experiment (UVTG_TN_GROUP_MID0=1): group A leaves behind layer 0's FFN half instead -- it then also carries layer 0's two FFN gradients
-  // (final by then), and layer 0's own group shrinks to the three attention-block gradients: 64 tiles = a quarter round, cut four ways
-  static const bool group_mid0 = uvtg_dev_env("UVTG_TN_GROUP_MID0") != nullptr;
-  const bool flush_mid0 = group_mid0 && flush_layer == 1;
   int events_done = 0;                           // ready_events[0 .. events_done) are recorded
   GemmTNBatch deferred[2 * MAXE + 1]; int n_deferred = 0;
   auto tn_encoder = [&](const GemmTNBatch& b) -> int {
@@ -1211,12 +1207,6 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
       tb.g[1] = tn_group(da, F, (const bf16_t*)ws.x1b[l], d, Mf, F, d, G(m.lay(l, L1W)), d, G(m.lay(l, L1B)));
       TRY(tn_encoder(tb));
     }
-    if (flush_mid0 && l == 0) {                  // (experiment) group A here: heads + layers E-1 .. 1 + this layer's FFN gradients
-      TRY(launch_ln_bwd_reduce_multi(lnm, s));
-      lnm.count = 0;
-      TRY(tn_flush_group());
-      for (; events_done < E; events_done++) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[events_done], s)) return (int)e; }
-    }
     g = gemm_base(da, F, w.w1T[l], F, Mf, d, F);                       // dx1 = da W1 + dy2
     g.residB = dyRes; g.ldrB = d; g.outB = ws.gxb[0]; g.ldoB = d;
     TRY(launch_gemm_nt_bf16(g, s));
@@ -1269,7 +1259,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     }
     gin = ws.gxb[1];  // consumed by the next (lower) layer's LN2 backward before gxb[0] / gxb[1] are rewritten
     if (n_events && !defer) { if (hipError_t e = hipEventRecord((hipEvent_t)ready_events[1 + (E - 1 - l)], s)) return (int)e; events_done = 2 + (E - 1 - l); }   // layer l gradients final
-    if (l == flush_layer && !flush_mid0) {       // group A: the heads + layers E-1 .. l, one LayerNorm fold + one hybrid launch, their events together
+    if (l == flush_layer) {                      // group A: the heads + layers E-1 .. l, one LayerNorm fold + one hybrid launch, their events together
       TRY(launch_ln_bwd_reduce_multi(lnm, s));
       lnm.count = 0;
       TRY(tn_flush_group());

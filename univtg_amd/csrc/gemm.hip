@@ -2363,7 +2363,7 @@ bool gemm_tn_multi_ok(const GemmTNMulti& b) {
   int full, nsplit, per;
   tnh_plan_counts(tnh_max_rows(b), tiles, tnh_cus(), full, nsplit, per);
   if (g_tnh_max_split < 0) g_tnh_max_split = uvtg_dev_env("UVTG_TN_HYBRID_MAXSPLIT") ? atoi(uvtg_dev_env("UVTG_TN_HYBRID_MAXSPLIT")) : 3;
-  if (nsplit > g_tnh_max_split && !(full == 0 && nsplit == 4)) return false;      // the last arriver of a tile folds nsplit - 1 slabs alone: only short folds pay (a launch of at most a quarter round may cut four ways)
+  if (nsplit > g_tnh_max_split) return false;                       // the last arriver of a tile folds nsplit - 1 slabs alone: only short folds pay
   if (full == 0 && nsplit == 0) return false;
   if ((long long)(tiles - full) * nsplit * TNH_SLAB > b.slab_floats || tiles - full > b.n_tickets) return false;
   return tnh_min_rows(b) >= 2048;
