@@ -813,7 +813,7 @@ def main():
         # from THESE kernels (the file carries the hash of the GEMM sources; the GPU box has no .git to compare a HEAD with)
         traffic, traffic_note, traffic_ratio = None, None, None
         alg_bytes = int(pby[dom] / max(1, n[dom])) if pby[dom] > 0 else None      # counted by the library on this run's own launches
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_nt256.json", "r04_pmc_nt256.json", "r03_pmc_nt256.json")) if os.path.exists(q)), None)
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_nt256.json", "r05_pmc_nt256.json", "r04_pmc_nt256.json")) if os.path.exists(q)), None)
         if fam[dom] == "gemm_nt256_kernel" and pmc:
             with open(pmc) as f:
                 pj = json.load(f)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-5 artifact set (lands in gpurun_out/; what is judged is copied into profiles/): GPU suite + smoke, PMC passes of the dominant GEMM (copied
+# Round-6 artifact set (round 5: the same script, tag r05) (lands in gpurun_out/; what is judged is copied into profiles/): GPU suite + smoke, PMC passes of the dominant GEMM (copied
 # into profiles/ ON THE BOX so that the bench line that follows quotes them), the default bench line (reference CPU baseline, every config as a
 # companion), rocprofv3 --kernel-trace --stats of the bench command, per-step kernel tables of configs 2 and 4, the inference line
 set -u
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r05}
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r06}
 OUT=$R/gpurun_out; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/${TAG}_pytest_gpu.log | cut -c1-200
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > $OUT/${TAG}_smoke.log; cat $OUT/${TAG}_smoke.log
