@@ -167,6 +167,21 @@ int uvtg_criterion_bwd(int B, int Lv, int d, int which, float eos_coef,
                        float* g_logits, float* g_spans, float* g_vid, float* g_txt, float* g_cos, float* g_vrow,
                        const float* cos_cached, const float* vnorm_cached, const float* qnorm_cached /* as passed to _fwd */,
                        uvtg_stream_t stream);
+/* ---- class term of the 'saliency_cls' loss: replaces model/univtg.py:314-324 and its autograd (the TAL pre-training branch, selected by
+ * 'tal' in train_path, model/univtg.py:436-438).  v_b = vid[b*vid_sb + pos_idx[b]*vid_st + .], cls [C,d] = cls_mem_proj (the class-name
+ * features pooled by the text path of uvtg_forward), cls_idx [B,C] 0 / 1 (multi-hot, as float):
+ * loss = - sum over marked (b,j) of log_softmax_j(cos(v_b, cls_j) / 0.07) / #marked.  `active` (device, may be NULL): losses_out + 5 of
+ * uvtg_criterion_fwd -- the saliency_scores.sum() == 0 early-out (model/univtg.py:288-290) zeroes loss and gradients without a host sync.
+ * ws: uvtg_cls_nce_ws_floats(B, C) floats, shared by _fwd and _bwd.  _bwd: go [1] = upstream gradient of the loss; g_vid is a gradient
+ * buffer for vid_mem_proj ZERO-FILLED by the caller, addressed like vid with (gv_sb, gv_st): row pos_idx[b] of sample b is written;
+ * g_cls [C,d] is overwritten. */
+long long uvtg_cls_nce_ws_floats(int B, int C);
+int uvtg_cls_nce_fwd(int B, int C, int d, const float* vid, long long vid_sb, long long vid_st, const long long* pos_idx,
+                     const float* cls, const float* cls_idx, const float* active, float* ws, float* loss_out, uvtg_stream_t stream);
+int uvtg_cls_nce_bwd(int B, int C, int d, const float* vid, long long vid_sb, long long vid_st, const long long* pos_idx,
+                     const float* cls, const float* cls_idx, const float* active, float* ws, const float* go,
+                     float* g_vid, long long gv_sb, long long gv_st, float* g_cls, uvtg_stream_t stream);
+
 /* Where the saliency pass of the last uvtg_forward on `workspace` left cosine(vid_mem_proj, txt_mem_proj) [B,Lv], |vid_mem_proj| [B,Lv] and
  * |txt_mem_proj| [B] (device addresses inside the workspace; valid until the next uvtg_forward on it). */
 int uvtg_forward_saliency_stats(const uvtg_dims* dm, void* workspace, const float** cosv, const float** vnorm, const float** qnorm);

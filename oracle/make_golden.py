@@ -95,16 +95,36 @@ def npify(prefix, d, store):
             store[f"{prefix}{k}"] = v.detach().cpu().numpy()
 
 
+def make_cls_inputs(cfg, B, n_cls, L_c, seed):
+    """Synthetic class-name token features of the TAL branch (main/train_vlp.py:116-122 hands the model `train_dataset.src_cls`, which no
+    shipped dataset defines -- shapes follow the text features: (n_cls, L_c, D_t) l2-normalised rows, prefix masks) and a multi-hot
+    targets['cls_idx'] (B, n_cls) with at least one class per sample."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, L_c + 1, (n_cls,), generator=g)
+    lens[0] = L_c
+    src_cls = torch.zeros(n_cls, L_c, cfg.t_feat_dim)
+    mask = torch.zeros(n_cls, L_c)
+    for j in range(n_cls):
+        src_cls[j, :int(lens[j])] = torch.nn.functional.normalize(torch.randn(int(lens[j]), cfg.t_feat_dim, generator=g), dim=1)
+        mask[j, :int(lens[j])] = 1
+    idx = torch.zeros(B, n_cls)
+    idx[torch.arange(B), torch.randint(n_cls, (B,), generator=g)] = 1
+    idx[0, torch.randint(n_cls, (1,), generator=g)] = 1          # one sample with (possibly) two classes
+    return src_cls, mask, idx
+
+
 def run_case(ref, name, cfg, B, L_v, L_t, seed, ragged, curve=False, train_droppath=False,
-             real_feats=False, dtype=torch.float32, dset_type="vlp", zero_saliency=False, drop_pos_labels=False):
+             real_feats=False, dtype=torch.float32, dset_type="vlp", zero_saliency=False, drop_pos_labels=False, tal=None):
     """dset_type='hl': the reference's loss subset ['labels', 'saliency'] (model/univtg.py:439-440); zero_saliency / drop_pos_labels:
     the two early-outs of loss_saliency (model/univtg.py:237-241) -- the loss dict then holds python floats 0.0."""
     torch.manual_seed(seed)
     params = O.init_params(cfg, seed=seed, dtype=dtype)
-    model, crit = build_reference(ref, cfg, params, dset_type=dset_type)
+    model, crit = build_reference(ref, cfg, params, dset_type=dset_type, **(dict(train_path=["tal"]) if tal else {}))
     assert list(crit.losses) == list(cfg.losses), (crit.losses, cfg.losses)
     inputs, targets = O.make_batch(cfg, B, L_v, L_t, seed=seed + 1, ragged=ragged, dtype=dtype,
                                    curve=curve)
+    if tal:      # the TAL pre-training branch (model/univtg.py:109-117,151-153,284-326): class-name features in, cls_idx in the targets
+        inputs["src_cls"], inputs["src_cls_mask"], targets["cls_idx"] = make_cls_inputs(cfg, B, tal["n_cls"], tal["L_c"], seed + 2)
     if zero_saliency:
         targets["saliency_scores"] = torch.zeros_like(targets["saliency_scores"])
     if real_feats:
@@ -128,7 +148,7 @@ def run_case(ref, name, cfg, B, L_v, L_t, seed, ragged, curve=False, train_dropp
     store = {}
     meta = dict(name=name, cfg=dict(vars(cfg)), B=B, L_v=L_v, L_t=L_t, seed=seed, ragged=ragged,
                 torch=torch.__version__, train_droppath=train_droppath, dset_type=dset_type,
-                zero_saliency=zero_saliency, drop_pos_labels=drop_pos_labels)
+                zero_saliency=zero_saliency, drop_pos_labels=drop_pos_labels, tal=tal)
     meta["cfg"]["losses"] = list(meta["cfg"]["losses"])
     npify("param/", params, store)
     npify("in/", inputs, store)
@@ -161,7 +181,7 @@ def run_case(ref, name, cfg, B, L_v, L_t, seed, ragged, curve=False, train_dropp
         out = model(**inputs)
     crit_targets = {k: v for k, v in targets.items() if not (drop_pos_labels and k == "saliency_pos_labels")}
     # gradients of the weighted total wrt the criterion's INPUTS (a second pass on detached leaves: pins the criterion kernels alone)
-    leaves = {k: out[k].detach().clone().requires_grad_(True) for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj")}
+    leaves = {k: out[k].detach().clone().requires_grad_(True) for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj", "cls_mem_proj") if k in out}
     l2 = crit(dict(out, **leaves), crit_targets)
     t2 = sum(l2[k] * crit.weight_dict[k] for k in l2 if k in crit.weight_dict)
     t2.backward()
@@ -185,6 +205,11 @@ def run_case(ref, name, cfg, B, L_v, L_t, seed, ragged, curve=False, train_dropp
     model.eval()
     with torch.no_grad():
         npify("evalout/", model(**inputs), store)
+    if tal:      # eval-mode criterion without cls_idx: the inter term only (model/univtg.py:312-313)
+        with torch.no_grad():
+            le = crit(model(**inputs), {k: v for k, v in crit_targets.items() if k != "cls_idx"})
+        meta["eval_loss_keys"] = sorted(le.keys())
+        store["evalloss/loss_s_inter"] = le["loss_s_inter"].numpy()
     durations = [float(inputs["src_vid_mask"][b].sum()) * 2.0 for b in range(inputs["src_vid"].shape[0])]
     qmeta = [dict(qid=b, query=f"q{b}", vid=f"v{b}", duration=durations[b]) for b in range(len(durations))]
     m = inputs["src_vid_mask"]
@@ -482,6 +507,14 @@ def run_branch_cases(ref, tiny):
     run_case(ref, "tiny_nproj1", O.make_cfg(**{**tiny, "n_input_proj": 1}), B=4, L_v=11, L_t=6, seed=24, ragged=True)
     run_case(ref, "tiny_nproj3", O.make_cfg(**{**tiny, "n_input_proj": 3}), B=4, L_v=11, L_t=6, seed=25, ragged=True)
     run_case(ref, "tiny_txt_pos", O.make_cfg(**{**tiny, "use_txt_pos": True}), B=5, L_v=12, L_t=9, seed=26, ragged=True)
+    run_tal_case(ref, tiny)
+
+
+def run_tal_case(ref, tiny):
+    """Round 6: the TAL pre-training branch -- src_cls / src_cls_mask through Model.forward and the 'saliency_cls' loss
+    (model/univtg.py:109-117,151-153,284-326,436-438; build_model selects it with 'tal' in train_path)."""
+    run_case(ref, "tiny_tal", O.make_cfg(**{**tiny, "losses": ("spans", "labels", "saliency_cls")}), B=5, L_v=13, L_t=7, seed=27, ragged=True,
+             curve=True, tal=dict(n_cls=6, L_c=4))
 
 
 def main():
@@ -491,6 +524,9 @@ def main():
                 max_q_l=16, input_dropout=0.0, dropout=0.0, droppath=0.0)
     if sys.argv[1:] == ["branches"]:            # round-4 fixtures only (the others are unchanged)
         run_branch_cases(ref, tiny)
+        return
+    if sys.argv[1:] == ["tal"]:                 # round-6 fixture only
+        run_tal_case(ref, tiny)
         return
     if sys.argv[1:] == ["detr_criterion"]:      # one fixture only (the others are unchanged)
         run_detr_criterion(ref)

@@ -213,10 +213,12 @@ def log_mask(mask01, dtype):
     return (mask01.to(torch.float32) + LOG_TINY).log().to(dtype)
 
 
-def forward(params, cfg, src_txt, src_txt_mask, src_vid, src_vid_mask, rng=None):
+def forward(params, cfg, src_txt, src_txt_mask, src_vid, src_vid_mask, src_cls=None, src_cls_mask=None, rng=None):
     """model/univtg.py:105-155.  ``rng`` (optional) is a dict of explicit stochastic masks for
     train-mode restatement: 'vid_keep'/'txt_keep' (lists of (B,L,K) 0/1 per projection block),
-    'dp_scale' (E,2,B), 'attn_keep' (E,B,H,S,S).  None => eval mode."""
+    'dp_scale' (E,2,B), 'attn_keep' (E,B,H,S,S).  None => eval mode.
+    ``src_cls`` / ``src_cls_mask`` (model/univtg.py:109-117,151-153): the class-name token features of the TAL pre-training branch -- they
+    take the TEXT projection and type embedding and are pooled to ``cls_mem_proj`` (n_cls, d); they never enter the encoder."""
     rng = rng or {}
     d = cfg.hidden_dim
     dt = src_vid.dtype
@@ -252,9 +254,13 @@ def forward(params, cfg, src_txt, src_txt_mask, src_vid, src_vid_mask, rng=None)
     pred_spans = torch.sigmoid(conv_head(params, "span_embed", vid_mem)) * sign  # :130-136
     pooled = weighted_pool(params, txt, src_txt_mask)                   # :146
     sal = F.cosine_similarity(vid, pooled.unsqueeze(1), dim=-1) + log_mask(src_vid_mask, dt)  # :147
-    return {"pred_logits": pred_logits, "pred_spans": pred_spans, "src_vid_mask": src_vid_mask,
-            "vid_mem_proj": vid, "txt_mem_proj": pooled.unsqueeze(1), "saliency_scores": sal,
-            "_memory": x}
+    out = {"pred_logits": pred_logits, "pred_spans": pred_spans, "src_vid_mask": src_vid_mask,
+           "vid_mem_proj": vid, "txt_mem_proj": pooled.unsqueeze(1), "saliency_scores": sal,
+           "_memory": x}
+    if src_cls is not None:
+        cls = input_projection(params, "input_txt_proj", src_cls, cfg.n_input_proj, cfg.input_dropout, rng.get("cls_keep")) + tt[0]   # :110-111,116-117
+        out["cls_mem_proj"] = weighted_pool(params, cls, src_cls_mask)                                                              # :151-153
+    return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -331,6 +337,28 @@ def loss_saliency(out, tg):
     return {"loss_s_inter": inter, "loss_s_intra": intra}
 
 
+def loss_saliency_cls(out, tg):
+    """model/univtg.py:284-326 (the 'saliency_cls' loss of the TAL pre-training branch, selected by 'tal' in train_path, :436-438): the
+    inter-video term of loss_saliency, and -- with targets['cls_idx'] (B, n_cls) -- the class term: log-softmax over the classes of the
+    cosine similarity between each sample's positive clip and every pooled class-name feature, averaged over the entries cls_idx marks."""
+    if "saliency_pos_labels" not in tg or float(tg["saliency_scores"].sum()) == 0:
+        return {"loss_s_inter": 0.0, "loss_s_intra": 0.0}
+    vid = out["vid_mem_proj"]
+    B = vid.shape[0]
+    bi = torch.arange(B)
+    pos = tg["saliency_pos_labels"][:, 0].long()
+    v = vid[bi, pos]
+    sim = cosine_matrix(v, out["txt_mem_proj"].squeeze(1))
+    inter = -torch.diag(F.log_softmax(sim / NCE_TAU, dim=1)).sum() / B \
+            - torch.diag(F.log_softmax(sim.t() / NCE_TAU, dim=1)).sum() / B
+    if "cls_idx" not in tg:                        # eval (:312-313)
+        return {"loss_s_inter": inter}
+    idx = tg["cls_idx"].bool()
+    lsm = F.log_softmax(cosine_matrix(v, out["cls_mem_proj"]) / NCE_TAU, dim=1)
+    picked = lsm[idx]
+    return {"loss_s_inter": inter, "loss_s_intra": -picked.sum() / len(picked)}
+
+
 def criterion(out, tg, cfg):
     """model/univtg.py:338-351 (SetCriterion.forward; indices=None, matcher unused)."""
     losses = {}
@@ -341,6 +369,8 @@ def criterion(out, tg, cfg):
             losses.update(loss_labels(out, tg, cfg.eos_coef))
         elif name == "saliency":
             losses.update(loss_saliency(out, tg))
+        elif name == "saliency_cls":
+            losses.update(loss_saliency_cls(out, tg))
         else:
             raise ValueError(name)
     return losses

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 CASES = ["tiny_eval_ragged", "tiny_eval_full", "config1_real_feats",
          # round 4 fixtures from the real reference: dset_type 'hl' loss subset, the two loss_saliency early-outs (model/univtg.py:237-241,
          # 439-440), n_input_proj 1 / 3 (model/univtg.py:89-100), --use_txt_pos (model/position_encoding.py:19-41)
-         "tiny_hl", "tiny_zero_saliency", "tiny_no_pos_labels", "tiny_nproj1", "tiny_nproj3", "tiny_txt_pos"]
+         "tiny_hl", "tiny_zero_saliency", "tiny_no_pos_labels", "tiny_nproj1", "tiny_nproj3", "tiny_txt_pos",
+         # round 6: the TAL pre-training branch -- src_cls / src_cls_mask through Model.forward, the 'saliency_cls' loss (model/univtg.py:109-117,151-153,284-326)
+         "tiny_tal"]
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +33,8 @@ def args_from_cfg(cfg, **over):
              v_feat_dim=cfg.v_feat_dim, span_loss_type="l1", use_txt_pos=bool(getattr(cfg, "use_txt_pos", False)), n_input_proj=cfg.n_input_proj,
              set_cost_span=10, set_cost_giou=1, set_cost_class=4, max_v_l=75, b_loss_coef=cfg.b_loss_coef,
              g_loss_coef=cfg.g_loss_coef, f_loss_coef=cfg.f_loss_coef, s_loss_intra_coef=cfg.s_loss_intra_coef,
-             s_loss_inter_coef=cfg.s_loss_inter_coef, dset_type="vlp" if "spans" in cfg.losses else "hl", train_path=["synthetic"], eos_coef=cfg.eos_coef,
+             s_loss_inter_coef=cfg.s_loss_inter_coef, dset_type="vlp" if "spans" in cfg.losses else "hl",
+             train_path=["tal"] if "saliency_cls" in cfg.losses else ["synthetic"], eos_coef=cfg.eos_coef,
              temperature=0.07, saliency_margin=0.2)
     a.update(over)
     return SimpleNamespace(**a)
@@ -78,9 +81,10 @@ def test_forward_fp32x3_matches_reference(dev, golden_dir, name):
     # north_star tolerance: saliency logits within 1e-4 of the reference CPU path (valid clips; padded = log-mask constant)
     assert float((sal - eval_ref["saliency_scores"])[valid].abs().max()) < 1e-4
     assert float((sal - eval_ref["saliency_scores"])[~valid].abs().max() if (~valid).any() else 0.0) < 1e-3
-    for k, tol in (("pred_logits", 2e-4), ("pred_spans", 2e-4), ("vid_mem_proj", 2e-4), ("txt_mem_proj", 2e-4)):
+    for k, tol in (("pred_logits", 2e-4), ("pred_spans", 2e-4), ("vid_mem_proj", 2e-4), ("txt_mem_proj", 2e-4)) + ((("cls_mem_proj", 2e-4),) if "cls_mem_proj" in eval_ref else ()):
         err = float((out[k].cpu() - eval_ref[k]).abs().max())
         assert err < tol, (k, err)
+    assert ("cls_mem_proj" in out) == ("src_cls" in inputs)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -167,6 +171,35 @@ def test_losses_and_grads_match_reference(dev, golden_dir, name):
     for k in meta["no_grad_params"]:
         assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
     assert {k for k, p in named.items() if p.grad is None} <= set(meta["no_grad_params"])
+
+
+def test_tal_branch_criterion_kernels_and_early_outs(dev, golden_dir):
+    """The 'saliency_cls' criterion alone on the reference's own outputs (tiny_tal fixture): values and the gradients with respect to the
+    criterion's inputs incl. cls_mem_proj (pins uvtg_cls_nce_fwd / _bwd apart from the model), the evaluation form without cls_idx (inter
+    term only, model/univtg.py:312-313) and both early-outs (:286-290) as zero tensors."""
+    meta, cfg, params, inputs, tg, out_ref, eval_ref, grads_ref, losses_ref = load_case(golden_dir, "tiny_tal")
+    _, crit = build(cfg, params, dev, "bf16")
+    assert list(crit.losses) == ["spans", "labels", "saliency_cls"]
+    leaves = {k: out_ref[k].clone().to(dev).requires_grad_(True) for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj", "cls_mem_proj")}
+    tgd = to_dev(tg, dev)
+    losses = crit(dict(leaves), tgd)
+    for k in ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra"):
+        assert abs(float(losses[k]) - losses_ref[k]) <= 2e-5 * max(1.0, abs(losses_ref[k])), (k, float(losses[k]), losses_ref[k])
+    sum(losses[k] * crit.weight_dict[k] for k in losses).backward()
+    for k, v in leaves.items():
+        ref = meta["dout"][k]
+        assert float((v.grad.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-8, k
+    # evaluation: no cls_idx in the targets -> the inter-video term only
+    z = np.load(os.path.join(golden_dir, "tiny_tal.npz"))
+    ev = crit({k: eval_ref[k].to(dev) for k in eval_ref}, {k: v for k, v in tgd.items() if k != "cls_idx"})
+    assert sorted(ev) == meta["eval_loss_keys"] and abs(float(ev["loss_s_inter"]) - float(z["evalloss/loss_s_inter"])) <= 2e-5
+    # early-outs: both keys, both exactly zero, no gradient
+    for tg2 in ({k: v for k, v in tgd.items() if k != "saliency_pos_labels"}, dict(tgd, saliency_scores=torch.zeros_like(tgd["saliency_scores"]))):
+        lv = {k: out_ref[k].clone().to(dev).requires_grad_(True) for k in leaves}
+        l2 = crit(dict(lv), tg2)
+        assert float(l2["loss_s_inter"]) == 0.0 and float(l2["loss_s_intra"]) == 0.0
+        (l2["loss_s_inter"] + l2["loss_s_intra"]).backward()
+        assert lv["cls_mem_proj"].grad is None or float(lv["cls_mem_proj"].grad.abs().max()) == 0.0
 
 
 def test_nt_loader_waves_do_not_change_the_train_step(dev):

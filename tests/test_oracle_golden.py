@@ -12,7 +12,9 @@ from oracle import univtg_oracle as O
 
 CASES = ["tiny_eval_ragged", "tiny_eval_full", "tiny_train_droppath", "config1_real_feats",
          # round 4: dset_type 'hl' loss subset, the two loss_saliency early-outs, n_input_proj 1 / 3, use_txt_pos
-         "tiny_hl", "tiny_zero_saliency", "tiny_no_pos_labels", "tiny_nproj1", "tiny_nproj3", "tiny_txt_pos"]
+         "tiny_hl", "tiny_zero_saliency", "tiny_no_pos_labels", "tiny_nproj1", "tiny_nproj3", "tiny_txt_pos",
+         # round 6: the TAL pre-training branch -- src_cls through the text projection + pool, the 'saliency_cls' loss (model/univtg.py:109-117,151-153,284-326)
+         "tiny_tal"]
 
 
 def load_case(golden_dir, name):
@@ -33,8 +35,13 @@ def test_forward_losses_grads_match_reference(golden_dir, name):
     meta, cfg, params, inputs, tg, out_ref, grads_ref, losses_ref, rng = load_case(golden_dir, name)
     params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     out = O.forward(params, cfg, rng=rng, **inputs)
-    for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj", "saliency_scores"):
+    for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj", "saliency_scores") + (("cls_mem_proj",) if "cls_mem_proj" in out_ref else ()):
         torch.testing.assert_close(out[k], out_ref[k], rtol=2e-5, atol=2e-6, msg=lambda m: f"{k}: {m}")
+    if meta.get("tal"):      # eval-mode criterion without cls_idx: the inter-video term only (model/univtg.py:312-313)
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        with torch.no_grad():
+            le = O.criterion(O.forward({k: v.detach() for k, v in params.items()}, cfg, **inputs), {k: v for k, v in tg.items() if k != "cls_idx"}, cfg)
+        assert sorted(le) == meta["eval_loss_keys"] and abs(float(le["loss_s_inter"]) - float(z["evalloss/loss_s_inter"])) <= 2e-5
     losses = O.criterion(out, tg, cfg)
     assert set(losses) == set(losses_ref) - {"total"}, (set(losses), set(losses_ref))        # 'hl': no loss_b / loss_g
     for k in meta.get("loss_is_float", []):                 # the early-outs hand out python floats 0.0 (model/univtg.py:237-241)

@@ -502,7 +502,7 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // include/uvtg.h changed.
 // 303 (round 5): the last encoder layer's FFN half runs on the clip rows only (last_layer_clip below); a bf16 training call with memory != NULL is
 // refused (-24) on the unpacked stream as it already was on the packed one; developer switches uvtg_debug_last_layer_clip, uvtg_debug_tn_conv_defer.
-// 304 (round 6): nothing in include/uvtg.h changed shape.  Behaviour: no entry point reads the process environment any more (developer switches:
+// 304 (round 6): nothing in include/uvtg.h changed shape; additive: uvtg_cls_nce_fwd / _bwd / _ws_floats.  Behaviour: no entry point reads the process environment any more (developer switches:
 // uvtg_dev_config_set / uvtg_dev_config_from_env, include/uvtg_dev.h); uvtg_backward records its ready_events in groups (heads + layers E-1 .. 1
 // behind layer 1, layer 0 behind the loop: the weight gradients stay deferred under events) and remembers the forward's last-layer row layout per workspace.
 extern "C" int uvtg_version(void) { return 304; }
@@ -1372,6 +1372,27 @@ LossArgs loss_args(int B, int Lv, int d, int which, float eos_coef, const float*
   return a;
 }
 }  // namespace
+
+extern "C" long long uvtg_cls_nce_ws_floats(int B, int C) { return (B > 0 && C > 0) ? cls_nce_ws_floats(B, C) : 0; }
+extern "C" int uvtg_cls_nce_fwd(int B, int C, int d, const float* vid, long long vid_sb, long long vid_st, const long long* pos_idx,
+                                const float* cls, const float* cls_idx, const float* active, float* ws, float* loss_out, uvtg_stream_t stream) {
+  if (B <= 0 || C <= 0 || d <= 0) return -11;
+  if (!vid || !pos_idx || !cls || !cls_idx || !ws || !loss_out) return -20;
+  ClsNceArgs a; memset(&a, 0, sizeof(a));
+  a.B = B; a.C = C; a.d = d; a.vid = vid; a.vid_sb = vid_sb; a.vid_st = vid_st; a.pos_idx = pos_idx; a.cls = cls; a.cls_idx = cls_idx;
+  a.active = active; a.ws = ws; a.loss = loss_out;
+  return launch_cls_nce_fwd(a, (hipStream_t)stream);
+}
+extern "C" int uvtg_cls_nce_bwd(int B, int C, int d, const float* vid, long long vid_sb, long long vid_st, const long long* pos_idx,
+                                const float* cls, const float* cls_idx, const float* active, float* ws, const float* go,
+                                float* g_vid, long long gv_sb, long long gv_st, float* g_cls, uvtg_stream_t stream) {
+  if (B <= 0 || C <= 0 || d <= 0) return -11;
+  if (!vid || !pos_idx || !cls || !cls_idx || !ws || !go || !g_vid || !g_cls) return -20;
+  ClsNceArgs a; memset(&a, 0, sizeof(a));
+  a.B = B; a.C = C; a.d = d; a.vid = vid; a.vid_sb = vid_sb; a.vid_st = vid_st; a.pos_idx = pos_idx; a.cls = cls; a.cls_idx = cls_idx;
+  a.active = active; a.ws = ws; a.go = go; a.g_vid = g_vid; a.gv_sb = gv_sb; a.gv_st = gv_st; a.g_cls = g_cls;
+  return launch_cls_nce_bwd(a, (hipStream_t)stream);
+}
 
 extern "C" int uvtg_criterion_fwd(int B, int Lv, int d, int which, float eos_coef, const float* pred_logits, const float* pred_spans,
                                   const float* vid, long long vid_sb, long long vid_st, const float* txt_mem,

@@ -418,6 +418,131 @@ __global__ __launch_bounds__(256) void loss_expand_txt_kernel(const LossArgs a) 
 
 long long loss_ws_floats(int B, int Lv, int d) { return 3LL * B * Lv + (long long)B * B + 5LL * B + 2LL * Lv + 2LL * B * d + 96; }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Class term of the 'saliency_cls' loss (model/univtg.py:314-324, the TAL pre-training branch): with v_b = vid_mem_proj[b, pos_b] and the
+// pooled class-name features c_j (cls_mem_proj), z_bj = cos(v_b, c_j) / 0.07 (sim_matrix: norms clamped at 1e-8),
+// loss = - sum_{(b,j): cls_idx[b,j]} log_softmax_j(z_b)[j] / #{(b,j): cls_idx[b,j]}.
+// One block per sample forward (cosines, log-sum-exp, the sample's partial), a one-block fold, and two gather-free backward kernels (block
+// per sample: d loss / d v_b; block per class: d loss / d c_j) -- a few hundred samples x classes x d, nowhere near a bound.
+// ws: cosine [B, C], lse [B], vnorm [B], cnorm [C], part [B] (sum of picked log-probabilities), npick [B], tot [2] (picked sum, count).
+// ------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct ClsWS {
+  float *cosm, *lse, *vn, *cn, *part, *npick, *tot;
+  __host__ __device__ ClsWS(const ClsNceArgs& a) {
+    float* p = a.ws;
+    cosm = p; p += (size_t)a.B * a.C;
+    lse = p; p += a.B; vn = p; p += a.B; cn = p; p += a.C; part = p; p += a.B; npick = p; p += a.B; tot = p;
+  }
+};
+__device__ __forceinline__ float block_sum256(float v, float* red) {      // 256 threads; red: 4 floats of LDS; every thread gets the sum
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void cls_nce_fwd_kernel(const ClsNceArgs a) {
+  extern __shared__ float sm[];                 // z_bj for the block's sample [C], then 4 reduction slots
+  float* red = sm + a.C;
+  const ClsWS w(a);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* v = a.vid + (size_t)b * a.vid_sb + (size_t)a.pos_idx[b] * a.vid_st;
+  float vv = 0.f;
+  for (int c = tid; c < a.d; c += 256) vv += v[c] * v[c];
+  const float vnorm = fmaxf(sqrtf(block_sum256(vv, red)), EPS);
+  for (int j = 0; j < a.C; j++) {
+    const float* cj = a.cls + (size_t)j * a.d;
+    float dot = 0.f, cc = 0.f;
+    for (int c = tid; c < a.d; c += 256) { const float x = cj[c]; dot += v[c] * x; cc += x * x; }
+    dot = block_sum256(dot, red);
+    cc = block_sum256(cc, red);
+    const float cnorm = fmaxf(sqrtf(cc), EPS);
+    if (tid == 0) { const float cs = dot / (vnorm * cnorm); sm[j] = cs / TAU; w.cosm[(size_t)b * a.C + j] = cs; if (b == 0) w.cn[j] = cnorm; }
+  }
+  __syncthreads();
+  if (tid == 0) {                               // C is small (class names): one lane walks the row
+    float m = -3.0e38f;
+    for (int j = 0; j < a.C; j++) m = fmaxf(m, sm[j]);
+    float se = 0.f;
+    for (int j = 0; j < a.C; j++) se += __expf(sm[j] - m);
+    const float lse = m + __logf(se);
+    float part = 0.f, np = 0.f;
+    for (int j = 0; j < a.C; j++) if (a.cls_idx[(size_t)b * a.C + j] != 0.f) { part += sm[j] - lse; np += 1.f; }
+    w.lse[b] = lse; w.vn[b] = vnorm; w.part[b] = part; w.npick[b] = np;
+  }
+}
+__global__ __launch_bounds__(256) void cls_nce_fold_kernel(const ClsNceArgs a) {
+  __shared__ float red[4];
+  const ClsWS w(a);
+  float ps = 0.f, pn = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) { ps += w.part[b]; pn += w.npick[b]; }
+  ps = block_sum256(ps, red);
+  pn = block_sum256(pn, red);
+  if (threadIdx.x == 0) {
+    w.tot[0] = ps; w.tot[1] = pn;
+    const float act = a.active ? *a.active : 1.f;
+    a.loss[0] = (act != 0.f && pn > 0.f) ? -ps / pn : 0.f;
+  }
+}
+// d loss / d z_bj = -(cls_idx_bj - npick_b softmax_bj) / N; z = cos / TAU; d cos / d v = (c^ - cos v^) / |v| (and symmetrically for c)
+__device__ __forceinline__ float cls_coef(const ClsNceArgs& a, const ClsWS& w, int b, int j, float scale) {
+  const float cs = w.cosm[(size_t)b * a.C + j];
+  const float p = __expf(cs / TAU - w.lse[b]);
+  return -scale * (a.cls_idx[(size_t)b * a.C + j] - w.npick[b] * p) / TAU;
+}
+__global__ __launch_bounds__(256) void cls_nce_bwd_v_kernel(const ClsNceArgs a) {
+  const ClsWS w(a);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float act = a.active ? *a.active : 1.f;
+  const float scale = (act != 0.f && w.tot[1] > 0.f) ? a.go[0] / w.tot[1] : 0.f;
+  const float* v = a.vid + (size_t)b * a.vid_sb + (size_t)a.pos_idx[b] * a.vid_st;
+  float* gv = a.g_vid + (size_t)b * a.gv_sb + (size_t)a.pos_idx[b] * a.gv_st;
+  const float vn = w.vn[b];
+  for (int c = tid; c < a.d; c += 256) {
+    float acc = 0.f;
+    const float vh = v[c] / vn;
+    for (int j = 0; j < a.C; j++) {
+      const float g = cls_coef(a, w, b, j, scale);
+      acc += g * (a.cls[(size_t)j * a.d + c] / w.cn[j] - w.cosm[(size_t)b * a.C + j] * vh);
+    }
+    gv[c] = acc / vn;
+  }
+}
+__global__ __launch_bounds__(256) void cls_nce_bwd_c_kernel(const ClsNceArgs a) {
+  const ClsWS w(a);
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const float act = a.active ? *a.active : 1.f;
+  const float scale = (act != 0.f && w.tot[1] > 0.f) ? a.go[0] / w.tot[1] : 0.f;
+  const float cn = w.cn[j];
+  for (int c = tid; c < a.d; c += 256) {
+    float acc = 0.f;
+    const float ch = a.cls[(size_t)j * a.d + c] / cn;
+    for (int b = 0; b < a.B; b++) {
+      const float g = cls_coef(a, w, b, j, scale);
+      const float* v = a.vid + (size_t)b * a.vid_sb + (size_t)a.pos_idx[b] * a.vid_st;
+      acc += g * (v[c] / w.vn[b] - w.cosm[(size_t)b * a.C + j] * ch);
+    }
+    a.g_cls[(size_t)j * a.d + c] = acc / cn;
+  }
+}
+}  // namespace
+long long cls_nce_ws_floats(int B, int C) { return (long long)B * C + 4LL * B + C + 8; }
+int launch_cls_nce_fwd(const ClsNceArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.C <= 0 || a.d <= 0 || a.C > 8192) return -11;
+  hipLaunchKernelGGL(cls_nce_fwd_kernel, dim3(a.B), dim3(256), (size_t)(a.C + 4) * sizeof(float), s, a);
+  hipLaunchKernelGGL(cls_nce_fold_kernel, dim3(1), dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+int launch_cls_nce_bwd(const ClsNceArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.C <= 0 || a.d <= 0) return -11;
+  hipLaunchKernelGGL(cls_nce_bwd_v_kernel, dim3(a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(cls_nce_bwd_c_kernel, dim3(a.C), dim3(256), 0, s, a);
+  UVTG_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_losses_fwd(const LossArgs& a, hipStream_t s) {
   const int n = a.B * a.Lv;
   const bool have_sal = a.do_saliency && a.sal_tgt && a.pos_idx;

@@ -374,5 +374,24 @@ struct LossArgs {
   float* g_vrow;              // [B, d]  inter-video gradient wrt vid_mem_proj[b, pos_b, :]
 };
 long long loss_ws_floats(int B, int Lv, int d);
+// class term of the 'saliency_cls' loss (model/univtg.py:314-324): see losses.hip, cls_nce_*
+struct ClsNceArgs {
+  int B, C, d;                  // samples, classes, width
+  const float* vid;             // vid_mem_proj addressed as vid[b * vid_sb + t * vid_st + c]
+  long long vid_sb, vid_st;
+  const long long* pos_idx;     // [B] positive clip of every sample
+  const float* cls;             // [C, d] pooled class-name features
+  const float* cls_idx;         // [B, C] 0 / 1 (multi-hot)
+  const float* active;          // device flag (losses_out[5] of uvtg_criterion_fwd: 0 when saliency_scores sums to zero) or NULL
+  float* ws;                    // uvtg_cls_nce_ws_floats
+  float* loss;                  // [1]
+  const float* go;              // backward: upstream gradient of the loss [1]
+  float* g_vid;                 // backward: dense [B, Lv, d] gradient buffer, ZERO-FILLED by the caller; row pos_idx[b] of sample b is written
+  long long gv_sb, gv_st;
+  float* g_cls;                 // backward: [C, d]
+};
+long long cls_nce_ws_floats(int B, int C);
+int launch_cls_nce_fwd(const ClsNceArgs& a, hipStream_t s);
+int launch_cls_nce_bwd(const ClsNceArgs& a, hipStream_t s);
 int launch_losses_fwd(const LossArgs& a, hipStream_t s);
 int launch_losses_bwd(const LossArgs& a, hipStream_t s);

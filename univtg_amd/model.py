@@ -325,8 +325,6 @@ class Model(nn.Module):
         self._param_epoch += 1
 
     def forward(self, src_txt, src_txt_mask, src_vid, src_vid_mask, src_cls=None, src_cls_mask=None):
-        if src_cls is not None:
-            raise NotImplementedError("src_cls (TAL 'saliency_cls' pre-training, main/train_vlp.py) is outside the accelerated path")
         if not src_vid.is_cuda:
             raise RuntimeError("univtg_amd runs on MI355X only: inputs must be on a ROCm device (no CPU fallback)")
         params = self._ordered_params()
@@ -338,6 +336,22 @@ class Model(nn.Module):
                "vid_mem_proj": vid_mem, "txt_mem_proj": txt_mem, "saliency_scores": sal}
         if self.return_memory:
             out["memory"] = res[6]
+        if src_cls is not None:
+            # TAL pre-training branch (model/univtg.py:109-117,151-153): the class-name token features take the TEXT projection, the text type
+            # embedding and the weighted pool -- exactly what the engine computes as txt_mem_proj.  They never enter the encoder, so they run as a
+            # second engine call whose "queries" are the class names (one dummy clip per class; its other outputs are dropped, and under autograd
+            # its backward hands the text projection / type embedding / pool their gradient through the same path as the real queries')
+            n_cls = src_cls.shape[0]
+            if src_cls_mask is None:
+                raise ValueError("src_cls needs src_cls_mask")
+            dummy_vid = torch.zeros(n_cls, 1, self.vid_dim, device=src_vid.device)
+            dummy_mask = torch.ones(n_cls, 1, device=src_vid.device)
+            was_mem, self.return_memory = self.return_memory, False
+            try:
+                cres = _UniVTGFunction.apply(self, need_grad, _f32c(src_cls), _f32c(src_cls_mask), dummy_vid, dummy_mask, *params)
+            finally:
+                self.return_memory = was_mem
+            out["cls_mem_proj"] = cres[3][:, 0]
         return out
 
 
@@ -358,7 +372,7 @@ class _CriterionFunction(torch.autograd.Function):
         ctx.which, ctx.eos, ctx.ws = which, eos_coef, ws
         ctx.shapes = (pred_logits.shape, pred_spans.shape, txt.shape)
         ctx.save_for_backward(pl, ps, vid, tx, timestamp, ts_mask, ts_window, span_nn, sal, pos_idx, losses)
-        return losses[:5].clone()
+        return losses[:6].clone()          # five losses + the device-side "saliency terms active" flag (the saliency_scores.sum() == 0 early-out)
 
     @staticmethod
     def backward(ctx, go):
@@ -377,6 +391,38 @@ class _CriterionFunction(torch.autograd.Function):
         return (None, None, g_l.view(sl), g_s.view(ss), g_v, g_t.view(st)) + (None,) * 6
 
 
+class _ClsNceFunction(torch.autograd.Function):
+    """Class term of the 'saliency_cls' loss (model/univtg.py:314-324) on device: uvtg_cls_nce_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, vid, cls, pos_idx, cls_idx, active):
+        lib = _lib.load()
+        B, Lv, d = vid.shape
+        C_ = cls.shape[0]
+        if vid.stride(2) != 1:
+            vid = vid.contiguous()
+        cls, cls_idx = _f32c(cls), _f32c(cls_idx)
+        ws = torch.empty(lib.uvtg_cls_nce_ws_floats(B, C_), device=vid.device)
+        loss = torch.empty(1, device=vid.device)
+        _lib.check(lib.uvtg_cls_nce_fwd(B, C_, d, _ptr(vid), vid.stride(0), vid.stride(1), _ptr(pos_idx), _ptr(cls), _ptr(cls_idx), _ptr(active),
+                                        _ptr(ws), _ptr(loss), _stream()), "uvtg_cls_nce_fwd")
+        ctx.save_for_backward(vid, cls, pos_idx, cls_idx, active, ws)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        lib = _lib.load()
+        vid, cls, pos_idx, cls_idx, active, ws = ctx.saved_tensors
+        B, Lv, d = vid.shape
+        C_ = cls.shape[0]
+        go = _f32c(go).reshape(1)
+        g_vid = torch.zeros(B, Lv, d, device=vid.device)          # (only row pos_idx[b] of every sample is non-zero)
+        g_cls = torch.empty(C_, d, device=vid.device)
+        _lib.check(lib.uvtg_cls_nce_bwd(B, C_, d, _ptr(vid), vid.stride(0), vid.stride(1), _ptr(pos_idx), _ptr(cls), _ptr(cls_idx), _ptr(active),
+                                        _ptr(ws), _ptr(go), _ptr(g_vid), Lv * d, d, _ptr(g_cls), _stream()), "uvtg_cls_nce_bwd")
+        return g_vid, g_cls, None, None, None
+
+
 class SetCriterion(nn.Module):
     """Dense UniVTG criterion (model/univtg.py:157-351) on device; same constructor, ``weight_dict`` and loss keys."""
 
@@ -390,11 +436,14 @@ class SetCriterion(nn.Module):
         empty_weight[-1] = eos_coef
         self.register_buffer("empty_weight", empty_weight)
         for name in losses:
-            if name not in ("spans", "labels", "saliency"):
-                raise NotImplementedError(f"loss '{name}' is outside the accelerated path (only spans/labels/saliency)")
+            if name not in ("spans", "labels", "saliency", "saliency_cls"):
+                raise NotImplementedError(f"loss '{name}' is outside the accelerated path (spans / labels / saliency / saliency_cls)")
+        if "saliency" in losses and "saliency_cls" in losses:
+            raise ValueError("'saliency' and 'saliency_cls' write the same loss keys (the reference's factory selects one, model/univtg.py:436-438)")
 
     def forward(self, outputs, targets, hl_only=False):
-        which = (1 if "spans" in self.losses else 0) | (2 if "labels" in self.losses else 0) | (4 if "saliency" in self.losses else 0)
+        cls_mode = "saliency_cls" in self.losses
+        which = (1 if "spans" in self.losses else 0) | (2 if "labels" in self.losses else 0) | (4 if ("saliency" in self.losses or cls_mode) else 0)
         pl = outputs["pred_logits"]
         if not pl.is_cuda:
             raise RuntimeError("univtg_amd criterion runs on MI355X only (no CPU fallback)")
@@ -410,8 +459,19 @@ class SetCriterion(nn.Module):
             out["loss_b"], out["loss_g"] = res[0], res[1]
         if which & 2:
             out["loss_f"] = res[2]
-        if which & 4:
+        if which & 4 and not cls_mode:
             out["loss_s_inter"], out["loss_s_intra"] = res[3], res[4]
+        elif cls_mode:
+            # 'saliency_cls' (model/univtg.py:284-326): the inter-video term is loss_saliency's (the intra-video term the kernel computes beside
+            # it is not used: no gradient flows into it); the class term only with targets['cls_idx'] (absent in evaluation, :312-313).  Both
+            # early-outs (:286-290) come out as zero tensors without a host synchronisation: no positive labels -> the kernel is given no
+            # saliency targets; saliency_scores.sum() == 0 -> the device-side flag res[5] zeroes value and gradient
+            out["loss_s_inter"] = res[3]
+            if "cls_idx" in targets or not has_sal:
+                if has_sal:
+                    out["loss_s_intra"] = _ClsNceFunction.apply(outputs["vid_mem_proj"], outputs["cls_mem_proj"], pos, targets["cls_idx"], res[5:6].detach())
+                else:
+                    out["loss_s_intra"] = res[4] * 0.0
         return out
 
 
@@ -484,7 +544,7 @@ def build_model(args):
         if "tal" not in args.train_path:
             losses = ["spans", "labels", "saliency"]
         else:
-            raise NotImplementedError("'saliency_cls' (TAL pre-training) is outside the accelerated path")
+            losses = ["spans", "labels", "saliency_cls"]      # model/univtg.py:436-438 (needs src_cls / src_cls_mask in the model call)
     elif args.dset_type in ["hl", "vs"]:
         losses = ["labels", "saliency"]
     else:

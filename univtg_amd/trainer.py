@@ -43,6 +43,9 @@ class TrainStep:
                  grad_comm_dtype="fp32", comm_cus=None, time_comm=False):
         if model.precision == "fp32x3":
             raise RuntimeError("training uses the bf16 arithmetic (precision='auto' or 'bf16'); 'fp32x3' is inference-only")
+        if "saliency_cls" in criterion.losses:
+            raise RuntimeError("the TAL branch ('saliency_cls' + src_cls) runs on the drop-in autograd path (model(..., src_cls=...) + criterion); "
+                               "TrainStep implements the dense spans / labels / saliency step")
         self.lib = _lib.load()
         self.model, self.crit = model, criterion
         self.flat = getattr(model, "_flat", None)
