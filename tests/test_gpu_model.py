@@ -534,7 +534,7 @@ def test_criterion_matches_oracle_fp32(dev, golden_dir):
     from univtg_amd.model import SetCriterion
     for name in CASES:
         meta, cfg, params, inputs, tg, out_ref, *_ = load_case(golden_dir, name)
-        outs = {k: out_ref[k].clone().requires_grad_(True) for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj")}
+        outs = {k: out_ref[k].clone().requires_grad_(True) for k in ("pred_logits", "pred_spans", "vid_mem_proj", "txt_mem_proj", "cls_mem_proj") if k in out_ref}
         lo = O.criterion(outs, tg, cfg)
         O.total_loss(lo, cfg).backward()
         crit = SetCriterion(None, O.weight_dict(cfg), cfg.eos_coef, list(cfg.losses), 0.07, "l1", 75).to(dev)
