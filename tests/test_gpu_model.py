@@ -202,6 +202,40 @@ def test_tal_branch_criterion_kernels_and_early_outs(dev, golden_dir):
         assert lv["cls_mem_proj"].grad is None or float(lv["cls_mem_proj"].grad.abs().max()) == 0.0
 
 
+def test_tal_branch_production_width_vs_oracle(dev):
+    """The TAL branch at production width (d = 1024, E = 4, D_v = 2818; 24 class names of up to 6 tokens, B = 32 ragged): cls_mem_proj through
+    the engine's text path within the saliency-class tolerance (fp32-class projections), the five losses, and the gradients the class term
+    sends into the shared text projection / type embedding / pool -- against the oracle (itself pinned to the real reference by tiny_tal)."""
+    from oracle import univtg_oracle as O
+    from oracle.make_golden import make_cls_inputs
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = O.make_cfg(input_dropout=0.0, dropout=0.0, droppath=0.0, losses=("spans", "labels", "saliency_cls"))
+    params = O.init_params(cfg, seed=81)
+    inputs, tg = O.make_batch(cfg, 32, 75, 32, seed=82, ragged=True)
+    inputs["src_cls"], inputs["src_cls_mask"], tg["cls_idx"] = make_cls_inputs(cfg, 32, 24, 6, 83)
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(p2, cfg, **inputs)
+    lref = O.criterion(ref, tg, cfg)
+    O.total_loss(lref, cfg).backward()
+    model, crit = build(cfg, params, dev, "bf16", proj_precise=True)
+    model.eval()
+    out = model(**to_dev(inputs, dev))
+    assert float((out["cls_mem_proj"].detach().cpu() - ref["cls_mem_proj"].detach()).abs().max()) < 1e-4
+    ld = crit(out, to_dev(tg, dev))
+    sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
+    assert set(ld) == set(lref)
+    for k in ("loss_s_inter", "loss_s_intra"):
+        assert abs(float(ld[k]) - float(lref[k])) < 2e-4 * max(1.0, abs(float(lref[k]))), (k, float(ld[k]), float(lref[k]))
+    for k in ("loss_b", "loss_g", "loss_f"):
+        assert abs(float(ld[k]) - float(lref[k])) < 3e-2 * max(1.0, abs(float(lref[k]))), (k, float(ld[k]), float(lref[k]))
+    named = dict(model.named_parameters())
+    for k in ("weightedpool.weight", "token_type_embeddings.weight", "input_txt_proj.0.net.1.weight", "input_txt_proj.1.net.1.weight",
+              "input_txt_proj.0.LayerNorm.weight", "input_txt_proj.1.net.1.bias"):
+        a, r = named[k].grad.cpu().double().flatten(), p2[k].grad.double().flatten()
+        cos, ratio = float((a @ r) / (a.norm() * r.norm() + 1e-30)), float(a.norm() / (r.norm() + 1e-30))
+        assert cos > 0.995 and abs(ratio - 1) < 0.04, (k, cos, ratio)
+
+
 def test_nt_loader_waves_do_not_change_the_train_step(dev):
     """The persistent NT GEMM's staging by one wave per SIMD (default) against every wave staging for itself, through a whole bf16 train-mode
     forward + criterion + backward at production width (the specialised bf16 / FFN / GELU' epilogues only the engine reaches; B = 192 puts
