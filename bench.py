@@ -834,9 +834,11 @@ def main():
                     avg_launch_us=round(raw_ms * 1e3 / max(1, n[dom]), 2),
                     event_pair_floor_us=round(floor * 1e3, 2), achieved_floor_corrected=round(ach_corr, 2),
                     note="achieved = sum(2MNK of the rows each launch executes) / sum(event-pair duration) over the launches, durations NOT floor-corrected",
-                    clock_note=("peak is the guide's dense bf16 figure at the 2.4 GHz nominal clock; measured inside this kernel (s_memtime against the 100 MHz "
-                                "wall clock, profiles/r04_nt_ktile_cycles.txt, not re-measured in this run) the shader clock is 1.6-1.7 GHz during the full-grid K "
-                                "loops -- clock-limited peak ~1.7 PFLOP/s -- and the K loop holds 81 % of the matrix rate that clock allows"),
+                    clock_note=("peak is the guide's dense bf16 figure at the 2.4 GHz nominal clock; the chip does not hold that clock under this load: a resident "
+                                "probe wave sampling s_memtime against the 100 MHz real-time counter (tools/clock_probe.py, profiles/r06_shader_clock_under_load.txt; "
+                                "not re-measured in this run) reads 2.40-2.42 GHz idle, 1.94 GHz mean (p5 1.48, median 1.90) while this kernel runs back to back and "
+                                "2.0-2.1 GHz over the training step -- the matrix cores' ceiling at the sustained clock is ~2.0 PFLOP/s; inside the full-grid K loops "
+                                "(profiles/r04_nt_ktile_cycles.txt) 1.6-1.7 GHz, where the K loop holds 81 % of the matrix rate that clock allows"),
                     algorithmic_gflop_per_launch=round(fl[dom] / max(1, n[dom]) / 1e9, 2),
                     all_gemm_kernels={fam[i]: dict(ms_per_step=round(ms[i] / max(1, args.profile_steps), 3),
                                                    tflops=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else 0.0,
