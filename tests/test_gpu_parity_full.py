@@ -826,13 +826,35 @@ def _ddp_worker(rank, world, port, out_path):
     tgd = {k: v[sl].to(dev) for k, v in tg.items() if torch.is_tensor(v)}
     model, crit = build(cfg, params, dev, "bf16")
     model.eval()
+    # round 6: the optimizer is built BEFORE the DDP wrap, as main/config.py:349-350 / main/train_vlp_ddp.py:272 do -- with FusedAdamWClip swapped
+    # in for torch.optim.AdamW (it re-homes the parameters into one flat buffer: DDP then wraps the re-homed parameters)
+    from univtg_amd.optim import FusedAdamWClip
+    group = [{"params": [p for n, p in model.named_parameters() if p.requires_grad]}]
+    opt = FusedAdamWClip(group, lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1, model=model)
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, find_unused_parameters=True)   # :272-275
     out = ddp(**ind)
     ld = crit(out, tgd)
+    opt.zero_grad()
     sum(ld[k] * crit.weight_dict[k] for k in ld).backward()
     torch.cuda.synchronize()
     g_ddp = torch.cat([p.grad.flatten() for p in model._ordered_params()]).double().cpu()
     unused = [k for k, p in model.named_parameters() if p.grad is None]
+    # ... and steps on DDP's averaged gradients (bucket copies, not the backward's flat buffer: the gather path): against clip_grad_norm_ +
+    # torch.optim.AdamW on shadow parameters fed the same gradients, and bit-identical across the two ranks
+    shadow = [p.detach().clone().requires_grad_(True) for p in group[0]["params"]]
+    for p, sp in zip(group[0]["params"], shadow):
+        sp.grad = None if p.grad is None else p.grad.detach().clone()
+    sopt = torch.optim.AdamW([{"params": shadow}], lr=1e-3, weight_decay=1e-4)
+    torch.nn.utils.clip_grad_norm_(shadow, 0.1)
+    sopt.step()
+    opt.step()
+    torch.cuda.synchronize()
+    fused_vs_shadow = max(float((p - sp).abs().max()) for p, sp in zip(group[0]["params"], shadow))
+    moved = max(float((p.detach().cpu() - params[n]).abs().max()) for n, p in model.named_parameters() if p.grad is not None)
+    flat = opt.flat.detach().cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ranks_equal = all(torch.equal(gathered[0], g) for g in gathered)
     # native exchange on the same shards
     model2, crit2 = build(cfg, params, dev, "bf16")
     model2.eval()
@@ -842,7 +864,8 @@ def _ddp_worker(rank, world, port, out_path):
     offs = model2._offsets(model2._dims(4, 30, 10, 514, 512, False))
     g_nat = torch.cat([step.grads[offs[i]: offs[i] + p.numel()] for i, p in enumerate(model2._ordered_params())]).double().cpu() / world
     if rank == 0:
-        torch.save(dict(ddp=g_ddp, native=g_nat, unused=unused, world=step.world), out_path)
+        torch.save(dict(ddp=g_ddp, native=g_nat, unused=unused, world=step.world, fused_vs_shadow=fused_vs_shadow, moved=moved, ranks_equal=ranks_equal,
+                        in_place_steps=opt.in_place_steps), out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -860,6 +883,8 @@ def test_drop_in_model_under_reference_ddp_wrapper(dev, tmp_path):
     a, b = r["ddp"], r["native"]
     assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())          # same kernels; fp32 atomic order only
     assert float((a @ b) / (a.norm() * b.norm())) > 0.99999
+    # FusedAdamWClip under the DDP wrapper: the same update as clip_grad_norm_ + torch.optim.AdamW on DDP's gradients, replicas bit-identical
+    assert r["moved"] > 5e-4 and r["fused_vs_shadow"] < 2e-6 and r["ranks_equal"], {k: r[k] for k in ("moved", "fused_vs_shadow", "ranks_equal", "in_place_steps")}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
