@@ -128,6 +128,10 @@ int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wc
  * encoder layer E-1-i are; everything else is final when the call's work completes.  An event is recorded no earlier than its range is
  * final and in index order, but several may be recorded at the same point of the stream: by default the weight gradients of the heads and of
  * layers E-1 .. 1 leave in ONE deferred launch behind layer 1's input gradient (events 0 .. E-1 there), layer 0's behind the loop. */
+/* How the ready_events of uvtg_backward are batched: writes into last_event[0 .. n) the index of the LAST event of each group (n = return value,
+ * <= E + 1; negative = error) -- the events of one group are recorded at the same point of the stream, so a data-parallel caller waits for
+ * the last event of a group and exchanges the group's ranges in ONE coalesced collective. */
+int uvtg_backward_event_groups(int E, int* last_event /* [E + 1] */);
 int uvtg_backward(const uvtg_dims* dm, const float* const* params, const void* wcache,
                   const float* src_txt, const float* src_txt_mask, const float* src_vid, const float* src_vid_mask,
                   const float* x0, const float* pred_logits, const float* pred_spans, const float* txt_mem_proj,

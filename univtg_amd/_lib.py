@@ -46,6 +46,7 @@ SIGNATURES = {
     "uvtg_criterion_fwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P] + [_P] * 3 + [_P]),
     "uvtg_criterion_bwd": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _LL, _LL, _P] + [_P] * 6 + [_P, _P, _P] + [_P] * 6 + [_P] * 3 + [_P]),
     "uvtg_forward_saliency_stats": (_I, [_DP, _P, _P, _P, _P]),
+    "uvtg_backward_event_groups": (_I, [_I, _P]),
     "uvtg_cls_nce_ws_floats": (_LL, [_I, _I]),
     "uvtg_cls_nce_fwd": (_I, [_I, _I, _I, _P, _LL, _LL, _P, _P, _P, _P, _P, _P, _P]),
     "uvtg_cls_nce_bwd": (_I, [_I, _I, _I, _P, _LL, _LL, _P, _P, _P, _P, _P, _P, _P, _LL, _LL, _P, _P]),

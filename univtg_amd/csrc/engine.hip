@@ -1028,7 +1028,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // its own gradients); UVTG_TN_DEFER_EVENTS=1: one launch behind the whole loop, every event there.
   static const bool events_per_layer = uvtg_dev_env("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
   const bool defer = (n_events == 0 || !events_per_layer) && !defer_off;
-  const int flush_layer = (n_events && defer && !defer_events && E >= 2) ? 1 : -1;      // events: group A is flushed behind this layer
+  const int flush_layer = (n_events && defer && !defer_events && E >= 2) ? 1 : -1;      // events: group A is flushed behind this layer (uvtg_backward_event_groups mirrors this)
   int events_done = 0;                           // ready_events[0 .. events_done) are recorded
   GemmTNBatch deferred[2 * MAXE + 1]; int n_deferred = 0;
   auto tn_encoder = [&](const GemmTNBatch& b) -> int {
@@ -1333,6 +1333,18 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   TRY(launch_sqsum_ranges(grads, zr_keep, ws.gnorm2, s));      // the gradients no weight-gradient launch assigned
   uvtg_prof_section(3, 1, s);
   return 0;
+}
+
+// How uvtg_backward batches its ready_events (include/uvtg.h): last_event[g] = index of the LAST event of group g; the events of a group are
+// recorded at the same point of the stream, so a caller can wait for the last one and exchange the group's ranges in one coalesced collective.
+extern "C" int uvtg_backward_event_groups(int E, int* last_event) {
+  if (E <= 0 || E > MAXE || !last_event) return -20;
+  const bool defer_off = uvtg_dev_env("UVTG_TN_DEFER_OFF") != nullptr, per_layer = uvtg_dev_env("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
+  const bool one_launch = uvtg_dev_env("UVTG_TN_DEFER_EVENTS") != nullptr;
+  if (defer_off || per_layer) { for (int i = 0; i <= E; i++) last_event[i] = i; return E + 1; }      // one event behind each range's own launches
+  if (one_launch || E < 2) { last_event[0] = E; return 1; }                                            // everything behind the loop
+  last_event[0] = E - 1; last_event[1] = E;                                                            // heads + layers E-1 .. 1 | layer 0
+  return 2;
 }
 
 // device address of the squared L2 norm of ALL gradients of the last uvtg_backward on this workspace (single-rank steps hand it to

@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import _lib
-from .dist import allreduce_flat_, broadcast_flat_
+from .dist import allreduce_flat_, allreduce_many_, broadcast_flat_
 from .model import Model, SetCriterion, _ptr, _stream
 
 LOSS_KEYS = ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra")
@@ -70,6 +70,7 @@ class TrainStep:
         # overlap_comm="force" runs the bucketed side-stream exchange even at world size 1 (single-GPU test of the plumbing)
         self.overlap = bool(overlap_comm) and (self.world > 1 or overlap_comm == "force") and dev.type == "cuda"
         self._events = self._ev_arr = self._comm_stream = None
+        self._groups = None
         # gradient buckets on the wire ("bf16 or fp32"): "bf16" halves the bytes every xGMI link carries (174 -> 87 MB per rank
         # and step); every range is rounded to bf16, SUM-reduced in bf16 and widened back (what DDP's bf16_compress_hook does)
         if grad_comm_dtype not in ("fp32", "bf16"):
@@ -303,16 +304,47 @@ class TrainStep:
 
     def _reduce_range(self, lo, hi):
         """SUM all-reduce of grads[lo:hi] on the CURRENT stream, in the configured wire dtype."""
-        if hi <= lo:
+        self._reduce_ranges([(lo, hi)])
+
+    def _reduce_ranges(self, ranges):
+        """SUM all-reduce of several ranges of the flat gradient buffer on the CURRENT stream as ONE coalesced collective (round 6): ranges that
+        touch are merged first (the encoder layers of one readiness group are one contiguous block of the buffer)."""
+        merged = []
+        for lo, hi in sorted((lo, hi) for lo, hi in ranges if hi > lo):
+            if merged and merged[-1][1] == lo:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        if not merged:
             return
+        if os.environ.get("UVTG_COMM_COALESCE_OFF"):
+            merged = [[lo, hi] for lo, hi in ranges if hi > lo]
+            if self._grads_b is None:
+                for lo, hi in merged:
+                    allreduce_flat_(self.grads[lo:hi], self.bucket, self.pg)
+                return
         if self._grads_b is None:
-            allreduce_flat_(self.grads[lo:hi], self.bucket, self.pg)
+            allreduce_many_([self.grads[lo:hi] for lo, hi in merged], self.bucket, self.pg)
             return
         st = _stream()
-        gb = self._grads_b[lo:hi]
-        _lib.check(self.lib.uvtg_cast_bf16(_ptr(self.grads[lo:hi]), _ptr(gb), hi - lo, st), "uvtg_cast_bf16")
-        allreduce_flat_(gb, 2 * self.bucket, self.pg)        # (same bytes per collective as the fp32 buckets)
-        _lib.check(self.lib.uvtg_cast_f32(_ptr(gb), _ptr(self.grads[lo:hi]), hi - lo, st), "uvtg_cast_f32")
+        for lo, hi in merged:
+            _lib.check(self.lib.uvtg_cast_bf16(_ptr(self.grads[lo:hi]), _ptr(self._grads_b[lo:hi]), hi - lo, st), "uvtg_cast_bf16")
+        allreduce_many_([self._grads_b[lo:hi] for lo, hi in merged], 2 * self.bucket, self.pg)        # (same bytes per collective as the fp32 buckets)
+        for lo, hi in merged:
+            _lib.check(self.lib.uvtg_cast_f32(_ptr(self._grads_b[lo:hi]), _ptr(self.grads[lo:hi]), hi - lo, st), "uvtg_cast_f32")
+
+    def _event_groups(self):
+        """Last event index of every readiness group (uvtg_backward_event_groups): the library records the events of a group together."""
+        if self._groups is None and os.environ.get("UVTG_COMM_COALESCE_OFF"):      # (A/B: one wait + one collective per range, rounds 2-5)
+            self._groups = list(range(self.model.enc_layers + 1))
+        if self._groups is None:
+            E = self.model.enc_layers
+            buf = (C.c_int * (E + 1))()
+            n = self.lib.uvtg_backward_event_groups(E, buf)
+            if n <= 0:
+                raise RuntimeError(f"uvtg_backward_event_groups failed ({n})")
+            self._groups = [int(buf[i]) for i in range(n)]
+        return self._groups
 
     def _exchange_gradients(self, dims):
         if not self.overlap:
@@ -321,10 +353,11 @@ class TrainStep:
         ranged, rest = self.bucket_ranges(dims)
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self._comm_stream):
-            for ev, (lo, hi) in zip(self._events, ranged):
-                self._comm_stream.wait_event(ev)             # that range is final on the compute stream
-                self._reduce_range(lo, hi)
+            first = 0
+            for last in self._event_groups():                # one wait + ONE coalesced collective per readiness group
+                self._comm_stream.wait_event(self._events[last])      # the group's ranges are final on the compute stream
+                self._reduce_ranges(ranged[first: last + 1])
+                first = last + 1
             self._comm_stream.wait_stream(main)              # end of backward: everything else is final
-            for lo, hi in rest:
-                self._reduce_range(lo, hi)
+            self._reduce_ranges(rest)
         main.wait_stream(self._comm_stream)                  # the optimizer step needs every reduced range
