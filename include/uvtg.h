@@ -126,8 +126,9 @@ int uvtg_forward(const uvtg_dims* dm, const float* const* params, const void* wc
  * ready_events (optional, for overlapping the data-parallel gradient exchange with the rest of backward): event 0 is recorded
  * on `stream` once the span_embed / class_embed gradients (table entries 12E+1 .. 12E+12) are final, event 1 + i once those of
  * encoder layer E-1-i are; everything else is final when the call's work completes.  An event is recorded no earlier than its range is
- * final and in index order, but several may be recorded at the same point of the stream: by default the weight gradients of the heads and of
- * layers E-1 .. 1 leave in ONE deferred launch behind layer 1's input gradient (events 0 .. E-1 there), layer 0's behind the loop. */
+ * final and in index order, but several may be recorded at the same point of the stream: by default every weight gradient of the heads and
+ * of the encoder leaves in ONE deferred launch behind the encoder loop and all E + 1 events are recorded there (uvtg_backward_event_groups
+ * reports the batching; a developer switch records the heads + layers E-1 .. 1 behind layer 1 instead). */
 /* How the ready_events of uvtg_backward are batched: writes into last_event[0 .. n) the index of the LAST event of each group (n = return value,
  * <= E + 1; negative = error) -- the events of one group are recorded at the same point of the stream, so a data-parallel caller waits for
  * the last event of a group and exchanges the group's ranges in ONE coalesced collective. */

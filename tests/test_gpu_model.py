@@ -990,13 +990,13 @@ def test_auto_projection_mode_training(dev, golden_dir, name):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("shape", ["toy_width", "production_width_grouped_deferral"])
+@pytest.mark.parametrize("shape", ["toy_width", "production_width"])
 def test_overlapped_gradient_exchange_single_rank(dev, shape):
     """The bucketed side-stream exchange (ready events recorded inside uvtg_backward, RCCL all-reduce per range on a comm
-    stream) at world size 1: must leave exactly the gradients / parameters of the plain path.  production_width_grouped_deferral: the round-6
-    default under events -- heads + layers E-1 .. 1 in one hybrid weight-gradient launch behind layer 1, layer 0 in a second one -- at
-    d = 1024, E = 4 (the toy width falls back to the per-batch launches).  (UVTG_TN_EVENTS_PER_LAYER=1 in the environment runs the same
-    test on the per-layer-event mode of rounds 2-5.)"""
+    stream, one coalesced collective per readiness group) at world size 1: must leave exactly the gradients / parameters of the plain path.
+    production_width: d = 1024, E = 4, where the weight gradients stay in the deferred hybrid launch under the events (the toy width falls back
+    to the per-batch launches).  (With UVTG_DEV_ENV=1 the same test covers UVTG_TN_EVENT_GROUPS=1 -- heads + layers E-1 .. 1 behind layer 1,
+    layer 0 in a second launch -- and UVTG_TN_EVENTS_PER_LAYER=1, the per-layer-event mode of rounds 2-5.)"""
     import torch.distributed as dist
     from oracle import univtg_oracle as O
     from univtg_amd.trainer import TrainStep

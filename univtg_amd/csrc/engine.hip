@@ -1016,16 +1016,13 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
   // rows at config 2, whole tiles per workgroup + half tiles for the remainder, no partial-slab reduce pass (gemm.hip, gemm_tn256h_kernel).
   // With events (data-parallel overlap) each layer's two batches run in place, as before, and their gradients are final at the event.
   static const bool defer_off = uvtg_dev_env("UVTG_TN_DEFER_OFF") != nullptr;
-  // UVTG_TN_DEFER_EVENTS=1 (opt-in, N > 1): keep the deferred launch under readiness events too -- every encoder layer's event is then recorded
-  // behind it, i.e. the encoder gradients' all-reduce overlaps only what follows the encoder (saliency branch + input projections).  Which of the
-  // two wins depends on the node's all-reduce time; the compute side is measured (bench.py --overlap force).
-  static const bool defer_events = uvtg_dev_env("UVTG_TN_DEFER_EVENTS") != nullptr;
-  // Round 6 (default under events): the deferral stays, in TWO groups -- the conv heads and layers E-1 .. 1 go out as ONE hybrid launch (and
-  // one LayerNorm fold) right behind layer 1's dgrad, their E events recorded together there, while layer 0 (a quarter of the tiles), the
-  // saliency branch and the input projections are still to run: the all-reduce of (E - 1) / E of the encoder gradients and of the heads
-  // overlaps them; layer 0's own group follows the loop.  The step then runs the kernels of the single-rank step plus one small hybrid launch
-  // (bench.py --overlap force).  UVTG_TN_EVENTS_PER_LAYER=1: the per-layer slab + reduce batches of rounds 2-5 (every layer's event behind
-  // its own gradients); UVTG_TN_DEFER_EVENTS=1: one launch behind the whole loop, every event there.
+    static const bool defer_events = uvtg_dev_env("UVTG_TN_EVENT_GROUPS") == nullptr;      // default: ONE launch behind the loop, every event there
+  // Round 6: the deferral stays under events.  Default: the ONE hybrid launch of the single-rank step, every event recorded behind it -- the
+  // N > 1 step then runs exactly the single-rank step's kernels (+1.2 % on one rank with the coalesced exchange, bench.py --overlap force) and
+  // the gradient exchange of the heads + encoder (150 MB) overlaps the saliency branch and the input projections (~1 ms).
+  // UVTG_TN_EVENT_GROUPS=1: TWO groups -- the conv heads and layers E-1 .. 1 go out as one hybrid launch (and one LayerNorm fold) right behind
+  // layer 1's dgrad, their E events recorded together there, layer 0's own group follows the loop: +2.8 % compute for ~2.3 ms of cover (the
+  // choice for a slow interconnect).  UVTG_TN_EVENTS_PER_LAYER=1: the per-layer slab + reduce batches of rounds 2-5 (+5.3 %).
   static const bool events_per_layer = uvtg_dev_env("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
   const bool defer = (n_events == 0 || !events_per_layer) && !defer_off;
   const int flush_layer = (n_events && defer && !defer_events && E >= 2) ? 1 : -1;      // events: group A is flushed behind this layer (uvtg_backward_event_groups mirrors this)
@@ -1340,7 +1337,7 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
 extern "C" int uvtg_backward_event_groups(int E, int* last_event) {
   if (E <= 0 || E > MAXE || !last_event) return -20;
   const bool defer_off = uvtg_dev_env("UVTG_TN_DEFER_OFF") != nullptr, per_layer = uvtg_dev_env("UVTG_TN_EVENTS_PER_LAYER") != nullptr;
-  const bool one_launch = uvtg_dev_env("UVTG_TN_DEFER_EVENTS") != nullptr;
+  const bool one_launch = uvtg_dev_env("UVTG_TN_EVENT_GROUPS") == nullptr;
   if (defer_off || per_layer) { for (int i = 0; i <= E; i++) last_event[i] = i; return E + 1; }      // one event behind each range's own launches
   if (one_launch || E < 2) { last_event[0] = E; return 1; }                                            // everything behind the loop
   last_event[0] = E - 1; last_event[1] = E;                                                            // heads + layers E-1 .. 1 | layer 0
