@@ -503,8 +503,8 @@ GemmArgs gemm_base(const void* A, int lda, const void* B, int ldb, int M, int N,
 // 303 (round 5): the last encoder layer's FFN half runs on the clip rows only (last_layer_clip below); a bf16 training call with memory != NULL is
 // refused (-24) on the unpacked stream as it already was on the packed one; developer switches uvtg_debug_last_layer_clip, uvtg_debug_tn_conv_defer.
 // 304 (round 6): nothing in include/uvtg.h changed shape; additive: uvtg_cls_nce_fwd / _bwd / _ws_floats.  Behaviour: no entry point reads the process environment any more (developer switches:
-// uvtg_dev_config_set / uvtg_dev_config_from_env, include/uvtg_dev.h); uvtg_backward records its ready_events in groups (heads + layers E-1 .. 1
-// behind layer 1, layer 0 behind the loop: the weight gradients stay deferred under events) and remembers the forward's last-layer row layout per workspace.
+// uvtg_dev_config_set / uvtg_dev_config_from_env, include/uvtg_dev.h); uvtg_backward keeps its deferred weight-gradient launch under ready_events
+// and records them in groups (uvtg_backward_event_groups, additive) and remembers the forward's last-layer row layout per workspace.
 extern "C" int uvtg_version(void) { return 304; }
 
 extern "C" const char* uvtg_strerror(int code) {
