@@ -26,9 +26,9 @@ rep("      eg[EOP ? i : 0][q] = *(const u32x4*)(esrc + orow * eld + (ncol ? n : 
     "      eg[EOP ? i : 0][q] = (epi_mode & 2) ? (u32x4){0, 0, 0, 0} : *(const u32x4*)(esrc + orow * eld + (ncol ? n : 0));")
 rep("        return *(const u32x4*)(esrc + orow * eld + (ncol ? n : 0));", "        return (epi_mode & 2) ? (u32x4){0, 0, 0, 0} : *(const u32x4*)(esrc + orow * eld + (ncol ? n : 0));")
 rep("          else if constexpr (EOP) eop = *(const u32x4*)(esrc + orow * eld + n);", "          else if constexpr (EOP) eop = (epi_mode & 2) ? (u32x4){0, 0, 0, 0} : *(const u32x4*)(esrc + orow * eld + n);")
-rep("static unsigned long long* g_trace_buf = nullptr;",
+rep("static int check_nt(const GemmArgs& a, int elem) {",
     "extern \"C\" int uvtg_debug_nt_epilogue_mode(int m) { hipLaunchKernelGGL(nt_epi_mode_set_kernel, dim3(1), dim3(1), 0, 0, m); return (int)hipDeviceSynchronize(); }\n"
-    "static unsigned long long* g_trace_buf = nullptr;")
+    "static int check_nt(const GemmArgs& a, int elem) {")
 os.makedirs("/tmp/uvtg_nostore", exist_ok=True)
 open("/tmp/uvtg_nostore/gemm_n.hip", "w").write(src)
 sys.path.insert(0, R)
