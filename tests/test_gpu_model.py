@@ -1204,7 +1204,7 @@ def test_pipeline_collate_upload_matches_reference(dev, golden_dir):
     assert np.array_equal(mi16["src_vid_mask"].cpu().numpy(), z["in/src_vid_mask"])
 
 
-@pytest.mark.parametrize("case", ["tiny_golden", "production_width", "long_sequence", "txt_pos_three_blocks"])
+@pytest.mark.parametrize("case", ["tiny_golden", "production_width", "long_sequence", "txt_pos_three_blocks", "tal_branch"])
 def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
     """Train-mode parity: input dropout (p=0.5), attention dropout and DropPath all on.  The kernels' counter-based masks are
     regenerated on the host (tests/philox_ref.py), handed to the CPU oracle as explicit Bernoulli masks, and outputs, losses and
@@ -1219,6 +1219,10 @@ def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
         cfg = O.make_cfg(input_dropout=0.5, dropout=0.1, droppath=0.25, enc_layers=1)
         params = O.init_params(cfg, seed=11)
         inputs, tg = O.make_batch(cfg, 4, 12, 5, seed=12, ragged=True)
+    elif case == "tal_branch":              # round 6: src_cls in TRAIN mode -- the class names' projection draws its own input-dropout masks (the
+        # second engine call of Model.forward: the next step seed), and the 'saliency_cls' class term sends gradients through them
+        meta, _, params, inputs, tg, *_ = load_case(golden_dir, "tiny_tal")
+        cfg = O.make_cfg(**{**meta["cfg"], "input_dropout": 0.5, "dropout": 0.1, "droppath": 0.25})
     elif case == "txt_pos_three_blocks":    # --use_txt_pos + --n_input_proj 3 in TRAIN mode: the text positions' own dropout (p = input_dropout,
         # position_encoding.py:113-115), three dropout streams per modality, the position table / LayerNorm gradients
         meta, _, params, inputs, tg, *_ = load_case(golden_dir, "tiny_txt_pos")
@@ -1250,15 +1254,20 @@ def test_train_mode_dropout_replayed_through_oracle(dev, golden_dir, case):
            "attn_keep": torch.stack([t(R.attn_keep(seed, l, B, H, S, 0.1)) for l in range(E)])}
     if getattr(cfg, "use_txt_pos", False):      # counters keyed by the token's row b * S + L_v + t of the padded layout (engine.hip, text_positions)
         rng["txtpos_keep"] = t(R.row_keep(seed, R.RNG_TXT_POS, B * S, d, 0.5)).view(B, S, d)[:, Lv:]
+    if "src_cls" in inputs:      # the class names go through the engine as a SECOND training call: step seed + 1, text-stream counters over n_cls x L_c rows
+        seed_cls = (20240917 * 1000003 + 2) & 0xFFFFFFFFFFFFFFFF
+        nc, Lc = inputs["src_cls"].shape[:2]
+        rng["cls_keep"] = [t(R.row_keep(seed_cls, R.RNG_IN_TXT + b, nc * Lc, Dt if b == 0 else d, 0.5)).view(nc, Lc, Dt if b == 0 else d) for b in range(nb)]
     assert 0 < float((rng["dp_scale"] == 0).float().mean()) < 1           # the case exercises dropped AND kept branches
     ref_params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    ref_out = O.forward(ref_params, cfg, inputs["src_txt"], inputs["src_txt_mask"], inputs["src_vid"], inputs["src_vid_mask"], rng=rng)
+    ref_out = O.forward(ref_params, cfg, inputs["src_txt"], inputs["src_txt_mask"], inputs["src_vid"], inputs["src_vid_mask"],
+                        inputs.get("src_cls"), inputs.get("src_cls_mask"), rng=rng)
     ref_losses = O.criterion(ref_out, tg, cfg)
     O.total_loss(ref_losses, cfg).backward()
 
     valid = inputs["src_vid_mask"].bool()
     assert float((out["saliency_scores"].detach().cpu() - ref_out["saliency_scores"].detach())[valid].abs().max()) < 2e-2
-    for k, tol in (("pred_logits", 4e-2), ("pred_spans", 4e-2), ("vid_mem_proj", 4e-2), ("txt_mem_proj", 4e-2)):
+    for k, tol in (("pred_logits", 4e-2), ("pred_spans", 4e-2), ("vid_mem_proj", 4e-2), ("txt_mem_proj", 4e-2)) + ((("cls_mem_proj", 4e-2),) if "cls_mem_proj" in ref_out else ()):
         err = float((out[k].detach().cpu() - ref_out[k].detach()).abs().max())
         assert err < tol, (k, err)
     for k in ("loss_b", "loss_g", "loss_f", "loss_s_inter", "loss_s_intra"):
