@@ -770,14 +770,20 @@ __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFina
   float* s_red = s_pool + a.d;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d;
   const float* xt = a.x0 + ((size_t)b * a.S + a.Lv) * d;      // text rows
-  for (int t = wave; t < a.Lt; t += 8) {
-    float acc = 0.f;
-    for (int c = lane * 4; c < d; c += 256) {
-      const f32x4 x = *(const f32x4*)(xt + (size_t)t * d + c), wv = *(const f32x4*)(a.w_pool + c);
-      acc += x[0] * wv[0] + x[1] * wv[1] + x[2] * wv[2] + x[3] * wv[3];
+  {   // pooling logits: the lane's 2 NPASS pieces of w_pool once, the pieces of a text row issued together (same sums in the same order as the rolled loop)
+    f32x4 wp[2 * NPASS];
+#pragma unroll
+    for (int i = 0; i < 2 * NPASS; i++) wp[i] = *(const f32x4*)(a.w_pool + lane * 4 + 256 * i);
+    for (int t = wave; t < a.Lt; t += 8) {
+      f32x4 x[2 * NPASS];
+#pragma unroll
+      for (int i = 0; i < 2 * NPASS; i++) x[i] = *(const f32x4*)(xt + (size_t)t * d + lane * 4 + 256 * i);
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * NPASS; i++) acc += x[i][0] * wp[i][0] + x[i][1] * wp[i][1] + x[i][2] * wp[i][2] + x[i][3] * wp[i][3];
+      acc = wave_sum(acc);
+      if (lane == 0) s_alpha[t] = acc + (1.0f - a.txt_mask[b * a.Lt + t]) * (-1e30f);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) s_alpha[t] = acc + (1.0f - a.txt_mask[b * a.Lt + t]) * (-1e30f);
   }
   __syncthreads();
   if (wave == 0) {
@@ -797,7 +803,7 @@ __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFina
   float nsq = 0.f;
   for (int c = tid; c < d; c += 512) {
     float acc = 0.f;
-#pragma unroll 8
+#pragma unroll 16
     for (int t = 0; t < a.Lt; t++) acc += s_alpha[t] * xt[(size_t)t * d + c];
     a.pooled[(size_t)b * d + c] = acc;
     s_pool[c] = acc;
@@ -833,16 +839,30 @@ __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFina
       os[ps] = *(const u32x4*)hr; oc[ps] = *(const u32x4*)(hr + d);
     }
   };
+  // the clip's own fp32 row for the cosine: 2 NPASS 16-byte pieces per lane, all issued together with the hidden row (round 6: with the column loop
+  // left rolled every piece was its own load -> use round trip -- 6.3 us per clip, 63 of the kernel's 83 us at config 2; holding the NEXT clip's
+  // pieces as well spills: the lane already keeps 144 tap weights and 48 registers of sliding hidden rows)
+  // (... and lane 0's three bias words and the clip's mask word were four more serial round trips per clip behind the wave sums: the biases are read
+  // once, the mask word with the clip's rows)
+  auto uniform = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };      // (scalar registers: the lane's vector file is full)
+  const float bs0 = uniform(h.b_span[0]), bs1 = uniform(h.b_span[1]), bc0 = uniform(h.b_cls[0]);
   if (t0 < t1 && t0 < kept) { load_row(fs + t0, rs[0], rc[0]); load_row(fs + t0 + 1, rs[1], rc[1]); }
   for (int t = t0; t < t1; t++) {
     const int row = b * a.Lv + t;
     const bool framed = t < kept;
     if (framed) load_row(fs + t + 2, rs[2], rc[2]);
-    // cosine saliency (lane owns 4 consecutive fp32 channels per pass)
-    const float* v = a.x0 + ((size_t)b * a.S + t) * d;
+    const float vmask = a.vid_mask[row];
+    f32x4 xv[2 * NPASS];
+    {
+      const float* v = a.x0 + ((size_t)b * a.S + t) * d + lane * 4;
+#pragma unroll
+      for (int i = 0; i < 2 * NPASS; i++) xv[i] = *(const f32x4*)(v + 256 * i);
+    }
+    // cosine saliency (lane owns 4 consecutive fp32 channels per piece)
     float dot = 0.f, vs = 0.f;
-    for (int c = lane * 4; c < d; c += 256) {
-      const f32x4 x = *(const f32x4*)(v + c), y = *(const f32x4*)(s_pool + c);
+#pragma unroll
+    for (int i = 0; i < 2 * NPASS; i++) {
+      const f32x4 x = xv[i], y = *(const f32x4*)(s_pool + lane * 4 + 256 * i);
       dot += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
       vs += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
     }
@@ -869,11 +889,11 @@ __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFina
       const float cs = dot / (fmaxf(vn, 1e-8f) * fmaxf(qn, 1e-8f));
       if (a.vnorm) a.vnorm[row] = vn;
       if (a.cosv) a.cosv[row] = cs;
-      a.sal[row] = cs + (a.vid_mask[row] != 0.f ? 0.f : UVTG_LOG_TINY);
+      a.sal[row] = cs + (vmask != 0.f ? 0.f : UVTG_LOG_TINY);
       if (framed) {
-        h.pred_spans[(size_t)row * 2 + 0] = -1.0f / (1.0f + expf(-(z0 + h.b_span[0])));
-        h.pred_spans[(size_t)row * 2 + 1] = 1.0f / (1.0f + expf(-(z1 + h.b_span[1])));
-        h.pred_logits[row] = 1.0f / (1.0f + expf(-(zc + h.b_cls[0])));
+        h.pred_spans[(size_t)row * 2 + 0] = -1.0f / (1.0f + expf(-(z0 + bs0)));
+        h.pred_spans[(size_t)row * 2 + 1] = 1.0f / (1.0f + expf(-(z1 + bs1)));
+        h.pred_logits[row] = 1.0f / (1.0f + expf(-(zc + bc0)));
       } else {
         h.pred_spans[(size_t)row * 2] = -0.5f; h.pred_spans[(size_t)row * 2 + 1] = 0.5f; h.pred_logits[row] = 0.5f;
       }

@@ -767,7 +767,12 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwdArgs a) {
 // whole column quads c4 = lane + 64 k (two 8-byte loads each: the rows are only 8-byte aligned), the two row sums are DPP wave sums (no LDS, no
 // barrier), and the dropout draw is one Philox call per owned quad -- the same (row, column) -> mask mapping as everywhere else
 // (counter = row * ceil(D / 4) + c / 4, word c % 4).  NQ = quads per lane (12 covers D <= 3072).
-template <int NQ>
+// Round 6: FULL = number of leading quad groups k that are complete for EVERY lane (64 (k + 1) * 4 <= D, chosen by the host: 11 at D = 2818) -- those
+// groups carry no per-lane column guards at all (the guarded code was 216 exec-mask branches per row for a kernel that is VALU-bound: 12 Philox
+// calls + 48 hi / lo splits per lane and row); only the groups k >= FULL keep them.  The fused multiply-adds are spelled out so that both
+// instantiations round alike (left to the compiler, the guarded code fused sq += t * t and the unguarded one did not: one sample of the index
+// clause's 1024 moved across its fp32 tie).
+template <int NQ, int FULL>
 __global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a) {
   const int lane = threadIdx.x & 63, D = a.D, D4 = (D + 3) >> 2;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -780,8 +785,8 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a
   for (int k = 0; k < NQ; k++) {
     const int c = (lane + 64 * k) * 4;
     v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
-    if (c + 1 < D) { const f32x2 t = *(const f32x2*)(xr + c); v[k][0] = t[0]; v[k][1] = t[1]; }
-    if (c + 3 < D) { const f32x2 t = *(const f32x2*)(xr + c + 2); v[k][2] = t[0]; v[k][3] = t[1]; }
+    if (k < FULL || c + 1 < D) { const f32x2 t = *(const f32x2*)(xr + c); v[k][0] = t[0]; v[k][1] = t[1]; }
+    if (k < FULL || c + 3 < D) { const f32x2 t = *(const f32x2*)(xr + c + 2); v[k][2] = t[0]; v[k][3] = t[1]; }
     sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
   const float mean = wave_sum_dpp(sum) / (float)D;
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a
   for (int k = 0; k < NQ; k++) {
     const int c = (lane + 64 * k) * 4;
 #pragma unroll
-    for (int e = 0; e < 4; e++) if (c + e < D) { const float t = v[k][e] - mean; sq += t * t; }
+    for (int e = 0; e < 4; e++) if (k < FULL || c + e < D) { const float t = v[k][e] - mean; sq = __builtin_fmaf(t, t, sq); }
   }
   const float rstd = rsqrtf(wave_sum_dpp(sq) / (float)D + a.eps);
   if (lane == 0) {
@@ -798,12 +803,13 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a
     if (a.rstd) a.rstd[row] = rstd;
   }
   const float inv = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  const int dmax = a.Dpad > D ? a.Dpad : D;
 #pragma unroll
   for (int k = 0; k < NQ; k++) {
     const int c4 = lane + 64 * k, c = c4 * 4;
-    if (c >= a.Dpad && c >= D) continue;
+    if (k >= FULL && c >= dmax) continue;
     float y[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < D) {
+    if (k < FULL || c < D) {
       float ks[4] = {1.f, 1.f, 1.f, 1.f};
       if (a.p_drop > 0.f) {
         unsigned r[4];
@@ -811,31 +817,32 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a
 #pragma unroll
         for (int e = 0; e < 4; e++) ks[e] = (u01(r[e]) >= a.p_drop) ? inv : 0.0f;
       }
-      if (c + 3 < D) {
+      if (k < FULL || c + 3 < D) {
         const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
 #pragma unroll
-        for (int e = 0; e < 4; e++) y[e] = ((v[k][e] - mean) * rstd * gm[e] + bt[e]) * ks[e];
+        for (int e = 0; e < 4; e++) y[e] = __builtin_fmaf((v[k][e] - mean) * rstd, gm[e], bt[e]) * ks[e];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; e++)
-          if (c + e < D) y[e] = ((v[k][e] - mean) * rstd * a.gamma[c + e] + a.beta[c + e]) * ks[e];
+          if (c + e < D) y[e] = __builtin_fmaf((v[k][e] - mean) * rstd, a.gamma[c + e], a.beta[c + e]) * ks[e];
       }
     }
     // (columns [D, Dpad) are written as zeros: the GEMM operand is zero-padded to whole K tiles)
+    const bool whole = k < FULL || c + 3 < dmax;
     if (a.yS) {      // fp16 hi / lo images of the split-operand projection GEMM (y == 0 in the padding columns: both images get zeros)
       unsigned short* o = a.yS + (size_t)row * a.ldyS + split_col(c);       // (c is a multiple of 4: the quad stays inside one 32-column block)
-      if (c + 3 < (a.Dpad > D ? a.Dpad : D)) { u32x2 h, l; split4_f16(y, a.sscale, h, l); *(u32x2*)o = h; *(u32x2*)(o + 32) = l; }
+      if (whole) { u32x2 h, l; split4_f16(y, a.sscale, h, l); *(u32x2*)o = h; *(u32x2*)(o + 32) = l; }
       else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) if (c + e < (a.Dpad > D ? a.Dpad : D)) { unsigned short h, l; split_f16(y[e] * a.sscale, h, l); o[e] = h; o[32 + e] = l; }
+        for (int e = 0; e < 4; e++) if (c + e < dmax) { unsigned short h, l; split_f16(y[e] * a.sscale, h, l); o[e] = h; o[32 + e] = l; }
       }
     }
     if (a.yB) {
       bf16_t* o = a.yB + (size_t)row * a.ldyB + c;
-      if (c + 3 < (a.Dpad > D ? a.Dpad : D)) { u32x2 t; t[0] = pack_bf2(y[0], y[1]); t[1] = pack_bf2(y[2], y[3]); *(u32x2*)o = t; }
+      if (whole) { u32x2 t; t[0] = pack_bf2(y[0], y[1]); t[1] = pack_bf2(y[2], y[3]); *(u32x2*)o = t; }
       else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) if (c + e < (a.Dpad > D ? a.Dpad : D)) o[e] = f2bf(y[e]);
+        for (int e = 0; e < 4; e++) if (c + e < dmax) o[e] = f2bf(y[e]);
       }
     }
   }
@@ -984,7 +991,11 @@ static int launch_ln_fwd_impl(const LnFwdArgs& a, hipStream_t s) {
     static const bool wave_off = uvtg_dev_env("UVTG_LN_WIDE_WAVE_OFF") != nullptr;     // experiment: the block-per-row kernel
     const int dmax = a.Dpad > a.D ? a.Dpad : a.D;
     if (!wave_off && dmax <= 3072 && (a.ldx % 2 == 0) && (!a.yB || a.ldyB % 4 == 0) && (!a.yS || a.ldyS % 4 == 0) && al(a.gamma, 0, 4, 16) && al(a.beta, 0, 4, 16))
-      hipLaunchKernelGGL((ln_fwd_wide_wave_kernel<12>), dim3(cdiv(a.rows, 4)), dim3(256), 0, s, a);     // wave per row
+    {                                                                                                     // wave per row
+      static const bool full_off = uvtg_dev_env("UVTG_LN_WIDE_FULL_OFF") != nullptr;                     // experiment: every quad group guarded (rounds 3-5)
+      if (a.D >= 11 * 256 && !full_off) hipLaunchKernelGGL((ln_fwd_wide_wave_kernel<12, 11>), dim3(cdiv(a.rows, 4)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((ln_fwd_wide_wave_kernel<12, 0>), dim3(cdiv(a.rows, 4)), dim3(256), 0, s, a);
+    }
     else
       hipLaunchKernelGGL((ln_fwd_wide_kernel<6>), dim3(min(a.rows, 4096)), dim3(256), 0, s, a);         // block per row (see the kernel)
     UVTG_CHECK_LAUNCH();
