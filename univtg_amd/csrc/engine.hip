@@ -1303,10 +1303,15 @@ extern "C" int uvtg_backward(const uvtg_dims* dm, const float* const* P, const v
     for (int b = nb - 1; b >= 0; b--) {
       const int Din = m.din(which, b), Kp = m.kp(which, b);
       GemmArgs g = gemm_base(gout[b], d, w.pwT[which][b], d, R, Kp, d);
-      g.outF = ws.dA[which]; g.ldoF = Kp;
+      // the wide feature LayerNorm has no upstream: its backward is the dgamma / dbeta column reduction alone, which takes the dgrad as a bf16
+      // stream like every other gradient stream of the step (round 6: the GEMM writes and the reduction reads half the bytes -- 2 x 110 MB at config 2)
+      static const bool dgrad_f32 = uvtg_dev_env("UVTG_PROJ_DGRAD_F32") != nullptr;      // experiment: fp32 as in rounds 1-5
+      const bool gbf = b == 0 && Din > 2048 && (Kp % 2 == 0) && !dgrad_f32;
+      if (gbf) { g.outB = (bf16_t*)ws.dA[which]; g.ldoB = Kp; } else { g.outF = ws.dA[which]; g.ldoF = Kp; }
       TRY(launch_gemm_nt_bf16(g, s));
       LnBwdArgs lb; memset(&lb, 0, sizeof(lb));
-      lb.g = ws.dA[which]; lb.ldg = Kp; lb.x = b == 0 ? src : ws.ph[which][b - 1]; lb.ldx = Din; lb.mean = ws.pm[which][b]; lb.rstd = ws.pr[which][b];
+      if (gbf) { lb.gB = (const bf16_t*)ws.dA[which]; lb.ldgB = Kp; } else { lb.g = ws.dA[which]; lb.ldg = Kp; }
+      lb.x = b == 0 ? src : ws.ph[which][b - 1]; lb.ldx = Din; lb.mean = ws.pm[which][b]; lb.rstd = ws.pr[which][b];
       lb.gamma = P[m.proj(which, b, PG)]; lb.rows = R; lb.D = Din; lb.p_drop = m.c.p_in; lb.seed = m.c.seed; lb.stream_id = rs + b;
       lb.dgamma = G(m.proj(which, b, PG)); lb.dbeta = G(m.proj(which, b, PBE)); lb.rs_seg = 1;
       if (b > 0) { lb.dxB = ws.dhb[which][b - 1]; lb.lddxB = d; lb.relu_from_x = 1; gout[b - 1] = ws.dhb[which][b - 1]; }

@@ -849,6 +849,9 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_wave_kernel(const LnFwdArgs a
 }
 // dgamma / dbeta only (the feature LayerNorm has no upstream: dx is never needed), i.e. a pure column reduction over the rows:
 // thread = 2 columns, block = 512 columns x a slice of rows, per-block partials folded by ln_bwd_reduce_kernel.
+// GB (round 6): the upstream gradient is a bf16 stream (a.gB) -- the projection dgrad GEMM that produces it then writes, and this pass reads, half
+// the bytes; x stays the fp32 feature rows.
+template <bool GB>
 __global__ __launch_bounds__(256) void ln_dgb_wide_kernel(const LnBwdArgs a, int rows_per_block) {
   const int tid = threadIdx.x, D = a.D, D4 = (D + 3) >> 2;
   const int c = (blockIdx.x * 256 + tid) * 2;
@@ -861,9 +864,9 @@ __global__ __launch_bounds__(256) void ln_dgb_wide_kernel(const LnBwdArgs a, int
     const float wb = (r + 1 < r1) ? 1.f : 0.f;
     float ga[2], xa[2], gb[2], xb[2];
     const int lr = a.src_rows ? a.src_rows[r] : r, lrb = a.src_rows ? a.src_rows[rb] : rb;
-    loadv<2>(a.g + (size_t)r * a.ldg + cc, ga);
+    if constexpr (GB) { loadb<2>(a.gB + (size_t)r * a.ldgB + cc, ga); loadb<2>(a.gB + (size_t)rb * a.ldgB + cc, gb); }
+    else { loadv<2>(a.g + (size_t)r * a.ldg + cc, ga); loadv<2>(a.g + (size_t)rb * a.ldg + cc, gb); }
     loadv<2>(a.x + (size_t)(a.gather_x ? lr : r) * a.ldx + cc, xa);
-    loadv<2>(a.g + (size_t)rb * a.ldg + cc, gb);
     loadv<2>(a.x + (size_t)(a.gather_x ? lrb : rb) * a.ldx + cc, xb);
     const float ma = a.mean[r], sa = a.rstd[r], mb = a.mean[rb], sb = a.rstd[rb];
     float ka[2] = {1.f, 1.f}, kb[2] = {1.f, 1.f};
@@ -1036,14 +1039,15 @@ static int launch_ln_bwd_impl(const LnBwdArgs& a, hipStream_t s) {
                       al(a.dxF, a.lddxF, 4, 8) && al(a.dxB, a.lddxB, 2, 4) && al(a.gamma, 0, 4, 8);
   const bool alignv8 = align16 && al(a.xB, a.ldxB, 2, 16) && al(a.gB, a.ldgB, 2, 16) && al(a.g2B, a.ldg2B, 2, 16) &&
                        al(a.dxB, a.lddxB, 2, 16) && al(a.dxB2, a.lddxB2, 2, 16);
-  if (a.D > 2048 && a.D % 2 == 0 && align8 && a.x && a.g && !a.g2 && !a.gB && !a.g2B && a.dgamma && a.dbeta && !a.dxF && !a.dxB && !a.dxB2 &&
+  if (a.D > 2048 && a.D % 2 == 0 && align8 && a.x && (a.g != nullptr) != (a.gB != nullptr) && !a.g2 && !a.g2B && a.dgamma && a.dbeta && !a.dxF && !a.dxB && !a.dxB2 &&
       a.partial) {
     // parameter gradients only: column reduction (ln_dgb_wide_kernel)
     int rpb = cdiv(a.rows, 384);
     rpb = (rpb < 32 ? 32 : rpb + (rpb & 1));
     const int rb = cdiv(a.rows, rpb);
     if ((long long)rb * 2 * a.D <= a.partial_floats) {
-      hipLaunchKernelGGL(ln_dgb_wide_kernel, dim3(cdiv(a.D, 512), rb), dim3(256), 0, s, a, rpb);
+      if (a.gB) hipLaunchKernelGGL(ln_dgb_wide_kernel<true>, dim3(cdiv(a.D, 512), rb), dim3(256), 0, s, a, rpb);
+      else hipLaunchKernelGGL(ln_dgb_wide_kernel<false>, dim3(cdiv(a.D, 512), rb), dim3(256), 0, s, a, rpb);
       hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a.D, 64), rb >= 128 ? 8 : 1), dim3(256), 0, s, a, rb);
       UVTG_CHECK_LAUNCH();
       return 0;
