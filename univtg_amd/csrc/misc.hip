@@ -585,9 +585,12 @@ __global__ __launch_bounds__(256) void heads_final_bwd_dh_kernel(const HeadsFina
 // One 1024-thread block per sample: 4 row groups x 256 threads, a thread owns 8 channels of the 2d-wide hidden row
 // (16-byte loads; every hidden row is loaded once and feeds all three taps), the 4 groups' partial sums are folded
 // through LDS and leave as one set of atomics per sample.
+// gridDim.y > 1 (round 6): the sample's hidden rows are cut into gridDim.y ranges, one block each, every block with its own partial slot -- with one
+// block per sample a batch of 32 samples x 1200 clips walked 300 rows per thread on 32 of the chip's 256 CUs (177 us at config 4).
 __global__ __launch_bounds__(1024) void heads_final_bwd_dw_kernel(const HeadsFinalArgs a) {
   extern __shared__ float sm[];                 // [3][Lv + 2] dz (zero at both ends) | [2][256][49] partial sums
   const int b = blockIdx.x, d = a.d, tid = threadIdx.x, Lv = a.Lv, grp = tid >> 8, t8 = tid & 255;
+  const int nsplit = gridDim.y, ys = blockIdx.y;
   float* s_dz = sm;
   float* s_part = sm + 3 * (Lv + 2);
   const bf16_t* h2 = (const bf16_t*)a.h2;
@@ -599,10 +602,11 @@ __global__ __launch_bounds__(1024) void heads_final_bwd_dw_kernel(const HeadsFin
     bs0 += d0; bs1 += d1; bsc += dc;
   }
   bs0 = wave_sum(bs0); bs1 = wave_sum(bs1); bsc = wave_sum(bsc);
-  if ((tid & 63) == 0 && (bs0 != 0.f || bs1 != 0.f || bsc != 0.f)) { atomicAdd(a.db_span, bs0); atomicAdd(a.db_span + 1, bs1); atomicAdd(a.db_cls, bsc); }
+  if (ys == 0 && (tid & 63) == 0 && (bs0 != 0.f || bs1 != 0.f || bsc != 0.f)) { atomicAdd(a.db_span, bs0); atomicAdd(a.db_span + 1, bs1); atomicAdd(a.db_cls, bsc); }
   __syncthreads();
   const int kc = a.kept ? a.kept[b] : Lv, fs = a.fstart ? a.fstart[b] : b * (Lv + 2);
-  const int per = (kc + 3) / 4, u0 = grp * per, u1 = min(kc, u0 + per);
+  const int perb = (kc + nsplit - 1) / nsplit, ub0 = ys * perb, ub1 = min(kc, ub0 + perb);       // this block's rows
+  const int per = (max(ub1 - ub0, 0) + 3) / 4, u0 = ub0 + grp * per, u1 = min(ub1, u0 + per);
   for (int c2 = t8 * 8; c2 < 2 * d + 2047; c2 += 2048) {        // block-uniform trip count; inactive threads only join the barriers
     const bool live = c2 < 2 * d;
     const bool cls = c2 >= d;
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(1024) void heads_final_bwd_dw_kernel(const HeadsFin
 #pragma unroll
       for (int i = 0; i < 24; i++) { acc0[i] += s_part[t8 * 49 + i]; acc1[i] += s_part[t8 * 49 + 24 + i]; }
       if (a.scratch) {        // per-sample partial in the final (j, c, tap) order; heads_final_dw_reduce_kernel sums over samples
-        float* part = a.scratch + (size_t)b * 9 * d;
+        float* part = a.scratch + ((size_t)b * nsplit + ys) * 9 * d;
         float* p0 = part + (cls ? (size_t)6 * d : 0) + (size_t)c * 3;
 #pragma unroll
         for (int q = 0; q < 6; q++) *(f32x4*)(p0 + 4 * q) = (f32x4){acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
@@ -665,12 +669,12 @@ __global__ __launch_bounds__(1024) void heads_final_bwd_dw_kernel(const HeadsFin
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void heads_final_dw_reduce_kernel(const HeadsFinalArgs a) {
+__global__ __launch_bounds__(256) void heads_final_dw_reduce_kernel(const HeadsFinalArgs a, const int nslots) {
   __shared__ float red[16][17];
-  const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;        // 16 outputs x 16 sample lanes per block
+  const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;        // 16 outputs x 16 slot lanes per block
   const int idx = blockIdx.x * 16 + il, n = 9 * a.d;
   float s = 0.f;
-  if (idx < n) for (int b = bl; b < a.B; b += 16) s += a.scratch[(size_t)b * n + idx];
+  if (idx < n) for (int b = bl; b < nslots; b += 16) s += a.scratch[(size_t)b * n + idx];
   red[bl][il] = s;
   __syncthreads();
   if (bl == 0 && idx < n) {
@@ -1283,9 +1287,14 @@ int launch_heads_final_bwd(const HeadsFinalArgs& a, hipStream_t s) {
   const size_t sh = (3 * (size_t)(a.Lv + 2) + 2 * 256 * 49) * sizeof(float);
   if (sh > 160 * 1024) return -11;
   HeadsFinalArgs b = a;
-  if (b.scratch && b.scratch_floats < (long long)b.B * 9 * b.d) b.scratch = nullptr;
-  hipLaunchKernelGGL(heads_final_bwd_dw_kernel, dim3(b.B), dim3(1024), sh, s, b);
-  if (b.scratch) hipLaunchKernelGGL(heads_final_dw_reduce_kernel, dim3(cdiv(9 * b.d, 16)), dim3(256), 0, s, b);
+  // blocks per sample: enough for one block per CU when the batch alone does not give that (B = 32, L_v = 1200: 8), never ranges under 16 rows;
+  // B >= 256 keeps one block per sample (and its summation order)
+  static const int split_env = uvtg_dev_env("UVTG_HEADS_DW_SPLIT") ? atoi(uvtg_dev_env("UVTG_HEADS_DW_SPLIT")) : 0;      // experiment: force
+  int nsplit = split_env > 0 ? split_env : max(1, min(cdiv(256, max(b.B, 1)), cdiv(b.Lv, 16)));
+  while (nsplit > 1 && b.scratch && b.scratch_floats < (long long)b.B * nsplit * 9 * b.d) nsplit--;
+  if (b.scratch && b.scratch_floats < (long long)b.B * nsplit * 9 * b.d) b.scratch = nullptr;
+  hipLaunchKernelGGL(heads_final_bwd_dw_kernel, dim3(b.B, nsplit), dim3(1024), sh, s, b);
+  if (b.scratch) hipLaunchKernelGGL(heads_final_dw_reduce_kernel, dim3(cdiv(9 * b.d, 16)), dim3(256), 0, s, b, b.B * nsplit);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
