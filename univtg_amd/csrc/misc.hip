@@ -11,55 +11,55 @@ namespace {
 // ---------------- position table + key validity ----------------
 // skip (optional, [B*Lv]): rows with skip[row] < 0 have no packed row and nobody reads their table entry (pk.vin_of)
 // dps (optional): the n_dp = 2 E B DropPath factors of the step, drawn by the first blocks of this launch (was its own 5 us launch)
-__global__ void seq_prep_kernel(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
+// Round 6: one WAVE per (b, t) row, four rows per block (was: a 256-thread block per row whose first wave walked the sample's mask in a rolled loop, the
+// others waiting at a barrier -- a load -> sum -> barrier -> sincos -> store chain per block, 19200 blocks in 9 rounds: 36 us at config 2, 105 us at
+// L_v = 1200).  The mask walk is the wave's own (unrolled loads, DPP-free shuffles, no barrier); sums of 0 / 1 are exact in any order.
+__global__ __launch_bounds__(256) void seq_prep_kernel(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
                                 const float* dim_t, float* pos, unsigned char* kvalid, const int* skip,
                                 float* dps, int n_dp, float p_path, unsigned long long seed, unsigned* zero_words, int n_zero) {
-  const int row = blockIdx.x;             // (b, t) over B*Lv
-  const int b = row / Lv, t = row % Lv;
-  if (row == 0 && zero_words)             // (the split-K tickets of the forward's small GEMMs: zero whatever an aborted call left behind)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;  // (b, t) over B*Lv
+  if (blockIdx.x == 0 && zero_words)      // (the split-K tickets of the forward's small GEMMs: zero whatever an aborted call left behind)
     for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
   if (dps) {
-    const int i = row * blockDim.x + threadIdx.x;
-    if (i < n_dp) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_dp; i += gridDim.x * blockDim.x) {
       unsigned r[4];
       philox4(seed, (unsigned long long)i, UVTG_RNG_PATH, r);
       const float keep = 1.0f - p_path;
       dps[i] = floorf(keep + u01(r[0])) / keep;     // drop_path(): mask = floor(keep + U[0,1)), x / keep * mask
     }
   }
+  if (row >= B * Lv) return;
+  const int b = row / Lv, t = row % Lv;
   if (t == 0) {
     const int S = Lv + Lt;
-    for (int s = threadIdx.x; s < S; s += blockDim.x)
+    for (int s = lane; s < S; s += 64)
       kvalid[b * S + s] = (s < Lv ? vid_mask[b * Lv + s] : txt_mask[b * Lt + (s - Lv)]) != 0.f;
   }
   if (skip && skip[row] < 0) return;
-  __shared__ float s_c, s_last;
-  if (threadIdx.x < 64) {
-    float c = 0.f, tot = 0.f;
-    for (int i = threadIdx.x; i < Lv; i += 64) {
-      const float m = vid_mask[b * Lv + i];
-      tot += m;
-      if (i <= t) c += m;
-    }
-    c = wave_sum(c); tot = wave_sum(tot);
-    if (threadIdx.x == 0) { s_c = c; s_last = tot; }
+  float c = 0.f, tot = 0.f;
+#pragma unroll 4
+  for (int i = lane; i < Lv; i += 64) {
+    const float m = vid_mask[b * Lv + i];
+    tot += m;
+    if (i <= t) c += m;
   }
-  __syncthreads();
+  c = wave_sum(c); tot = wave_sum(tot);
   // x_embed / (x_embed[:, -1:] + eps) * scale, all in fp32 (position_encoding.py:70-73)
-  const float e = s_c / (s_last + 1e-6f) * 6.283185307179586f;
+  const float e = c / (tot + 1e-6f) * 6.283185307179586f;
   if ((d & 1) == 0) {
     // columns 2j (sin) and 2j + 1 (cos) share their denominator (dim_t[2j] == dim_t[2j + 1], position_encoding.py:75-78): one angle,
     // one sincosf, one 8-byte store per pair
-    for (int c = threadIdx.x * 2; c < d; c += blockDim.x * 2) {
-      const float a0 = e / dim_t[c], a1 = e / dim_t[c + 1];
+    for (int cc = lane * 2; cc < d; cc += 128) {
+      const float a0 = e / dim_t[cc], a1 = e / dim_t[cc + 1];
       float sv, cv;
       if (a0 == a1) sincosf(a0, &sv, &cv); else { sv = sinf(a0); cv = cosf(a1); }
-      *(f32x2*)(pos + (size_t)row * d + c) = (f32x2){sv, cv};
+      *(f32x2*)(pos + (size_t)row * d + cc) = (f32x2){sv, cv};
     }
   } else {
-    for (int c = threadIdx.x; c < d; c += blockDim.x) {
-      const float ang = e / dim_t[c];
-      pos[(size_t)row * d + c] = (c & 1) ? cosf(ang) : sinf(ang);
+    for (int cc = lane; cc < d; cc += 64) {
+      const float ang = e / dim_t[cc];
+      pos[(size_t)row * d + cc] = (cc & 1) ? cosf(ang) : sinf(ang);
     }
   }
 }
@@ -1126,11 +1126,7 @@ int launch_pack_reduce_dvm(const bf16_t* dvm, const PackTables& t, int B, int S,
 int launch_seq_prep(const float* vid_mask, const float* txt_mask, int B, int Lv, int Lt, int d,
                     const float* dim_t, float* pos, unsigned char* kvalid, const int* skip, hipStream_t s,
                     float* dps, int n_dp, float p_path, unsigned long long seed, unsigned* zero_words, int n_zero) {
-  if (dps && (long long)B * Lv * 256 < n_dp) {        // (never at real shapes: the grid has B * Lv blocks of 256 threads)
-    if (int e = launch_droppath_scales(dps, n_dp / B, B, p_path, seed, s)) return e;
-    dps = nullptr;
-  }
-  hipLaunchKernelGGL(seq_prep_kernel, dim3(B * Lv), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, skip, dps, n_dp, p_path, seed, zero_words, n_zero);
+  hipLaunchKernelGGL(seq_prep_kernel, dim3(cdiv(B * Lv, 4)), dim3(256), 0, s, vid_mask, txt_mask, B, Lv, Lt, d, dim_t, pos, kvalid, skip, dps, n_dp, p_path, seed, zero_words, n_zero);
   UVTG_CHECK_LAUNCH();
   return 0;
 }
