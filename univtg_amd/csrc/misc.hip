@@ -913,17 +913,18 @@ __global__ __launch_bounds__(512) void heads_saliency_fwd_kernel(const HeadsFina
 //   text row s : g = dx0 + alpha dq + dlog w_pool,  dlog = alpha (dq.x_s - sum alpha dq.x);  dw_pool += sum dlog x_s
 // block = 64 columns x 4 row phases (one block per (sample, 256 columns) with a serial walk over the clips was latency-bound:
 // 535 us at L_v = 1200): thread (cc, ph) walks clips ph, ph + 4, ...; the four phases meet in LDS
-__global__ __launch_bounds__(256) void saliency_dq_kernel(const SaliencyArgs a) {
-  extern __shared__ float sm[];                 // [Lv] gs | [Lv] |v| | [Lv] cos | [256] partial sums
+// (round 6: blockDim.x / 64 row phases -- 4 at L_v <= 256, 16 above: at L_v = 1200 a thread of the 4-phase block walked 300 clips, 61 us at config 4)
+__global__ __launch_bounds__(1024) void saliency_dq_kernel(const SaliencyArgs a) {
+  extern __shared__ float sm[];                 // [Lv] gs | [Lv] |v| | [Lv] cos | [blockDim.x] partial sums
   float* s_gs = sm;
   float* s_vn = s_gs + a.Lv;
   float* s_cs = s_vn + a.Lv;
   float* red = s_cs + a.Lv;
   const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
-  const int cc = tid & 63, ph = tid >> 6;
+  const int cc = tid & 63, ph = tid >> 6, nph = blockDim.x >> 6;
   const int c = blockIdx.y * 64 + cc;
   const float qn = fmaxf(a.qnorm[b], 1e-8f);
-  for (int t = tid; t < a.Lv; t += 256) {
+  for (int t = tid; t < a.Lv; t += blockDim.x) {
     s_gs[t] = a.g_sal ? a.g_sal[b * a.Lv + t] : 0.f;
     s_vn[t] = fmaxf(a.vnorm[b * a.Lv + t], 1e-8f);
     s_cs[t] = a.cosv[b * a.Lv + t];
@@ -934,15 +935,18 @@ __global__ __launch_bounds__(256) void saliency_dq_kernel(const SaliencyArgs a) 
   float acc = 0.f;
   if (c < d) {
 #pragma unroll 4
-    for (int t = ph; t < a.Lv; t += 4) {
+    for (int t = ph; t < a.Lv; t += nph) {
       const float gs = s_gs[t];
       acc += gs * (xv[(size_t)t * d + c] / s_vn[t] - s_cs[t] * qh);
     }
   }
   red[tid] = acc;
   __syncthreads();
-  if (ph == 0 && c < d)
-    a.dq[(size_t)b * d + c] = (a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f) + (red[cc] + red[64 + cc] + red[128 + cc] + red[192 + cc]) / qn;
+  if (ph == 0 && c < d) {
+    float t4 = red[cc] + red[64 + cc] + red[128 + cc] + red[192 + cc];      // (the four-phase order of rounds 2-5)
+    for (int k = 4; k < nph; k++) t4 += red[64 * k + cc];
+    a.dq[(size_t)b * d + c] = (a.g_pooled ? a.g_pooled[(size_t)b * d + c] : 0.f) + t4 / qn;
+  }
 }
 __global__ __launch_bounds__(1024) void saliency_dlog_kernel(const SaliencyArgs a) {
   extern __shared__ float sm[];                 // [Lt] da
@@ -1318,7 +1322,8 @@ int launch_heads_saliency_fwd(const HeadsFinalArgs& h, const SaliencyArgs& a, hi
   return 0;
 }
 int launch_saliency_bwd(const SaliencyArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 64)), dim3(256), (3 * a.Lv + 256) * sizeof(float), s, a);
+  const int dq_threads = a.Lv > 256 ? 1024 : 256;
+  hipLaunchKernelGGL(saliency_dq_kernel, dim3(a.B, cdiv(a.d, 64)), dim3(dq_threads), (3 * a.Lv + dq_threads) * sizeof(float), s, a);
   hipLaunchKernelGGL(saliency_dlog_kernel, dim3(a.B), dim3(1024), a.Lt * sizeof(float), s, a);
   const dim3 grid(a.B, cdiv(a.Lv, SAL_CHUNK) + (SAL_TXT ? cdiv(a.Lt, SAL_TXT) : 1));
   if (a.d == 1024) hipLaunchKernelGGL(saliency_rows_kernel<4>, grid, dim3(256), 0, s, a);
