@@ -1,7 +1,7 @@
 """eval-mode batch independence at BASELINE config 2: rows of a 32-sample slice vs the same rows of the 256-sample call (split-K of the small launches
 sums K in another order than the unsplit large ones)"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from oracle import univtg_oracle as O
 from tests.test_gpu_model import build, to_dev

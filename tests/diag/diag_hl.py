@@ -1,11 +1,11 @@
 """diagnosis: per-parameter gradient agreement of the tiny fixtures (bf16 training arithmetic vs the reference's fp32 gradients)"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import test_gpu_model as T
 dev = torch.device("cuda:0")
-gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden")
 for name in ("tiny_eval_ragged", "tiny_hl", "tiny_zero_saliency"):
     meta, cfg, params, inputs, tg, out_ref, eval_ref, grads_ref, losses_ref = T.load_case(gd, name)
     for pp in (True,):
